@@ -1,0 +1,730 @@
+/*
+ * oracle/em_oracle.c -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Scalar, f64, single-threaded restatement of the sampling hot path of
+ * Airspace-Encounter-Models/em-model-manned-bayes (MATLAB).  It is the CHECKER
+ * for the HIP kernels in em_model_manned_bayes_amd/csrc and is never linked,
+ * imported or executed by the product path: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may use it.
+ *
+ * PARITY PINNING: the reference is MATLAB-only, ships no tests / golden vectors
+ * and cannot be executed in the build container (no MATLAB, no Octave).
+ * ==> "parity unpinned" against real MATLAB output.  What pins this file:
+ *   (1) the RNG-free known answers derived from the cited lines (SURVEY.md
+ *       Appendix D), (2) an independently written numpy restatement
+ *       (oracle/pyref.py) that uses numpy's MT19937 (== MATLAB rng(s,'twister'))
+ *       and must agree with this file draw-for-draw, (3) the Random123
+ *       Philox4x32-10 known-answer vectors, (4) chi-square tests against the CPTs.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * code/matlab/ of the reference).  All indices are 1-based like the reference
+ * unless a comment says otherwise.
+ *
+ * Two uniform sources:
+ *   EM_RNG_MT19937 : one global MT19937 stream, genrand_res53 doubles, consumed in
+ *                    exactly the order the reference calls rand.
+ *   EM_RNG_PHILOX  : counter-based Philox4x32-10; every reference rand call site
+ *                    has a fixed SLOT (section, a, idx) so that the result does not
+ *                    depend on draw order, GPU count or launch shape.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#if defined(__GNUC__)
+#pragma STDC FP_CONTRACT OFF
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* MT19937 (Matsumoto & Nishimura 1998/2002): init_genrand + genrand_res53.   */
+/* MATLAB rng(seed,'twister'); rand  ==  this stream.         */
+/* ------------------------------------------------------------------------- */
+#define MT_N 624
+#define MT_M 397
+typedef struct { uint32_t mt[MT_N]; int mti; } em_mt_t;
+
+static void mt_seed(em_mt_t *s, uint32_t seed) {
+    s->mt[0] = seed;
+    for (int i = 1; i < MT_N; i++)
+        s->mt[i] = 1812433253u * (s->mt[i - 1] ^ (s->mt[i - 1] >> 30)) + (uint32_t)i;
+    s->mti = MT_N;
+}
+static uint32_t mt_u32(em_mt_t *s) {
+    static const uint32_t mag01[2] = {0u, 0x9908b0dfu};
+    uint32_t y;
+    if (s->mti >= MT_N) {
+        int kk;
+        for (kk = 0; kk < MT_N - MT_M; kk++) {
+            y = (s->mt[kk] & 0x80000000u) | (s->mt[kk + 1] & 0x7fffffffu);
+            s->mt[kk] = s->mt[kk + MT_M] ^ (y >> 1) ^ mag01[y & 1u];
+        }
+        for (; kk < MT_N - 1; kk++) {
+            y = (s->mt[kk] & 0x80000000u) | (s->mt[kk + 1] & 0x7fffffffu);
+            s->mt[kk] = s->mt[kk + (MT_M - MT_N)] ^ (y >> 1) ^ mag01[y & 1u];
+        }
+        y = (s->mt[MT_N - 1] & 0x80000000u) | (s->mt[0] & 0x7fffffffu);
+        s->mt[MT_N - 1] = s->mt[MT_M - 1] ^ (y >> 1) ^ mag01[y & 1u];
+        s->mti = 0;
+    }
+    y = s->mt[s->mti++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+static double mt_res53(em_mt_t *s) {
+    uint32_t a = mt_u32(s) >> 5, b = mt_u32(s) >> 6;
+    return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Philox4x32-10 (Salmon et al., SC'11; Random123 v1.14 philox.h constants).  */
+/* ------------------------------------------------------------------------- */
+void em_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Slot sections.  ctr = {gidx_lo, gidx_hi, attempt,
+ * section<<28 | a<<20 | (idx>>2)}, word = idx & 3, key = {seed_lo, seed_hi}. */
+enum {
+    EM_SEC_INIT = 1,         /* bn_sample draw of initial node: a=0, idx = var-1            */
+    EM_SEC_DEDISC_INIT = 2,  /* dediscretize of initial var:    a=0, idx = var-1            */
+    EM_SEC_TRANS = 3,        /* transition draw producing column c: a = tvar-1, idx = c     */
+    EM_SEC_RES = 4,          /* resample Bernoulli of second tau:   a = var-1,  idx = tau   */
+    EM_SEC_DEDISC_RES = 5,   /* dediscretize of a resample event:   a = var-1,  idx = tau   */
+    EM_SEC_DEDISC_TRANS = 6, /* dediscretize of a transition event: a = var-1,  idx = c     */
+    EM_SEC_LAYER = 7,        /* UncorEncounterModel.sample 'layers' draw: a=0, idx=0        */
+    EM_SEC_GEOM_DEDISC = 8   /* CorTerminalModel.sample dediscretize: a=0, idx = var-1      */
+};
+
+enum { EM_RNG_MT19937 = 0, EM_RNG_PHILOX = 1 };
+
+typedef struct {
+    int32_t mode;
+    uint32_t key[2];
+    uint64_t gidx;
+    uint32_t attempt;
+    em_mt_t mt;
+    uint64_t n_draws; /* statistics: number of uniforms consumed */
+} em_rng_t;
+
+void em_rng_init(em_rng_t *g, int mode, uint64_t seed) {
+    memset(g, 0, sizeof *g);
+    g->mode = mode;
+    g->key[0] = (uint32_t)seed;
+    g->key[1] = (uint32_t)(seed >> 32);
+    if (mode == EM_RNG_MT19937) mt_seed(&g->mt, (uint32_t)seed);
+}
+
+/* uniform32: x' = min(x, 2^32-2); u = (x' + 0.5) * 2^-32  in (0,1)   */
+double em_uniform32(uint32_t x) {
+    if (x > 0xFFFFFFFEu) x = 0xFFFFFFFEu;
+    return ((double)x + 0.5) * (1.0 / 4294967296.0);
+}
+
+uint32_t em_philox_word(const em_rng_t *g, uint32_t section, uint32_t a, uint32_t idx) {
+    uint32_t ctr[4], out[4];
+    ctr[0] = (uint32_t)g->gidx;
+    ctr[1] = (uint32_t)(g->gidx >> 32);
+    ctr[2] = g->attempt;
+    ctr[3] = (section << 28) | (a << 20) | (idx >> 2);
+    em_philox4x32_10(ctr, g->key, out);
+    return out[idx & 3u];
+}
+
+/* One MATLAB `rand` call.  In MT mode the slot is ignored. */
+static double em_rand(em_rng_t *g, uint32_t section, uint32_t a, uint32_t idx) {
+    g->n_draws++;
+    if (g->mode == EM_RNG_MT19937) return mt_res53(&g->mt);
+    return em_uniform32(em_philox_word(g, section, a, idx));
+}
+
+/* ------------------------------------------------------------------------- */
+/* Model container (flat arrays; filled by oracle/oracle.py)                  */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_initial, n_transition, n_dyn, _pad;
+    const uint8_t *G_initial;        /* n_i x n_i row-major, [parent][child] (em_read.m:204) */
+    const uint8_t *G_transition;     /* n_t x n_t row-major                                  */
+    const int32_t *r_initial;        /* n_i                                                  */
+    const int32_t *r_transition;     /* n_t                                                  */
+    const int32_t *order_initial;    /* n_i, 1-based variable ids (bn_sort)                  */
+    const int32_t *order_transition; /* n_t                                                  */
+    const int32_t *temporal_map;     /* n_dyn x 2 row-major, 1-based (var@t, var@t+1)        */
+    const double *N_initial;         /* concatenated r_i x q_i column-major (em_read.m:191)  */
+    const double *A_initial;         /* alpha, same layout (bn_dirichlet_prior.m)            */
+    const int64_t *off_initial;      /* n_i offsets into N_initial / A_initial               */
+    const double *N_transition;      /* nodes n_i+1..n_t (em_read.m:92)                      */
+    const double *A_transition;
+    const int64_t *off_transition;   /* n_t offsets; -1 for nodes without a table            */
+    const double *boundaries;        /* concatenated per initial var                         */
+    const int32_t *bnd_off;          /* n_i                                                  */
+    const int32_t *bnd_len;          /* n_i ; 0 => empty ('*' in the file, em_read.m:97-99)  */
+    const int32_t *zero_bins;        /* n_i ; 0 => none                                      */
+    const double *resample_rates;    /* n_i                                                  */
+    const int32_t *start;            /* n_i ; 0 => unset                                     */
+} em_model_t;
+
+typedef struct {
+    double dt;      /* seconds since the previous row                                        */
+    int32_t var;    /* 1-based initial-network variable id; 0 = terminator                   */
+    int32_t bin;    /* discrete value                                                        */
+    double val;     /* dediscretised value (== bin until dediscretize ran)                   */
+    int32_t kind;   /* 0 = transition event, 1 = resample event, 2 = terminator              */
+    int32_t atime;  /* absolute time of the row in seconds since the start (1..T)            */
+} em_event_t;
+
+/* ------------------------------------------------------------------------- */
+/* a1  asub2ind.m:13-14                                                       */
+/* ------------------------------------------------------------------------- */
+int64_t em_asub2ind(const int32_t *siz, const int32_t *x, int n) {
+    /* k = [1 cumprod(siz(1:end-1))]; ndx = k*(x-1) + 1 */
+    int64_t k = 1, ndx = 1;
+    for (int i = 0; i < n; i++) {
+        ndx += k * (int64_t)(x[i] - 1);
+        k *= siz[i];
+    }
+    return ndx;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a2  select_random.m:14-20 with the uniform injected                        */
+/* ------------------------------------------------------------------------- */
+int em_select_random_r(const double *weights, int n, double r) {
+    /* s = cumsum(weights); sthres = s(end)*r; index = find(s >= sthres, 1, 'first') */
+    double s_end = 0.0;
+    for (int i = 0; i < n; i++) s_end += weights[i];   /* sequential sum == cumsum(end) */
+    double sthres = s_end * r;
+    double s = 0.0;
+    for (int i = 0; i < n; i++) {
+        s += weights[i];
+        if (s >= sthres) return i + 1;
+    }
+    return n; /* unreachable for r < 1 */
+}
+
+/* weights = N{i}(:,j) + alpha{i}(:,j)  (bn_sample.m:55, dbn_sample.m:77,123-127) */
+static void column_weights(const double *N, const double *A, int64_t off, int r, int64_t j, double *w) {
+    const double *n = N + off + (j - 1) * r;
+    const double *a = A + off + (j - 1) * r;
+    for (int k = 0; k < r; k++) w[k] = n[k] + a[k];
+}
+
+/* j = asub2ind(r(parents), x(parents)) with parents = logical column G(:,i)
+ * (bn_sample.m:42,53; dbn_sample.m:72-75): parents ascend in variable index. */
+static int64_t parent_config(const uint8_t *G, int n, const int32_t *r, const int32_t *x, int child) {
+    int32_t siz[64], sub[64];
+    int np = 0;
+    for (int p = 0; p < n; p++)
+        if (G[p * n + (child - 1)]) { siz[np] = r[p]; sub[np] = x[p]; np++; }
+    if (np == 0) return 1;
+    return em_asub2ind(siz, sub, np);
+}
+
+#define EM_MAX_R 64
+
+/* ------------------------------------------------------------------------- */
+/* a4  bn_sample.m:39-57 (one sample).  Returns 0, or -1 for                  */
+/* 'Attempt to preset a dependent variable' (bn_sample.m:45-47).              */
+/* r must be indexable by every node of G (the reference passes r_transition  */
+/* from dbn_sample.m:36, r_initial from @CorTerminalModel/sample.m:34).       */
+/* ------------------------------------------------------------------------- */
+int em_bn_sample(const em_model_t *m, em_rng_t *g, const int32_t *r, int32_t *S /* n_initial */) {
+    int n = m->n_initial;
+    double w[EM_MAX_R];
+    for (int i = 0; i < n; i++) S[i] = 0;
+    for (int oi = 0; oi < n; oi++) {
+        int i = m->order_initial[oi]; /* 1-based */
+        int has_par = 0, n_par = 0, n_par_set = 0;
+        for (int p = 0; p < n; p++)
+            if (m->G_initial[p * n + (i - 1)]) { has_par = 1; n_par++; if (m->start[p] != 0) n_par_set++; }
+        if (m->start[i - 1] != 0) {
+            if (has_par && n_par_set < n_par) return -1;
+            S[i - 1] = m->start[i - 1];
+        } else {
+            int64_t j = 1;
+            if (has_par) j = parent_config(m->G_initial, n, r, S, i);
+            column_weights(m->N_initial, m->A_initial, m->off_initial[i - 1], r[i - 1], j, w);
+            double u = em_rand(g, EM_SEC_INIT, 0, (uint32_t)(i - 1));
+            S[i - 1] = em_select_random_r(w, r[i - 1], u);
+        }
+    }
+    return 0;
+}
+
+static int is_dynamic(const em_model_t *m, int var) {
+    for (int k = 0; k < m->n_dyn; k++) if (m->temporal_map[2 * k + 1] == var) return 1;
+    return 0;
+}
+
+/* dbn_sample.m:55  is_dynvar_depend = any(G_transition(dyn,dyn),'all') */
+int em_is_dynvar_depend(const em_model_t *m) {
+    int nt = m->n_transition;
+    for (int a = 0; a < m->n_dyn; a++)
+        for (int b = 0; b < m->n_dyn; b++)
+            if (m->G_transition[(m->temporal_map[2 * a + 1] - 1) * nt + (m->temporal_map[2 * b + 1] - 1)]) return 1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a5/a6  dbn_sample.m:36-166.  per_step: 0 = REFERENCE_AUTO (branch chosen   */
+/* by is_dynvar_depend, dbn_sample.m:55), 1 = force the dependent branch      */
+/* (true per-timestep DBN; not reference behaviour for "fast" models).        */
+/* events: rows (dt, var, bin); returns row count, or <0 on error.            */
+/* ------------------------------------------------------------------------- */
+int em_dbn_sample(const em_model_t *m, em_rng_t *g, int t_max, int per_step,
+                  int32_t *initial, em_event_t *events, int cap) {
+    int ni = m->n_initial, nt = m->n_transition, nd = m->n_dyn;
+    int32_t x[128], x_old[128];
+    double w[EM_MAX_R];
+    if (em_bn_sample(m, g, m->r_transition ? m->r_transition : m->r_initial, initial) != 0) return -1;
+    if (nd == 0 || t_max < 2) return 0;
+    for (int i = 0; i < ni; i++) x[i] = initial[i];
+    for (int i = ni; i < nt; i++) x[i] = 0;      /* x = [initial zeros(...)]  dbn_sample.m:40 */
+    double delta_t = 0;
+    int counter = 0;
+    int depend = per_step ? 1 : em_is_dynvar_depend(m);
+
+    /* thresholds of the fast branch: s{ii}, sthres(:,ii)  dbn_sample.m:104-135 */
+    double *scum = NULL, *sthres = NULL;
+    if (!depend) {
+        scum = (double *)calloc((size_t)nt * EM_MAX_R, sizeof(double));
+        sthres = (double *)calloc((size_t)nt * (size_t)t_max, sizeof(double));
+        for (int oi = 0; oi < nt; oi++) {
+            int ii = m->order_transition[oi];
+            if (!is_dynamic(m, ii)) continue;
+            int64_t j = parent_config(m->G_transition, nt, m->r_transition, x, ii); /* :111-120 */
+            int r = m->r_transition[ii - 1];
+            column_weights(m->N_transition, m->A_transition, m->off_transition[ii - 1], r, j, w);
+            double s = 0;
+            for (int k = 0; k < r; k++) { s += w[k]; scum[(ii - 1) * EM_MAX_R + k] = s; }  /* :130 */
+            /* sthres(:,ii) = s{ii}(end) * rand(t_max,1)  :133.  Row 1 is drawn but unused. */
+            for (int t = 1; t <= t_max; t++) {
+                double u;
+                if (g->mode == EM_RNG_MT19937 || t >= 2) u = em_rand(g, EM_SEC_TRANS, (uint32_t)(ii - 1), (uint32_t)(t - 1));
+                else u = 0.0; /* Philox mode: slot (ii, c=0) is never used, skip the draw */
+                sthres[(size_t)(ii - 1) * t_max + (t - 1)] = s * u;
+            }
+        }
+    }
+
+    for (int t = 2; t <= t_max; t++) {                                   /* :66 / :138 */
+        delta_t += 1;
+        memcpy(x_old, x, sizeof(int32_t) * nt);
+        for (int oi = 0; oi < nt; oi++) {
+            int i = m->order_transition[oi];
+            if (!is_dynamic(m, i)) continue;
+            int r = m->r_transition[i - 1];
+            if (depend) {
+                int64_t j = parent_config(m->G_transition, nt, m->r_transition, x, i);   /* :72-75 */
+                column_weights(m->N_transition, m->A_transition, m->off_transition[i - 1], r, j, w);
+                double u = em_rand(g, EM_SEC_TRANS, (uint32_t)(i - 1), (uint32_t)(t - 1));
+                x[i - 1] = em_select_random_r(w, r, u);                                   /* :77 */
+            } else {
+                /* x(ii) = find(s{ii} >= sthres(t,ii), 1, 'first')  :144 */
+                double th = sthres[(size_t)(i - 1) * t_max + (t - 1)];
+                int k = 0;
+                while (k < r - 1 && !(scum[(i - 1) * EM_MAX_R + k] >= th)) k++;
+                x[i - 1] = k + 1;
+            }
+        }
+        for (int k = 0; k < nd; k++) x[m->temporal_map[2 * k] - 1] = x[m->temporal_map[2 * k + 1] - 1]; /* :82/:149 */
+        for (int i = 0; i < ni; i++) {                                                    /* :84-91 / :151-161 */
+            if (x[i] != x_old[i]) {
+                if (counter >= cap) { free(scum); free(sthres); return -2; }
+                events[counter].dt = delta_t;
+                events[counter].var = i + 1;
+                events[counter].bin = x[i];
+                events[counter].val = x[i];
+                events[counter].kind = 0;
+                events[counter].atime = t - 1;
+                counter++;
+                delta_t = 0;
+            }
+        }
+    }
+    free(scum); free(sthres);
+    return counter;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a8  resample_events.m:16-37                                                */
+/* ------------------------------------------------------------------------- */
+int em_resample_events(const em_model_t *m, em_rng_t *g, const int32_t *initial,
+                       const em_event_t *ev, int n, em_event_t *out, int cap) {
+    int ni = m->n_initial;
+    int32_t x[128];
+    int k = 0, sec = 0; /* sec: 0-based absolute second of the next draw */
+    for (int i = 0; i < ni; i++) x[i] = initial[i];
+    for (int ii = 0; ii < n; ii++) {
+        int holdtime = (int)ev[ii].dt;
+        if (holdtime == 0) {
+            if (k >= cap) return -2;
+            out[k++] = ev[ii];                                                  /* :19-20 */
+        } else {
+            double delta_t = 0;
+            for (int j = 1; j <= holdtime; j++) {
+                /* changes = find(rand(size(rates)) < rates)  :24 -- n_initial uniforms */
+                int first = 1;
+                uint8_t ch[128];
+                for (int v = 0; v < ni; v++) {
+                    double rate = m->resample_rates[v];
+                    double u;
+                    if (g->mode == EM_RNG_MT19937 || rate > 0.0) u = em_rand(g, EM_SEC_RES, (uint32_t)v, (uint32_t)sec);
+                    else u = 1.0; /* Philox mode: a draw compared with rate 0 never hits; skip it */
+                    ch[v] = (u < rate);
+                }
+                delta_t += 1;                                                   /* :25 */
+                for (int v = 0; v < ni; v++) {
+                    if (!ch[v]) continue;
+                    if (k >= cap) return -2;
+                    out[k].dt = first ? delta_t : 0;                            /* :27 */
+                    out[k].var = v + 1;
+                    out[k].bin = x[v];
+                    out[k].val = x[v];
+                    out[k].kind = 1;
+                    out[k].atime = sec + 1;
+                    k++;
+                    if (first) { first = 0; }
+                }
+                if (!first) delta_t = 0;                                        /* :28 */
+                sec++;
+            }
+            if (k >= cap) return -2;
+            out[k] = ev[ii];                                                    /* :31 */
+            out[k].dt = delta_t;
+            k++;
+        }
+        if (ev[ii].var > 0) x[ev[ii].var - 1] = ev[ii].bin;                     /* :33-35 */
+    }
+    return k;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a9  dediscretize.m:7-40 (scalar d; wrap is never requested by any caller)  */
+/* ------------------------------------------------------------------------- */
+double em_dediscretize_u(int d, const double *params, int n_params, int zero_bin, double u, int *used) {
+    *used = 0;
+    if (n_params == 0) return (double)d;          /* :7-10 */
+    if (zero_bin != 0 && zero_bin == d) return 0; /* :24-25 */
+    double a = params[d - 1];
+    double b = params[d];
+    *used = 1;
+    return a + (b - a) * u;                       /* :39 */
+}
+
+static double dedisc(const em_model_t *m, em_rng_t *g, int var, int d, uint32_t section, uint32_t idx) {
+    int np = m->bnd_len[var - 1];
+    if (np == 0) return (double)d;
+    if (m->zero_bins[var - 1] != 0 && m->zero_bins[var - 1] == d) return 0.0;
+    const double *p = m->boundaries + m->bnd_off[var - 1];
+    double u = em_rand(g, section, (section == EM_SEC_DEDISC_INIT || section == EM_SEC_GEOM_DEDISC) ? 0u : (uint32_t)(var - 1), idx);
+    double a = p[d - 1], b = p[d];
+    return a + (b - a) * u;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a7  dbn_hierarchical_sample.m:9-37                                         */
+/* initial_bin: discrete initial sample; initial_val: dediscretised.          */
+/* Returns number of event rows (incl. terminator) or <0.                     */
+/* ------------------------------------------------------------------------- */
+int em_dbn_hierarchical_sample(const em_model_t *m, em_rng_t *g, int sample_time, int per_step,
+                               int32_t *initial_bin, double *initial_val,
+                               em_event_t *events, int cap) {
+    int ni = m->n_initial;
+    em_event_t *raw = (em_event_t *)malloc(sizeof(em_event_t) * (size_t)cap);
+    int n = em_dbn_sample(m, g, sample_time, per_step, initial_bin, raw, cap - 1);
+    if (n < 0) { free(raw); return n; }
+    /* terminator row [sample_time - sum(events(:,1)) 0 0]  :15-19 */
+    double sum = 0;
+    for (int i = 0; i < n; i++) sum += raw[i].dt;
+    raw[n].dt = sample_time - sum; raw[n].var = 0; raw[n].bin = 0; raw[n].val = 0; raw[n].kind = 2; raw[n].atime = sample_time;
+    n++;
+    int k = em_resample_events(m, g, initial_bin, raw, n, events, cap);          /* :22 */
+    free(raw);
+    if (k < 0) return k;
+    for (int ii = 1; ii <= ni; ii++) {                                           /* :25-31 */
+        int r_rows = m->r_initial[ii - 1]; /* size(parms.N_initial{ii},1) */
+        if (m->bnd_len[ii - 1] == r_rows - 2) {
+            initial_val[ii - 1] = initial_bin[ii - 1];  /* :26 branch body is empty: left as the bin */
+        } else {
+            initial_val[ii - 1] = dedisc(m, g, ii, initial_bin[ii - 1], EM_SEC_DEDISC_INIT, (uint32_t)(ii - 1));
+        }
+    }
+    for (int ii = 0; ii < k - 1; ii++) {                                         /* :33-37 */
+        em_event_t *e = &events[ii];
+        if (e->kind == 1) e->val = dedisc(m, g, e->var, e->bin, EM_SEC_DEDISC_RES, (uint32_t)(e->atime - 1));
+        else              e->val = dedisc(m, g, e->var, e->bin, EM_SEC_DEDISC_TRANS, (uint32_t)e->atime);
+    }
+    return k;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a10 events2samples.m:9-26 on (value) and, in parallel, on (bin)            */
+/* d: n_initial x T column-major (like MATLAB). Returns columns filled.       */
+/* ------------------------------------------------------------------------- */
+int em_events2samples(int n_initial, const double *initial_val, const int32_t *initial_bin,
+                      const em_event_t *ev, int n, double *d_val, int32_t *d_bin, int T_cap) {
+    double xv[128]; int32_t xb[128];
+    for (int i = 0; i < n_initial; i++) { xv[i] = initial_val[i]; xb[i] = initial_bin ? initial_bin[i] : 0; }
+    int t = 0, filled = 0;
+    for (int e = 0; e < n; e++) {
+        int delta_t = (int)ev[e].dt;
+        int c0, c1;
+        if (ev[e].var == 0) {
+            t = t + 1;                       /* :17-18  d(:, t:t+delta_t-1) = x */
+            c0 = t; c1 = t + delta_t - 1;
+        } else {
+            c0 = t + 1; c1 = t + delta_t;    /* :20-23  d(:, t+1:t+delta_t) = x; t = t+delta_t */
+            if (delta_t > 0) t = t + delta_t;
+        }
+        for (int c = c0; c <= c1; c++) {
+            if (c > T_cap) return -2;
+            for (int i = 0; i < n_initial; i++) {
+                d_val[(size_t)(c - 1) * n_initial + i] = xv[i];
+                if (d_bin) d_bin[(size_t)(c - 1) * n_initial + i] = xb[i];
+            }
+            if (c > filled) filled = c;
+        }
+        if (ev[e].var != 0) {                /* :25 */
+            xv[ev[e].var - 1] = ev[e].val;
+            xb[ev[e].var - 1] = ev[e].bin;
+        }
+    }
+    return filled;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a10 events2controls.m:11-31.  controls: rows x (1+n_dyn) row-major.        */
+/* ------------------------------------------------------------------------- */
+int em_events2controls(const em_model_t *m, const double *initial_val, const em_event_t *ev, int n, double *controls) {
+    double x[128];
+    int nd = m->n_dyn;
+    for (int i = 0; i < m->n_initial; i++) x[i] = initial_val[i];
+    double t = 0; int counter = 0;
+    for (int e = 0; e < n; e++) {
+        double delta_t = ev[e].dt;
+        if (delta_t > 0) {
+            controls[(size_t)counter * (1 + nd)] = t;
+            for (int k = 0; k < nd; k++) controls[(size_t)counter * (1 + nd) + 1 + k] = x[m->temporal_map[2 * k] - 1];
+            counter++;
+            t += delta_t;
+        }
+        if (ev[e].var > 0) x[ev[e].var - 1] = ev[e].val;
+    }
+    return counter;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a11 @UncorEncounterModel/UncorEncounterModel.m:244-281, one sample with    */
+/* its rejection loop.  idx*: 1-based variable ids (0 = absent).              */
+/* layers: r_L x 2 row-major or NULL.  Returns event rows; *attempts_out =    */
+/* number of attempts used (>=1); -3 if max_attempts exceeded.                */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t idxL, idxV, idxDH, is_quantize500;
+    const double *layers;
+    int32_t max_attempts, per_step;
+} em_uncor_opts_t;
+
+static double round500(double num) { /* UncorEncounterModel.m:196 */
+    return 500.0 * (floor(num / 500.0) + ((fmod(num, 500.0) > 250.0) ? 1.0 : 0.0));
+}
+
+int em_uncor_sample_one(const em_model_t *m, em_rng_t *g, int sample_time, const em_uncor_opts_t *o,
+                        int32_t *initial_bin, double *initial_val, em_event_t *events, int cap, int32_t *attempts_out) {
+    for (uint32_t attempt = 0; attempt < (uint32_t)o->max_attempts; attempt++) {
+        g->attempt = attempt;
+        int k = em_dbn_hierarchical_sample(m, g, sample_time, o->per_step, initial_bin, initial_val, events, cap); /* :253 */
+        if (k < 0) return k;
+        double h_ft;
+        if (o->layers && o->idxL > 0) {                                             /* :259-260 */
+            int b = (int)initial_val[o->idxL - 1];
+            double lo = o->layers[2 * (b - 1)], hi = o->layers[2 * (b - 1) + 1];
+            h_ft = lo + em_rand(g, EM_SEC_LAYER, 0, 0) * (hi - lo);
+        } else {
+            h_ft = o->idxL > 0 ? initial_val[o->idxL - 1] : 0.0;
+        }
+        if (o->idxDH > 0 && initial_val[o->idxDH - 1] == 0 && o->is_quantize500) h_ft = round500(h_ft); /* :266-268 */
+        if ((o->layers || o->is_quantize500) && o->idxL > 0) initial_val[o->idxL - 1] = h_ft;          /* :270-272 */
+        int good = 1;
+        if (o->idxV > 0 && o->idxDH > 0)
+            good = (initial_val[o->idxV - 1] * 1.68781 > fabs(initial_val[o->idxDH - 1]) / 60.0);      /* :275 */
+        if (good) { *attempts_out = (int32_t)attempt + 1; return k; }
+    }
+    return -3;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Batch driver used by tests and by bench.py's cpu_baseline leg.             */
+/* Philox: trajectory ii uses gidx = first_index + ii.  MT: one stream seeded */
+/* once (UncorEncounterModel.m:213-216) that runs on across samples.          */
+/* Outputs (any may be NULL):                                                 */
+/*   init_bin  int32 [n][n_i], init_val f64 [n][n_i]                          */
+/*   ev_*: event lists, ev_cap rows per sample, ev_count[n]                   */
+/*   dense_bin uint8 [n][T][n_dyn], dense_val f64 [n][T][n_dyn]: the columns  */
+/*     of events2samples restricted to temporal_map(:,1), bins alongside.     */
+/* ------------------------------------------------------------------------- */
+int64_t em_uncor_sample_batch(const em_model_t *m, int mode, uint64_t seed, uint64_t first_index, int64_t n,
+                              int sample_time, const em_uncor_opts_t *o,
+                              int32_t *init_bin, double *init_val,
+                              double *ev_dt, int32_t *ev_var, int32_t *ev_bin, double *ev_val, int32_t *ev_count, int ev_cap,
+                              uint8_t *dense_bin, double *dense_val, int32_t *attempts, uint64_t *n_draws_out) {
+    em_rng_t g;
+    em_rng_init(&g, mode, seed);
+    int ni = m->n_initial, nd = m->n_dyn, T = sample_time;
+    int cap = (ni + nd + 1) * T + 8;
+    if (cap < 64) cap = 64;
+    em_event_t *ev = (em_event_t *)malloc(sizeof(em_event_t) * (size_t)cap);
+    int32_t ib[128]; double iv[128];
+    double *dv = (double *)malloc(sizeof(double) * (size_t)ni * (size_t)(T + 1));
+    int32_t *db = (int32_t *)malloc(sizeof(int32_t) * (size_t)ni * (size_t)(T + 1));
+    int64_t rc = 0;
+    for (int64_t ii = 0; ii < n; ii++) {
+        g.gidx = first_index + (uint64_t)ii;
+        int32_t att = 0;
+        int k = em_uncor_sample_one(m, &g, T, o, ib, iv, ev, cap, &att);
+        if (k < 0) { rc = k; break; }
+        if (attempts) attempts[ii] = att;
+        for (int i = 0; i < ni; i++) {
+            if (init_bin) init_bin[ii * ni + i] = ib[i];
+            if (init_val) init_val[ii * ni + i] = iv[i];
+        }
+        if (ev_count) {
+            ev_count[ii] = k;
+            if (k > ev_cap) { rc = -2; break; }
+            for (int e = 0; e < k; e++) {
+                ev_dt[ii * ev_cap + e] = ev[e].dt; ev_var[ii * ev_cap + e] = ev[e].var;
+                ev_bin[ii * ev_cap + e] = ev[e].bin; ev_val[ii * ev_cap + e] = ev[e].val;
+            }
+        }
+        if (dense_bin || dense_val) {
+            /* the value row of L may have been overwritten by layers/quantize; dense covers dynamic vars only */
+            int Tt = em_events2samples(ni, iv, ib, ev, k, dv, db, T);
+            if (Tt != T) { rc = -4; break; }
+            for (int c = 0; c < T; c++)
+                for (int q = 0; q < nd; q++) {
+                    int v = m->temporal_map[2 * q] - 1;
+                    if (dense_bin) dense_bin[((size_t)ii * T + c) * nd + q] = (uint8_t)db[(size_t)c * ni + v];
+                    if (dense_val) dense_val[((size_t)ii * T + c) * nd + q] = dv[(size_t)c * ni + v];
+                }
+        }
+    }
+    if (n_draws_out) *n_draws_out = g.n_draws;
+    free(ev); free(dv); free(db);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a14 @CorTerminalModel/sample.m:29-77 -- geometry BN, one sample with its   */
+/* rejection loop: bn_sample + dediscretize (:34-42), bounds box (:45-53),    */
+/* speed limits (:64-70).  bounds_sample: n_i x 2 row-major or NULL.          */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    const double *bounds_sample;
+    int32_t idx_own_speed, idx_int_speed;   /* 1-based, 0 = no speed check */
+    double min1, max1, min2, max2;
+    int32_t max_attempts, _pad;
+} em_geom_opts_t;
+
+int64_t em_geom_sample_batch(const em_model_t *m, int mode, uint64_t seed, uint64_t first_index, int64_t n,
+                             const em_geom_opts_t *o, int32_t *out_bin, double *out_val, int32_t *attempts) {
+    em_rng_t g;
+    em_rng_init(&g, mode, seed);
+    int ni = m->n_initial;
+    int32_t S[128]; double v[128];
+    for (int64_t ii = 0; ii < n; ii++) {
+        g.gidx = first_index + (uint64_t)ii;
+        int good = 0;
+        uint32_t attempt;
+        for (attempt = 0; attempt < (uint32_t)o->max_attempts && !good; attempt++) {
+            g.attempt = attempt;
+            if (em_bn_sample(m, &g, m->r_initial, S) != 0) return -1;
+            for (int kk = 1; kk <= ni; kk++) v[kk - 1] = dedisc(m, &g, kk, S[kk - 1], EM_SEC_GEOM_DEDISC, (uint32_t)(kk - 1));
+            good = 1;
+            if (o->bounds_sample)
+                for (int kk = 0; kk < ni; kk++)
+                    if (!(v[kk] >= o->bounds_sample[2 * kk] && v[kk] <= o->bounds_sample[2 * kk + 1])) good = 0;
+            if (good && o->idx_own_speed > 0) {
+                double s1 = v[o->idx_own_speed - 1], s2 = v[o->idx_int_speed - 1];
+                if (!(s1 <= o->max1 && s1 >= o->min1 && s2 <= o->max2 && s2 >= o->min2)) good = 0;
+            }
+        }
+        if (!good) return -3;
+        if (attempts) attempts[ii] = (int32_t)attempt;
+        for (int i = 0; i < ni; i++) { if (out_bin) out_bin[ii * ni + i] = S[i]; if (out_val) out_val[ii * ni + i] = v[i]; }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Plain dbn_sample batch (no resample / dediscretize): raw events            */
+/* ------------------------------------------------------------------------- */
+int64_t em_dbn_sample_batch(const em_model_t *m, int mode, uint64_t seed, uint64_t first_index, int64_t n,
+                            int t_max, int per_step, int32_t *init_bin,
+                            double *ev_dt, int32_t *ev_var, int32_t *ev_bin, int32_t *ev_count, int ev_cap) {
+    em_rng_t g;
+    em_rng_init(&g, mode, seed);
+    int ni = m->n_initial;
+    int cap = (ni + 1) * t_max + 8;
+    em_event_t *ev = (em_event_t *)malloc(sizeof(em_event_t) * (size_t)cap);
+    int32_t ib[128];
+    int64_t rc = 0;
+    for (int64_t ii = 0; ii < n; ii++) {
+        g.gidx = first_index + (uint64_t)ii;
+        int k = em_dbn_sample(m, &g, t_max, per_step, ib, ev, cap);
+        if (k < 0) { rc = k; break; }
+        for (int i = 0; i < ni; i++) init_bin[ii * ni + i] = ib[i];
+        ev_count[ii] = k;
+        if (k > ev_cap) { rc = -2; break; }
+        for (int e = 0; e < k; e++) { ev_dt[ii * ev_cap + e] = ev[e].dt; ev_var[ii * ev_cap + e] = ev[e].var; ev_bin[ii * ev_cap + e] = ev[e].bin; }
+    }
+    free(ev);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a16 discretize_bayes.m:14-22                                               */
+/* ------------------------------------------------------------------------- */
+int em_discretize_bayes(double x, const double *thresholds, int n) {
+    if (x >= thresholds[n - 1]) return n + 1;
+    for (int i = 0; i < n; i++) if (x < thresholds[i]) return i + 1;
+    return n + 1;
+}
+
+/* a17 bn_dirichlet_prior.m:18-37 ('dbe' => 1/(r*q); numeric => constant), one node */
+void em_dirichlet_prior_node(int r, int64_t q, int is_dbe, double prior, double *alpha) {
+    double p = is_dbe ? 1.0 / ((double)r * (double)q) : prior;
+    for (int64_t i = 0; i < (int64_t)r * q; i++) alpha[i] = p;
+}
+
+/* a17 setTransitionPriors.m:20-27, one node: alpha (r_jj x q) column-major,
+ * alpha(kk, n*(kk-1)+1 : n*kk) = prior with n = q / r_jj */
+void em_transition_prior_node(int r_jj, int64_t q, double prior, double *alpha) {
+    int64_t n = q / r_jj;
+    for (int64_t i = 0; i < (int64_t)r_jj * q; i++) alpha[i] = 0;
+    for (int kk = 1; kk <= r_jj; kk++)
+        for (int64_t c = n * (kk - 1) + 1; c <= n * kk; c++)
+            alpha[(c - 1) * r_jj + (kk - 1)] = prior;
+}
+
+/* MT19937 helpers for tests */
+void em_mt_doubles(uint32_t seed, int n, double *out) {
+    em_mt_t s; mt_seed(&s, seed);
+    for (int i = 0; i < n; i++) out[i] = mt_res53(&s);
+}
+int em_sizeof_model(void) { return (int)sizeof(em_model_t); }

@@ -1,0 +1,452 @@
+"""oracle/oracle.py -- ctypes front-end of the CPU oracle (oracle/em_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never by the product package.
+
+Also holds an independent numpy parser of the reference's model .txt format
+(em_read.m:47-141) so that the product's C++ loader can be checked against it.
+"parity unpinned" against MATLAB: see the header of em_oracle.c.
+"""
+import ctypes as C
+import heapq
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+RNG_MT19937 = 0
+RNG_PHILOX = 1
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libem_oracle.so")
+    src = os.path.join(_HERE, "em_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libem_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = build()
+        _LIB = C.CDLL(so)
+        _LIB.em_asub2ind.restype = C.c_int64
+        _LIB.em_select_random_r.restype = C.c_int
+        _LIB.em_uniform32.restype = C.c_double
+        _LIB.em_uniform32.argtypes = [C.c_uint32]
+        _LIB.em_dediscretize_u.restype = C.c_double
+        _LIB.em_uncor_sample_batch.restype = C.c_int64
+        _LIB.em_geom_sample_batch.restype = C.c_int64
+        _LIB.em_dbn_sample_batch.restype = C.c_int64
+    return _LIB
+
+
+# ---------------------------------------------------------------------------
+# bn_sort.m:17-20 -- toposort(digraph(G),'Order','stable').  ASSUMED semantics
+# of 'stable' (unverifiable without MATLAB): lexicographically smallest
+# topological order == Kahn's algorithm always taking the lowest-index ready node.
+# ---------------------------------------------------------------------------
+def bn_sort(G):
+    G = np.asarray(G, dtype=bool)
+    n = G.shape[0]
+    indeg = G.sum(axis=0).astype(int)
+    heap = [i for i in range(n) if indeg[i] == 0]
+    heapq.heapify(heap)
+    order = []
+    while heap:
+        i = heapq.heappop(heap)
+        order.append(i + 1)
+        for c in np.nonzero(G[i])[0]:
+            indeg[c] -= 1
+            if indeg[c] == 0:
+                heapq.heappush(heap, int(c))
+    if len(order) != n:
+        raise ValueError("Network could not be hierarchically sorted")
+    return np.array(order, dtype=np.int32)
+
+
+def _extract_temporal_map(labels):
+    # em_read.m:158-177
+    tm = []
+    for ii, lab in enumerate(labels):
+        t = lab.find("(t)")
+        if t >= 0:
+            base = lab[: t + 1]
+            fut = [k for k, l in enumerate(labels) if (base + "t+1)") in l]
+            past = [k for k, l in enumerate(labels) if (base + "t-1)") in l]
+            for k in fut:
+                tm.append((ii + 1, k + 1))
+            for k in past:
+                tm.append((ii + 1, k + 1))
+    return np.array(tm, dtype=np.int32).reshape(-1, 2)
+
+
+def _extract_zero_bins(boundaries):
+    # em_read.m:143-156: last j with b(j-1) < 0 < b(j)  ->  bin j-1
+    out = []
+    for b in boundaries:
+        z = 0
+        if len(b) > 2:
+            for j in range(1, len(b)):
+                if b[j - 1] < 0 and b[j] > 0:
+                    z = j
+        out.append(z)
+    return np.array(out, dtype=np.int32)
+
+
+def parse_model_txt(path, idx_zero_boundaries=(1, 2, 3), is_overwrite_zero_boundaries=False):
+    """Independent numpy restatement of em_read.m:47-141.  Returns a dict."""
+    with open(path, "r") as f:
+        lines = [ln.strip("\r\n") for ln in f.read().split("\n")]
+    lines = [ln for ln in lines if ln.strip() != ""]
+    p = {}
+    i = 0
+
+    def nums(s):
+        return np.array(s.split(), dtype=np.float64)
+
+    while i < len(lines):
+        ln = lines[i].strip()
+        if not ln.startswith("#"):
+            i += 1
+            continue
+        field = ln
+        row = i + 1
+        if field == "# labels_initial":
+            p["labels_initial"] = [s.strip() for s in lines[row].split(",")]
+            p["n_initial"] = len(p["labels_initial"])
+        elif field == "# G_initial":
+            n = p["n_initial"]
+            p["G_initial"] = np.array([nums(lines[row + k]) for k in range(n)]) != 0
+        elif field == "# r_initial":
+            p["r_initial"] = nums(lines[row]).astype(np.int32)
+        elif field == "# N_initial":
+            p["_N_initial_flat"] = nums(lines[row])
+        elif field == "# labels_transition":
+            p["labels_transition"] = [s.strip() for s in lines[row].split(",")]
+            p["n_transition"] = len(p["labels_transition"])
+        elif field == "# G_transition":
+            n = p["n_transition"]
+            p["G_transition"] = np.array([nums(lines[row + k]) for k in range(n)]) != 0
+        elif field == "# r_transition":
+            p["r_transition"] = nums(lines[row]).astype(np.int32)
+        elif field == "# N_transition":
+            p["_N_transition_flat"] = nums(lines[row])
+        elif field == "# boundaries":
+            b = []
+            for k in range(p["n_initial"]):
+                s = lines[row + k].strip()
+                b.append(np.zeros(0) if s == "*" else nums(s))
+            p["boundaries"] = b
+        elif field == "# resample_rates":
+            p["resample_rates"] = nums(lines[row])
+        else:
+            raise ValueError("Unknown field: %s" % field)
+        i += 1
+
+    # array2cells / getdims (em_read.m:191-206)
+    def cells(flat, G, r, vars_):
+        out = {}
+        idx = 0
+        for v in vars_:
+            q = int(np.prod(r[G[:, v]])) if G[:, v].any() else 1
+            cnt = int(r[v]) * q
+            out[v] = flat[idx: idx + cnt].reshape(q, int(r[v])).T.copy()  # column-major r x q
+            idx += cnt
+        assert idx == len(flat), (idx, len(flat))
+        return out
+
+    ni = p["n_initial"]
+    p["N_initial"] = cells(p.pop("_N_initial_flat"), p["G_initial"], p["r_initial"], range(ni))
+    p["order_initial"] = bn_sort(p["G_initial"])
+    if "labels_transition" in p:
+        nt = p["n_transition"]
+        p["N_transition"] = cells(p.pop("_N_transition_flat"), p["G_transition"], p["r_transition"], range(ni, nt))
+        p["order_transition"] = bn_sort(p["G_transition"])
+        p["temporal_map"] = _extract_temporal_map(p["labels_transition"])
+    else:
+        p["n_transition"] = 0
+        p["temporal_map"] = np.zeros((0, 2), dtype=np.int32)
+    if "boundaries" in p:
+        p["zero_bins"] = _extract_zero_bins(p["boundaries"])
+        if is_overwrite_zero_boundaries:
+            for k in idx_zero_boundaries:
+                p["boundaries"][k - 1] = np.zeros(0)
+    if "resample_rates" not in p:
+        p["resample_rates"] = np.zeros(ni)
+    return p
+
+
+# ---------------------------------------------------------------------------
+class _EmModel(C.Structure):
+    _fields_ = [
+        ("n_initial", C.c_int32), ("n_transition", C.c_int32), ("n_dyn", C.c_int32), ("_pad", C.c_int32),
+        ("G_initial", C.c_void_p), ("G_transition", C.c_void_p),
+        ("r_initial", C.c_void_p), ("r_transition", C.c_void_p),
+        ("order_initial", C.c_void_p), ("order_transition", C.c_void_p),
+        ("temporal_map", C.c_void_p),
+        ("N_initial", C.c_void_p), ("A_initial", C.c_void_p), ("off_initial", C.c_void_p),
+        ("N_transition", C.c_void_p), ("A_transition", C.c_void_p), ("off_transition", C.c_void_p),
+        ("boundaries", C.c_void_p), ("bnd_off", C.c_void_p), ("bnd_len", C.c_void_p),
+        ("zero_bins", C.c_void_p), ("resample_rates", C.c_void_p), ("start", C.c_void_p),
+    ]
+
+
+class _UncorOpts(C.Structure):
+    _fields_ = [("idxL", C.c_int32), ("idxV", C.c_int32), ("idxDH", C.c_int32), ("is_quantize500", C.c_int32),
+                ("layers", C.c_void_p), ("max_attempts", C.c_int32), ("per_step", C.c_int32)]
+
+
+class _GeomOpts(C.Structure):
+    _fields_ = [("bounds_sample", C.c_void_p), ("idx_own_speed", C.c_int32), ("idx_int_speed", C.c_int32),
+                ("min1", C.c_double), ("max1", C.c_double), ("min2", C.c_double), ("max2", C.c_double),
+                ("max_attempts", C.c_int32), ("_pad", C.c_int32)]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleModel:
+    """Flat-array view of a parsed model for em_oracle.c.
+
+    parms: dict as returned by parse_model_txt (or the product's em_read).
+    prior: 0 / float constant / 'dbe' (bn_dirichlet_prior.m:18-37), or
+    alpha_initial / alpha_transition dicts {var0: r x q array} given explicitly.
+    start: sequence of n_initial ints, 0/None = unset.
+    """
+
+    def __init__(self, parms, prior=0.0, start=None, alpha_initial=None, alpha_transition=None):
+        p = parms
+        ni = int(p["n_initial"])
+        nt = int(p.get("n_transition", 0)) or 0
+        self.parms = p
+        self.n_initial, self.n_transition = ni, nt
+        self._keep = []
+
+        def keep(a):
+            self._keep.append(a)
+            return a
+
+        def prior_of(N):
+            if isinstance(prior, str):
+                if prior.lower() != "dbe":
+                    raise ValueError("prior:notdbe")
+                return np.full(N.shape, 1.0 / (N.shape[0] * N.shape[1]))
+            return np.full(N.shape, float(prior))
+
+        Gi = keep(np.ascontiguousarray(np.asarray(p["G_initial"], dtype=np.uint8)))
+        ri = keep(np.ascontiguousarray(np.asarray(p["r_initial"], dtype=np.int32)))
+        oi = keep(np.ascontiguousarray(np.asarray(p["order_initial"], dtype=np.int32)))
+        Nf, Af, off = [], [], []
+        pos = 0
+        for v in range(ni):
+            N = np.asarray(p["N_initial"][v], dtype=np.float64)
+            A = np.asarray(alpha_initial[v], dtype=np.float64) if alpha_initial is not None else prior_of(N)
+            off.append(pos)
+            Nf.append(N.T.reshape(-1))
+            Af.append(A.T.reshape(-1))
+            pos += N.size
+        Ni = keep(np.ascontiguousarray(np.concatenate(Nf)))
+        Ai = keep(np.ascontiguousarray(np.concatenate(Af)))
+        offi = keep(np.array(off, dtype=np.int64))
+
+        m = _EmModel()
+        m.n_initial, m.n_transition = ni, nt
+        m.G_initial, m.r_initial, m.order_initial = _ptr(Gi), _ptr(ri), _ptr(oi)
+        m.N_initial, m.A_initial, m.off_initial = _ptr(Ni), _ptr(Ai), _ptr(offi)
+        tm = np.asarray(p.get("temporal_map", np.zeros((0, 2))), dtype=np.int32).reshape(-1, 2)
+        tm = keep(np.ascontiguousarray(tm))
+        m.n_dyn = tm.shape[0]
+        m.temporal_map = _ptr(tm)
+        self.temporal_map = tm
+        if nt > 0:
+            Gt = keep(np.ascontiguousarray(np.asarray(p["G_transition"], dtype=np.uint8)))
+            rt = keep(np.ascontiguousarray(np.asarray(p["r_transition"], dtype=np.int32)))
+            ot = keep(np.ascontiguousarray(np.asarray(p["order_transition"], dtype=np.int32)))
+            Nf, Af, off = [], [], []
+            pos = 0
+            for v in range(nt):
+                if v in p["N_transition"]:
+                    N = np.asarray(p["N_transition"][v], dtype=np.float64)
+                    if alpha_transition is not None and v in alpha_transition and alpha_transition[v] is not None:
+                        A = np.asarray(alpha_transition[v], dtype=np.float64)
+                    else:
+                        A = prior_of(N)
+                    off.append(pos)
+                    Nf.append(N.T.reshape(-1))
+                    Af.append(A.T.reshape(-1))
+                    pos += N.size
+                else:
+                    off.append(-1)
+            Nt = keep(np.ascontiguousarray(np.concatenate(Nf)))
+            At = keep(np.ascontiguousarray(np.concatenate(Af)))
+            offt = keep(np.array(off, dtype=np.int64))
+            m.G_transition, m.r_transition, m.order_transition = _ptr(Gt), _ptr(rt), _ptr(ot)
+            m.N_transition, m.A_transition, m.off_transition = _ptr(Nt), _ptr(At), _ptr(offt)
+        b = p.get("boundaries", [np.zeros(0)] * ni)
+        blen = keep(np.array([len(x) for x in b], dtype=np.int32))
+        boff = keep(np.concatenate([[0], np.cumsum(blen)[:-1]]).astype(np.int32))
+        bflat = keep(np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64) for x in b] + [np.zeros(1)])))
+        zb = keep(np.ascontiguousarray(np.asarray(p.get("zero_bins", np.zeros(ni)), dtype=np.int32)))
+        rr = keep(np.ascontiguousarray(np.asarray(p.get("resample_rates", np.zeros(ni)), dtype=np.float64)))
+        st = np.zeros(ni, dtype=np.int32)
+        if start is not None:
+            for k, s in enumerate(start):
+                st[k] = 0 if (s is None or (isinstance(s, float) and np.isnan(s))) else int(s)
+        st = keep(st)
+        m.boundaries, m.bnd_off, m.bnd_len = _ptr(bflat), _ptr(boff), _ptr(blen)
+        m.zero_bins, m.resample_rates, m.start = _ptr(zb), _ptr(rr), _ptr(st)
+        self.c = m
+        assert C.sizeof(_EmModel) == lib().em_sizeof_model()
+
+    def is_dynvar_depend(self):
+        return bool(lib().em_is_dynvar_depend(C.byref(self.c)))
+
+    def label_index(self, name):
+        """1-based index of a label such as 'v' (labels keep their quotes, UncorEncounterModel.m:225)."""
+        q = '"%s"' % name
+        labs = self.parms["labels_initial"]
+        return labs.index(q) + 1 if q in labs else 0
+
+
+def uncor_sample(om, n, T, seed, mode=RNG_PHILOX, first_index=0, per_step=False,
+                 is_quantize500=False, layers=None, max_attempts=1000,
+                 want_events=True, want_dense=True, ev_cap=None):
+    """UncorEncounterModel.sample restated (UncorEncounterModel.m:192-313), n samples.
+
+    Returns dict: init_bin [n,ni] int32, init_val [n,ni] f64, events (list of
+    [K,4] arrays: dt, var, value, bin), dense_bin [n,T,nd] u8, dense_val [n,T,nd] f64,
+    attempts [n], n_draws.
+    """
+    L = lib()
+    ni, nd = om.n_initial, om.temporal_map.shape[0]
+    o = _UncorOpts()
+    o.idxL, o.idxV, o.idxDH = om.label_index("L"), om.label_index("v"), om.label_index("\\dot h")
+    o.is_quantize500 = int(bool(is_quantize500))
+    lay = None
+    if layers is not None:
+        lay = np.ascontiguousarray(np.asarray(layers, dtype=np.float64).reshape(-1, 2))
+        o.layers = _ptr(lay)
+    o.max_attempts, o.per_step = int(max_attempts), int(bool(per_step))
+    init_bin = np.zeros((n, ni), dtype=np.int32)
+    init_val = np.zeros((n, ni), dtype=np.float64)
+    attempts = np.zeros(n, dtype=np.int32)
+    ndraw = C.c_uint64(0)
+    if ev_cap is None:
+        ev_cap = (ni + nd + 1) * T + 8
+    if want_events:
+        ev_dt = np.zeros((n, ev_cap)); ev_val = np.zeros((n, ev_cap))
+        ev_var = np.zeros((n, ev_cap), dtype=np.int32); ev_bin = np.zeros((n, ev_cap), dtype=np.int32)
+        ev_cnt = np.zeros(n, dtype=np.int32)
+        evp = (_ptr(ev_dt), _ptr(ev_var), _ptr(ev_bin), _ptr(ev_val), _ptr(ev_cnt), C.c_int(ev_cap))
+    else:
+        evp = (None, None, None, None, None, C.c_int(0))
+    if want_dense:
+        dense_bin = np.zeros((n, T, nd), dtype=np.uint8)
+        dense_val = np.zeros((n, T, nd), dtype=np.float64)
+        dp = (_ptr(dense_bin), _ptr(dense_val))
+    else:
+        dp = (None, None)
+    rc = L.em_uncor_sample_batch(C.byref(om.c), C.c_int(mode), C.c_uint64(seed), C.c_uint64(first_index), C.c_int64(n),
+                                 C.c_int(T), C.byref(o), _ptr(init_bin), _ptr(init_val), *evp, *dp,
+                                 _ptr(attempts), C.byref(ndraw))
+    if rc != 0:
+        raise RuntimeError("em_uncor_sample_batch failed rc=%d" % rc)
+    out = {"init_bin": init_bin, "init_val": init_val, "attempts": attempts, "n_draws": ndraw.value}
+    if want_events:
+        out["events"] = [np.stack([ev_dt[i, :k], ev_var[i, :k].astype(float), ev_val[i, :k], ev_bin[i, :k].astype(float)], axis=1)
+                         for i, k in enumerate(ev_cnt)]
+    if want_dense:
+        out["dense_bin"], out["dense_val"] = dense_bin, dense_val
+    return out
+
+
+def dbn_sample(om, n, t_max, seed, mode=RNG_PHILOX, first_index=0, per_step=False):
+    """dbn_sample.m restated: returns init_bin [n,ni], list of raw events [K,3] (dt, var, bin)."""
+    L = lib()
+    ni = om.n_initial
+    cap = (ni + 1) * t_max + 8
+    init_bin = np.zeros((n, ni), dtype=np.int32)
+    ev_dt = np.zeros((n, cap)); ev_var = np.zeros((n, cap), dtype=np.int32); ev_bin = np.zeros((n, cap), dtype=np.int32)
+    cnt = np.zeros(n, dtype=np.int32)
+    rc = L.em_dbn_sample_batch(C.byref(om.c), C.c_int(mode), C.c_uint64(seed), C.c_uint64(first_index), C.c_int64(n),
+                               C.c_int(t_max), C.c_int(int(per_step)), _ptr(init_bin), _ptr(ev_dt), _ptr(ev_var), _ptr(ev_bin),
+                               _ptr(cnt), C.c_int(cap))
+    if rc != 0:
+        raise RuntimeError("em_dbn_sample_batch failed rc=%d" % rc)
+    ev = [np.stack([ev_dt[i, :k], ev_var[i, :k].astype(float), ev_bin[i, :k].astype(float)], axis=1) for i, k in enumerate(cnt)]
+    return init_bin, ev
+
+
+def geom_sample(om, n, seed, mode=RNG_PHILOX, first_index=0, bounds_sample=None,
+                idx_own_speed=0, idx_int_speed=0, lim1=(0.0, np.inf), lim2=(0.0, np.inf), max_attempts=100000):
+    """@CorTerminalModel/sample.m:29-77 restated."""
+    L = lib()
+    ni = om.n_initial
+    o = _GeomOpts()
+    bs = None
+    if bounds_sample is not None:
+        bs = np.ascontiguousarray(np.asarray(bounds_sample, dtype=np.float64).reshape(ni, 2))
+        o.bounds_sample = _ptr(bs)
+    o.idx_own_speed, o.idx_int_speed = int(idx_own_speed), int(idx_int_speed)
+    o.min1, o.max1, o.min2, o.max2 = float(lim1[0]), float(lim1[1]), float(lim2[0]), float(lim2[1])
+    o.max_attempts = int(max_attempts)
+    ob = np.zeros((n, ni), dtype=np.int32); ov = np.zeros((n, ni)); att = np.zeros(n, dtype=np.int32)
+    rc = L.em_geom_sample_batch(C.byref(om.c), C.c_int(mode), C.c_uint64(seed), C.c_uint64(first_index), C.c_int64(n),
+                                C.byref(o), _ptr(ob), _ptr(ov), _ptr(att))
+    if rc != 0:
+        raise RuntimeError("em_geom_sample_batch failed rc=%d" % rc)
+    return ob, ov, att
+
+
+def philox4x32_10(ctr, key):
+    out = (C.c_uint32 * 4)()
+    lib().em_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+    return [int(x) for x in out]
+
+
+def mt_doubles(seed, n):
+    out = np.zeros(n)
+    lib().em_mt_doubles(C.c_uint32(seed), C.c_int(n), _ptr(out))
+    return out
+
+
+def events2samples(initial, events):
+    """events2samples.m restated by em_oracle.c; events [K,3] (dt,var,value). Returns n x T."""
+    initial = np.asarray(initial, dtype=np.float64)
+    n = len(initial)
+
+    class Ev(C.Structure):
+        _fields_ = [("dt", C.c_double), ("var", C.c_int32), ("bin", C.c_int32), ("val", C.c_double),
+                    ("kind", C.c_int32), ("atime", C.c_int32)]
+    K = len(events)
+    arr = (Ev * max(K, 1))()
+    for i, e in enumerate(events):
+        arr[i].dt, arr[i].var, arr[i].val = float(e[0]), int(e[1]), float(e[2])
+    T = int(sum(e[0] for e in events))
+    d = np.zeros((T, n))
+    r = lib().em_events2samples(C.c_int(n), _ptr(initial), None, arr, C.c_int(K), _ptr(d), None, C.c_int(T))
+    assert r == T, (r, T)
+    return d.T.copy()
+
+
+def events2controls(om, initial, events):
+    """events2controls.m restated; returns [rows, 1+n_dyn]."""
+    initial = np.asarray(initial, dtype=np.float64)
+
+    class Ev(C.Structure):
+        _fields_ = [("dt", C.c_double), ("var", C.c_int32), ("bin", C.c_int32), ("val", C.c_double),
+                    ("kind", C.c_int32), ("atime", C.c_int32)]
+    K = len(events)
+    arr = (Ev * max(K, 1))()
+    for i, e in enumerate(events):
+        arr[i].dt, arr[i].var, arr[i].val = float(e[0]), int(e[1]), float(e[2])
+    nd = om.temporal_map.shape[0]
+    ctl = np.zeros((max(K, 1), 1 + nd))
+    r = lib().em_events2controls(C.byref(om.c), _ptr(initial), arr, C.c_int(K), _ptr(ctl))
+    return ctl[:r].copy()
