@@ -1,0 +1,141 @@
+"""ctypes binding of libemgpu.so (include/emgpu.h).
+
+The product path has no CPU fallback: if the HIP library is missing this module
+raises at import of the symbol table, and creating a Context without a GPU raises
+EmgpuError(EMGPU_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libemgpu.so")
+
+OK = 0
+ERR_ARG, ERR_IO, ERR_PARSE, ERR_PRESET, ERR_HIP = -1, -2, -3, -4, -5
+ERR_REJECT_CAP, ERR_EVENT_CAP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_PRIOR, ERR_SORT = -6, -7, -8, -9, -10, -11
+
+# field ids (emgpu.h)
+F_R_INITIAL, F_R_TRANSITION, F_ORDER_INITIAL, F_ORDER_TRANSITION, F_TEMPORAL_MAP = 1, 2, 3, 4, 5
+F_ZERO_BINS, F_START, F_G_INITIAL, F_G_TRANSITION = 6, 7, 8, 9
+F_N_INITIAL, F_N_TRANSITION, F_ALPHA_INITIAL, F_ALPHA_TRANSITION, F_BOUNDARIES, F_RESAMPLE_RATES = 32, 33, 34, 35, 36, 37
+F_LABELS_INITIAL, F_LABELS_TRANSITION = 64, 65
+
+TRANSITION_REFERENCE_AUTO, TRANSITION_PER_STEP = 0, 1
+FLAG_QUANTIZE500, FLAG_NO_RESAMPLE, FLAG_NO_DEDISC, FLAG_NO_TERMINATOR = 1, 2, 4, 8
+
+# MATLAB error identifiers the reference raises for the same condition
+_MATLAB_IDS = {
+    ERR_PRESET: "Attempt to preset a dependent variable",     # bn_sample.m:47
+    ERR_PRIOR: "prior:notdbe",                                # bn_dirichlet_prior.m:28
+    ERR_SORT: "Network could not be hierarchically sorted",   # bn_sort.m:23
+}
+
+
+class EmgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("emgpu error %d: %s" % (code, msg))
+        self.code = code
+        self.identifier = _MATLAB_IDS.get(code, "emgpu:error%d" % -code)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("n_initial", C.c_int32), ("n_transition", C.c_int32), ("n_dyn", C.c_int32), ("_pad", C.c_int32),
+                ("G_initial", C.c_void_p), ("G_transition", C.c_void_p),
+                ("r_initial", C.c_void_p), ("r_transition", C.c_void_p),
+                ("temporal_map", C.c_void_p),
+                ("N_initial", C.c_void_p), ("n_N_initial", C.c_int64),
+                ("N_transition", C.c_void_p), ("n_N_transition", C.c_int64),
+                ("boundaries", C.c_void_p), ("bnd_len", C.c_void_p), ("zero_bins", C.c_void_p),
+                ("resample_rates", C.c_void_p),
+                ("labels_initial", C.c_char_p), ("labels_transition", C.c_char_p)]
+
+
+class ModelInfo(C.Structure):
+    _fields_ = [("n_initial", C.c_int32), ("n_transition", C.c_int32), ("n_dyn", C.c_int32),
+                ("is_dynvar_depend", C.c_int32), ("n_N_initial", C.c_int64), ("n_N_transition", C.c_int64),
+                ("max_r", C.c_int32), ("n_resample_active", C.c_int32)]
+
+
+class SampleParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64),
+                ("sample_time", C.c_int32), ("transition_mode", C.c_int32), ("flags", C.c_uint32),
+                ("max_attempts", C.c_int32), ("idx_L", C.c_int32), ("idx_v", C.c_int32), ("idx_dh", C.c_int32),
+                ("n_layers", C.c_int32), ("layers", C.c_void_p), ("event_cap", C.c_int32), ("_pad", C.c_int32)]
+
+
+class SampleOut(C.Structure):
+    _fields_ = [("init_bin", C.c_void_p), ("init_val", C.c_void_p), ("dyn_bin", C.c_void_p), ("dyn_val", C.c_void_p),
+                ("ev_count", C.c_void_p), ("events", C.c_void_p), ("attempts", C.c_void_p)]
+
+
+class BnParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("flags", C.c_uint32),
+                ("max_attempts", C.c_int32), ("bounds_sample", C.c_void_p),
+                ("idx_own_speed", C.c_int32), ("idx_int_speed", C.c_int32),
+                ("min_vel1", C.c_double), ("max_vel1", C.c_double), ("min_vel2", C.c_double), ("max_vel2", C.c_double)]
+
+
+# every symbol include/emgpu.h declares (tests check the list against the header)
+SYMBOLS = [
+    "emgpu_last_error", "emgpu_version", "emgpu_model_load_txt", "emgpu_model_from_arrays", "emgpu_model_free",
+    "emgpu_model_info", "emgpu_model_get_i32", "emgpu_model_get_f64", "emgpu_model_get_text", "emgpu_model_set_f64",
+    "emgpu_model_set_prior", "emgpu_model_set_transition_stay_prior", "emgpu_model_set_start",
+    "emgpu_ctx_create", "emgpu_ctx_set_stream", "emgpu_ctx_sync", "emgpu_ctx_free",
+    "emgpu_sample_dbn_device", "emgpu_sample_dbn_host", "emgpu_sample_bn_device", "emgpu_sample_bn_host",
+    "emgpu_last_kernel_name", "emgpu_discretize_bayes", "emgpu_asub2ind",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libemgpu.so; fail loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libemgpu.so not found at %s: build it with `make -C em_model_manned_bayes_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        getattr(L, s)  # AttributeError if the ABI is incomplete
+    L.emgpu_last_error.restype = C.c_char_p
+    L.emgpu_version.restype = C.c_char_p
+    L.emgpu_last_kernel_name.restype = C.c_char_p
+    L.emgpu_last_kernel_name.argtypes = [C.c_void_p]
+    L.emgpu_model_load_txt.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.emgpu_model_from_arrays.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]
+    L.emgpu_model_free.argtypes = [C.c_void_p]
+    L.emgpu_model_free.restype = None
+    L.emgpu_model_info.argtypes = [C.c_void_p, C.POINTER(ModelInfo)]
+    L.emgpu_model_get_i32.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    L.emgpu_model_get_i32.restype = C.c_int64
+    L.emgpu_model_get_f64.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
+    L.emgpu_model_get_f64.restype = C.c_int64
+    L.emgpu_model_get_text.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    L.emgpu_model_get_text.restype = C.c_int64
+    L.emgpu_model_set_f64.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
+    L.emgpu_model_set_prior.argtypes = [C.c_void_p, C.c_int32, C.c_double]
+    L.emgpu_model_set_transition_stay_prior.argtypes = [C.c_void_p, C.c_double]
+    L.emgpu_model_set_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.emgpu_ctx_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
+    L.emgpu_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.emgpu_ctx_sync.argtypes = [C.c_void_p]
+    L.emgpu_ctx_free.argtypes = [C.c_void_p]
+    L.emgpu_ctx_free.restype = None
+    L.emgpu_sample_dbn_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SampleParams), C.POINTER(SampleOut)]
+    L.emgpu_sample_dbn_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SampleParams), C.POINTER(SampleOut)]
+    L.emgpu_sample_bn_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BnParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emgpu_sample_bn_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BnParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emgpu_discretize_bayes.argtypes = [C.c_double, C.c_void_p, C.c_int32]
+    L.emgpu_discretize_bayes.restype = C.c_int32
+    L.emgpu_asub2ind.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.emgpu_asub2ind.restype = C.c_int64
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        raise EmgpuError(int(rc), lib().emgpu_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,546 @@
+// emgpu_capi.cpp -- the C ABI declared in include/emgpu.h.
+// No CPU fallback anywhere: without a HIP device emgpu_ctx_create fails with EMGPU_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/emgpu.h"
+#include "emgpu_launch.h"
+#include "emgpu_model.hpp"
+
+using emgpu::CompiledPlan;
+using emgpu::Error;
+using emgpu::Model;
+
+struct emgpu_model {
+    Model m;
+};
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define EMGPU_TRY try {
+#define EMGPU_CATCH                                                      \
+    }                                                                    \
+    catch (const Error &e) { return fail(e.code, e.what()); }            \
+    catch (const std::bad_alloc &) { return fail(EMGPU_ERR_ARG, "out of host memory"); } \
+    catch (const std::exception &e) { return fail(EMGPU_ERR_ARG, e.what()); }
+
+#define HIP_OK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct Uploaded {
+    uint64_t version = 0;
+    CompiledPlan cp;
+    uint32_t *d_thr = nullptr;
+    double *d_bnd = nullptr;
+};
+} // namespace
+
+struct emgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    uint32_t *d_status = nullptr;
+    uint32_t *h_status = nullptr; // pinned
+    std::map<const emgpu_model *, Uploaded> cache;
+    std::string last_kernel;
+    double *d_layers = nullptr;
+    size_t d_layers_cap = 0;
+};
+
+template <typename T, typename V>
+static int64_t copy_out(const V &v, T *out, int64_t cap) {
+    if (out) {
+        if ((int64_t)v.size() > cap) return fail(EMGPU_ERR_ARG, "output buffer too small");
+        for (size_t i = 0; i < v.size(); i++) out[i] = (T)v[i];
+    }
+    return (int64_t)v.size();
+}
+
+extern "C" {
+
+const char *emgpu_last_error(void) { return g_err.c_str(); }
+const char *emgpu_version(void) { return "emgpu 0.1 (gfx950)"; }
+
+int emgpu_model_load_txt(const char *path, const int32_t *idx_zero_boundaries, int32_t n_idx,
+                         int32_t is_overwrite_zero_boundaries, emgpu_model **out) {
+    EMGPU_TRY
+    if (!path || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    std::unique_ptr<Model> m(emgpu::load_txt(path, idx_zero_boundaries, n_idx, is_overwrite_zero_boundaries != 0));
+    *out = new emgpu_model{std::move(*m)};
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+static std::vector<std::string> split_nl(const char *s) {
+    std::vector<std::string> out;
+    if (!s) return out;
+    std::string cur;
+    for (const char *p = s; *p; p++) {
+        if (*p == '\n') { out.push_back(cur); cur.clear(); }
+        else cur.push_back(*p);
+    }
+    out.push_back(cur);
+    return out;
+}
+
+int emgpu_model_from_arrays(const emgpu_model_desc *d, emgpu_model **out) {
+    EMGPU_TRY
+    if (!d || !out || d->n_initial <= 0 || !d->G_initial || !d->r_initial || !d->N_initial) return fail(EMGPU_ERR_ARG, "null/empty argument");
+    std::unique_ptr<emgpu_model> h(new emgpu_model());
+    Model &m = h->m;
+    const int ni = d->n_initial, nt = d->n_transition;
+    m.n_initial = ni;
+    m.n_transition = nt;
+    m.G_initial.assign(d->G_initial, d->G_initial + (size_t)ni * ni);
+    m.r_initial.assign(d->r_initial, d->r_initial + ni);
+    m.labels_initial = split_nl(d->labels_initial);
+    m.labels_transition = split_nl(d->labels_transition);
+    auto q_of = [](const std::vector<uint8_t> &G, int n, const std::vector<int> &r, int c) {
+        int64_t q = 1;
+        for (int p = 0; p < n; p++) if (G[(size_t)p * n + c]) q *= r[p];
+        return q;
+    };
+    m.N_initial.resize(ni);
+    int64_t idx = 0;
+    for (int i = 0; i < ni; i++) {
+        int64_t cnt = q_of(m.G_initial, ni, m.r_initial, i) * m.r_initial[i];
+        if (idx + cnt > d->n_N_initial) return fail(EMGPU_ERR_ARG, "N_initial too short");
+        m.N_initial[i].assign(d->N_initial + idx, d->N_initial + idx + cnt);
+        idx += cnt;
+    }
+    if (idx != d->n_N_initial) return fail(EMGPU_ERR_ARG, "N_initial length mismatch");
+    if (nt > 0) {
+        if (!d->G_transition || !d->r_transition || !d->N_transition || nt < ni) return fail(EMGPU_ERR_ARG, "transition arrays missing");
+        m.G_transition.assign(d->G_transition, d->G_transition + (size_t)nt * nt);
+        m.r_transition.assign(d->r_transition, d->r_transition + nt);
+        m.N_transition.resize(nt);
+        idx = 0;
+        for (int i = ni; i < nt; i++) {
+            int64_t cnt = q_of(m.G_transition, nt, m.r_transition, i) * m.r_transition[i];
+            if (idx + cnt > d->n_N_transition) return fail(EMGPU_ERR_ARG, "N_transition too short");
+            m.N_transition[i].assign(d->N_transition + idx, d->N_transition + idx + cnt);
+            idx += cnt;
+        }
+        if (idx != d->n_N_transition) return fail(EMGPU_ERR_ARG, "N_transition length mismatch");
+        if (d->temporal_map)
+            for (int k = 0; k < d->n_dyn; k++) m.temporal_map.push_back({d->temporal_map[2 * k], d->temporal_map[2 * k + 1]});
+    }
+    m.boundaries.assign(ni, {});
+    if (d->boundaries && d->bnd_len) {
+        int64_t o = 0;
+        for (int i = 0; i < ni; i++) {
+            m.boundaries[i].assign(d->boundaries + o, d->boundaries + o + d->bnd_len[i]);
+            o += d->bnd_len[i];
+        }
+    }
+    if (d->zero_bins) m.zero_bins.assign(d->zero_bins, d->zero_bins + ni);
+    if (d->resample_rates) m.resample_rates.assign(d->resample_rates, d->resample_rates + ni);
+    m.finalize();
+    *out = h.release();
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+void emgpu_model_free(emgpu_model *m) { delete m; }
+
+int emgpu_model_info(const emgpu_model *h, emgpu_model_info_t *out) {
+    if (!h || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    const Model &m = h->m;
+    memset(out, 0, sizeof *out);
+    out->n_initial = m.n_initial;
+    out->n_transition = m.n_transition;
+    out->n_dyn = m.n_dyn();
+    out->is_dynvar_depend = (m.n_transition > 0 && m.n_dyn() > 0) ? (int)m.is_dynvar_depend() : 0;
+    for (auto &v : m.N_initial) out->n_N_initial += (int64_t)v.size();
+    for (auto &v : m.N_transition) out->n_N_transition += (int64_t)v.size();
+    for (int r : m.r_initial) out->max_r = r > out->max_r ? r : out->max_r;
+    for (int r : m.r_transition) out->max_r = r > out->max_r ? r : out->max_r;
+    for (double r : m.resample_rates) out->n_resample_active += r > 0.0;
+    return EMGPU_OK;
+}
+
+int64_t emgpu_model_get_i32(const emgpu_model *h, int32_t field, int32_t *out, int64_t cap) {
+    if (!h) return fail(EMGPU_ERR_ARG, "null model");
+    const Model &m = h->m;
+    switch (field) {
+    case EMGPU_F_R_INITIAL: return copy_out(m.r_initial, out, cap);
+    case EMGPU_F_R_TRANSITION: return copy_out(m.r_transition, out, cap);
+    case EMGPU_F_ORDER_INITIAL: return copy_out(m.order_initial, out, cap);
+    case EMGPU_F_ORDER_TRANSITION: return copy_out(m.order_transition, out, cap);
+    case EMGPU_F_ZERO_BINS: return copy_out(m.zero_bins, out, cap);
+    case EMGPU_F_START: return copy_out(m.start, out, cap);
+    case EMGPU_F_G_INITIAL: return copy_out(m.G_initial, out, cap);
+    case EMGPU_F_G_TRANSITION: return copy_out(m.G_transition, out, cap);
+    case EMGPU_F_TEMPORAL_MAP: {
+        std::vector<int> f;
+        for (auto &t : m.temporal_map) { f.push_back(t[0]); f.push_back(t[1]); }
+        return copy_out(f, out, cap);
+    }
+    default: return fail(EMGPU_ERR_ARG, "unknown i32 field");
+    }
+}
+
+int64_t emgpu_model_get_f64(const emgpu_model *h, int32_t field, int32_t node, double *out, int64_t cap) {
+    if (!h) return fail(EMGPU_ERR_ARG, "null model");
+    const Model &m = h->m;
+    auto in_range = [&](size_t n) { return node >= 1 && (size_t)node <= n; };
+    switch (field) {
+    case EMGPU_F_N_INITIAL: if (!in_range(m.N_initial.size())) break; return copy_out(m.N_initial[node - 1], out, cap);
+    case EMGPU_F_ALPHA_INITIAL: if (!in_range(m.A_initial.size())) break; return copy_out(m.A_initial[node - 1], out, cap);
+    case EMGPU_F_N_TRANSITION: if (!in_range(m.N_transition.size())) break; return copy_out(m.N_transition[node - 1], out, cap);
+    case EMGPU_F_ALPHA_TRANSITION: if (!in_range(m.A_transition.size())) break; return copy_out(m.A_transition[node - 1], out, cap);
+    case EMGPU_F_BOUNDARIES: if (!in_range(m.boundaries.size())) break; return copy_out(m.boundaries[node - 1], out, cap);
+    case EMGPU_F_RESAMPLE_RATES: return copy_out(m.resample_rates, out, cap);
+    default: return fail(EMGPU_ERR_ARG, "unknown f64 field");
+    }
+    return fail(EMGPU_ERR_ARG, "node out of range");
+}
+
+int64_t emgpu_model_get_text(const emgpu_model *h, int32_t field, char *out, int64_t cap) {
+    if (!h) return fail(EMGPU_ERR_ARG, "null model");
+    const std::vector<std::string> *v = field == EMGPU_F_LABELS_INITIAL ? &h->m.labels_initial
+                                      : field == EMGPU_F_LABELS_TRANSITION ? &h->m.labels_transition : nullptr;
+    if (!v) return fail(EMGPU_ERR_ARG, "unknown text field");
+    std::string s;
+    for (size_t i = 0; i < v->size(); i++) { if (i) s.push_back('\n'); s += (*v)[i]; }
+    if (out) {
+        if ((int64_t)s.size() + 1 > cap) return fail(EMGPU_ERR_ARG, "output buffer too small");
+        memcpy(out, s.c_str(), s.size() + 1);
+    }
+    return (int64_t)s.size() + 1;
+}
+
+int emgpu_model_set_f64(emgpu_model *h, int32_t field, int32_t node, const double *v, int64_t n) {
+    EMGPU_TRY
+    if (!h || !v) return fail(EMGPU_ERR_ARG, "null argument");
+    Model &m = h->m;
+    auto assign_same = [&](std::vector<std::vector<double>> &dst) {
+        if (node < 1 || (size_t)node > dst.size()) throw Error(EMGPU_ERR_ARG, "node out of range");
+        if ((int64_t)dst[node - 1].size() != n) throw Error(EMGPU_ERR_ARG, "size mismatch: tables keep their r x q shape");
+        dst[node - 1].assign(v, v + n);
+    };
+    switch (field) {
+    case EMGPU_F_N_INITIAL: assign_same(m.N_initial); break;
+    case EMGPU_F_N_TRANSITION: assign_same(m.N_transition); break;
+    case EMGPU_F_ALPHA_INITIAL: assign_same(m.A_initial); break;
+    case EMGPU_F_ALPHA_TRANSITION: assign_same(m.A_transition); break;
+    case EMGPU_F_BOUNDARIES:
+        if (node < 1 || node > m.n_initial) throw Error(EMGPU_ERR_ARG, "node out of range");
+        m.boundaries[node - 1].assign(v, v + n);
+        break;
+    case EMGPU_F_RESAMPLE_RATES:
+        if (n != m.n_initial) throw Error(EMGPU_ERR_ARG, "resample_rates needs n_initial entries");
+        m.resample_rates.assign(v, v + n);
+        break;
+    default: throw Error(EMGPU_ERR_ARG, "field is not settable");
+    }
+    m.version++;
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_model_set_prior(emgpu_model *h, int32_t kind, double value) {
+    EMGPU_TRY
+    if (!h) return fail(EMGPU_ERR_ARG, "null model");
+    if (kind != 0 && kind != 1) return fail(EMGPU_ERR_PRIOR, "Unknown prior, if char expecting prior = 'dbe'");
+    h->m.set_prior(kind, value);
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_model_set_transition_stay_prior(emgpu_model *h, double prior) {
+    EMGPU_TRY
+    if (!h) return fail(EMGPU_ERR_ARG, "null model");
+    h->m.set_transition_stay_prior(prior);
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_model_set_start(emgpu_model *h, const int32_t *start, int32_t n) {
+    if (!h || !start || n != h->m.n_initial) return fail(EMGPU_ERR_ARG, "start needs n_initial entries");
+    for (int i = 0; i < n; i++)
+        if (start[i] < 0 || start[i] > h->m.r_initial[i]) return fail(EMGPU_ERR_ARG, "start bin out of range");
+    h->m.start.assign(start, start + n);
+    h->m.version++;
+    return EMGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int emgpu_ctx_create(int32_t device, emgpu_ctx **out) {
+    EMGPU_TRY
+    if (!out) return fail(EMGPU_ERR_ARG, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(EMGPU_ERR_NO_DEVICE, "no HIP device visible: libemgpu has no CPU path");
+    if (device < 0 || device >= count) return fail(EMGPU_ERR_ARG, "device index out of range");
+    std::unique_ptr<emgpu_ctx> c(new emgpu_ctx());
+    c->device = device;
+    HIP_OK(hipSetDevice(device));
+    HIP_OK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_OK(hipMalloc((void **)&c->d_status, sizeof(uint32_t)));
+    HIP_OK(hipMemset(c->d_status, 0, sizeof(uint32_t)));
+    HIP_OK(hipHostMalloc((void **)&c->h_status, sizeof(uint32_t), hipHostMallocDefault));
+    *c->h_status = 0;
+    *out = c.release();
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_ctx_set_stream(emgpu_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail(EMGPU_ERR_ARG, "null ctx");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return EMGPU_OK;
+}
+
+int emgpu_ctx_sync(emgpu_ctx *ctx) {
+    EMGPU_TRY
+    if (!ctx) return fail(EMGPU_ERR_ARG, "null ctx");
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_OK(hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream));
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    const uint32_t st = *ctx->h_status;
+    if (st & 1u) return fail(EMGPU_ERR_REJECT_CAP, "rejection loop reached max_attempts for at least one trajectory");
+    if (st & 2u) return fail(EMGPU_ERR_EVENT_CAP, "an event list did not fit event_cap rows");
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+void emgpu_ctx_free(emgpu_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto &kv : ctx->cache) { (void)hipFree(kv.second.d_thr); (void)hipFree(kv.second.d_bnd); }
+    (void)hipFree(ctx->d_status);
+    (void)hipFree(ctx->d_layers);
+    (void)hipHostFree(ctx->h_status);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *emgpu_last_kernel_name(const emgpu_ctx *ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h) {
+    Uploaded &u = ctx->cache[h];
+    if (u.version == h->m.version && u.d_thr) return u;
+    // (re)compile: tables depend on N, alpha, start, boundaries, rates
+    CompiledPlan cp = emgpu::compile_plan(h->m);
+    HIP_OK(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read the old tables
+    if (u.d_thr) { HIP_OK(hipFree(u.d_thr)); u.d_thr = nullptr; }
+    if (u.d_bnd) { HIP_OK(hipFree(u.d_bnd)); u.d_bnd = nullptr; }
+    const size_t nthr = cp.thr.size() ? cp.thr.size() : 1;
+    HIP_OK(hipMalloc((void **)&u.d_thr, nthr * sizeof(uint32_t)));
+    HIP_OK(hipMalloc((void **)&u.d_bnd, cp.bnd.size() * sizeof(double)));
+    if (!cp.thr.empty()) HIP_OK(hipMemcpy(u.d_thr, cp.thr.data(), cp.thr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(u.d_bnd, cp.bnd.data(), cp.bnd.size() * sizeof(double), hipMemcpyHostToDevice));
+    u.cp = std::move(cp);
+    u.cp.plan.thr = u.d_thr;
+    u.cp.plan.bnd = u.d_bnd;
+    u.version = h->m.version;
+    return u;
+}
+
+static void fill_run(emgpu_ctx *ctx, const Uploaded &u, const Model &m, const emgpu_sample_params *p, EmgpuRun &A) {
+    memset(&A, 0, sizeof A);
+    if (p->n < 0 || p->sample_time < 1 || p->sample_time > 65535) throw Error(EMGPU_ERR_ARG, "n < 0 or sample_time outside 1..65535");
+    if (p->max_attempts < 1) throw Error(EMGPU_ERR_ARG, "max_attempts must be >= 1");
+    A.seed = p->seed; A.first_index = p->first_index; A.n = p->n; A.T = p->sample_time;
+    A.per_step = p->transition_mode == EMGPU_TRANSITION_PER_STEP;
+    A.flags = p->flags; A.max_attempts = p->max_attempts;
+    auto pos = [&](int idx1) -> int {
+        if (idx1 == 0) return -1;
+        if (idx1 < 1 || idx1 > m.n_initial) throw Error(EMGPU_ERR_ARG, "variable index out of range");
+        return u.cp.pos_of_var[idx1 - 1];
+    };
+    A.pos_L = pos(p->idx_L); A.pos_v = pos(p->idx_v); A.pos_dh = pos(p->idx_dh);
+    A.n_layers = 0; A.layers = nullptr;
+    if (p->layers && p->n_layers > 0) {
+        if (p->idx_L == 0) throw Error(EMGPU_ERR_ARG, "layers given without idx_L");
+        if (!m.boundaries[p->idx_L - 1].empty() && !(p->flags & EMGPU_FLAG_NO_DEDISC))
+            throw Error(EMGPU_ERR_ARG, "layers need L to stay a bin index (isOverwriteZeroBoundaries)");
+        if (p->n_layers < m.r_initial[p->idx_L - 1]) throw Error(EMGPU_ERR_ARG, "layers has fewer rows than L has bins");
+        const size_t bytes = (size_t)p->n_layers * 2 * sizeof(double);
+        if (ctx->d_layers_cap < bytes) {
+            HIP_OK(hipStreamSynchronize(ctx->stream));
+            if (ctx->d_layers) HIP_OK(hipFree(ctx->d_layers));
+            HIP_OK(hipMalloc((void **)&ctx->d_layers, bytes));
+            ctx->d_layers_cap = bytes;
+        }
+        HIP_OK(hipMemcpyAsync(ctx->d_layers, p->layers, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream)); // p->layers is caller memory
+        A.layers = ctx->d_layers; A.n_layers = p->n_layers;
+    }
+    A.event_cap = p->event_cap;
+    A.status = ctx->d_status;
+}
+
+extern "C" {
+
+int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sample_params *p, const emgpu_sample_out *out) {
+    EMGPU_TRY
+    if (!ctx || !h || !p || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    HIP_OK(hipSetDevice(ctx->device));
+    Uploaded &u = get_uploaded(ctx, h);
+    EmgpuRun A;
+    fill_run(ctx, u, h->m, p, A);
+    if ((out->ev_count != nullptr) != (out->events != nullptr)) return fail(EMGPU_ERR_ARG, "ev_count and events go together");
+    if (out->events && p->event_cap < 1) return fail(EMGPU_ERR_ARG, "event_cap must be >= 1");
+    A.init_bin = out->init_bin; A.init_val = out->init_val; A.dyn_bin = out->dyn_bin; A.dyn_val = out->dyn_val;
+    A.ev_count = out->ev_count; A.events = reinterpret_cast<uint64_t *>(out->events); A.attempts = out->attempts;
+    const char *name = "";
+    hipError_t e;
+    if (emgpu::fast_uncor_eligible(u.cp.plan, A)) e = emgpu::launch_uncor_fast(u.cp.plan, A, ctx->stream, &name);
+    else e = emgpu::launch_dbn_generic(u.cp.plan, A, ctx->stream, &name);
+    ctx->last_kernel = name;
+    if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sample_params *p, const emgpu_sample_out *out) {
+    EMGPU_TRY
+    if (!ctx || !h || !p || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    HIP_OK(hipSetDevice(ctx->device));
+    const Model &m = h->m;
+    const size_t n = (size_t)(p->n > 0 ? p->n : 0), ni = m.n_initial, nd = m.n_dyn();
+    const size_t G4 = ((size_t)p->sample_time + 3) / 4;
+    emgpu_sample_out d{};
+    std::vector<void *> allocs;
+    auto dalloc = [&](size_t bytes) -> void * {
+        void *ptr = nullptr;
+        HIP_OK(hipMalloc(&ptr, bytes ? bytes : 1));
+        allocs.push_back(ptr);
+        return ptr;
+    };
+    int rc = EMGPU_OK;
+    try {
+        const size_t b_ib = ni * n, b_iv = ni * n * 4, b_db = G4 * nd * n * 4, b_dv = G4 * nd * n * 16;
+        const size_t b_ec = n * 4, b_ev = n * (size_t)(p->event_cap > 0 ? p->event_cap : 0) * 8, b_at = n * 4;
+        if (out->init_bin) d.init_bin = (uint8_t *)dalloc(b_ib);
+        if (out->init_val) d.init_val = (float *)dalloc(b_iv);
+        if (out->dyn_bin) d.dyn_bin = (uint32_t *)dalloc(b_db);
+        if (out->dyn_val) d.dyn_val = (float *)dalloc(b_dv);
+        if (out->ev_count) d.ev_count = (uint32_t *)dalloc(b_ec);
+        if (out->events) d.events = (emgpu_event *)dalloc(b_ev);
+        if (out->attempts) d.attempts = (int32_t *)dalloc(b_at);
+        rc = emgpu_sample_dbn_device(ctx, h, p, &d);
+        if (rc == EMGPU_OK) {
+            auto back = [&](void *dst, const void *src, size_t bytes) {
+                if (dst && bytes) HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            };
+            back(out->init_bin, d.init_bin, b_ib); back(out->init_val, d.init_val, b_iv);
+            back(out->dyn_bin, d.dyn_bin, b_db); back(out->dyn_val, d.dyn_val, b_dv);
+            back(out->ev_count, d.ev_count, b_ec); back(out->events, d.events, b_ev);
+            back(out->attempts, d.attempts, b_at);
+            rc = emgpu_ctx_sync(ctx);
+        }
+    } catch (...) {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void *ptr : allocs) (void)hipFree(ptr);
+        throw;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void *ptr : allocs) (void)hipFree(ptr);
+    return rc;
+    EMGPU_CATCH
+}
+
+static void fill_bn(emgpu_ctx *ctx, const Uploaded &u, const Model &m, const emgpu_bn_params *p, EmgpuBnRun &A) {
+    memset(&A, 0, sizeof A);
+    if (p->n < 0 || p->max_attempts < 1) throw Error(EMGPU_ERR_ARG, "n < 0 or max_attempts < 1");
+    A.seed = p->seed; A.first_index = p->first_index; A.n = p->n; A.flags = p->flags; A.max_attempts = p->max_attempts;
+    A.has_bounds = p->bounds_sample != nullptr;
+    if (p->bounds_sample)
+        for (int v = 0; v < m.n_initial; v++) {
+            A.bounds[u.cp.pos_of_var[v]][0] = p->bounds_sample[2 * v];
+            A.bounds[u.cp.pos_of_var[v]][1] = p->bounds_sample[2 * v + 1];
+        }
+    A.pos_own_speed = A.pos_int_speed = -1;
+    if (p->idx_own_speed > 0 || p->idx_int_speed > 0) {
+        if (p->idx_own_speed < 1 || p->idx_own_speed > m.n_initial || p->idx_int_speed < 1 || p->idx_int_speed > m.n_initial)
+            throw Error(EMGPU_ERR_ARG, "speed variable index out of range");
+        A.pos_own_speed = u.cp.pos_of_var[p->idx_own_speed - 1];
+        A.pos_int_speed = u.cp.pos_of_var[p->idx_int_speed - 1];
+    }
+    A.min1 = p->min_vel1; A.max1 = p->max_vel1; A.min2 = p->min_vel2; A.max2 = p->max_vel2;
+    A.status = ctx->d_status;
+}
+
+int emgpu_sample_bn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_bn_params *p, uint8_t *out_bin, float *out_val, int32_t *attempts) {
+    EMGPU_TRY
+    if (!ctx || !h || !p) return fail(EMGPU_ERR_ARG, "null argument");
+    HIP_OK(hipSetDevice(ctx->device));
+    Uploaded &u = get_uploaded(ctx, h);
+    EmgpuBnRun A;
+    fill_bn(ctx, u, h->m, p, A);
+    A.out_bin = out_bin; A.out_val = out_val; A.attempts = attempts;
+    const char *name = "";
+    hipError_t e = emgpu::launch_bn(u.cp.plan, A, ctx->stream, &name);
+    ctx->last_kernel = name;
+    if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_sample_bn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_bn_params *p, uint8_t *out_bin, float *out_val, int32_t *attempts) {
+    EMGPU_TRY
+    if (!ctx || !h || !p) return fail(EMGPU_ERR_ARG, "null argument");
+    HIP_OK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)(p->n > 0 ? p->n : 0), ni = h->m.n_initial;
+    uint8_t *db = nullptr; float *dv = nullptr; int32_t *da = nullptr;
+    int rc;
+    try {
+        if (out_bin) HIP_OK(hipMalloc((void **)&db, ni * n + 1));
+        if (out_val) HIP_OK(hipMalloc((void **)&dv, ni * n * 4 + 4));
+        if (attempts) HIP_OK(hipMalloc((void **)&da, n * 4 + 4));
+        rc = emgpu_sample_bn_device(ctx, h, p, db, dv, da);
+        if (rc == EMGPU_OK) {
+            if (out_bin && n) HIP_OK(hipMemcpyAsync(out_bin, db, ni * n, hipMemcpyDeviceToHost, ctx->stream));
+            if (out_val && n) HIP_OK(hipMemcpyAsync(out_val, dv, ni * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (attempts && n) HIP_OK(hipMemcpyAsync(attempts, da, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            rc = emgpu_ctx_sync(ctx);
+        }
+    } catch (...) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(db); (void)hipFree(dv); (void)hipFree(da);
+        throw;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(db); (void)hipFree(dv); (void)hipFree(da);
+    return rc;
+    EMGPU_CATCH
+}
+
+int32_t emgpu_discretize_bayes(double x, const double *thresholds, int32_t n) {
+    // discretize_bayes.m:17-21
+    if (n <= 0 || !thresholds) return 1;
+    if (x >= thresholds[n - 1]) return n + 1;
+    for (int i = 0; i < n; i++)
+        if (x < thresholds[i]) return i + 1;
+    return n + 1;
+}
+
+int64_t emgpu_asub2ind(const int32_t *siz, const int32_t *x, int32_t n) {
+    // asub2ind.m:13-14
+    int64_t k = 1, ndx = 1;
+    for (int i = 0; i < n; i++) { ndx += k * (int64_t)(x[i] - 1); k *= siz[i]; }
+    return ndx;
+}
+
+} // extern "C"

@@ -1,0 +1,478 @@
+// emgpu_model.cpp -- model .txt loader (replaces em_read.m), priors (bn_dirichlet_prior.m,
+// setTransitionPriors.m), topological sort (bn_sort.m) and the plan compiler that turns CPT
+// columns into u32 quantile thresholds for the HIP kernels.  Host only.
+#include "emgpu_model.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <queue>
+
+#include "../../include/emgpu.h"
+
+namespace emgpu {
+
+// ---------------------------------------------------------------------------------------------
+// bn_sort.m:17-20  toposort(digraph(G),'Order','stable').  'stable' is taken to mean the
+// lexicographically smallest topological order (Kahn's algorithm, lowest ready index first);
+// identity for every upper-triangular G.  MATLAB is not available to confirm.
+// ---------------------------------------------------------------------------------------------
+std::vector<int> bn_sort(const std::vector<uint8_t> &G, int n) {
+    std::vector<int> indeg(n, 0), order;
+    for (int p = 0; p < n; p++)
+        for (int c = 0; c < n; c++)
+            if (G[(size_t)p * n + c]) indeg[c]++;
+    std::priority_queue<int, std::vector<int>, std::greater<int>> ready;
+    for (int i = 0; i < n; i++)
+        if (indeg[i] == 0) ready.push(i);
+    while (!ready.empty()) {
+        int i = ready.top();
+        ready.pop();
+        order.push_back(i + 1);
+        for (int c = 0; c < n; c++)
+            if (G[(size_t)i * n + c] && --indeg[c] == 0) ready.push(c);
+    }
+    if ((int)order.size() != n) throw Error(EMGPU_ERR_SORT, "Network could not be hierarchically sorted");
+    return order;
+}
+
+// em_read.m:143-156
+std::vector<int> extract_zero_bins(const std::vector<std::vector<double>> &b) {
+    std::vector<int> z(b.size(), 0);
+    for (size_t i = 0; i < b.size(); i++)
+        if (b[i].size() > 2)
+            for (size_t j = 1; j < b[i].size(); j++)
+                if (b[i][j - 1] < 0 && b[i][j] > 0) z[i] = (int)j;
+    return z;
+}
+
+// em_read.m:158-177
+static std::vector<std::array<int, 2>> extract_temporal_map(const std::vector<std::string> &labels) {
+    std::vector<std::array<int, 2>> tm;
+    for (size_t ii = 0; ii < labels.size(); ii++) {
+        size_t t = labels[ii].find("(t)");
+        if (t == std::string::npos) continue;
+        std::string base = labels[ii].substr(0, t + 1);
+        for (const char *suffix : {"t+1)", "t-1)"}) {
+            std::string pat = base + suffix;
+            for (size_t k = 0; k < labels.size(); k++)
+                if (labels[k].find(pat) != std::string::npos) tm.push_back({(int)ii + 1, (int)k + 1});
+        }
+    }
+    return tm;
+}
+
+static std::string rtrim(std::string s) {
+    while (!s.empty() && (s.back() == ' ' || s.back() == '\t')) s.pop_back();
+    return s;
+}
+static std::string trim(std::string s) {
+    s = rtrim(s);
+    size_t i = 0;
+    while (i < s.size() && (s[i] == ' ' || s[i] == '\t')) i++;
+    return s.substr(i);
+}
+
+// textscan(line,'%f','Delimiter',' ')
+static void scan_numbers(const std::string &line, std::vector<double> &out) {
+    const char *p = line.c_str();
+    char *end;
+    for (;;) {
+        while (*p == ' ' || *p == '\t' || *p == ',') p++;
+        if (!*p) break;
+        double v = strtod(p, &end);
+        if (end == p) throw Error(EMGPU_ERR_PARSE, std::string("cannot parse number near '") + std::string(p).substr(0, 16) + "'");
+        out.push_back(v);
+        p = end;
+    }
+}
+
+static std::vector<std::string> split_labels(const std::string &line) { // strtrim(strsplit(line, ','))
+    std::vector<std::string> out;
+    size_t pos = 0;
+    for (;;) {
+        size_t c = line.find(',', pos);
+        out.push_back(trim(line.substr(pos, c == std::string::npos ? std::string::npos : c - pos)));
+        if (c == std::string::npos) break;
+        pos = c + 1;
+    }
+    return out;
+}
+
+static int64_t parent_count(const std::vector<uint8_t> &G, int n, const std::vector<int> &r, int child) {
+    int64_t q = 1; // getdims, em_read.m:200-206
+    for (int p = 0; p < n; p++)
+        if (G[(size_t)p * n + child]) q *= r[p];
+    return q;
+}
+
+bool Model::is_dynvar_depend() const {
+    for (auto &a : temporal_map)
+        for (auto &b : temporal_map)
+            if (G_transition[(size_t)(a[1] - 1) * n_transition + (b[1] - 1)]) return true;
+    return false;
+}
+
+void Model::set_prior(int kind, double value) {
+    auto fill = [&](std::vector<std::vector<double>> &A, const std::vector<std::vector<double>> &N, const std::vector<int> &r) {
+        A.resize(N.size());
+        for (size_t i = 0; i < N.size(); i++) {
+            A[i].assign(N[i].size(), 0.0);
+            if (N[i].empty()) continue;
+            double q = (double)N[i].size() / r[i];
+            double p = kind == 1 ? 1.0 / ((double)r[i] * q) : value; // bn_dirichlet_prior.m:22-25 / :31-35
+            std::fill(A[i].begin(), A[i].end(), p);
+        }
+    };
+    fill(A_initial, N_initial, r_initial);
+    if (n_transition > 0) fill(A_transition, N_transition, r_transition);
+    version++;
+}
+
+void Model::set_transition_stay_prior(double prior) {
+    // setTransitionPriors.m:12-33
+    for (auto &tm : temporal_map) {
+        int ii = tm[1] - 1, jj = tm[0] - 1;
+        if (N_transition[ii].empty()) continue;
+        bool has_par = false;
+        for (int p = 0; p < n_transition; p++) has_par |= G_transition[(size_t)p * n_transition + ii] != 0;
+        if (!has_par) continue;
+        int rj = r_transition[jj];
+        int64_t n = q_transition[ii];
+        if ((int64_t)rj * n != (int64_t)N_transition[ii].size())
+            throw Error(EMGPU_ERR_ARG, "setTransitionPriors: r of the variable at t differs from its t+1 table");
+        std::fill(A_transition[ii].begin(), A_transition[ii].end(), 0.0);
+        int64_t nn = n / rj;
+        for (int kk = 1; kk <= rj; kk++)
+            for (int64_t c = nn * (kk - 1) + 1; c <= nn * kk; c++) A_transition[ii][(size_t)(c - 1) * rj + (kk - 1)] = prior;
+    }
+    version++;
+}
+
+void Model::finalize() {
+    if (n_initial <= 0) throw Error(EMGPU_ERR_PARSE, "model has no initial network");
+    if ((int)r_initial.size() != n_initial) throw Error(EMGPU_ERR_PARSE, "r_initial size mismatch");
+    order_initial = bn_sort(G_initial, n_initial);
+    q_initial.resize(n_initial);
+    for (int i = 0; i < n_initial; i++) {
+        q_initial[i] = parent_count(G_initial, n_initial, r_initial, i);
+        if ((int64_t)N_initial[i].size() != q_initial[i] * r_initial[i]) throw Error(EMGPU_ERR_PARSE, "N_initial size mismatch");
+    }
+    if (n_transition > 0) {
+        if ((int)r_transition.size() != n_transition) throw Error(EMGPU_ERR_PARSE, "r_transition size mismatch");
+        order_transition = bn_sort(G_transition, n_transition);
+        q_transition.assign(n_transition, 0);
+        N_transition.resize(n_transition);
+        for (int i = n_initial; i < n_transition; i++) {
+            q_transition[i] = parent_count(G_transition, n_transition, r_transition, i);
+            if ((int64_t)N_transition[i].size() != q_transition[i] * r_transition[i]) throw Error(EMGPU_ERR_PARSE, "N_transition size mismatch");
+        }
+        if (temporal_map.empty() && !labels_transition.empty()) temporal_map = extract_temporal_map(labels_transition);
+    }
+    if (boundaries.empty()) boundaries.assign(n_initial, {});
+    if (zero_bins.empty()) zero_bins = extract_zero_bins(boundaries);
+    if (resample_rates.empty()) resample_rates.assign(n_initial, 0.0);
+    if (start.empty()) start.assign(n_initial, 0);
+    set_prior(0, 0.0); // EncounterModel.m:45 prior = 0
+}
+
+// ---------------------------------------------------------------------------------------------
+// em_read.m:47-141
+// ---------------------------------------------------------------------------------------------
+Model *load_txt(const char *path, const int32_t *idx_zero, int n_idx, bool overwrite) {
+    FILE *f = fopen(path, "rb");
+    if (!f) throw Error(EMGPU_ERR_IO, std::string("cannot open ") + path);
+    std::string text;
+    char buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, got);
+    fclose(f);
+    // textscan(fid,'%s','EndOfLine','\r\n','Whitespace','\r\n'): one string per non-empty line
+    std::vector<std::string> lines;
+    size_t pos = 0;
+    while (pos <= text.size()) {
+        size_t e = text.find_first_of("\r\n", pos);
+        if (e == std::string::npos) e = text.size();
+        if (e > pos) lines.push_back(text.substr(pos, e - pos));
+        pos = e + 1;
+    }
+    std::unique_ptr<Model> m(new Model());
+    std::vector<double> flat_init, flat_trans;
+    bool have_bnd = false;
+    size_t n_fields = 0;
+    for (size_t i = 0; i < lines.size(); i++) {
+        if (lines[i].find('#') == std::string::npos) continue;
+        std::string field = rtrim(lines[i]);
+        size_t row = i + 1;
+        auto need = [&](size_t k) {
+            if (row + k > lines.size()) throw Error(EMGPU_ERR_PARSE, "truncated section " + field);
+        };
+        n_fields++;
+        if (field == "# labels_initial") {
+            need(1);
+            m->labels_initial = split_labels(lines[row]);
+            m->n_initial = (int)m->labels_initial.size();
+        } else if (field == "# G_initial") {
+            need(m->n_initial);
+            for (int k = 0; k < m->n_initial; k++) {
+                std::vector<double> v;
+                scan_numbers(lines[row + k], v);
+                if ((int)v.size() != m->n_initial) throw Error(EMGPU_ERR_PARSE, "G_initial row width");
+                for (double x : v) m->G_initial.push_back(x != 0);
+            }
+        } else if (field == "# r_initial") {
+            need(1);
+            std::vector<double> v;
+            scan_numbers(lines[row], v);
+            for (double x : v) m->r_initial.push_back((int)x);
+        } else if (field == "# N_initial") {
+            need(1);
+            scan_numbers(lines[row], flat_init);
+        } else if (field == "# labels_transition") {
+            need(1);
+            m->labels_transition = split_labels(lines[row]);
+            m->n_transition = (int)m->labels_transition.size();
+        } else if (field == "# G_transition") {
+            need(m->n_transition);
+            for (int k = 0; k < m->n_transition; k++) {
+                std::vector<double> v;
+                scan_numbers(lines[row + k], v);
+                if ((int)v.size() != m->n_transition) throw Error(EMGPU_ERR_PARSE, "G_transition row width");
+                for (double x : v) m->G_transition.push_back(x != 0);
+            }
+        } else if (field == "# r_transition") {
+            need(1);
+            std::vector<double> v;
+            scan_numbers(lines[row], v);
+            for (double x : v) m->r_transition.push_back((int)x);
+        } else if (field == "# N_transition") {
+            need(1);
+            scan_numbers(lines[row], flat_trans);
+        } else if (field == "# boundaries") {
+            need(m->n_initial);
+            m->boundaries.resize(m->n_initial);
+            for (int k = 0; k < m->n_initial; k++) {
+                std::string s = trim(lines[row + k]);
+                if (s != "*") scan_numbers(s, m->boundaries[k]); // '*' -> textscan yields empty (em_read.m:97-99)
+            }
+            have_bnd = true;
+        } else if (field == "# resample_rates") {
+            need(1);
+            scan_numbers(lines[row], m->resample_rates);
+        } else {
+            throw Error(EMGPU_ERR_PARSE, "Unknown field: " + field); // em_read.m:104
+        }
+    }
+    if (n_fields == 0 || m->n_initial == 0) throw Error(EMGPU_ERR_PARSE, "no '# labels_initial' section");
+    if ((int)m->G_initial.size() != m->n_initial * m->n_initial || (int)m->r_initial.size() != m->n_initial)
+        throw Error(EMGPU_ERR_PARSE, "G_initial / r_initial missing or malformed");
+    // array2cells (em_read.m:191-198)
+    {
+        m->N_initial.resize(m->n_initial);
+        size_t idx = 0;
+        for (int i = 0; i < m->n_initial; i++) {
+            size_t cnt = (size_t)parent_count(m->G_initial, m->n_initial, m->r_initial, i) * m->r_initial[i];
+            if (idx + cnt > flat_init.size()) throw Error(EMGPU_ERR_PARSE, "N_initial too short");
+            m->N_initial[i].assign(flat_init.begin() + idx, flat_init.begin() + idx + cnt);
+            idx += cnt;
+        }
+        if (idx != flat_init.size()) throw Error(EMGPU_ERR_PARSE, "N_initial has trailing values");
+    }
+    if (m->n_transition > 0) {
+        if ((int)m->G_transition.size() != m->n_transition * m->n_transition || (int)m->r_transition.size() != m->n_transition)
+            throw Error(EMGPU_ERR_PARSE, "G_transition / r_transition missing or malformed");
+        m->N_transition.resize(m->n_transition);
+        size_t idx = 0;
+        for (int i = m->n_initial; i < m->n_transition; i++) {
+            size_t cnt = (size_t)parent_count(m->G_transition, m->n_transition, m->r_transition, i) * m->r_transition[i];
+            if (idx + cnt > flat_trans.size()) throw Error(EMGPU_ERR_PARSE, "N_transition too short");
+            m->N_transition[i].assign(flat_trans.begin() + idx, flat_trans.begin() + idx + cnt);
+            idx += cnt;
+        }
+        if (idx != flat_trans.size()) throw Error(EMGPU_ERR_PARSE, "N_transition has trailing values");
+    }
+    if (have_bnd) {
+        m->zero_bins = extract_zero_bins(m->boundaries); // before the overwrite, em_read.m:116-121
+        if (overwrite) {
+            static const int32_t dflt[3] = {1, 2, 3};
+            if (!idx_zero) { idx_zero = dflt; n_idx = 3; }
+            for (int k = 0; k < n_idx; k++) {
+                if (idx_zero[k] < 1 || idx_zero[k] > m->n_initial) throw Error(EMGPU_ERR_ARG, "idxZeroBoundaries out of range");
+                m->boundaries[idx_zero[k] - 1].clear();
+            }
+        }
+    }
+    m->finalize();
+    return m.release();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quantile thresholds (select_random.m:17-20 folded into integers)
+// ---------------------------------------------------------------------------------------------
+void column_thresholds(const double *w, int r, uint32_t *out) {
+    double s[EMGPU_MAX_R];
+    double acc = 0.0;
+    for (int k = 0; k < r; k++) { acc += w[k]; s[k] = acc; } // cumsum
+    const double total = s[r - 1];
+    for (int k = 0; k < r - 1; k++) {
+        const double sk = s[k];
+        // pred(x') := !(s_k >= total * u(x')) : "bin k is NOT selected, look further"
+        auto pred = [&](uint32_t x) { return !(sk >= total * uniform32(x)); };
+        if (sk >= total) { out[k] = 0xFFFFFFFFu; continue; }   // fl(total*u) <= total for u < 1
+        if (pred(0u)) { out[k] = 0u; continue; }
+        uint32_t lo = 0u, hi = 0xFFFFFFFFu;                      // hi == "never"
+        while (lo < hi) {
+            uint32_t mid = lo + (hi - lo) / 2u;                  // mid <= 2^32-2
+            if (pred(mid)) hi = mid; else lo = mid + 1u;
+        }
+        out[k] = lo;
+    }
+}
+
+uint32_t bernoulli_threshold(double rate) {
+    // hit(x') := u(x') < rate (resample_events.m:24); R = #{x' in [0, 2^32-2] : hit}
+    auto hit = [&](uint32_t x) { return uniform32(x) < rate; };
+    if (!(rate > 0.0) || !hit(0u)) return 0u;
+    uint32_t lo = 0u, hi = 0xFFFFFFFFu;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2u;
+        if (!hit(mid)) hi = mid; else lo = mid + 1u;
+    }
+    return lo;
+}
+
+CompiledPlan compile_plan(const Model &m) {
+    CompiledPlan cp;
+    EmgpuPlan &P = cp.plan;
+    const int ni = m.n_initial, nt = m.n_transition, nd = m.n_dyn();
+    if (ni > EMGPU_MAX_NI) throw Error(EMGPU_ERR_UNSUPPORTED, "n_initial exceeds EMGPU_MAX_NI");
+    if (nd > EMGPU_MAX_ND) throw Error(EMGPU_ERR_UNSUPPORTED, "more dynamic variables than EMGPU_MAX_ND");
+    for (int r : m.r_initial) if (r < 1 || r > EMGPU_MAX_R) throw Error(EMGPU_ERR_UNSUPPORTED, "r out of range");
+    for (int r : m.r_transition) if (r < 1 || r > EMGPU_MAX_R) throw Error(EMGPU_ERR_UNSUPPORTED, "r out of range");
+    P.ni = ni; P.nd = nd; P.depend = (nt > 0 && nd > 0) ? (int)m.is_dynvar_depend() : 0;
+    // dbn_sample.m:36 hands r_transition to bn_sample; CorTerminalModel/sample.m:34 hands r_initial
+    const std::vector<int> &r_par = nt > 0 ? m.r_transition : m.r_initial;
+    cp.pos_of_var.assign(ni, -1);
+    for (int p = 0; p < ni; p++) cp.pos_of_var[m.order_initial[p] - 1] = p;
+    // boundaries table
+    std::vector<int> boff(ni, 0);
+    for (int v = 0; v < ni; v++) {
+        boff[v] = (int)cp.bnd.size();
+        if (m.boundaries[v].size() > 255) throw Error(EMGPU_ERR_UNSUPPORTED, "too many boundaries");
+        if (!m.boundaries[v].empty() && (int)m.boundaries[v].size() < m.r_initial[v] + 1)
+            throw Error(EMGPU_ERR_ARG, "boundaries shorter than r+1 (dediscretize.m:33-38 would fail)");
+        cp.bnd.insert(cp.bnd.end(), m.boundaries[v].begin(), m.boundaries[v].end());
+    }
+    cp.bnd.push_back(0.0);
+    if (cp.bnd.size() > 65535) throw Error(EMGPU_ERR_UNSUPPORTED, "boundary table too large");
+
+    double w[EMGPU_MAX_R];
+    auto emit_node = [&](const std::vector<double> &N, const std::vector<double> &A, int r, int64_t q) -> uint32_t {
+        size_t off = cp.thr.size();
+        if (off + (size_t)q * (r - 1) > 0xFFFFFFF0ull) throw Error(EMGPU_ERR_UNSUPPORTED, "threshold table too large");
+        cp.thr.resize(off + (size_t)q * (r - 1));
+        for (int64_t j = 0; j < q; j++) {
+            for (int k = 0; k < r; k++) w[k] = N[(size_t)j * r + k] + A[(size_t)j * r + k]; // bn_sample.m:55
+            if (r > 1) column_thresholds(w, r, cp.thr.data() + off + (size_t)j * (r - 1));
+        }
+        return (uint32_t)off;
+    };
+
+    for (int p = 0; p < ni; p++) {
+        int v = m.order_initial[p] - 1;
+        P.i_var[p] = (uint8_t)v;
+        P.i_r[p] = (uint8_t)m.r_initial[v];
+        P.i_start[p] = (uint8_t)m.start[v];
+        if (m.start[v] < 0 || m.start[v] > m.r_initial[v]) throw Error(EMGPU_ERR_ARG, "start bin out of range");
+        P.i_nb[p] = (uint8_t)m.boundaries[v].size();
+        P.i_zero[p] = (uint8_t)m.zero_bins[v];
+        P.i_skip[p] = (uint8_t)((int)m.boundaries[v].size() == m.r_initial[v] - 2); // dbn_hierarchical_sample.m:26
+        P.i_boff[p] = (uint16_t)boff[v];
+        int64_t stride = 1;
+        int n_par = 0, n_par_set = 0;
+        for (int u = 0; u < ni; u++) {
+            if (!m.G_initial[(size_t)u * ni + v]) continue;
+            int q = cp.pos_of_var[u];
+            if (q >= p) throw Error(EMGPU_ERR_SORT, "parent after child in topological order");
+            P.i_stride[p][q] = (uint32_t)stride;
+            stride *= r_par[u];
+            n_par++;
+            if (m.start[u] != 0) n_par_set++;
+        }
+        if (m.start[v] != 0 && n_par > 0 && n_par_set < n_par)
+            throw Error(EMGPU_ERR_PRESET, "Attempt to preset a dependent variable"); // bn_sample.m:45-47
+        if (stride != m.q_initial[v] && nt > 0) {
+            // r_transition(parents) disagrees with the table width: the reference would index out of range
+            bool same = true;
+            for (int u = 0; u < ni; u++) same &= (m.r_transition[u] == m.r_initial[u]);
+            if (!same) throw Error(EMGPU_ERR_ARG, "r_transition(1:n_initial) differs from r_initial");
+        }
+        P.i_off[p] = emit_node(m.N_initial[v], m.A_initial[v], m.r_initial[v], m.q_initial[v]);
+    }
+
+    // dynamic variables in sampling order (dbn_sample.m:68-69: order_transition, dynamic only)
+    if (nd > 0) {
+        std::vector<int> k_of_tvar(nt, -1), k_of_ivar(ni, -1);
+        int k = 0;
+        for (int oi = 0; oi < nt; oi++) {
+            int tv = m.order_transition[oi] - 1;
+            int row = -1;
+            for (int q = 0; q < nd; q++)
+                if (m.temporal_map[q][1] - 1 == tv) {
+                    if (row >= 0) throw Error(EMGPU_ERR_UNSUPPORTED, "variable appears twice in the temporal map");
+                    row = q;
+                }
+            if (row < 0) continue;
+            int iv = m.temporal_map[row][0] - 1;
+            if (iv < 0 || iv >= ni || tv < ni || k_of_ivar[iv] >= 0) throw Error(EMGPU_ERR_UNSUPPORTED, "unsupported temporal map");
+            if (m.N_transition[tv].empty()) throw Error(EMGPU_ERR_ARG, "dynamic variable without a transition table");
+            P.d_tvar[k] = (uint8_t)tv; P.d_ivar[k] = (uint8_t)iv; P.d_ipos[k] = (uint8_t)cp.pos_of_var[iv];
+            P.d_r[k] = (uint8_t)m.r_transition[tv]; P.d_row[k] = (uint8_t)row;
+            P.d_nb[k] = (uint8_t)m.boundaries[iv].size(); P.d_zero[k] = (uint8_t)m.zero_bins[iv]; P.d_boff[k] = (uint16_t)boff[iv];
+            if (m.r_transition[tv] != m.r_initial[iv]) throw Error(EMGPU_ERR_UNSUPPORTED, "t and t+1 copies of a variable differ in r");
+            k_of_tvar[tv] = k; k_of_ivar[iv] = k;
+            k++;
+        }
+        if (k != nd) throw Error(EMGPU_ERR_UNSUPPORTED, "temporal map rows not found in order_transition");
+        // emission order: ascending initial variable id (dbn_sample.m:86 / :152 loop 1:n_initial)
+        std::vector<int> ks(nd);
+        for (int q = 0; q < nd; q++) ks[q] = q;
+        std::sort(ks.begin(), ks.end(), [&](int a, int b) { return P.d_ivar[a] < P.d_ivar[b]; });
+        for (int e = 0; e < nd; e++) P.d_emit[e] = (uint8_t)ks[e];
+        for (k = 0; k < nd; k++) {
+            int tv = P.d_tvar[k];
+            int64_t stride = 1;
+            for (int u = 0; u < nt; u++) {
+                if (!m.G_transition[(size_t)u * nt + tv]) continue;
+                if (u < ni) {
+                    if (k_of_ivar[u] >= 0) P.d_stride_cur[k][k_of_ivar[u]] = (uint32_t)stride;
+                    else P.d_stride_static[k][cp.pos_of_var[u]] = (uint32_t)stride;
+                } else {
+                    int kp = k_of_tvar[u];
+                    if (kp < 0 || kp >= k) throw Error(EMGPU_ERR_UNSUPPORTED, "transition parent is not an earlier dynamic variable");
+                    P.d_stride_new[k][kp] = (uint32_t)stride;
+                }
+                stride *= m.r_transition[u];
+            }
+            P.d_off[k] = emit_node(m.N_transition[tv], m.A_transition[tv], m.r_transition[tv], m.q_transition[tv]);
+        }
+    }
+    // resample_events.m:24
+    int na = 0;
+    for (int v = 0; v < ni; v++) {
+        if (!(m.resample_rates[v] > 0.0)) continue;
+        P.a_var[na] = (uint8_t)v; P.a_pos[na] = (uint8_t)cp.pos_of_var[v];
+        P.a_dyn[na] = -1;
+        for (int k = 0; k < nd; k++) if (P.d_ivar[k] == v) P.a_dyn[na] = (int8_t)k;
+        P.a_R[na] = bernoulli_threshold(m.resample_rates[v]);
+        na++;
+    }
+    P.nact = na;
+    return cp;
+}
+
+} // namespace emgpu

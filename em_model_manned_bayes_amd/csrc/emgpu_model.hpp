@@ -1,0 +1,71 @@
+// emgpu_model.hpp -- host-side model IR (what em_read.m returns / EncounterModel.m holds) and the
+// plan compiler.  No HIP in this header.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "emgpu_plan.h"
+
+namespace emgpu {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+struct Model {
+    // em_read.m:47-107 fields
+    std::vector<std::string> labels_initial, labels_transition;
+    int n_initial = 0, n_transition = 0;
+    std::vector<uint8_t> G_initial, G_transition; // row-major [parent][child]
+    std::vector<int> r_initial, r_transition;
+    std::vector<int> order_initial, order_transition; // 1-based ids (bn_sort.m)
+    std::vector<std::array<int, 2>> temporal_map;     // 1-based (var@t, var@t+1)
+    // N{i}: r_i x q_i column-major.  N_transition is indexed by variable id (0..n_transition-1),
+    // empty for nodes without a table (em_read.m:92).
+    std::vector<std::vector<double>> N_initial, N_transition;
+    std::vector<std::vector<double>> A_initial, A_transition; // alpha (dirichlet_*), same shapes
+    std::vector<int64_t> q_initial, q_transition;
+    std::vector<std::vector<double>> boundaries;
+    std::vector<int> zero_bins; // 0 = none
+    std::vector<double> resample_rates;
+    std::vector<int> start; // 0 = unset
+    uint64_t version = 1;   // bumped by every setter: invalidates uploaded plans
+
+    int n_dyn() const { return (int)temporal_map.size(); }
+    bool is_dynvar_depend() const;
+    int rows_initial(int v) const { return r_initial[v]; }
+    int rows_transition(int v) const { return r_transition[v]; }
+
+    void finalize();                         // orders, q's, default alphas, start
+    void set_prior(int kind, double value);  // bn_dirichlet_prior.m:18-37
+    void set_transition_stay_prior(double p); // setTransitionPriors.m:12-33
+};
+
+Model *load_txt(const char *path, const int32_t *idx_zero, int n_idx, bool overwrite);
+std::vector<int> bn_sort(const std::vector<uint8_t> &G, int n);
+std::vector<int> extract_zero_bins(const std::vector<std::vector<double>> &b);
+
+// uniform32: the ONLY definition of the uniform on the host side.
+inline double uniform32(uint32_t x) {
+    if (x > 0xFFFFFFFEu) x = 0xFFFFFFFEu;
+    return ((double)x + 0.5) * (1.0 / 4294967296.0);
+}
+
+struct CompiledPlan {
+    EmgpuPlan plan{};             // thr / bnd pointers are filled at upload time
+    std::vector<uint32_t> thr;
+    std::vector<double> bnd;
+    std::vector<int> pos_of_var;  // variable id (0-based) -> topological position
+};
+// Throws Error(EMGPU_ERR_UNSUPPORTED / EMGPU_ERR_PRESET / ...) when the model cannot be planned.
+CompiledPlan compile_plan(const Model &m);
+
+// Quantile thresholds of one CPT column (r weights): out[r-1].
+void column_thresholds(const double *w, int r, uint32_t *out);
+uint32_t bernoulli_threshold(double rate);
+
+} // namespace emgpu

@@ -1,0 +1,101 @@
+// emgpu_plan.h -- POD "plan" handed to the HIP kernels (by value, in the kernarg segment) and the
+// RNG slot map shared by every kernel.  Built on the host by emgpu_model.cpp (compile_plan).
+//
+// The plan restates a model in the form the device wants:
+//   * the initial network relabelled into topological order (bn_sort.m / bn_sample.m:41), so the
+//     kernel walks positions 0..ni-1 and never indexes registers dynamically;
+//   * asub2ind (asub2ind.m:13-14) folded into per-parent column strides (0 for non-parents);
+//   * select_random (select_random.m:14-20) folded into u32 "quantile thresholds": for CPT column
+//     j of a node with r bins, X[j][k] (k < r-1) is the smallest 32-bit draw x for which
+//     s_k < s_end * u(x); the sampled bin is 1 + #{k : x >= X[j][k]}.  Exactly equivalent to the
+//     reference's f64 compare for the uniform u(x) defined below.
+#pragma once
+#include <stdint.h>
+
+#define EMGPU_MAX_NI 16 // initial-network variables
+#define EMGPU_MAX_ND 4  // dynamic variables (rows of the temporal map)
+#define EMGPU_MAX_R 64  // bins per variable
+
+// ---- RNG slot map -------------------------------------------------------
+// Philox4x32-10, key = {seed_lo, seed_hi},
+// ctr = {gidx_lo, gidx_hi, attempt, section<<28 | a<<20 | (idx>>2)}, word = idx & 3.
+// uniform: x' = min(x, 2^32-2); u = (x' + 0.5) * 2^-32.
+#define EMGPU_SEC_INIT 1u
+#define EMGPU_SEC_DEDISC_INIT 2u
+#define EMGPU_SEC_TRANS 3u
+#define EMGPU_SEC_RES 4u
+#define EMGPU_SEC_DEDISC_RES 5u
+#define EMGPU_SEC_DEDISC_TRANS 6u
+#define EMGPU_SEC_LAYER 7u
+#define EMGPU_SEC_GEOM_DEDISC 8u
+
+struct EmgpuPlan {
+    int32_t ni, nd, nact, depend; // depend: is_dynvar_depend (dbn_sample.m:55)
+    // ---- initial network, by topological position p
+    uint8_t i_var[EMGPU_MAX_NI];   // 0-based variable id
+    uint8_t i_r[EMGPU_MAX_NI];     // bins
+    uint8_t i_start[EMGPU_MAX_NI]; // 0 = unset, else preset bin (1-based)
+    uint32_t i_off[EMGPU_MAX_NI];  // offset of the node's thresholds in thr[]
+    uint32_t i_stride[EMGPU_MAX_NI][EMGPU_MAX_NI]; // [p][q<p]: column stride of parent at position q
+    // ---- dediscretize, by topological position p (dediscretize.m:7-40)
+    uint8_t i_nb[EMGPU_MAX_NI];    // number of boundaries (0 => categorical: value = bin)
+    uint8_t i_zero[EMGPU_MAX_NI];  // zero bin (0 = none)
+    uint8_t i_skip[EMGPU_MAX_NI];  // dbn_hierarchical_sample.m:26 length(params)==r-2 branch
+    uint16_t i_boff[EMGPU_MAX_NI]; // offset into bnd[]
+    // ---- dynamic variables, k in sampling order (order_transition restricted to dynamic vars)
+    uint8_t d_tvar[EMGPU_MAX_ND]; // 0-based id of the (t+1) node in the transition network (RNG slot)
+    uint8_t d_ivar[EMGPU_MAX_ND]; // 0-based id of the mapped initial variable (RNG slot, event var)
+    uint8_t d_ipos[EMGPU_MAX_ND]; // topological position of that initial variable
+    uint8_t d_r[EMGPU_MAX_ND];
+    uint8_t d_row[EMGPU_MAX_ND];  // row of the temporal map == output slot (ascending variable id)
+    uint8_t d_emit[EMGPU_MAX_ND]; // d_emit[e] = k of the e-th dynamic variable in ascending ivar order
+    uint8_t d_nb[EMGPU_MAX_ND], d_zero[EMGPU_MAX_ND];
+    uint16_t d_boff[EMGPU_MAX_ND];
+    uint32_t d_off[EMGPU_MAX_ND];
+    uint32_t d_stride_static[EMGPU_MAX_ND][EMGPU_MAX_NI]; // parents that never change, by position p
+    uint32_t d_stride_cur[EMGPU_MAX_ND][EMGPU_MAX_ND];    // time-t node of dynamic var k' as parent
+    uint32_t d_stride_new[EMGPU_MAX_ND][EMGPU_MAX_ND];    // (t+1) node of dynamic var k' (sampled earlier)
+    // ---- resample_events.m:24: variables with rate > 0, ascending variable id
+    uint8_t a_var[EMGPU_MAX_NI];  // 0-based variable id
+    uint8_t a_pos[EMGPU_MAX_NI];  // topological position
+    int8_t a_dyn[EMGPU_MAX_NI];   // k if dynamic else -1
+    uint32_t a_R[EMGPU_MAX_NI];   // hit  <=>  x' < R
+    // ---- device tables
+    const uint32_t *thr; // quantile thresholds, node after node, column after column, r-1 each
+    const double *bnd;   // boundaries
+};
+
+struct EmgpuRun {
+    uint64_t seed, first_index;
+    int64_t n;
+    int32_t T, per_step;
+    uint32_t flags;
+    int32_t max_attempts;
+    int32_t pos_L, pos_v, pos_dh; // topological positions, -1 = absent
+    int32_t n_layers;
+    const double *layers;
+    int32_t event_cap, _pad;
+    // outputs
+    uint8_t *init_bin;
+    float *init_val;
+    uint32_t *dyn_bin;
+    float *dyn_val;
+    uint32_t *ev_count;
+    uint64_t *events; // emgpu_event rows as packed 64-bit words
+    int32_t *attempts;
+    uint32_t *status; // device word: bit0 = rejection cap hit, bit1 = event cap hit
+};
+
+struct EmgpuBnRun {
+    uint64_t seed, first_index;
+    int64_t n;
+    uint32_t flags;
+    int32_t max_attempts;
+    int32_t has_bounds, pos_own_speed, pos_int_speed, _pad;
+    double bounds[EMGPU_MAX_NI][2]; // by topological position
+    double min1, max1, min2, max2;
+    uint8_t *out_bin;
+    float *out_val;
+    int32_t *attempts;
+    uint32_t *status;
+};

@@ -1,0 +1,271 @@
+"""Thin object layer over the C ABI: NativeModel (emgpu_model*), Context (emgpu_ctx*) and the
+sampling calls with numpy (host) or raw device pointers (torch tensors' data_ptr()).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+EVENT_DTYPE = np.dtype([("dt", "<u2"), ("var", "u1"), ("bin", "u1"), ("value", "<f4")])
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class NativeModel:
+    """Owns an emgpu_model handle (what em_read.m returns plus priors and start)."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+        self._refresh()
+
+    def _refresh(self):
+        info = L.ModelInfo()
+        L.check(L.lib().emgpu_model_info(self._h, C.byref(info)))
+        self.info = info
+        self.n_initial, self.n_transition, self.n_dyn = info.n_initial, info.n_transition, info.n_dyn
+        self.is_dynvar_depend = bool(info.is_dynvar_depend)
+
+    @classmethod
+    def load_txt(cls, path, idx_zero_boundaries=(1, 2, 3), is_overwrite_zero_boundaries=False):
+        idx = np.asarray(list(idx_zero_boundaries), dtype=np.int32)
+        h = C.c_void_p()
+        L.check(L.lib().emgpu_model_load_txt(str(path).encode(), _p(idx), len(idx), int(bool(is_overwrite_zero_boundaries)), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_arrays(cls, G_initial, r_initial, N_initial, G_transition=None, r_transition=None, N_transition=None,
+                    temporal_map=None, boundaries=None, zero_bins=None, resample_rates=None,
+                    labels_initial=None, labels_transition=None):
+        """N_initial: list of r_i x q_i arrays (all nodes); N_transition: list/dict for nodes n_i+1..n_t."""
+        ni = len(r_initial)
+        d = L.ModelDesc()
+        keep = []
+
+        def k(a, dt):
+            a = np.ascontiguousarray(np.asarray(a, dtype=dt))
+            keep.append(a)
+            return a
+        Gi = k(np.asarray(G_initial) != 0, np.uint8)
+        ri = k(r_initial, np.int32)
+        Ni = k(np.concatenate([np.asarray(N, dtype=np.float64).T.reshape(-1) for N in N_initial]), np.float64)
+        d.n_initial = ni
+        d.G_initial, d.r_initial, d.N_initial, d.n_N_initial = _p(Gi), _p(ri), _p(Ni), Ni.size
+        if G_transition is not None and len(r_transition) > 0:
+            nt = len(r_transition)
+            Gt = k(np.asarray(G_transition) != 0, np.uint8)
+            rt = k(r_transition, np.int32)
+            if isinstance(N_transition, dict):
+                seq = [N_transition[v] for v in range(ni, nt)]
+            else:
+                seq = list(N_transition)
+                if len(seq) == nt:
+                    seq = seq[ni:]
+            Nt = k(np.concatenate([np.asarray(N, dtype=np.float64).T.reshape(-1) for N in seq]), np.float64)
+            d.n_transition = nt
+            d.G_transition, d.r_transition, d.N_transition, d.n_N_transition = _p(Gt), _p(rt), _p(Nt), Nt.size
+            if temporal_map is not None:
+                tm = k(np.asarray(temporal_map).reshape(-1, 2), np.int32)
+                d.temporal_map, d.n_dyn = _p(tm), tm.shape[0]
+        if boundaries is not None:
+            bl = k([len(b) for b in boundaries], np.int32)
+            bf = k(np.concatenate([np.asarray(b, dtype=np.float64).reshape(-1) for b in boundaries] + [np.zeros(1)]), np.float64)
+            d.boundaries, d.bnd_len = _p(bf), _p(bl)
+        if zero_bins is not None:
+            zb = k([0 if (z is None or (hasattr(z, "__len__") and len(z) == 0)) else int(np.asarray(z).reshape(-1)[0]) for z in zero_bins], np.int32)
+            d.zero_bins = _p(zb)
+        if resample_rates is not None:
+            rr = k(resample_rates, np.float64)
+            d.resample_rates = _p(rr)
+        if labels_initial:
+            d.labels_initial = "\n".join(labels_initial).encode()
+        if labels_transition:
+            d.labels_transition = "\n".join(labels_transition).encode()
+        h = C.c_void_p()
+        L.check(L.lib().emgpu_model_from_arrays(C.byref(d), C.byref(h)))
+        return cls(h.value)
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().emgpu_model_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- field access
+    def get_i32(self, field):
+        n = L.check(L.lib().emgpu_model_get_i32(self._h, field, None, 0))
+        out = np.zeros(n, dtype=np.int32)
+        L.check(L.lib().emgpu_model_get_i32(self._h, field, _p(out), n))
+        return out
+
+    def get_f64(self, field, node=0):
+        n = L.check(L.lib().emgpu_model_get_f64(self._h, field, node, None, 0))
+        out = np.zeros(n, dtype=np.float64)
+        L.check(L.lib().emgpu_model_get_f64(self._h, field, node, _p(out), n))
+        return out
+
+    def get_labels(self, field):
+        n = L.check(L.lib().emgpu_model_get_text(self._h, field, None, 0))
+        buf = C.create_string_buffer(n)
+        L.check(L.lib().emgpu_model_get_text(self._h, field, buf, n))
+        s = buf.value.decode()
+        return s.split("\n") if s else []
+
+    def set_f64(self, field, node, values):
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1))
+        L.check(L.lib().emgpu_model_set_f64(self._h, field, node, _p(v), v.size))
+
+    def set_prior(self, prior):
+        """EncounterModel.prior semantics: number or 'dbe' (bn_dirichlet_prior.m:18-37)."""
+        if isinstance(prior, str):
+            if prior.lower() != "dbe":
+                raise L.EmgpuError(L.ERR_PRIOR, "Unknown prior of %s, if char expecting prior = 'dbe'" % prior)
+            L.check(L.lib().emgpu_model_set_prior(self._h, 1, 0.0))
+        elif isinstance(prior, (int, float, np.floating, np.integer)):
+            L.check(L.lib().emgpu_model_set_prior(self._h, 0, float(prior)))
+        else:
+            raise L.EmgpuError(L.ERR_PRIOR, "Second argument must be a char or double")
+
+    def set_transition_stay_prior(self, prior):
+        L.check(L.lib().emgpu_model_set_transition_stay_prior(self._h, float(prior)))
+
+    def set_start(self, start):
+        st = np.zeros(self.n_initial, dtype=np.int32)
+        for i, s in enumerate(start):
+            if s is None:
+                continue
+            a = np.asarray(s, dtype=np.float64).reshape(-1)
+            if a.size == 0 or np.isnan(a[0]):
+                continue
+            st[i] = int(a[0])
+        L.check(L.lib().emgpu_model_set_start(self._h, _p(st), st.size))
+
+
+class Context:
+    """One device + one stream (emgpu_ctx).  Raises EmgpuError(ERR_NO_DEVICE) without a GPU."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        L.check(L.lib().emgpu_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream_ptr):
+        L.check(L.lib().emgpu_ctx_set_stream(self._h, C.c_void_p(int(stream_ptr) if stream_ptr else 0)))
+
+    def sync(self):
+        L.check(L.lib().emgpu_ctx_sync(self._h))
+
+    def last_kernel(self):
+        return L.lib().emgpu_last_kernel_name(self._h).decode()
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().emgpu_ctx_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def make_params(n, sample_time, seed, first_index=0, transition_mode=L.TRANSITION_REFERENCE_AUTO, flags=0,
+                max_attempts=1000, idx_L=0, idx_v=0, idx_dh=0, layers=None, event_cap=0):
+    p = L.SampleParams()
+    p.seed, p.first_index, p.n, p.sample_time = int(seed) & (2**64 - 1), int(first_index), int(n), int(sample_time)
+    p.transition_mode, p.flags, p.max_attempts = int(transition_mode), int(flags), int(max_attempts)
+    p.idx_L, p.idx_v, p.idx_dh = int(idx_L), int(idx_v), int(idx_dh)
+    keep = None
+    if layers is not None:
+        keep = np.ascontiguousarray(np.asarray(layers, dtype=np.float64).reshape(-1, 2))
+        p.layers, p.n_layers = _p(keep), keep.shape[0]
+    p.event_cap = int(event_cap)
+    return p, keep
+
+
+def sample_dbn_device(ctx, model, params, init_bin=0, init_val=0, dyn_bin=0, dyn_val=0, ev_count=0, events=0, attempts=0):
+    """Asynchronous launch with raw device pointers (ints, 0 = skip)."""
+    o = L.SampleOut()
+    o.init_bin, o.init_val, o.dyn_bin, o.dyn_val = init_bin or None, init_val or None, dyn_bin or None, dyn_val or None
+    o.ev_count, o.events, o.attempts = ev_count or None, events or None, attempts or None
+    L.check(L.lib().emgpu_sample_dbn_device(ctx._h, model._h, C.byref(params), C.byref(o)))
+
+
+def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_events=False, event_cap=None, **kw):
+    """Synchronous host-buffer call.  Returns a dict of numpy arrays in user-facing shapes:
+    init_bin [n, n_i] u8, init_val [n, n_i] f32, dyn_bin [n, T, n_d] u8, dyn_val [n, T, n_d] f32,
+    events: list of structured arrays (EVENT_DTYPE), attempts [n].
+    """
+    ni, nd, T = model.n_initial, model.n_dyn, int(sample_time)
+    if want_events and event_cap is None:
+        event_cap = min((ni + nd + 1) * T + 2, 4096)
+    p, keep = make_params(n, T, seed, event_cap=event_cap or 0, **kw)
+    G4 = (T + 3) // 4
+    o = L.SampleOut()
+    ib = np.zeros((ni, n), dtype=np.uint8)
+    iv = np.zeros((ni, n), dtype=np.float32)
+    att = np.zeros(n, dtype=np.int32)
+    o.init_bin, o.init_val, o.attempts = _p(ib), _p(iv), _p(att)
+    if want_dense and nd > 0:
+        db = np.zeros((G4, nd, n), dtype=np.uint32)
+        dv = np.zeros((G4, nd, n, 4), dtype=np.float32)
+        o.dyn_bin, o.dyn_val = _p(db), _p(dv)
+    if want_events:
+        ec = np.zeros(n, dtype=np.uint32)
+        ev = np.zeros((n, event_cap), dtype=EVENT_DTYPE)
+        o.ev_count, o.events = _p(ec), _p(ev)
+    L.check(L.lib().emgpu_sample_dbn_host(ctx._h, model._h, C.byref(p), C.byref(o)))
+    out = {"init_bin": ib.T.copy(), "init_val": iv.T.copy(), "attempts": att, "kernel": ctx.last_kernel()}
+    if want_dense and nd > 0:
+        out["dyn_bin"] = unpack_dyn_bin(db, T)
+        out["dyn_val"] = unpack_dyn_val(dv, T)
+    if want_events:
+        out["events"] = [ev[i, : ec[i]] for i in range(n)]
+        out["ev_count"] = ec
+    return out
+
+
+def unpack_dyn_bin(db, T):
+    """[G4][nd][n] uint32 (4 seconds per word) -> [n, T, nd] uint8."""
+    G4, nd, n = db.shape
+    b = db.view(np.uint8).reshape(G4, nd, n, 4)          # little endian: byte w = column 4g+w
+    return np.ascontiguousarray(b.transpose(2, 0, 3, 1).reshape(n, G4 * 4, nd)[:, :T, :])
+
+
+def unpack_dyn_val(dv, T):
+    """[G4][nd][n][4] f32 -> [n, T, nd] f32."""
+    G4, nd, n, _ = dv.shape
+    return np.ascontiguousarray(dv.transpose(2, 0, 3, 1).reshape(n, G4 * 4, nd)[:, :T, :])
+
+
+def sample_bn_host(ctx, model, n, seed, first_index=0, dediscretize=False, max_attempts=100000, bounds_sample=None,
+                   idx_own_speed=0, idx_int_speed=0, lim1=(0.0, np.inf), lim2=(0.0, np.inf)):
+    """bn_sample.m (dediscretize=False) or the CorTerminalModel geometry draw (sample.m:29-77)."""
+    p = L.BnParams()
+    p.seed, p.first_index, p.n = int(seed) & (2**64 - 1), int(first_index), int(n)
+    p.flags = 0 if dediscretize else L.FLAG_NO_DEDISC
+    p.max_attempts = int(max_attempts)
+    bs = None
+    if bounds_sample is not None:
+        bs = np.ascontiguousarray(np.asarray(bounds_sample, dtype=np.float64).reshape(model.n_initial, 2))
+        p.bounds_sample = _p(bs)
+    p.idx_own_speed, p.idx_int_speed = int(idx_own_speed), int(idx_int_speed)
+    p.min_vel1, p.max_vel1, p.min_vel2, p.max_vel2 = float(lim1[0]), float(lim1[1]), float(lim2[0]), float(lim2[1])
+    ob = np.zeros((model.n_initial, n), dtype=np.uint8)
+    ov = np.zeros((model.n_initial, n), dtype=np.float32)
+    att = np.zeros(n, dtype=np.int32)
+    L.check(L.lib().emgpu_sample_bn_host(ctx._h, model._h, C.byref(p), _p(ob), _p(ov), _p(att)))
+    return ob.T.copy(), ov.T.copy(), att

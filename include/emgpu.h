@@ -1,0 +1,215 @@
+/*
+ * emgpu.h -- C ABI of libemgpu.so: the MI355X-native replacement of the sampling hot path of
+ * Airspace-Encounter-Models/em-model-manned-bayes.
+ *
+ * The reference has no FFI boundary of its own (plain MATLAB functions and handle classes); this
+ * header is the boundary a maintainer binds instead.  Every entry point cites the reference
+ * interface it replaces (paths relative to the reference's code/matlab/).  The MATLAB-side mex
+ * binding and the Python ctypes binding are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - C linkage, plain pointers and sizes, no C++/torch types.
+ *   - Every function returns an int status (EMGPU_OK or a negative EMGPU_ERR_*); the text of the
+ *     last error of the calling thread is returned by emgpu_last_error().
+ *   - The caller owns every output buffer.  The library owns only emgpu_model / emgpu_ctx handles.
+ *   - Variable ids, bins and the temporal map are 1-based at this boundary, like the reference.
+ *   - Matrices that mirror MATLAB arrays are column-major (N{i} is r_i x q_i, em_read.m:191-198).
+ *   - Re-entrant per ctx; a ctx is bound to one device and launches on one HIP stream.
+ */
+#ifndef EMGPU_H
+#define EMGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMGPU_OK 0
+#define EMGPU_ERR_ARG (-1)          /* bad argument / shape                                        */
+#define EMGPU_ERR_IO (-2)           /* file could not be opened                                    */
+#define EMGPU_ERR_PARSE (-3)        /* 'Unknown field' em_read.m:104, malformed sections           */
+#define EMGPU_ERR_PRESET (-4)       /* 'Attempt to preset a dependent variable' bn_sample.m:47     */
+#define EMGPU_ERR_HIP (-5)          /* HIP runtime error                                           */
+#define EMGPU_ERR_REJECT_CAP (-6)   /* rejection loop hit max_attempts (reference loops forever)   */
+#define EMGPU_ERR_EVENT_CAP (-7)    /* an event list did not fit event_cap rows                    */
+#define EMGPU_ERR_NO_DEVICE (-8)    /* no HIP device: the product path has no CPU fallback         */
+#define EMGPU_ERR_UNSUPPORTED (-9)  /* model shape beyond the compiled maxima                      */
+#define EMGPU_ERR_PRIOR (-10)       /* 'prior:notdbe' / 'prior:unknown' bn_dirichlet_prior.m:28,37 */
+#define EMGPU_ERR_SORT (-11)        /* 'Network could not be hierarchically sorted' bn_sort.m:23   */
+
+typedef struct emgpu_model emgpu_model; /* parsed model + priors + start (EncounterModel.m:5-70)   */
+typedef struct emgpu_ctx emgpu_ctx;     /* one device + one stream + uploaded tables               */
+
+const char *emgpu_last_error(void);
+const char *emgpu_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model: replaces em_read.m:1-206 and the data half of @EncounterModel/EncounterModel.m
+ * ---------------------------------------------------------------------------------------------- */
+
+/* em_read(parameters_filename, 'idxZeroBoundaries', idx, 'isOverwriteZeroBoundaries', flag)
+ * (em_read.m:1,41-42).  idx_zero_boundaries may be NULL (=> [1 2 3], em_read.m:42). */
+int emgpu_model_load_txt(const char *path, const int32_t *idx_zero_boundaries, int32_t n_idx,
+                         int32_t is_overwrite_zero_boundaries, emgpu_model **out);
+
+/* Build a model from caller arrays (the MATLAB struct contract of dbn_sample.m:25-33), so that
+ * MATLAB-side edits of N_initial / N_transition / boundaries propagate.
+ *   G_*: n x n row-major uint8, [parent][child] (em_read.m:204, bn_sample.m:42).
+ *   N_initial: concatenation over nodes 1..n_initial of r_i x q_i column-major counts.
+ *   N_transition: concatenation over nodes n_initial+1..n_transition (em_read.m:92).
+ *   temporal_map: n_dyn x 2 row-major (var at t, var at t+1), may be NULL when n_transition==0.
+ *   boundaries: concatenated, bnd_len[i]==0 means '*' (em_read.m:97-99).  zero_bins (0 = none)
+ *   may be NULL => derived like extract_zero_bins (em_read.m:143-156).
+ *   labels_* : '\n'-separated, may be NULL. */
+typedef struct {
+    int32_t n_initial, n_transition, n_dyn, _pad;
+    const uint8_t *G_initial, *G_transition;
+    const int32_t *r_initial, *r_transition;
+    const int32_t *temporal_map;
+    const double *N_initial;
+    int64_t n_N_initial;
+    const double *N_transition;
+    int64_t n_N_transition;
+    const double *boundaries;
+    const int32_t *bnd_len;
+    const int32_t *zero_bins;
+    const double *resample_rates;
+    const char *labels_initial, *labels_transition;
+} emgpu_model_desc;
+int emgpu_model_from_arrays(const emgpu_model_desc *d, emgpu_model **out);
+void emgpu_model_free(emgpu_model *m);
+
+typedef struct {
+    int32_t n_initial, n_transition, n_dyn;
+    int32_t is_dynvar_depend;  /* any(G_transition(dyn,dyn),'all')  dbn_sample.m:55 */
+    int64_t n_N_initial, n_N_transition;
+    int32_t max_r, n_resample_active;
+} emgpu_model_info_t;
+int emgpu_model_info(const emgpu_model *m, emgpu_model_info_t *out);
+
+/* Field access.  get_* copy into out (cap elements) and return the element count (>=0) or an
+ * error (<0); passing out==NULL returns the count only. */
+enum {
+    EMGPU_F_R_INITIAL = 1, EMGPU_F_R_TRANSITION, EMGPU_F_ORDER_INITIAL, EMGPU_F_ORDER_TRANSITION,
+    EMGPU_F_TEMPORAL_MAP,   /* n_dyn x 2 row-major                                         */
+    EMGPU_F_ZERO_BINS, EMGPU_F_START, EMGPU_F_G_INITIAL, EMGPU_F_G_TRANSITION, /* n*n row-major */
+    EMGPU_F_N_INITIAL = 32, EMGPU_F_N_TRANSITION, EMGPU_F_ALPHA_INITIAL, EMGPU_F_ALPHA_TRANSITION,
+                            /* node = 1-based variable id; r x q column-major                */
+    EMGPU_F_BOUNDARIES,     /* node = 1-based initial variable                               */
+    EMGPU_F_RESAMPLE_RATES,
+    EMGPU_F_LABELS_INITIAL = 64, EMGPU_F_LABELS_TRANSITION /* '\n'-separated, via get_text   */
+};
+int64_t emgpu_model_get_i32(const emgpu_model *m, int32_t field, int32_t *out, int64_t cap);
+int64_t emgpu_model_get_f64(const emgpu_model *m, int32_t field, int32_t node, double *out, int64_t cap);
+int64_t emgpu_model_get_text(const emgpu_model *m, int32_t field, char *out, int64_t cap);
+int emgpu_model_set_f64(emgpu_model *m, int32_t field, int32_t node, const double *v, int64_t n);
+
+/* EncounterModel.prior / set.prior (EncounterModel.m:45,194-203) -> bn_dirichlet_prior.m:18-37.
+ * kind: 0 = numeric constant `value`; 1 = 'dbe' (1/(r*q)).  Rebuilds both alpha sets. */
+int emgpu_model_set_prior(emgpu_model *m, int32_t kind, double value);
+/* setTransitionPriors.m:12-33: alpha_transition{ii}(kk, n(kk-1)+1:n*kk) = prior for every dynamic
+ * variable that has parents (used by createEncounter.m:129). */
+int emgpu_model_set_transition_stay_prior(emgpu_model *m, double prior);
+/* EncounterModel.start (EncounterModel.m:52,205-207): n_initial entries, 0 = unset ([] or NaN). */
+int emgpu_model_set_start(emgpu_model *m, const int32_t *start, int32_t n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Context
+ * ---------------------------------------------------------------------------------------------- */
+int emgpu_ctx_create(int32_t device, emgpu_ctx **out);
+/* Launch on a caller stream (a hipStream_t passed as void*; NULL = the ctx's own stream). */
+int emgpu_ctx_set_stream(emgpu_ctx *ctx, void *hip_stream);
+/* Wait for the ctx stream and report deferred per-trajectory errors of *_device calls
+ * (EMGPU_ERR_REJECT_CAP / EMGPU_ERR_EVENT_CAP). */
+int emgpu_ctx_sync(emgpu_ctx *ctx);
+void emgpu_ctx_free(emgpu_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampling: replaces UncorEncounterModel.sample (UncorEncounterModel.m:192-313) and what it calls:
+ * dbn_hierarchical_sample.m:1, dbn_sample.m:1, bn_sample.m:1, select_random.m:1, asub2ind.m:1,
+ * resample_events.m:1, dediscretize.m:1.
+ * ---------------------------------------------------------------------------------------------- */
+enum { EMGPU_TRANSITION_REFERENCE_AUTO = 0, EMGPU_TRANSITION_PER_STEP = 1 };
+#define EMGPU_FLAG_QUANTIZE500 1u /* 'isQuantize500' UncorEncounterModel.m:202,266-268            */
+#define EMGPU_FLAG_NO_RESAMPLE 2u /* skip resample_events (plain dbn_sample.m semantics)           */
+#define EMGPU_FLAG_NO_DEDISC 4u   /* skip dediscretize: values are the bin indices                 */
+#define EMGPU_FLAG_NO_TERMINATOR 8u /* event lists end without the [T-sum(dt) 0 0] row            */
+
+typedef struct {
+    uint64_t seed;        /* Philox key.  'seed' of .sample (UncorEncounterModel.m:201)            */
+    uint64_t first_index; /* global index of trajectory 0 of this call (multi-GPU sharding)        */
+    int64_t n;            /* n_samples                                                             */
+    int32_t sample_time;  /* T, seconds (>=1)                                                      */
+    int32_t transition_mode;
+    uint32_t flags;
+    int32_t max_attempts; /* rejection cap (reference: unbounded while, UncorEncounterModel.m:248) */
+    int32_t idx_L, idx_v, idx_dh; /* 1-based ids of "L","v","\dot h" (UncorEncounterModel.m:225-229);
+                                     idx_v==0 || idx_dh==0 disables the rejection test (:275)      */
+    int32_t n_layers;     /* rows of `layers` (r_L) or 0                                           */
+    const double *layers; /* n_layers x 2 row-major [lo hi] (UncorEncounterModel.m:204,259-260)    */
+    int32_t event_cap;    /* rows per trajectory in `events`                                       */
+    int32_t _pad;
+} emgpu_sample_params;
+
+/* Event row (8 bytes): what one row [dt var value] of out_events{i} carries. */
+typedef struct {
+    uint16_t dt;  /* seconds since the previous row                                               */
+    uint8_t var;  /* 1-based initial-network variable, 0 = terminator row                         */
+    uint8_t bin;  /* discrete value                                                               */
+    float value;  /* dediscretised value                                                          */
+} emgpu_event;
+
+/* Device-native outputs (time-blocked SoA; any pointer may be NULL to skip that output).
+ * G4 = ceil(T/4).  Column c of trajectory i (c = 0 is the initial state, events2samples.m:15-26):
+ *   dyn_bin[((c/4)*n_dyn + k)*n + i]        byte (c%4) of the uint32 = bin (1-based)
+ *   dyn_val[(((c/4)*n_dyn + k)*n + i)*4 + c%4]
+ * with k = row of the temporal map (ascending variable id).  Padding columns >= T are 0. */
+typedef struct {
+    uint8_t *init_bin;   /* [n_initial][n]                                                        */
+    float *init_val;     /* [n_initial][n]                                                        */
+    uint32_t *dyn_bin;   /* [G4][n_dyn][n]                                                        */
+    float *dyn_val;      /* [G4][n_dyn][n][4]                                                     */
+    uint32_t *ev_count;  /* [n] rows written (may exceed event_cap => EMGPU_ERR_EVENT_CAP)        */
+    emgpu_event *events; /* [n][event_cap]                                                        */
+    int32_t *attempts;   /* [n] attempts used by the rejection loop; <0 => cap hit                */
+} emgpu_sample_out;
+
+/* Asynchronous: enqueue on the ctx stream with DEVICE pointers in `out`; returns after launch.
+ * Deferred errors are reported by emgpu_ctx_sync. */
+int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_sample_params *p,
+                            const emgpu_sample_out *out);
+/* Synchronous convenience for the MATLAB/Python class layer: HOST pointers in `out`; allocates
+ * device buffers, runs, copies back (PCIe-inclusive; never the benchmarked path). */
+int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_sample_params *p,
+                          const emgpu_sample_out *out);
+
+/* bn_sample(G,r,N,alpha,num_samples,start,order) (bn_sample.m:1) on the initial network with an
+ * optional dediscretize + rejection stage = the geometry draw of @CorTerminalModel/sample.m:29-77.
+ * out_bin [n_initial][n] uint8, out_val [n_initial][n] float (device or host per the suffix). */
+typedef struct {
+    uint64_t seed, first_index;
+    int64_t n;
+    uint32_t flags;          /* EMGPU_FLAG_NO_DEDISC => plain bn_sample                           */
+    int32_t max_attempts;
+    const double *bounds_sample; /* n_initial x 2 row-major or NULL (sample.m:45-53)              */
+    int32_t idx_own_speed, idx_int_speed; /* 1-based; 0 = no speed test (sample.m:64-70)          */
+    double min_vel1, max_vel1, min_vel2, max_vel2;
+} emgpu_bn_params;
+int emgpu_sample_bn_device(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_bn_params *p,
+                           uint8_t *out_bin, float *out_val, int32_t *attempts);
+int emgpu_sample_bn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_bn_params *p,
+                         uint8_t *out_bin, float *out_val, int32_t *attempts);
+
+/* Introspection for benchmarks/tests: name of the kernel variant the last *_device call used and
+ * the algorithmic output bytes per trajectory of that call (5*n_i + 5*T*n_d for dense output). */
+const char *emgpu_last_kernel_name(const emgpu_ctx *ctx);
+
+/* Host helpers that mirror small reference functions (used by the class layer and tests). */
+int32_t emgpu_discretize_bayes(double x, const double *thresholds, int32_t n); /* discretize_bayes.m:14-22 */
+int64_t emgpu_asub2ind(const int32_t *siz, const int32_t *x, int32_t n);       /* asub2ind.m:13-14        */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMGPU_H */

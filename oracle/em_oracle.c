@@ -103,10 +103,14 @@ void em_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
 enum {
     EM_SEC_INIT = 1,         /* bn_sample draw of initial node: a=0, idx = var-1            */
     EM_SEC_DEDISC_INIT = 2,  /* dediscretize of initial var:    a=0, idx = var-1            */
-    EM_SEC_TRANS = 3,        /* transition draw producing column c: a = tvar-1, idx = c     */
-    EM_SEC_RES = 4,          /* resample Bernoulli of second tau:   a = var-1,  idx = tau   */
-    EM_SEC_DEDISC_RES = 5,   /* dediscretize of a resample event:   a = var-1,  idx = tau   */
-    EM_SEC_DEDISC_TRANS = 6, /* dediscretize of a transition event: a = var-1,  idx = c     */
+    /* per-second slots are keyed by the ABSOLUTE EVENT TIME at = 1..T: the time (seconds since
+     * the start) at which the row the draw produces appears in the event list; a transition
+     * at `at` produces column c = at of events2samples (0-based), a resample hit of the at-th
+     * second takes effect from column at. */
+    EM_SEC_TRANS = 3,        /* transition draw:                    a = tvar-1, idx = at    */
+    EM_SEC_RES = 4,          /* resample Bernoulli:                 a = var-1,  idx = at    */
+    EM_SEC_DEDISC_RES = 5,   /* dediscretize of a resample event:   a = var-1,  idx = at    */
+    EM_SEC_DEDISC_TRANS = 6, /* dediscretize of a transition event: a = var-1,  idx = at    */
     EM_SEC_LAYER = 7,        /* UncorEncounterModel.sample 'layers' draw: a=0, idx=0        */
     EM_SEC_GEOM_DEDISC = 8   /* CorTerminalModel.sample dediscretize: a=0, idx = var-1      */
 };
@@ -384,7 +388,7 @@ int em_resample_events(const em_model_t *m, em_rng_t *g, const int32_t *initial,
                 for (int v = 0; v < ni; v++) {
                     double rate = m->resample_rates[v];
                     double u;
-                    if (g->mode == EM_RNG_MT19937 || rate > 0.0) u = em_rand(g, EM_SEC_RES, (uint32_t)v, (uint32_t)sec);
+                    if (g->mode == EM_RNG_MT19937 || rate > 0.0) u = em_rand(g, EM_SEC_RES, (uint32_t)v, (uint32_t)(sec + 1));
                     else u = 1.0; /* Philox mode: a draw compared with rate 0 never hits; skip it */
                     ch[v] = (u < rate);
                 }
@@ -467,7 +471,7 @@ int em_dbn_hierarchical_sample(const em_model_t *m, em_rng_t *g, int sample_time
     }
     for (int ii = 0; ii < k - 1; ii++) {                                         /* :33-37 */
         em_event_t *e = &events[ii];
-        if (e->kind == 1) e->val = dedisc(m, g, e->var, e->bin, EM_SEC_DEDISC_RES, (uint32_t)(e->atime - 1));
+        if (e->kind == 1) e->val = dedisc(m, g, e->var, e->bin, EM_SEC_DEDISC_RES, (uint32_t)e->atime);
         else              e->val = dedisc(m, g, e->var, e->bin, EM_SEC_DEDISC_TRANS, (uint32_t)e->atime);
     }
     return k;

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def model_dir(tmp_path_factory):
+    """Directory with the packed models materialised as reference-format .txt files."""
+    return str(tmp_path_factory.mktemp("models_txt"))
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    from em_model_manned_bayes_amd import native
+    return native.Context(0)
