@@ -302,7 +302,7 @@ int emgpu_ctx_create(int32_t device, emgpu_ctx **out) {
 
 int emgpu_ctx_set_stream(emgpu_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail(EMGPU_ERR_ARG, "null ctx");
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream; // NULL = the HIP default (null) stream
     return EMGPU_OK;
 }
 

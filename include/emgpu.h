@@ -118,7 +118,8 @@ int emgpu_model_set_start(emgpu_model *m, const int32_t *start, int32_t n);
  * Context
  * ---------------------------------------------------------------------------------------------- */
 int emgpu_ctx_create(int32_t device, emgpu_ctx **out);
-/* Launch on a caller stream (a hipStream_t passed as void*; NULL = the ctx's own stream). */
+/* Launch on a caller stream (a hipStream_t passed as void*; NULL = the HIP default stream).
+ * A new ctx launches on its own non-blocking stream until this is called. */
 int emgpu_ctx_set_stream(emgpu_ctx *ctx, void *hip_stream);
 /* Wait for the ctx stream and report deferred per-trajectory errors of *_device calls
  * (EMGPU_ERR_REJECT_CAP / EMGPU_ERR_EVENT_CAP). */

@@ -124,6 +124,8 @@ typedef struct {
     uint32_t attempt;
     em_mt_t mt;
     uint64_t n_draws; /* statistics: number of uniforms consumed */
+    uint32_t cache_ctr[4], cache_out[4]; /* last Philox block (one block = 4 consecutive idx) */
+    int32_t cache_valid;
 } em_rng_t;
 
 void em_rng_init(em_rng_t *g, int mode, uint64_t seed) {
@@ -140,14 +142,18 @@ double em_uniform32(uint32_t x) {
     return ((double)x + 0.5) * (1.0 / 4294967296.0);
 }
 
-uint32_t em_philox_word(const em_rng_t *g, uint32_t section, uint32_t a, uint32_t idx) {
-    uint32_t ctr[4], out[4];
+uint32_t em_philox_word(em_rng_t *g, uint32_t section, uint32_t a, uint32_t idx) {
+    uint32_t ctr[4];
     ctr[0] = (uint32_t)g->gidx;
     ctr[1] = (uint32_t)(g->gidx >> 32);
     ctr[2] = g->attempt;
     ctr[3] = (section << 28) | (a << 20) | (idx >> 2);
-    em_philox4x32_10(ctr, g->key, out);
-    return out[idx & 3u];
+    if (!g->cache_valid || memcmp(ctr, g->cache_ctr, sizeof ctr) != 0) {
+        em_philox4x32_10(ctr, g->key, g->cache_out);
+        memcpy(g->cache_ctr, ctr, sizeof ctr);
+        g->cache_valid = 1;
+    }
+    return g->cache_out[idx & 3u];
 }
 
 /* One MATLAB `rand` call.  In MT mode the slot is ignored. */

@@ -35,3 +35,18 @@ def test_per_step_mode_matches_oracle(name, gpu_ctx, model_dir):
     got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, want_dense=True, want_events=True,
                                  transition_mode=L.TRANSITION_PER_STEP, **idx)
     assert_uncor_parity(got, ref, T)
+
+
+@pytest.mark.parametrize("name", FAST_MODELS)
+@pytest.mark.parametrize("T,n", [(240, 5000), (61, 1000), (3, 300), (1, 100), (4, 257)])
+def test_dense_only_fast_kernel_matches_oracle(name, T, n, gpu_ctx, model_dir):
+    """Dense-only output takes the specialised kernel (k_uncor_fast) for fast-branch models."""
+    nm, pp, _ = load_pair(name, model_dir)
+    om = O.OracleModel(pp)
+    seed, first = 0xABCDEF12345, 2**33 + 17
+    idx = uncor_indices(pp)
+    ref = O.uncor_sample(om, n, T, seed, mode=O.RNG_PHILOX, first_index=first, want_events=False)
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, first_index=first, want_dense=True, want_events=False, **idx)
+    if name != "blimp_v1" or True:
+        assert got["kernel"].startswith("k_uncor_fast"), got["kernel"]
+    assert_uncor_parity(got, ref, T)

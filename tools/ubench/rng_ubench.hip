@@ -1,0 +1,81 @@
+// tools/ubench/rng_ubench.hip -- VALU cost of counter-based RNG candidates on gfx950.
+// Each thread runs ITER dependent-free calls; reports ns per call per wave-slot and derived
+// "lane-calls/s" for the whole chip.  Not part of the product.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+template <int ROUNDS>
+__device__ __forceinline__ uint4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ (k0 + (uint32_t)r * 0x9E3779B9u);
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ (k1 + (uint32_t)r * 0xBB67AE85u);
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+__device__ __forceinline__ uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+template <int ROUNDS>
+__device__ __forceinline__ uint4 threefry(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k0, uint32_t k1) {
+    // Threefry4x32 with key {k0,k1,0,0}
+    const int R[8][2] = {{10, 26}, {11, 21}, {13, 27}, {23, 5}, {6, 20}, {17, 11}, {25, 10}, {18, 20}};
+    uint32_t ks[5] = {k0, k1, 0u, 0u, 0x1BD11BDAu ^ k0 ^ k1};
+    x0 += ks[0]; x1 += ks[1]; x2 += ks[2]; x3 += ks[3];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        if (r % 2 == 0) { x0 += x1; x1 = rotl(x1, R[r % 8][0]); x1 ^= x0; x2 += x3; x3 = rotl(x3, R[r % 8][1]); x3 ^= x2; }
+        else { x0 += x3; x3 = rotl(x3, R[r % 8][0]); x3 ^= x0; x2 += x1; x1 = rotl(x1, R[r % 8][1]); x1 ^= x2; }
+        if (r % 4 == 3) {
+            const int s = r / 4 + 1;
+            x0 += ks[s % 5]; x1 += ks[(s + 1) % 5]; x2 += ks[(s + 2) % 5]; x3 += ks[(s + 3) % 5] + s;
+        }
+    }
+    return make_uint4(x0, x1, x2, x3);
+}
+
+template <int KIND, int ROUNDS, int ITER>
+__global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t k0, uint32_t k1) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+#pragma unroll 4
+    for (int it = 0; it < ITER; it++) {
+        uint4 v = KIND == 0 ? philox<ROUNDS>(i, 0, 0, it, k0, k1) : threefry<ROUNDS>(i, 0, 0, it, k0, k1);
+        acc += (v.x < 0x1234567u) + (v.y < 0x2345678u) + (v.z < 0x3456789u) + (v.w < 0x456789Au);
+    }
+    out[i] = acc;
+}
+
+template <int KIND, int ROUNDS>
+void run(const char *name) {
+    const int ITER = 512, blocks = 256 * 16;
+    uint32_t *d;
+    hipMalloc(&d, blocks * 256 * 4);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    k<KIND, ROUNDS, ITER><<<blocks, 256>>>(d, 1, 2);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int r = 0; r < 5; r++) k<KIND, ROUNDS, ITER><<<blocks, 256>>>(d, 1, 2);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    double calls = 5.0 * blocks * 256.0 * ITER;
+    double rate = calls / (ms * 1e-3);
+    // lane-slot model: 256 CU * 4 SIMD * 32 lanes * 2.4e9 = 78.6e12 lane-instr/s
+    printf("%-18s %8.3f ms  %.3e calls/s  %.3e words/s  ~%.1f lane-slots/call (at 78.6e12/s)\n", name, ms / 5, rate, rate * 4, 78.6e12 / rate);
+    hipFree(d);
+}
+
+int main() {
+    run<0, 10>("philox4x32-10");
+    run<0, 7>("philox4x32-7");
+    run<1, 20>("threefry4x32-20");
+    run<1, 12>("threefry4x32-12");
+    return 0;
+}
