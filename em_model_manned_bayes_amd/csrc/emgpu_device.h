@@ -37,6 +37,19 @@ struct Rng {
 // word w of a block; w is compile-time or wave-uniform at every call site
 __device__ __forceinline__ uint32_t word_of(const uint4 &v, int w) { return w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w)); }
 
+// halfword j (0..7) of a block, already shifted into the HIGH half of a 32-bit word
+__device__ __forceinline__ uint32_t half_hi(const uint4 &v, int j) {
+    const uint32_t w = word_of(v, j >> 1);
+    return (j & 1) ? (w & 0xFFFF0000u) : (w << 16);
+}
+// halfword j (0..7) of a block in the LOW half
+__device__ __forceinline__ uint32_t half_lo(const uint4 &v, int j) {
+    const uint32_t w = word_of(v, j >> 1);
+    return (j & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
+// split slot: the full 32-bit draw from its primary (hi) and secondary (lo) blocks
+__device__ __forceinline__ uint32_t split_draw(const uint4 &hi, const uint4 &lo, int j) { return half_hi(hi, j) | half_lo(lo, j); }
+
 // x' of uniform32
 __device__ __forceinline__ uint32_t clamp32(uint32_t x) { return x < 0xFFFFFFFEu ? x : 0xFFFFFFFEu; }
 
@@ -61,13 +74,27 @@ __device__ __forceinline__ double dedisc_f64(const double *__restrict__ bnd, int
     return a + m;
 }
 
-// run-time (wave-uniform) index into a tiny register array without scratch
-template <int N, typename T>
-__device__ __forceinline__ T pick(const T (&a)[N], int idx) {
-    T r = a[0];
+// run-time (wave-uniform) index into a tiny register array without scratch.  Written with bit
+// masks on purpose: a ?: chain over a[q] is folded by LLVM into a variable-index load, which
+// forces the whole array into scratch/LDS.
+__device__ __forceinline__ uint32_t pick_bits(uint32_t v, bool sel) { return v & (sel ? 0xFFFFFFFFu : 0u); }
+template <int N>
+__device__ __forceinline__ int pick(const int (&a)[N], int idx) {
+    uint32_t r = 0u;
 #pragma unroll
-    for (int q = 1; q < N; q++) r = (idx == q) ? a[q] : r;
-    return r;
+    for (int q = 0; q < N; q++) r |= pick_bits((uint32_t)a[q], idx == q);
+    return (int)r;
+}
+template <int N>
+__device__ __forceinline__ double pick(const double (&a)[N], int idx) {
+    uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+    for (int q = 0; q < N; q++) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(a[q]);
+        lo |= pick_bits((uint32_t)b, idx == q);
+        hi |= pick_bits((uint32_t)(b >> 32), idx == q);
+    }
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 template <int N, typename T>
 __device__ __forceinline__ void put(T (&a)[N], int idx, T v) {
@@ -93,10 +120,9 @@ __device__ __forceinline__ int32_t init_network(const EmgpuPlan &P, const EmgpuR
         int wblk = -1;
 #pragma unroll
         for (int p = 0; p < NI; p++) {
-            if (p >= P.ni) continue;
-            if (P.i_start[p] != 0) { // bn_sample.m:44-50
+            if (p < P.ni && P.i_start[p] != 0) { // bn_sample.m:44-50
                 bin[p] = (int)P.i_start[p] - 1;
-            } else {
+            } else if (p < P.ni) {
                 uint32_t col = 0; // asub2ind.m:13-14 as strides
 #pragma unroll
                 for (int q = 0; q < p; q++) col += P.i_stride[p][q] * (uint32_t)bin[q];
@@ -110,9 +136,8 @@ __device__ __forceinline__ int32_t init_network(const EmgpuPlan &P, const EmgpuR
         wblk = -1;
 #pragma unroll
         for (int p = 0; p < NI; p++) {
-            if (p >= P.ni) continue;
             double v = (double)(bin[p] + 1);
-            if (!no_dedisc && P.i_nb[p] != 0 && !P.i_skip[p]) {
+            if (p < P.ni && !no_dedisc && P.i_nb[p] != 0 && !P.i_skip[p]) {
                 const int var = P.i_var[p];
                 if ((var >> 2) != wblk) { wblk = var >> 2; wc = rng.block(EMGPU_SEC_DEDISC_INIT, 0u, (uint32_t)wblk); }
                 v = (P.i_zero[p] == bin[p] + 1) ? 0.0 : dedisc_f64(P.bnd, P.i_boff[p], bin[p], word_of(wc, var & 3));

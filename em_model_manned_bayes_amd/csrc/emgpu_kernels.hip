@@ -85,33 +85,44 @@ __global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const Em
     };
 
     const int G4 = (T + 3) >> 2;
-    const int Gloop = (want_events && !no_resample) ? (T >> 2) + 1 : G4;
-    for (int g = 0; g < Gloop; g++) {
-        uint4 tw[ND], rw[NA];
+    const int G8 = (want_events && !no_resample) ? (T >> 3) + 1 : (T + 7) >> 3;
+    for (int g8 = 0; g8 < G8; g8++) {
+        // split slots (TRANS, RES): primary and secondary block of the 8 seconds 8*g8 .. 8*g8+7
+        uint4 th[ND], tl[ND], rh[NA], rl[NA];
 #pragma unroll
         for (int k = 0; k < ND; k++) {
-            tw[k] = make_uint4(0, 0, 0, 0);
-            if (k < P.nd) tw[k] = rng.block(EMGPU_SEC_TRANS, P.d_tvar[k], (uint32_t)g);
+            th[k] = tl[k] = make_uint4(0, 0, 0, 0);
+            if (k < P.nd) {
+                th[k] = rng.block(EMGPU_SEC_TRANS, P.d_tvar[k], (uint32_t)g8);
+                tl[k] = rng.block(EMGPU_SEC_TRANS_LO, P.d_tvar[k], (uint32_t)g8);
+            }
         }
 #pragma unroll
         for (int a = 0; a < NA; a++) {
-            rw[a] = make_uint4(0, 0, 0, 0);
-            if (a < P.nact && !no_resample) rw[a] = rng.block(EMGPU_SEC_RES, P.a_var[a], (uint32_t)g);
+            rh[a] = rl[a] = make_uint4(0, 0, 0, 0);
+            if (a < P.nact && !no_resample) {
+                rh[a] = rng.block(EMGPU_SEC_RES, P.a_var[a], (uint32_t)g8);
+                rl[a] = rng.block(EMGPU_SEC_RES_LO, P.a_var[a], (uint32_t)g8);
+            }
         }
-        uint32_t pb[ND];
-        float pv[ND][4];
+        uint32_t pb[ND][2];
+        float pv[ND][2][4];
 #pragma unroll
-        for (int k = 0; k < ND; k++) { pb[k] = 0; pv[k][0] = pv[k][1] = pv[k][2] = pv[k][3] = 0.f; }
+        for (int k = 0; k < ND; k++)
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const int c = 4 * g + w; // absolute event time == column produced
+            for (int h = 0; h < 2; h++) { pb[k][h] = 0; pv[k][h][0] = pv[k][h][1] = pv[k][h][2] = pv[k][h][3] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = 8 * g8 + j; // absolute event time == column produced
+            const int w = j & 3, hb = j >> 2;
+            const uint32_t g4 = (uint32_t)(2 * g8 + hb); // word-slot block of time c
             if (c >= 1 && c <= T) {
                 // ---- resample_events.m:23-29: hits of the c-th second, ascending variable id
                 if (!no_resample) {
 #pragma unroll
                     for (int a = 0; a < NA; a++) {
                         if (a >= P.nact) continue;
-                        const bool hit = clamp32(word_of(rw[a], w)) < P.a_R[a];
+                        const bool hit = clamp32(split_draw(rh[a], rl[a], j)) < P.a_R[a];
                         const int k = P.a_dyn[a];
                         const int b0 = (k >= 0) ? pick<ND>(cur, k) : pick<NI>(bin, P.a_pos[a]);
                         if (hit) {
@@ -120,7 +131,7 @@ __global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const Em
                             if (!no_dedisc && nb != 0) {
                                 if (zero == b0 + 1) v = 0.f;
                                 else v = (float)dedisc_f64(P.bnd, P.i_boff[P.a_pos[a]], b0,
-                                                           word_of(rng.block(EMGPU_SEC_DEDISC_RES, P.a_var[a], (uint32_t)g), w));
+                                                           word_of(rng.block(EMGPU_SEC_DEDISC_RES, P.a_var[a], g4), w));
                             }
                             if (k >= 0) put<ND>(cval, k, v);
                             if (want_events) emit(c, (int)P.a_var[a] + 1, b0 + 1, v);
@@ -143,7 +154,7 @@ __global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const Em
                             for (int q = 0; q < k; q++) col += P.d_stride_new[k][q] * (uint32_t)nbin[q];
                             t = P.thr + P.d_off[k] + (size_t)col * (uint32_t)(P.d_r[k] - 1);
                         }
-                        nbin[k] = draw_bin(t, P.d_r[k], word_of(tw[k], w));
+                        nbin[k] = draw_bin(t, P.d_r[k], split_draw(th[k], tl[k], j));
                     }
                     // map back (:82/:149) and event rows in ascending variable id (:84-91/:151-161)
 #pragma unroll
@@ -157,7 +168,7 @@ __global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const Em
                             if (!no_dedisc && nb != 0) {
                                 if (zero == nbk + 1) v = 0.f;
                                 else v = (float)dedisc_f64(P.bnd, P.d_boff[k], nbk,
-                                                           word_of(rng.block(EMGPU_SEC_DEDISC_TRANS, P.d_ivar[k], (uint32_t)g), w));
+                                                           word_of(rng.block(EMGPU_SEC_DEDISC_TRANS, P.d_ivar[k], g4), w));
                             }
                             put<ND>(cur, k, nbk);
                             put<ND>(cval, k, v);
@@ -169,18 +180,21 @@ __global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const Em
             if (c < T) { // events2samples.m:15-26 column c
 #pragma unroll
                 for (int k = 0; k < ND; k++) {
-                    pb[k] |= (uint32_t)(cur[k] + 1) << (8 * w);
-                    pv[k][w] = cval[k];
+                    pb[k][hb] |= (uint32_t)(cur[k] + 1) << (8 * w);
+                    pv[k][hb][w] = cval[k];
                 }
             }
         }
-        if (g < G4) {
+#pragma unroll
+        for (int hb = 0; hb < 2; hb++) {
+            const int g = 2 * g8 + hb;
+            if (g >= G4) continue;
 #pragma unroll
             for (int k = 0; k < ND; k++) {
                 if (k >= P.nd) continue;
                 const size_t o = ((size_t)g * P.nd + P.d_row[k]) * (size_t)A.n + (size_t)i;
-                if (A.dyn_bin) A.dyn_bin[o] = pb[k];
-                if (A.dyn_val) reinterpret_cast<float4 *>(A.dyn_val)[o] = make_float4(pv[k][0], pv[k][1], pv[k][2], pv[k][3]);
+                if (A.dyn_bin) A.dyn_bin[o] = pb[k][hb];
+                if (A.dyn_val) reinterpret_cast<float4 *>(A.dyn_val)[o] = make_float4(pv[k][hb][0], pv[k][hb][1], pv[k][hb][2], pv[k][hb][3]);
             }
         }
     }

@@ -1,14 +1,22 @@
 // emgpu_kernels_fast.hip -- the benchmarked kernel: uncorrelated DBN, REFERENCE_AUTO semantics on a
 // "fast-branch" model (dbn_sample.m:95-166: parent configuration frozen at the initial state),
-// compact dense trace output.  One lane = one trajectory, 3 dynamic variables.
+// compact dense trace output.  One lane = one trajectory, 3 dynamic variables, 8 seconds per
+// loop iteration.
 //
-// Per trajectory and 4-second block: 3 Philox calls for the transition draws (dbn_sample.m:133,144),
-// 3 for the resample Bernoullis of the dynamic variables (resample_events.m:24; variables that are
-// not dynamic cannot change the dense trace, SURVEY.md section 8d scope note), u32 threshold compares on
-// register-resident quantile thresholds (select_random.m:17-20), rare dediscretize draws
-// (dediscretize.m:39) and one 4-byte + one 16-byte store per variable (time-blocked SoA).
+// Work per trajectory and 8-second block
+//   * 6 Philox4x32-10 calls: the PRIMARY (high) halfwords of the 24 transition draws
+//     (dbn_sample.m:133,144) and 24 resample Bernoullis (resample_events.m:24) of the dynamic
+//     variables.  Variables that are not dynamic cannot change the dense trace.
+//     A draw is decided from its high 16 bits alone unless they tie with a threshold's high half
+//     (p ~ 1e-4 per draw); only then are the SECONDARY (low) halfwords fetched and the 8 seconds
+//     of that variable redone exactly -- the value drawn is the same 32-bit uniform either way.
+//   * u32 compares against register-resident quantile thresholds (select_random.m:17-20).
+//   * the rare dediscretize draws (dediscretize.m:39; ~0.3 per lane and block) are compacted
+//     across the 64 lanes of the wave through LDS and computed by "worker" lanes: one Philox call
+//     per wave serves them all instead of one divergent call per event.
+//   * 2 x (4-byte + 16-byte) stores per variable: time-blocked SoA, 1 KiB contiguous per wave store.
 // Bound: HBM writes (3635 B / trajectory) co-limited by the integer multiplies of Philox4x32-10
-// (DESIGN.md section 5); no MFMA: there is no contraction on this path.
+// (DESIGN.md section 5).  No MFMA: there is no contraction on this path.
 #include <hip/hip_runtime.h>
 
 #include "emgpu_device.h"
@@ -17,17 +25,22 @@
 namespace emgpu {
 
 struct FastArgs {
-    uint32_t Rk[3];   // resample hit threshold of dynamic variable k (0 = rate 0)
+    uint32_t Rk[3];   // resample hit threshold of dynamic variable k (0 = rate 0), < 0xFFFFFFFF
     uint32_t slot[3]; // output row of dynamic variable k
 };
 
-template <int R>
-__device__ __forceinline__ int draw_reg(const uint32_t (&th)[R - 1], uint32_t x) {
-    const uint32_t xp = clamp32(x);
-    int b = 0;
-#pragma unroll
-    for (int j = 0; j < R - 1; j++) b += (xp >= th[j]) ? 1 : 0;
-    return b;
+constexpr int kQueueCap = 192; // request descriptors per wave and compaction round
+constexpr int kResStride = 28; // floats per lane in the result area (24 used; 28 keeps b128 reads conflict-free)
+
+struct WaveLds {
+    uint32_t queue[kQueueCap];
+    float res[64 * kResStride];
+    uint32_t attempt[64];
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 template <int R>
@@ -36,34 +49,132 @@ __device__ __forceinline__ void load_thr(uint32_t (&th)[R - 1], const uint32_t *
     for (int j = 0; j < R - 1; j++) th[j] = p[j];
 }
 
+// Eight seconds of one dynamic variable.  Outputs: bins packed 1-based 4 per word (pbA: seconds
+// 0-3, pbB: 4-7) and three 8-bit flag streams, MSB-first (bit 7-j belongs to second j):
+//   hit8  -- resample Bernoulli hit (resample_events.m:24)
+//   chg8  -- the transition draw changed the bin (dbn_sample.m:151-161)
+//   zer8  -- the bin after the draw is the zero bin (dediscretize.m:24-25)
+// EXACT = false: decide from the high halfwords only and report `amb` when some compare could
+// flip with the low halfword; EXACT = true: full 32-bit draws.  Every flag is accumulated with
+// x = x + x + carry so that one v_cmp + one v_addc serve per flag and second.
+template <int R, bool EXACT>
+__device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 &rh, const uint4 &tl, const uint4 &rl, int g8, int T,
+                                                   const uint32_t (&thr)[R - 1], uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
+                                                   uint32_t &cur_out, uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
+    bool amb = false;
+    uint32_t c1 = cur_in;
+    pbA = pbB = hit8 = chg8 = zer8 = 0u;
+    const uint32_t Rhi = Rres & 0xFFFF0000u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = 8 * g8 + j; // absolute event time == column produced
+        uint32_t h = 0u, ch = 0u, z = 0u;
+        if (c >= 1 && c < T) {   // wave-uniform
+            uint32_t xr = half_hi(rh, j), xt = half_hi(th, j);
+            if (EXACT) { xr |= half_lo(rl, j); xt = clamp32(xt | half_lo(tl, j)); }
+            h = (xr < Rres) ? 1u : 0u;
+            uint32_t borrows = 0u, dmax = 0u;
+#pragma unroll
+            for (int t = 0; t < R - 1; t++) {                 // select_random.m:19-20 on thresholds
+                borrows += (xt < thr[t]) ? 1u : 0u;
+                const uint32_t d = xt - thr[t];
+                dmax = d > dmax ? d : dmax;
+            }
+            if (!EXACT) amb = amb | (xr == Rhi) | (dmax >= 0xFFFF0001u);
+            const uint32_t nb1 = (uint32_t)R - borrows;       // 1 + #{t : xt >= thr[t]}  (dbn_sample.m:144)
+            ch = (nb1 != c1) ? 1u : 0u;
+            c1 = nb1;                                         // map back, dbn_sample.m:149
+            z = (nb1 == zbin1) ? 1u : 0u;
+        }
+        hit8 = hit8 + hit8 + h;
+        chg8 = chg8 + chg8 + ch;
+        zer8 = zer8 + zer8 + z;
+        const uint32_t b = (c < T) ? (c1 << (8 * (j & 3))) : 0u;
+        if (j < 4) pbA |= b; else pbB |= b;
+    }
+    cur_out = c1;
+    return amb;
+}
+
+// rare path, kept out of line so that the hot loop stays small in the instruction cache
+template <int R>
+__device__ __attribute__((noinline)) void eight_seconds_exact(uint32_t c0, uint32_t c1r, uint32_t attempt, uint32_t k0, uint32_t k1,
+                                                              uint4 th, uint4 rh, uint32_t tvar, uint32_t ivar, int g8, int T,
+                                                              const uint32_t *thr_in, uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
+                                                              uint32_t *out /* cur, pbA, pbB, hit8, chg8, zer8 */) {
+    const Rng rng{c0, c1r, attempt, k0, k1};
+    const uint4 tl = rng.block(EMGPU_SEC_TRANS_LO, tvar, (uint32_t)g8);
+    const uint4 rl = rng.block(EMGPU_SEC_RES_LO, ivar, (uint32_t)g8);
+    uint32_t thr[R - 1];
+#pragma unroll
+    for (int t = 0; t < R - 1; t++) thr[t] = thr_in[t];
+    uint32_t cur, a, b, h, c, z;
+    eight_seconds_pass<R, true>(th, rh, tl, rl, g8, T, thr, Rres, zbin1, cur_in, cur, a, b, h, c, z);
+    out[0] = cur; out[1] = a; out[2] = b; out[3] = h; out[4] = c; out[5] = z;
+}
+
+template <int R>
+__device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uint32_t ivar, int g8, int T,
+                                              const uint32_t (&thr)[R - 1], uint32_t Rres, uint32_t zbin1, uint32_t &cur1,
+                                              uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
+    const uint4 th = rng.block(EMGPU_SEC_TRANS, tvar, (uint32_t)g8);
+    const uint4 rh = rng.block(EMGPU_SEC_RES, ivar, (uint32_t)g8);
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    uint32_t cur_out;
+    const bool amb = eight_seconds_pass<R, false>(th, rh, z4, z4, g8, T, thr, Rres, zbin1, cur1, cur_out, pbA, pbB, hit8, chg8, zer8);
+    // If ANY lane of the wave met a tie, every lane recomputes exactly from the full 32-bit draws
+    // (lanes without a tie get the same answers again): control flow stays wave-uniform.
+    if (__ballot(amb) != 0ull) {
+        uint32_t tmp[R - 1], out[6];
+#pragma unroll
+        for (int t = 0; t < R - 1; t++) tmp[t] = thr[t];
+        eight_seconds_exact<R>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, tmp, Rres, zbin1, cur1, out);
+        cur_out = out[0]; pbA = out[1]; pbB = out[2]; hit8 = out[3]; chg8 = out[4]; zer8 = out[5];
+    }
+    cur1 = cur_out;
+}
+
 template <int NI, int R0, int R1, int R2>
-__global__ void __launch_bounds__(256) k_uncor_fast(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= A.n) return;
+__global__ void __launch_bounds__(256, 4) k_uncor_fast(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
+    __shared__ WaveLds s_wave[4];
+    __shared__ double s_bnd[3][16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    WaveLds &W = s_wave[tid >> 6];
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    const bool valid = i < A.n; // lanes past the end stay alive: they serve as workers for their wave
     const uint64_t gidx = A.first_index + (uint64_t)i;
     Rng rng{(uint32_t)gidx, (uint32_t)(gidx >> 32), 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
     const int T = A.T;
+    if (tid < 48) {
+        const int k = tid >> 4, q = tid & 15;
+        s_bnd[k][q] = (q < (int)P.d_nb[k]) ? P.bnd[P.d_boff[k] + q] : 0.0;
+    }
 
     int bin[NI];
     double val[NI];
 #pragma unroll
     for (int p = 0; p < NI; p++) { bin[p] = 0; val[p] = 0.0; }
     const int32_t attempts_used = init_network<NI>(P, A, rng, bin, val);
-    if (attempts_used < 0) atomicOr(A.status, 1u);
-    if (A.attempts) A.attempts[i] = attempts_used;
+    if (valid) {
+        if (attempts_used < 0) atomicOr(A.status, 1u);
+        if (A.attempts) A.attempts[i] = attempts_used;
 #pragma unroll
-    for (int p = 0; p < NI; p++) {
-        if (p >= P.ni) continue;
-        if (A.init_bin) A.init_bin[(size_t)P.i_var[p] * A.n + i] = (uint8_t)(bin[p] + 1);
-        if (A.init_val) A.init_val[(size_t)P.i_var[p] * A.n + i] = (float)val[p];
+        for (int p = 0; p < NI; p++) {
+            if (p < P.ni) {
+                if (A.init_bin) A.init_bin[(size_t)P.i_var[p] * A.n + i] = (uint8_t)(bin[p] + 1);
+                if (A.init_val) A.init_val[(size_t)P.i_var[p] * A.n + i] = (float)val[p];
+            }
+        }
     }
+    W.attempt[lane] = rng.attempt;
+    __syncthreads(); // s_bnd visible to every wave (the only block-wide barrier)
 
     // frozen parent configuration -> one CPT column per dynamic variable (dbn_sample.m:110-135)
-    int cur[3];
+    uint32_t cur1[3];
     float cval[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        cur[k] = pick<NI>(bin, P.d_ipos[k]);
+        cur1[k] = (uint32_t)pick<NI>(bin, P.d_ipos[k]) + 1u;
         cval[k] = (float)pick<NI>(val, P.d_ipos[k]);
     }
     uint32_t th0[R0 - 1], th1[R1 - 1], th2[R2 - 1];
@@ -75,59 +186,110 @@ __global__ void __launch_bounds__(256) k_uncor_fast(const EmgpuPlan P, const Emg
 #pragma unroll
             for (int p = 0; p < NI; p++) c += P.d_stride_static[k][p] * (uint32_t)bin[p];
 #pragma unroll
-            for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)cur[q];
+            for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)(cur1[q] - 1);
             col[k] = c;
         }
         load_thr<R0>(th0, P.thr + P.d_off[0] + (size_t)col[0] * (R0 - 1));
         load_thr<R1>(th1, P.thr + P.d_off[1] + (size_t)col[1] * (R1 - 1));
         load_thr<R2>(th2, P.thr + P.d_off[2] + (size_t)col[2] * (R2 - 1));
     }
+    const uint32_t iv0 = P.d_ivar[0], iv1 = P.d_ivar[1], iv2 = P.d_ivar[2];
 
-    const int G4 = (T + 3) >> 2;
-    for (int g = 0; g < G4; g++) {
-        uint4 tw[3], rw[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            tw[k] = rng.block(EMGPU_SEC_TRANS, P.d_tvar[k], (uint32_t)g);
-            rw[k] = rng.block(EMGPU_SEC_RES, P.d_ivar[k], (uint32_t)g);
-        }
-        uint32_t pb[3] = {0u, 0u, 0u};
-        float pv[3][4];
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const int c = 4 * g + w; // absolute event time == column produced
-            if (c >= 1 && c < T) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const bool hit = clamp32(word_of(rw[k], w)) < F.Rk[k];                 // resample_events.m:24
-                    const int nb = k == 0 ? draw_reg<R0>(th0, word_of(tw[0], w))
-                                 : k == 1 ? draw_reg<R1>(th1, word_of(tw[1], w))
-                                          : draw_reg<R2>(th2, word_of(tw[2], w));         // dbn_sample.m:144
-                    const bool changed = nb != cur[k];
-                    cur[k] = nb;                                                           // map back, dbn_sample.m:149
-                    const bool zero = (int)P.d_zero[k] == nb + 1;                          // dediscretize.m:24-25
-                    if (changed && zero) cval[k] = 0.f;
-                    if ((changed || hit) && !zero) {
-                        // a transition event hides a resample event of the same second in the dense trace
-                        const uint32_t sec = changed ? EMGPU_SEC_DEDISC_TRANS : EMGPU_SEC_DEDISC_RES;
-                        const uint4 dw = rng.block(sec, P.d_ivar[k], (uint32_t)g);
-                        cval[k] = (float)dedisc_f64(P.bnd, P.d_boff[k], nb, word_of(dw, w));  // dediscretize.m:39
-                    }
-                }
-            }
+    const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
+    for (int g8 = 0; g8 < G8; g8++) {
+        uint32_t pbA[3], pbB[3], need8[3], kind8[3], zero8[3];
+        {
+            uint32_t hit8[3], chg8[3], zer8[3];
+            eight_seconds<R0>(rng, P.d_tvar[0], iv0, g8, T, th0, F.Rk[0], (uint32_t)P.d_zero[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
+            eight_seconds<R1>(rng, P.d_tvar[1], iv1, g8, T, th1, F.Rk[1], (uint32_t)P.d_zero[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
+            eight_seconds<R2>(rng, P.d_tvar[2], iv2, g8, T, th2, F.Rk[2], (uint32_t)P.d_zero[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const bool live = c < T;
-                pb[k] |= live ? ((uint32_t)(cur[k] + 1) << (8 * w)) : 0u;
-                pv[k][w] = live ? cval[k] : 0.f;
+                // flag streams are MSB-first: bit (7-j) <-> second j; turn them into bit j <-> second j
+                const uint32_t h = __brev(hit8[k]) >> 24, c = __brev(chg8[k]) >> 24, z = __brev(zer8[k]) >> 24;
+                need8[k] = (h | c) & ~z;   // a dediscretize draw is due (dediscretize.m:24-39)
+                kind8[k] = c;              // 1 = transition event (it hides a resample event of the same second)
+                zero8[k] = c & z;          // changed into the zero bin: value 0, no draw
             }
         }
+        const uint32_t need24 = valid ? (need8[0] | (need8[1] << 8) | (need8[2] << 16)) : 0u;
+        const uint32_t kind24 = kind8[0] | (kind8[1] << 8) | (kind8[2] << 16);
+
+        // ---- wave-cooperative dediscretize (dediscretize.m:39) of the flagged positions s = 8k + j
+        uint32_t m = need24;
+        unsigned long long bal = __ballot(m != 0u);
+        while (bal != 0ull) {
+            uint32_t base = 0u; // wave-uniform number of queued requests in this round
+            while (bal != 0ull && base + 64u <= (uint32_t)kQueueCap) {
+                if (m != 0u) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    const uint32_t s = (uint32_t)__ffs((int)m) - 1u;
+                    const uint32_t k = s >> 3, j = s & 7u;
+                    const uint32_t wA = k == 0 ? pbA[0] : (k == 1 ? pbA[1] : pbA[2]);
+                    const uint32_t wB = k == 0 ? pbB[0] : (k == 1 ? pbB[1] : pbB[2]);
+                    const uint32_t b1 = (((j & 4u) ? wB : wA) >> (8u * (j & 3u))) & 0xFFu;
+                    W.queue[base + rank] = (uint32_t)lane | (s << 6) | (((kind24 >> s) & 1u) << 11) | (b1 << 12);
+                    m &= m - 1u;
+                }
+                base += (uint32_t)__popcll(bal);
+                bal = __ballot(m != 0u);
+            }
+            wave_sync();
+            for (uint32_t q0 = 0u; q0 < base; q0 += 64u) {
+                const uint32_t q = q0 + (uint32_t)lane;
+                if (q < base) {
+                    const uint32_t d = W.queue[q];
+                    const uint32_t owner = d & 63u, s = (d >> 6) & 31u, kind = (d >> 11) & 1u, b1 = (d >> 12) & 63u;
+                    const uint32_t k = s >> 3, j = s & 7u;
+                    const uint64_t go = gidx - (uint64_t)lane + (uint64_t)owner;
+                    const uint32_t ivar = k == 0 ? iv0 : (k == 1 ? iv1 : iv2);
+                    const uint32_t sec = kind ? EMGPU_SEC_DEDISC_TRANS : EMGPU_SEC_DEDISC_RES;
+                    const uint4 r4 = philox4x32_10((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner],
+                                                   (sec << 28) | (ivar << 20) | (uint32_t)(2 * g8 + (int)(j >> 2)), rng.k0, rng.k1);
+                    const uint32_t w = j & 3u;
+                    const uint32_t x = w == 0 ? r4.x : (w == 1 ? r4.y : (w == 2 ? r4.z : r4.w));
+                    double v;
+                    {
+#pragma clang fp contract(off)
+                        const double a = s_bnd[k][b1 - 1u], b = s_bnd[k][b1];
+                        const double dd = b - a;
+                        const double mm = dd * uniform32(x);
+                        v = a + mm;
+                    }
+                    W.res[owner * kResStride + s] = (float)v;
+                }
+            }
+            wave_sync();
+            bal = __ballot(m != 0u);
+        }
+
+        // ---- values: forward fill across the 8 seconds, then the two 4-second output blocks
+        const float4 *rp = reinterpret_cast<const float4 *>(&W.res[lane * kResStride]);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const size_t o = ((size_t)g * 3 + F.slot[k]) * (size_t)A.n + (size_t)i;
-            if (A.dyn_bin) A.dyn_bin[o] = pb[k];
-            if (A.dyn_val) reinterpret_cast<float4 *>(A.dyn_val)[o] = make_float4(pv[k][0], pv[k][1], pv[k][2], pv[k][3]);
+            const float4 ra = rp[2 * k], rb = rp[2 * k + 1];
+            const float r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+            float pv[8];
+            float v = cval[k];
+            const uint32_t nd8 = valid ? need8[k] : 0u, z8 = zero8[k];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                v = ((nd8 >> j) & 1u) ? r[j] : (((z8 >> j) & 1u) ? 0.f : v);
+                pv[j] = (8 * g8 + j < T) ? v : 0.f;
+            }
+            cval[k] = v;
+            if (valid) {
+                const size_t o = ((size_t)(2 * g8) * 3 + F.slot[k]) * (size_t)A.n + (size_t)i;
+                if (A.dyn_bin) A.dyn_bin[o] = pbA[k];
+                if (A.dyn_val) reinterpret_cast<float4 *>(A.dyn_val)[o] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                if (2 * g8 + 1 < G4) {
+                    const size_t o2 = o + (size_t)3 * (size_t)A.n;
+                    if (A.dyn_bin) A.dyn_bin[o2] = pbB[k];
+                    if (A.dyn_val) reinterpret_cast<float4 *>(A.dyn_val)[o2] = make_float4(pv[4], pv[5], pv[6], pv[7]);
+                }
+            }
         }
+        wave_sync(); // results of this block are consumed before the next block's workers overwrite them
     }
 }
 
@@ -135,8 +297,11 @@ bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     if (P.nd != 3 || P.depend || A.per_step) return false;
     if (A.ev_count != nullptr || A.events != nullptr) return false;
     if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
-    for (int k = 0; k < 3; k++)
-        if (P.d_nb[k] == 0) return false;
+    for (int k = 0; k < 3; k++) {
+        if (P.d_nb[k] == 0 || P.d_nb[k] > 16) return false;
+        for (int a = 0; a < P.nact; a++)
+            if (P.a_dyn[a] == k && P.a_R[a] == 0xFFFFFFFFu) return false; // rate ~ 1: generic path
+    }
     const int r0 = P.d_r[0], r1 = P.d_r[1], r2 = P.d_r[2];
     if (P.ni <= 7 && r0 == 5 && r1 == 7 && r2 == 7) return true;
     if (P.ni <= 7 && r0 == 5 && r1 == 9 && r2 == 7) return true;

@@ -18,7 +18,7 @@
 
 // ---- RNG slot map -------------------------------------------------------
 // Philox4x32-10, key = {seed_lo, seed_hi},
-// ctr = {gidx_lo, gidx_hi, attempt, section<<28 | a<<20 | (idx>>2)}, word = idx & 3.
+// ctr = {gidx_lo, gidx_hi, attempt, section<<28 | a<<20 | block}.
 // uniform: x' = min(x, 2^32-2); u = (x' + 0.5) * 2^-32.
 #define EMGPU_SEC_INIT 1u
 #define EMGPU_SEC_DEDISC_INIT 2u
@@ -28,6 +28,12 @@
 #define EMGPU_SEC_DEDISC_TRANS 6u
 #define EMGPU_SEC_LAYER 7u
 #define EMGPU_SEC_GEOM_DEDISC 8u
+// TRANS and RES are SPLIT slots: x = (H << 16) | L, H = halfword (idx & 7) of block
+// (section, a, idx >> 3), L = halfword (idx & 7) of block (section + 6, a, idx >> 3); halfword h of
+// a block = word h >> 1, upper 16 bits when h is odd, lower 16 bits when h is even.  Every other
+// section is a WORD slot: word (idx & 3) of block (section, a, idx >> 2).
+#define EMGPU_SEC_TRANS_LO 9u
+#define EMGPU_SEC_RES_LO 10u
 
 struct EmgpuPlan {
     int32_t ni, nd, nact, depend; // depend: is_dynvar_depend (dbn_sample.m:55)

@@ -112,7 +112,14 @@ enum {
     EM_SEC_DEDISC_RES = 5,   /* dediscretize of a resample event:   a = var-1,  idx = at    */
     EM_SEC_DEDISC_TRANS = 6, /* dediscretize of a transition event: a = var-1,  idx = at    */
     EM_SEC_LAYER = 7,        /* UncorEncounterModel.sample 'layers' draw: a=0, idx=0        */
-    EM_SEC_GEOM_DEDISC = 8   /* CorTerminalModel.sample dediscretize: a=0, idx = var-1      */
+    EM_SEC_GEOM_DEDISC = 8,  /* CorTerminalModel.sample dediscretize: a=0, idx = var-1      */
+    /* TRANS and RES are SPLIT slots: the 32-bit draw is x = (H << 16) | L where H is halfword
+     * (idx & 7) of block (section, a, idx >> 3) and L is halfword (idx & 7) of block
+     * (section + 6, a, idx >> 3).  Halfword h of a block: word h >> 1, upper 16 bits when h is
+     * odd, lower 16 bits when h is even.  (A kernel can decide almost every compare from H alone
+     * and fetch L lazily; the value drawn is the same full 32-bit uniform either way.) */
+    EM_SEC_TRANS_LO = 9,
+    EM_SEC_RES_LO = 10
 };
 
 enum { EM_RNG_MT19937 = 0, EM_RNG_PHILOX = 1 };
@@ -156,10 +163,26 @@ uint32_t em_philox_word(em_rng_t *g, uint32_t section, uint32_t a, uint32_t idx)
     return g->cache_out[idx & 3u];
 }
 
+static uint32_t em_philox_half(em_rng_t *g, uint32_t section, uint32_t a, uint32_t idx) {
+    uint32_t ctr[4], out[4];
+    const uint32_t h = idx & 7u;
+    ctr[0] = (uint32_t)g->gidx;
+    ctr[1] = (uint32_t)(g->gidx >> 32);
+    ctr[2] = g->attempt;
+    ctr[3] = (section << 28) | (a << 20) | (idx >> 3);
+    em_philox4x32_10(ctr, g->key, out);
+    return (h & 1u) ? (out[h >> 1] >> 16) : (out[h >> 1] & 0xFFFFu);
+}
+
 /* One MATLAB `rand` call.  In MT mode the slot is ignored. */
 static double em_rand(em_rng_t *g, uint32_t section, uint32_t a, uint32_t idx) {
     g->n_draws++;
     if (g->mode == EM_RNG_MT19937) return mt_res53(&g->mt);
+    if (section == EM_SEC_TRANS || section == EM_SEC_RES) { /* split slot */
+        const uint32_t hi = em_philox_half(g, section, a, idx);
+        const uint32_t lo = em_philox_half(g, section + 6u, a, idx);
+        return em_uniform32((hi << 16) | lo);
+    }
     return em_uniform32(em_philox_word(g, section, a, idx));
 }
 
