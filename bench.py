@@ -51,7 +51,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from em_model_manned_bayes_amd import em_io, native, _lib as L
+    from em_model_manned_bayes_amd import em_io, native, sharding, _lib as L
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -82,7 +82,7 @@ def main():
     mode = L.TRANSITION_PER_STEP if args.per_step else L.TRANSITION_REFERENCE_AUTO
 
     def step(k):
-        first = (k * world + rank) * n  # fresh global indices every step, disjoint across ranks
+        first = sharding.step_first_index(k, rank, world, n)  # fresh global indices every step, disjoint across ranks
         p, _ = native.make_params(n, T, SEED, first_index=first, transition_mode=mode,
                                   idx_L=lab("L"), idx_v=lab("v"), idx_dh=lab("\\dot h"))
         native.sample_dbn_device(ctx, model, p, init_bin=init_bin.data_ptr(), init_val=init_val.data_ptr(),

@@ -83,6 +83,7 @@ SYMBOLS = [
     "emgpu_ctx_create", "emgpu_ctx_set_stream", "emgpu_ctx_sync", "emgpu_ctx_free",
     "emgpu_sample_dbn_device", "emgpu_sample_dbn_host", "emgpu_sample_bn_device", "emgpu_sample_bn_host",
     "emgpu_last_kernel_name", "emgpu_discretize_bayes", "emgpu_asub2ind",
+    "emgpu_debug_column_thresholds", "emgpu_debug_bernoulli_threshold",
 ]
 
 _lib = None
@@ -131,6 +132,9 @@ def lib():
     L.emgpu_discretize_bayes.restype = C.c_int32
     L.emgpu_asub2ind.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.emgpu_asub2ind.restype = C.c_int64
+    L.emgpu_debug_column_thresholds.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.emgpu_debug_bernoulli_threshold.argtypes = [C.c_double]
+    L.emgpu_debug_bernoulli_threshold.restype = C.c_uint32
     _lib = L
     return L
 

@@ -527,6 +527,14 @@ int emgpu_sample_bn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_bn_pa
     EMGPU_CATCH
 }
 
+int emgpu_debug_column_thresholds(const double *weights, int32_t r, uint32_t *out) {
+    if (!weights || !out || r < 1 || r > EMGPU_MAX_R) return fail(EMGPU_ERR_ARG, "bad arguments");
+    if (r > 1) emgpu::column_thresholds(weights, r, out);
+    return EMGPU_OK;
+}
+
+uint32_t emgpu_debug_bernoulli_threshold(double rate) { return emgpu::bernoulli_threshold(rate); }
+
 int32_t emgpu_discretize_bayes(double x, const double *thresholds, int32_t n) {
     // discretize_bayes.m:17-21
     if (n <= 0 || !thresholds) return 1;

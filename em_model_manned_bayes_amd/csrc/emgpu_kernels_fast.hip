@@ -30,7 +30,13 @@ struct FastArgs {
 };
 
 constexpr int kQueueCap = 192; // request descriptors per wave and compaction round
-constexpr int kResStride = 28; // floats per lane in the result area (24 used; 28 keeps b128 reads conflict-free)
+#ifndef EMGPU_FAST_WAVES
+#define EMGPU_FAST_WAVES 4
+#endif
+#ifndef EMGPU_RES_STRIDE
+#define EMGPU_RES_STRIDE 28
+#endif
+constexpr int kResStride = EMGPU_RES_STRIDE; // floats per lane in the result area (24 used; 28 keeps b128 reads conflict-free)
 
 struct WaveLds {
     uint32_t queue[kQueueCap];
@@ -135,7 +141,7 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
 }
 
 template <int NI, int R0, int R1, int R2>
-__global__ void __launch_bounds__(256, 4) k_uncor_fast(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
+__global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
     __shared__ WaveLds s_wave[4];
     __shared__ double s_bnd[3][16];
     const int tid = threadIdx.x, lane = tid & 63;

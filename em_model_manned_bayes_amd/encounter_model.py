@@ -1,0 +1,437 @@
+"""Class-level mirror of the reference's model classes:
+
+  EncounterModel         @EncounterModel/EncounterModel.m:1-353
+  EncounterModelEvents   @EncounterModelEvents/EncounterModelEvents.m:1-91
+  UncorEncounterModel    @UncorEncounterModel/UncorEncounterModel.m (constructor, .sample)
+  CorTerminalModel       @CorTerminalModel/CorTerminalModel.m, sample.m, getDynamicLimits.m
+
+Same property and method names and argument meaning.  `.sample` runs on the GPU through
+libemgpu (there is no CPU path).  `.track` needs the un-vendored em-core dynamics
+(run_dynamics_fast, placeTrack) and is outside this hot path: it raises NotImplementedError.
+"""
+import os
+
+import numpy as np
+
+from . import _lib as L
+from . import em_io, native
+from .functions import (_take, bn_dirichlet_prior, events2controls, events2samples, hierarchical_cutpoints)
+
+
+class EncounterModelEvents:
+    """[time_s, verticalRate_fps, turnRate_radps, longitudeAccel_ftpss] container
+    (EncounterModelEvents.m:19-74)."""
+
+    def __init__(self, event=None, time_s=0.0, verticalRate_fps=0.0, turnRate_radps=0.0, longitudeAccel_ftpss=0.0):
+        if event is not None:
+            self.event = event
+        else:
+            self.time_s = np.atleast_1d(np.asarray(time_s, dtype=np.float64))
+            self.verticalRate_fps = np.atleast_1d(np.asarray(verticalRate_fps, dtype=np.float64))
+            self.turnRate_radps = np.atleast_1d(np.asarray(turnRate_radps, dtype=np.float64))
+            self.longitudeAccel_ftpss = np.atleast_1d(np.asarray(longitudeAccel_ftpss, dtype=np.float64))
+            sizes = {a.shape for a in (self.time_s, self.verticalRate_fps, self.turnRate_radps, self.longitudeAccel_ftpss)}
+            assert len(sizes) == 1, "Sizes of time_s, verticalRate_fps, turnRate_radps, longitudeAccel_ftpss are not equal"
+
+    @property
+    def event(self):
+        m = np.stack([self.time_s.reshape(-1), self.verticalRate_fps.reshape(-1), self.turnRate_radps.reshape(-1),
+                      self.longitudeAccel_ftpss.reshape(-1)], axis=1)
+        return m if m.shape[0] else np.zeros((1, 4))  # always at least one row (EncounterModelEvents.m:41-47)
+
+    @event.setter
+    def event(self, m):
+        m = np.asarray(m, dtype=np.float64).reshape(-1, 4)
+        self.time_s, self.verticalRate_fps, self.turnRate_radps, self.longitudeAccel_ftpss = m[:, 0], m[:, 1], m[:, 2], m[:, 3]
+
+
+class EncounterModel:
+    """Holds the model parameters (EncounterModel.m:5-70) and a native emgpu_model that every
+    mutable property is pushed into (N_*, prior, start, boundaries, resample_rates)."""
+
+    def __init__(self, parameters_filename="", idxZeroBoundaries=(), isOverwriteZeroBoundaries=False, **fields):
+        self.isAutoUpdate = False
+        self._native = None
+        self._prior = 0
+        if parameters_filename:
+            p = em_io.em_read(parameters_filename, idxZeroBoundaries=idxZeroBoundaries or (1, 2, 3),
+                              isOverwriteZeroBoundaries=isOverwriteZeroBoundaries)
+            self._native = p["native"]
+        else:
+            p = dict(fields)
+        self.parameters_filename = parameters_filename
+        self.labels_initial = list(p.get("labels_initial", []))
+        self.labels_transition = list(p.get("labels_transition", []))
+        self.temporal_map = np.asarray(p.get("temporal_map", np.zeros((0, 2))), dtype=np.int64).reshape(-1, 2)
+        self.G_initial = np.asarray(p.get("G_initial", np.zeros((0, 0))), dtype=bool)
+        self.G_transition = np.asarray(p.get("G_transition", np.zeros((0, 0))), dtype=bool)
+        self.bounds_initial = np.asarray(p.get("bounds_initial", np.zeros((0, 2))), dtype=np.float64).reshape(-1, 2)
+        self.cutpoints_initial = [np.asarray(c, dtype=np.float64).reshape(-1) for c in p.get("cutpoints_initial", [])]
+        self._boundaries = [np.asarray(b, dtype=np.float64).reshape(-1) for b in p.get("boundaries", [])]
+        self.zero_bins = list(p.get("zero_bins", []))
+        self._N_initial = [np.asarray(N, dtype=np.float64) for N in p.get("N_initial", [])]
+        self._N_transition = [np.asarray(N, dtype=np.float64) for N in p.get("N_transition", [])]
+        self._resample_rates = np.asarray(p.get("resample_rates", np.zeros(len(self.labels_initial))), dtype=np.float64).reshape(-1)
+        self.all_repeat = None
+        self.all_change = None
+        if not self._N_initial and self.labels_initial:
+            self.preallocNInitial()
+        self.preallocStart()
+        self.updateDirichletInitial()
+        self.updateDirichletTransition()
+        self.isAutoUpdate = True
+
+    # ---- dependent properties (EncounterModel.m:290-350)
+    @property
+    def n_initial(self):
+        return len(self.labels_initial)
+
+    @property
+    def n_transition(self):
+        return len(self.labels_transition)
+
+    @property
+    def order_initial(self):
+        return self.native.get_i32(L.F_ORDER_INITIAL)
+
+    @property
+    def order_transition(self):
+        return self.native.get_i32(L.F_ORDER_TRANSITION)
+
+    @property
+    def r_initial(self):
+        return np.array([len(c) + 1 for c in self.cutpoints_initial], dtype=np.int64)
+
+    @property
+    def cutpoints_transition(self):
+        is_dot = ["\\dot" in lab for lab in self.labels_initial]
+        return list(self.cutpoints_initial) + [c for c, d in zip(self.cutpoints_initial, is_dot) if d]
+
+    @property
+    def r_transition(self):
+        # EncounterModel.m:313-318 (appends every "\dot" variable; wrong for the correlated models,
+        # SURVEY.md Appendix C).  The sampling path uses r from the file / the N shapes instead.
+        return np.array([len(c) + 1 for c in self.cutpoints_transition], dtype=np.int64)
+
+    @property
+    def bounds_transition(self):
+        is_dot = np.array(["\\dot" in lab for lab in self.labels_initial], dtype=bool)
+        return np.vstack([self.bounds_initial, self.bounds_initial[is_dot]])
+
+    @property
+    def dediscretize_parameters(self):
+        out = []
+        for i in range(self.n_initial):
+            if self.bounds_initial[i, 0] == self.bounds_initial[i, 1]:
+                out.append(np.zeros(0))
+            else:
+                out.append(np.concatenate([[self.bounds_initial[i, 0]], self.cutpoints_initial[i], [self.bounds_initial[i, 1]]]))
+        return out
+
+    @property
+    def cutpoints_fine(self):
+        out = []
+        for i in range(self.n_initial):
+            if self.bounds_initial[i, 0] == self.bounds_initial[i, 1]:
+                out.append([])
+            else:
+                out.append(hierarchical_cutpoints(self.cutpoints_initial[i], self.bounds_initial[i], 3))
+        return out
+
+    # ---- native handle, rebuilt lazily when the structure was given by arrays
+    @property
+    def native(self):
+        if self._native is None:
+            nt = self.n_transition
+            r_i = [N.shape[0] for N in self._N_initial]
+            r_t = r_i + [self._N_transition[v].shape[0] for v in range(self.n_initial, nt)] if nt else None
+            self._native = native.NativeModel.from_arrays(
+                self.G_initial, r_i, self._N_initial, self.G_transition if nt else None, r_t,
+                self._N_transition if nt else None, self.temporal_map if nt else None,
+                self._boundaries or None, self.zero_bins or None, self._resample_rates, self.labels_initial, self.labels_transition or None)
+            self._push_prior()
+            self._native.set_start(self._start)
+        return self._native
+
+    # ---- mutable properties with write-through (EncounterModel.m:156-210)
+    @property
+    def N_initial(self):
+        return self._N_initial
+
+    @N_initial.setter
+    def N_initial(self, v):
+        self._N_initial = [np.asarray(N, dtype=np.float64) for N in v]
+        if self._native is not None:
+            for i, N in enumerate(self._N_initial):
+                self._native.set_f64(L.F_N_INITIAL, i + 1, N.T.reshape(-1))
+
+    @property
+    def N_transition(self):
+        return self._N_transition
+
+    @N_transition.setter
+    def N_transition(self, v):
+        self._N_transition = [np.asarray(N, dtype=np.float64) for N in v]
+        if self._native is not None:
+            for i, N in enumerate(self._N_transition):
+                if N.size:
+                    self._native.set_f64(L.F_N_TRANSITION, i + 1, N.T.reshape(-1))
+
+    @property
+    def boundaries(self):
+        return self._boundaries
+
+    @boundaries.setter
+    def boundaries(self, v):
+        self._boundaries = [np.asarray(b, dtype=np.float64).reshape(-1) for b in v]
+        if self._native is not None:
+            for i, b in enumerate(self._boundaries):
+                self._native.set_f64(L.F_BOUNDARIES, i + 1, b)
+
+    @property
+    def resample_rates(self):
+        return self._resample_rates
+
+    @resample_rates.setter
+    def resample_rates(self, v):
+        self._resample_rates = np.asarray(v, dtype=np.float64).reshape(-1)
+        if self._native is not None:
+            self._native.set_f64(L.F_RESAMPLE_RATES, 0, self._resample_rates)
+
+    @property
+    def prior(self):
+        return self._prior
+
+    @prior.setter
+    def prior(self, v):
+        old = self._prior
+        if not isinstance(v, (str, int, float, np.floating, np.integer)):
+            raise L.EmgpuError(L.ERR_PRIOR, "Second argument must be a char or double")
+        self._prior = v
+        if self.isAutoUpdate and str(old).lower() != str(v).lower():  # EncounterModel.m:194-203
+            self.updateDirichletInitial()
+            self.updateDirichletTransition()
+
+    @property
+    def start(self):
+        return self._start
+
+    @start.setter
+    def start(self, v):
+        v = list(v)
+        assert len(v) == len(self._N_initial)
+        self._start = v
+        if self._native is not None:
+            self._native.set_start(v)
+
+    def _push_prior(self):
+        if self._native is not None:
+            self._native.set_prior(self._prior)
+
+    def updateDirichletInitial(self):
+        self.dirichlet_initial = bn_dirichlet_prior(self._N_initial, self._prior)
+        self._push_prior()
+
+    def updateDirichletTransition(self):
+        self.dirichlet_transition = bn_dirichlet_prior(self._N_transition, self._prior)
+        self._push_prior()
+
+    def updateBoundaries(self):
+        _ = self.dediscretize_parameters  # EncounterModel.m:235-237 assigns to a local: a no-op in the reference too
+
+    def updateResampleRates(self):
+        if self.all_change is None or self.all_repeat is None:
+            return
+        nv = np.asarray(self.all_change, dtype=np.float64) / (np.asarray(self.all_repeat, dtype=np.float64) + np.asarray(self.all_change, dtype=np.float64))
+        nv = nv.reshape(-1)
+        nv[:2] = 0
+        self.resample_rates = nv
+
+    def preallocStart(self):
+        self._start = [None] * len(self._N_initial)
+        if self._native is not None:
+            self._native.set_start(self._start)
+
+    def preallocNInitial(self):
+        r = self.r_initial
+        self._N_initial = [np.zeros((int(r[i]), int(np.prod(r[self.G_initial[:, i]])))) for i in range(self.n_initial)]
+
+    def setParameters(self, N_initial, N_transition, all_repeat, all_change):
+        self.N_initial, self.N_transition, self.all_repeat, self.all_change = N_initial, N_transition, all_repeat, all_change
+        self.updateResampleRates()
+
+    def struct(self):
+        """Cast to a plain dict (EncounterModel.m:217-233): what dbn_sample's `parms` argument reads."""
+        keys = ["labels_initial", "labels_transition", "temporal_map", "G_initial", "G_transition", "bounds_initial",
+                "cutpoints_initial", "boundaries", "zero_bins", "N_initial", "N_transition", "resample_rates", "prior",
+                "dirichlet_initial", "dirichlet_transition", "start", "n_initial", "n_transition", "order_initial",
+                "r_initial", "dediscretize_parameters"]
+        s = em_io.Parms({k: getattr(self, k) for k in keys})
+        if self.n_transition:
+            s["order_transition"] = self.order_transition
+            s["r_transition"] = self.native.get_i32(L.F_R_TRANSITION)
+        s["native"] = self.native
+        return s
+
+
+class UncorEncounterModel(EncounterModel):
+    """@UncorEncounterModel/UncorEncounterModel.m.  Default model: uncor_1200only_fwse_v1p2 (:26)."""
+
+    def __init__(self, parameters_filename=None, idxZeroBoundaries=(1, 2, 3), isOverwriteZeroBoundaries=False, input_type="file"):
+        if input_type != "file":
+            raise NotImplementedError("input_type '%s': the training-side constructors are outside the sampling path" % input_type)
+        if parameters_filename is None:
+            base = os.environ.get("AEM_DIR_BAYES")
+            if base:
+                parameters_filename = os.path.join(base, "model", "uncor_1200only_fwse_v1p2.txt")
+            else:
+                import tempfile
+                parameters_filename = em_io.materialize_model("uncor_1200only_fwse_v1p2", tempfile.mkdtemp(prefix="emgpu_model_"))
+        super().__init__(parameters_filename=parameters_filename, idxZeroBoundaries=idxZeroBoundaries,
+                         isOverwriteZeroBoundaries=isOverwriteZeroBoundaries)
+        self.isRotorcraft = "rotorcraft" in os.path.basename(str(parameters_filename))  # :181-185
+
+    def sample(self, n_samples, sample_time, seed=None, isQuantize500=False, layers=None,
+               transition_mode=L.TRANSITION_REFERENCE_AUTO, max_attempts=1000, first_index=None, ctx=None):
+        """[out_inits, out_events, out_samples, out_EME] = sample(self, n_samples, sample_time, 'seed', s,
+        'isQuantize500', b, 'layers', L)   (UncorEncounterModel.m:192-313)."""
+        labs = self.labels_initial
+
+        def find(name):
+            q = '"%s"' % name
+            return labs.index(q) + 1 if q in labs else 0
+        idxL, idxV, idxDV, idxDH, idxDPsi = find("L"), find("v"), find("\\dot v"), find("\\dot h"), find("\\dot \\psi")
+        if not (idxDV and idxDH and idxDPsi):  # :231-234
+            e = L.EmgpuError(L.ERR_ARG, "Model does not have a dynamic variable for either acceleration, vertical rate, or turn rate")
+            e.identifier = "dynvar:empty"
+            raise e
+        s, first = _take(seed, n_samples)
+        if first_index is not None:
+            first = int(first_index)
+        ctx = ctx or native.default_context()
+        m = self.native
+        flags = L.FLAG_QUANTIZE500 if isQuantize500 else 0
+        n_samples = int(n_samples)
+        ni, T = self.n_initial, int(sample_time)
+        out_inits = np.zeros((n_samples, ni))
+        out_events, out_samples, out_EME = [None] * n_samples, [None] * n_samples, [None] * n_samples
+        tm = self.temporal_map
+        idxEME = [int(np.nonzero(tm[:, 0] == v)[0][0]) + 1 for v in (idxDH, idxDPsi, idxDV)]  # :291
+        chunk, cap, pos = 32768, 256, 0
+        while pos < n_samples:
+            nn = min(chunk, n_samples - pos)
+            try:
+                res = native.sample_dbn_host(ctx, m, nn, T, s, first_index=first + pos, want_dense=False, want_events=True,
+                                             event_cap=cap, flags=flags, layers=layers, transition_mode=transition_mode,
+                                             max_attempts=max_attempts, idx_L=idxL, idx_v=idxV, idx_dh=idxDH)
+            except L.EmgpuError as e:
+                if e.code == L.ERR_EVENT_CAP:   # longest event list did not fit: retry this chunk with more room
+                    cap *= 2
+                    continue
+                raise
+            iv = res["init_val"].astype(np.float64)
+            for k in range(nn):
+                e = res["events"][k]
+                ev = np.stack([e["dt"].astype(np.float64), e["var"].astype(np.float64), e["value"].astype(np.float64)], axis=1)
+                initial = iv[k]
+                samples = events2samples(initial, ev)                      # :283
+                controls = events2controls(initial, ev, {"temporal_map": tm})  # :286
+                controls = controls[:, [0] + idxEME]                        # :292
+                controls[:, 1] = controls[:, 1] / 60.0                      # dh: fpm -> fps          :295
+                controls[:, 2] = np.deg2rad(controls[:, 2])                 # dpsi: deg/s -> rad/s    :296
+                controls[:, 3] = controls[:, 3] * 1.68780972222222          # dv: kt/s -> ft/s^2      :297
+                out_inits[pos + k] = initial
+                out_events[pos + k] = ev
+                out_samples[pos + k] = samples
+                out_EME[pos + k] = EncounterModelEvents(event=controls)
+            pos += nn
+        return out_inits, out_events, out_samples, out_EME
+
+    def track(self, *a, **k):
+        raise NotImplementedError("UncorEncounterModel.track needs em-core (run_dynamics_fast, placeTrack), which the reference "
+                                  "does not vendor; it is outside the sampling hot path (SURVEY.md section 8 f1)")
+
+
+# @CorTerminalModel/getDynamicLimits.m:15-62
+_DYN_LIMITS = {
+    "GENERIC": dict(minVel_ft_s=50, maxVel_ft_s=506, maxTurnRate_deg_s=12, maxAltitude_ft=5000, maxVertRate_ft_s=6000 / 60, maxCumTurn_deg=np.inf, pitch_deg=np.inf),
+    "RTCA228_A1": dict(minVel_ft_s=169, maxVel_ft_s=491, maxTurnRate_deg_s=1.5, maxAltitude_ft=5000, maxVertRate_ft_s=2500 / 60, maxCumTurn_deg=180, pitch_deg=15),
+    "RTCA228_A2": dict(minVel_ft_s=68, maxVel_ft_s=338, maxTurnRate_deg_s=3, maxAltitude_ft=5000, maxVertRate_ft_s=1500 / 60, maxCumTurn_deg=180, pitch_deg=15),
+    "RTCA228_A3": dict(minVel_ft_s=68, maxVel_ft_s=186, maxTurnRate_deg_s=7, maxAltitude_ft=5000, maxVertRate_ft_s=500 / 60, maxCumTurn_deg=180, pitch_deg=15),
+    "TEST": dict(minVel_ft_s=68, maxVel_ft_s=186, maxTurnRate_deg_s=7, maxAltitude_ft=1200, maxVertRate_ft_s=500 / 60, maxCumTurn_deg=180, pitch_deg=15),
+}
+
+
+class CorTerminalModel(EncounterModel):
+    """@CorTerminalModel: the encounter-geometry Bayesian network and its rejection sampler
+    (CorTerminalModel.m:45-111, sample.m:1-82).  The 20 trajectory-model files are absent from the
+    reference mount (.MISSING_LARGE_BLOBS), so only the geometry model is loaded; .track needs them
+    and em-core and raises NotImplementedError."""
+
+    def __init__(self, srcData="terminalradar", parameters_directory=None):
+        self.srcData = srcData
+        name = {"terminalradar": "terminal_v3_radar_encounter_model", "opensky": "terminal_v3_opensky_encounter_model"}.get(srcData)
+        if parameters_directory is None:
+            base = os.environ.get("AEM_DIR_BAYES")
+            if base and os.path.isdir(os.path.join(base, "model", "correlated_terminal", srcData)):
+                parameters_directory = os.path.join(base, "model", "correlated_terminal", srcData)
+        if parameters_directory is not None:
+            import glob
+            hits = glob.glob(os.path.join(parameters_directory, "*_encounter_model.txt"))
+            if not hits:
+                raise FileNotFoundError("no *_encounter_model.txt in %s" % parameters_directory)
+            fname = hits[0]
+        else:
+            if name is None:
+                raise ValueError("unknown srcData %r" % srcData)
+            import tempfile
+            fname = em_io.materialize_model(name, tempfile.mkdtemp(prefix="emgpu_model_"))
+        self.parameters_directory = parameters_directory
+        super().__init__(parameters_filename=fname, idxZeroBoundaries=(1, 2, 3), isOverwriteZeroBoundaries=False)
+        self.bounds_sample = np.column_stack([-np.inf * np.ones(self.n_initial), np.inf * np.ones(self.n_initial)])
+        self.acType1 = "GENERIC"
+        self.acType2 = "GENERIC"
+
+    def getDynamicLimits(self, acId):
+        if acId not in (1, 2):
+            raise ValueError("acId must be either 1 or 2")
+        actype = (self.acType1 if acId == 1 else self.acType2).upper()
+        if actype not in _DYN_LIMITS:
+            raise ValueError("Unknown aircraft type of %s" % actype)
+        d = dict(_DYN_LIMITS[actype])
+        # maxAccel_ft_s_s = max(diff(cutpoints_initial{speed})) of the ownship trajectory model (:78-79);
+        # that file is absent, the geometry model's own_speed cut points have the same grid.
+        q = '"own_speed"'
+        if q in self.labels_initial:
+            d["maxAccel_ft_s_s"] = float(np.max(np.diff(self.cutpoints_initial[self.labels_initial.index(q)])))
+        return d
+
+    @property
+    def dynLimits1(self):
+        return self.getDynamicLimits(1)
+
+    @property
+    def dynLimits2(self):
+        return self.getDynamicLimits(2)
+
+    def sample(self, nSamples, seed=None, max_attempts=100000, first_index=None, ctx=None):
+        """[outInits, outSamples] = sample(self, nSamples, 'seed', s)  (@CorTerminalModel/sample.m:1-82)."""
+        s, first = _take(seed, nSamples)
+        if first_index is not None:
+            first = int(first_index)
+        labs = self.labels_initial
+        io, ii = labs.index('"own_speed"') + 1, labs.index('"int_speed"') + 1
+        d1, d2 = self.dynLimits1, self.dynLimits2
+        bs = None if np.all(np.isinf(self.bounds_sample)) else self.bounds_sample
+        _, ov, _ = native.sample_bn_host(ctx or native.default_context(), self.native, int(nSamples), s, first_index=first,
+                                         dediscretize=True, max_attempts=max_attempts, bounds_sample=bs,
+                                         idx_own_speed=io, idx_int_speed=ii,
+                                         lim1=(d1["minVel_ft_s"], d1["maxVel_ft_s"]), lim2=(d2["minVel_ft_s"], d2["maxVel_ft_s"]))
+        outInits = ov.astype(np.float64)
+        names = [lab.replace('"', "") for lab in labs]
+        outSamples = [dict(zip(names, row)) for row in outInits]
+        return outInits, outSamples
+
+    def track(self, *a, **k):
+        raise NotImplementedError("CorTerminalModel.track needs the terminal trajectory-model files (absent from the reference "
+                                  "mount) and em-core; outside the sampling hot path (SURVEY.md section 8 f2)")

@@ -1,0 +1,22 @@
+"""Multi-GPU sharding of a batch of independent trajectories.
+
+Every trajectory is keyed by its GLOBAL sample index (the Philox counter), so a batch can be cut
+into contiguous index ranges, one per rank, with no collective on the data path and results that
+do not depend on the number of GPUs.
+"""
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous block [lo, hi) of rank `rank` when n_total indices are split over `world` ranks
+    (the first n_total % world ranks get one extra)."""
+    n_total, rank, world = int(n_total), int(rank), int(world)
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def step_first_index(step, rank, world, n_per_rank):
+    """Weak-scaling benchmark layout: step k of rank r samples indices [(k*world + r)*n, ... + n)."""
+    return (int(step) * int(world) + int(rank)) * int(n_per_rank)

@@ -206,6 +206,13 @@ int emgpu_sample_bn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_bn_pa
  * the algorithmic output bytes per trajectory of that call (5*n_i + 5*T*n_d for dense output). */
 const char *emgpu_last_kernel_name(const emgpu_ctx *ctx);
 
+/* Test hooks into the plan compiler (host only): the u32 quantile thresholds of one CPT column
+ * (r weights -> r-1 thresholds; bin = 1 + #{k : min(x, 2^32-2) >= out[k]} reproduces
+ * select_random.m:17-20 for u = (min(x, 2^32-2) + 0.5) * 2^-32) and the resample hit threshold
+ * (hit <=> min(x, 2^32-2) < R reproduces `u < rate`, resample_events.m:24). */
+int emgpu_debug_column_thresholds(const double *weights, int32_t r, uint32_t *out);
+uint32_t emgpu_debug_bernoulli_threshold(double rate);
+
 /* Host helpers that mirror small reference functions (used by the class layer and tests). */
 int32_t emgpu_discretize_bayes(double x, const double *thresholds, int32_t n); /* discretize_bayes.m:14-22 */
 int64_t emgpu_asub2ind(const int32_t *siz, const int32_t *x, int32_t n);       /* asub2ind.m:13-14        */

@@ -50,3 +50,226 @@ def test_dense_only_fast_kernel_matches_oracle(name, T, n, gpu_ctx, model_dir):
     if name != "blimp_v1" or True:
         assert got["kernel"].startswith("k_uncor_fast"), got["kernel"]
     assert_uncor_parity(got, ref, T)
+
+
+# ---------------------------------------------------------------------------------------------
+import glob
+import os
+
+import em_model_manned_bayes_amd as E
+from em_model_manned_bayes_amd import em_io
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _unpack_events(cnt, flat):
+    out, pos = [], 0
+    for c in cnt:
+        out.append(flat[pos: pos + c]); pos += c
+    return out
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*_philox_*.npz"))))
+def test_hip_path_reproduces_committed_golden_vectors(path, gpu_ctx, model_dir):
+    g = np.load(path)
+    n, T, seed, first, per_step = [int(x) for x in g["meta"]]
+    name = os.path.basename(path).split("_philox_")[0]
+    nm, pp, _ = load_pair(name, model_dir)
+    ref = {k: g[k] for k in ("init_bin", "init_val", "dense_bin", "dense_val", "attempts")}
+    ref["events"] = _unpack_events(g["ev_count"], g["ev_flat"])
+    mode = L.TRANSITION_PER_STEP if per_step else L.TRANSITION_REFERENCE_AUTO
+    for want_events in (False, True):
+        got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, first_index=first, want_dense=True, want_events=want_events,
+                                     transition_mode=mode, **uncor_indices(pp))
+        assert_uncor_parity(got, ref, T)
+
+
+@pytest.mark.parametrize("name", ["cor_v1", "littoral_cor_v1"])
+def test_correlated_model_matches_oracle(name, gpu_ctx, model_dir):
+    """16 initial / 4 dynamic variables; cor_v1 takes the dependent branch, littoral_cor_v1 the fast
+    branch (which errors in the reference, dbn_sample.m:61,156; here it just works)."""
+    nm, pp, _ = load_pair(name, model_dir)
+    om = O.OracleModel(pp)
+    n, T, seed = 1500, 120, 31337
+    ref = O.uncor_sample(om, n, T, seed)           # no "v"/"\dot h" labels -> rejection test disabled on both sides
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, want_dense=True, want_events=True)
+    assert_uncor_parity(got, ref, T)
+
+
+def test_start_presets_prior_layers_quantize(gpu_ctx, model_dir):
+    nm, pp, path = load_pair("uncor_1200only_fwse_v1p2", model_dir, is_overwrite_zero_boundaries=True)
+    idx = uncor_indices(pp)
+    start = [1, 4, 2, 0, 0, 0, 0]                   # RUN_uncor.m:43-45
+    layers = np.array([[50, 500], [500, 1200], [1200, 3000], [3000, 5000]], dtype=np.float64)
+    n, T, seed = 2000, 90, 5
+    nm.set_start(start)
+    nm.set_prior("dbe")
+    try:
+        om = O.OracleModel(pp, prior="dbe", start=start)
+        for kw in (dict(), dict(layers=layers), dict(is_quantize500=True), dict(layers=layers, is_quantize500=True)):
+            ref = O.uncor_sample(om, n, T, seed, layers=kw.get("layers"), is_quantize500=kw.get("is_quantize500", False))
+            flags = L.FLAG_QUANTIZE500 if kw.get("is_quantize500") else 0
+            got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, want_dense=True, want_events=True, flags=flags,
+                                         layers=kw.get("layers"), **idx)
+            assert_uncor_parity(got, ref, T)
+            assert np.all(got["init_bin"][:, :3] == [1, 4, 2])
+            if kw.get("is_quantize500"):
+                level = got["init_val"][:, 5] == 0
+                assert np.all(got["init_val"][level, 2] % 500 == 0)
+    finally:
+        nm.set_start([0] * 7)
+        nm.set_prior(0)
+    with pytest.raises(E.EmgpuError) as ei:          # bn_sample.m:45-47
+        nm.set_start([0, 0, 0, 0, 3, 0, 0])
+        native.sample_dbn_host(gpu_ctx, nm, 8, 10, 1)
+    assert ei.value.code == L.ERR_PRESET
+    nm.set_start([0] * 7)
+
+
+def test_dbn_sample_and_hierarchical_functions(gpu_ctx, model_dir):
+    path = em_io.materialize_model("uncor_1200code_v1", model_dir)
+    p = E.em_read(path)
+    pp = O.parse_model_txt(path)
+    om = O.OracleModel(pp)
+    di = E.bn_dirichlet_prior(p["N_initial"], 0)
+    dt = E.bn_dirichlet_prior(p["N_transition"], 0)
+    inits, evs = E.dbn_sample(p, di, dt, 40, seed=77, num_samples=300, ctx=gpu_ctx)
+    rb, rev = O.dbn_sample(om, 300, 40, 77)
+    assert np.array_equal(inits, rb)
+    for a, b in zip(evs, rev):
+        assert np.array_equal(a, b)                 # rows (dt, variable, new bin), dbn_sample.m:84-91
+    iv, ev = E.dbn_hierarchical_sample(p, di, dt, 40, p["boundaries"], p["zero_bins"], p["resample_rates"], [None] * 6,
+                                       seed=77, num_samples=200, ctx=gpu_ctx)
+    om2 = O.OracleModel(pp)
+    L_ = O.lib()
+    import ctypes as C
+    o = O._UncorOpts(); o.max_attempts = 1          # no rejection test in dbn_hierarchical_sample itself
+    ref = O.uncor_sample(om2, 200, 40, 77)
+    # uncor_sample adds only the (rarely failing) rejection test on top; compare the never-rejected ones
+    keep = ref["attempts"] == 1
+    assert keep.sum() > 150
+    for i in np.nonzero(keep)[0]:
+        assert np.array_equal(iv[i].astype(np.float32), ref["init_val"][i].astype(np.float32))
+        assert np.array_equal(ev[i][:, :2], ref["events"][i][:, :2])
+        assert np.array_equal(ev[i][:, 2].astype(np.float32), ref["events"][i][:, 2].astype(np.float32))
+
+
+def test_bn_sample_function_and_terminal_geometry(gpu_ctx, model_dir):
+    path = em_io.materialize_model("terminal_v3_radar_encounter_model", model_dir)
+    p = E.em_read(path)
+    pp = O.parse_model_txt(path)
+    om = O.OracleModel(pp)
+    n, seed = 4000, 2024
+    S = E.bn_sample(p["G_initial"], p["r_initial"], p["N_initial"], E.bn_dirichlet_prior(p["N_initial"], 0), n,
+                    [None] * 15, p["order_initial"], seed=seed, ctx=gpu_ctx)
+    ob, _, _ = O.geom_sample(om, n, seed, max_attempts=1)
+    assert np.array_equal(S, ob)                     # bn_sample.m:39-57, r up to 36 bins
+    # @CorTerminalModel/sample.m:29-77 with the GENERIC speed limits and a bounds box
+    t = E.CorTerminalModel(srcData="terminalradar")
+    labs = t.labels_initial
+    io, ii = labs.index('"own_speed"') + 1, labs.index('"int_speed"') + 1
+    outInits, outSamples = t.sample(n, seed=seed, ctx=gpu_ctx)
+    rb, rv, ra = O.geom_sample(om, n, seed, idx_own_speed=io, idx_int_speed=ii, lim1=(50, 506), lim2=(50, 506))
+    assert np.array_equal(outInits.astype(np.float32), rv.astype(np.float32))
+    t.acType1, t.acType2 = "RTCA228_A1", "RTCA228_A3"  # 169-491 ft/s and 68-186 ft/s: the speed test rejects
+    outInits, _ = t.sample(n, seed=seed, ctx=gpu_ctx)
+    rb, rv, ra = O.geom_sample(om, n, seed, idx_own_speed=io, idx_int_speed=ii, lim1=(169, 491), lim2=(68, 186))
+    assert np.array_equal(outInits.astype(np.float32), rv.astype(np.float32))
+    assert ra.max() > 1                              # the rejection loop was exercised
+    assert outInits[:, io - 1].min() >= 169 and outInits[:, ii - 1].max() <= 186
+    t.acType1 = t.acType2 = "GENERIC"
+    assert set(outSamples[0].keys()) == {lab.replace('"', "") for lab in labs}
+    bs = np.column_stack([-np.inf * np.ones(15), np.inf * np.ones(15)])
+    bs[labs.index('"own_distance"')] = [0, 3]
+    t.bounds_sample = bs
+    outInits, _ = t.sample(1000, seed=9, ctx=gpu_ctx)
+    _, rv, _ = O.geom_sample(om, 1000, 9, bounds_sample=bs, idx_own_speed=io, idx_int_speed=ii, lim1=(50, 506), lim2=(50, 506))
+    assert np.array_equal(outInits.astype(np.float32), rv.astype(np.float32))
+    assert outInits[:, labs.index('"own_distance"')].max() <= 3
+
+
+def test_uncor_class_sample_matches_reference_outputs(gpu_ctx, model_dir):
+    """UncorEncounterModel.sample end to end: out_inits, out_events, out_samples, out_EME
+    (UncorEncounterModel.m:283-300) against the oracle's events2samples / events2controls."""
+    path = em_io.materialize_model("uncor_1200code_v2p1", model_dir)
+    mdl = E.UncorEncounterModel(parameters_filename=path)
+    pp = O.parse_model_txt(path)
+    om = O.OracleModel(pp)
+    n, T, seed = 100, 120, 1                         # the shape of BASELINE.json configs[0]
+    out_inits, out_events, out_samples, out_EME = mdl.sample(n, T, seed=seed, ctx=gpu_ctx)
+    ref = O.uncor_sample(om, n, T, seed)
+    assert out_inits.shape == (n, 7) and len(out_events) == n
+    for i in range(n):
+        r32 = ref["events"][i].copy()
+        assert np.array_equal(out_events[i][:, :2], r32[:, :2])
+        assert np.array_equal(out_events[i][:, 2].astype(np.float32), r32[:, 2].astype(np.float32))
+        np.testing.assert_allclose(out_inits[i], ref["init_val"][i], rtol=1e-6)
+        s = O.events2samples(ref["init_val"][i], r32[:, :3])
+        assert out_samples[i].shape == (7, T)
+        np.testing.assert_allclose(out_samples[i], s, rtol=1e-6, atol=0)
+        ctl = O.events2controls(om, ref["init_val"][i], r32[:, :3])[:, [0, 2, 3, 1]]
+        ctl[:, 1] /= 60.0; ctl[:, 2] = np.deg2rad(ctl[:, 2]); ctl[:, 3] *= 1.68780972222222
+        np.testing.assert_allclose(out_EME[i].event, ctl, rtol=1e-6, atol=0)
+        assert out_EME[i].event[0, 0] == 0
+    with pytest.raises(E.EmgpuError) as ei:          # UncorEncounterModel.m:231-234
+        E.UncorEncounterModel(parameters_filename=em_io.materialize_model("balloon_v1", model_dir)).sample(1, 10, seed=1, ctx=gpu_ctx)
+    assert ei.value.identifier == "dynvar:empty"
+
+
+def test_sharded_calls_equal_one_call(gpu_ctx, model_dir):
+    """Multi-GPU rule on one GPU: two calls over [0, n/2) and [n/2, n) equal one call over [0, n)."""
+    nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
+    idx = uncor_indices(pp)
+    n, T, seed = 6000, 240, 0x5EED0004
+    full = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, first_index=0, want_dense=True, want_events=False, **idx)
+    a = native.sample_dbn_host(gpu_ctx, nm, 2500, T, seed, first_index=0, want_dense=True, want_events=False, **idx)
+    b = native.sample_dbn_host(gpu_ctx, nm, 3500, T, seed, first_index=2500, want_dense=True, want_events=False, **idx)
+    for k in ("init_bin", "init_val", "dyn_bin", "dyn_val"):
+        assert np.array_equal(np.concatenate([a[k], b[k]]), full[k]), k
+
+
+def test_full_size_properties(gpu_ctx, model_dir):
+    """BASELINE.json configs[1] at full size (10 M x 240 s, device resident): size-independent
+    properties -- determinism, bins in range, column 0 == initial state, values inside their bin's
+    boundaries (dediscretize.m:33-39) or exactly 0 in the zero bin, and a spot check of 4096
+    trajectories out of the middle of the batch against the oracle."""
+    import torch
+    nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
+    idx = uncor_indices(pp)
+    n, T, seed = 10_000_000, 240, 0x5EED0002
+    dev = torch.device("cuda", 0)
+    ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    G4 = T // 4
+    ib = torch.empty((7, n), dtype=torch.uint8, device=dev); iv = torch.empty((7, n), dtype=torch.float32, device=dev)
+    db = torch.empty((G4, 3, n), dtype=torch.int32, device=dev); dv = torch.empty((G4, 3, n, 4), dtype=torch.float32, device=dev)
+    p, _ = native.make_params(n, T, seed, **idx)
+    native.sample_dbn_device(ctx, nm, p, init_bin=ib.data_ptr(), init_val=iv.data_ptr(), dyn_bin=db.data_ptr(), dyn_val=dv.data_ptr())
+    ctx.sync()
+    assert ctx.last_kernel().startswith("k_uncor_fast")
+    chk = int(db.to(torch.int64).sum().item()), float(dv.double().sum().item())
+    bytes_ = db.view(torch.uint8).view(G4, 3, n, 4)
+    r_dyn = [5, 7, 7]
+    bnd = [pp["boundaries"][v] for v in (4, 5, 6)]
+    zb = [3, 4, 4]
+    for k in range(3):
+        bk = bytes_[:, k]
+        assert int(bk.min()) >= 1 and int(bk.max()) <= r_dyn[k]
+        assert torch.equal(bk[0, :, 0], ib[4 + k])                       # column 0 is the initial state
+        assert torch.equal(dv[0, k, :, 0], iv[4 + k])
+        lo = torch.tensor(bnd[k][:-1], dtype=torch.float32, device=dev)[bk.long() - 1]
+        hi = torch.tensor(bnd[k][1:], dtype=torch.float32, device=dev)[bk.long() - 1]
+        v = dv[:, k]
+        zero = bk == zb[k]
+        assert bool(((v == 0) | ~zero).all())                 # zero bin => exactly 0 (dediscretize.m:24-25)
+        assert bool((((v >= lo) & (v <= hi)) | zero).all())   # otherwise inside [b(d), b(d+1)]
+        del lo, hi, zero
+    # determinism: a second launch writes identical bytes
+    native.sample_dbn_device(ctx, nm, p, init_bin=ib.data_ptr(), init_val=iv.data_ptr(), dyn_bin=db.data_ptr(), dyn_val=dv.data_ptr())
+    ctx.sync()
+    assert chk == (int(db.to(torch.int64).sum().item()), float(dv.double().sum().item()))
+    # spot check against the oracle in the middle of the batch
+    lo_i, m = 5_000_000, 4096
+    ref = O.uncor_sample(O.OracleModel(pp), m, T, seed, first_index=lo_i, want_events=False)
+    gb = native.unpack_dyn_bin(db[:, :, lo_i: lo_i + m].contiguous().cpu().numpy().view(np.uint32), T)
+    gv = native.unpack_dyn_val(dv[:, :, lo_i: lo_i + m].contiguous().cpu().numpy(), T)
+    assert np.array_equal(gb, ref["dense_bin"]) and np.array_equal(gv, ref["dense_val"].astype(np.float32))

@@ -1,0 +1,220 @@
+"""CPU tests of the product's host side: the C ABI exports, the .txt loader (against the oracle's
+independent parser and the data invariants of SURVEY.md section 8c), em_write round trips, priors,
+presets, error behaviour, the plan compiler's integer thresholds, and the sharding rule."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as O
+import em_model_manned_bayes_amd as E
+from em_model_manned_bayes_amd import _lib as L, em_io, native, sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALL_MODELS = sorted(os.path.splitext(f)[0] for f in os.listdir(os.path.join(ROOT, "models")) if f.endswith(".npz"))
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    hdr = open(os.path.join(ROOT, "include", "emgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(emgpu_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    lib = L.lib()
+    for s in declared:
+        assert hasattr(lib, s)
+    assert lib.emgpu_version().decode().startswith("emgpu")
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(E.EmgpuError) as ei:
+        native.Context(0)
+    assert ei.value.code == L.ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("name", ALL_MODELS)
+def test_loader_matches_independent_parser(name, model_dir):
+    path = em_io.materialize_model(name, model_dir)
+    p = E.em_read(path)
+    q = O.parse_model_txt(path)
+    assert p["labels_initial"] == q["labels_initial"] and p["n_initial"] == q["n_initial"]
+    assert np.array_equal(p["G_initial"], q["G_initial"]) and np.array_equal(p["r_initial"], q["r_initial"])
+    assert np.array_equal(p["order_initial"], q["order_initial"])
+    for v in range(p["n_initial"]):
+        assert np.array_equal(p["N_initial"][v], q["N_initial"][v])
+        assert np.array_equal(p["boundaries"][v], q["boundaries"][v])
+    assert [0 if z == [] else z for z in p["zero_bins"]] == q["zero_bins"].tolist()
+    assert np.array_equal(p["resample_rates"], q["resample_rates"])
+    if q["n_transition"]:
+        assert p["labels_transition"] == q["labels_transition"]
+        assert np.array_equal(p["G_transition"], q["G_transition"]) and np.array_equal(p["r_transition"], q["r_transition"])
+        assert np.array_equal(p["order_transition"], q["order_transition"])
+        assert np.array_equal(p["temporal_map"], q["temporal_map"])
+        for v, N in q["N_transition"].items():
+            assert np.array_equal(p["N_transition"][v], N)
+        assert p["native"].is_dynvar_depend == O.OracleModel(q).is_dynvar_depend()
+    # em_write -> em_read round trip keeps every number
+    out = os.path.join(model_dir, name + "_roundtrip.txt")
+    E.em_write(p, out)
+    p2 = E.em_read(out)
+    for v in range(p["n_initial"]):
+        assert np.array_equal(p["N_initial"][v], p2["N_initial"][v]) and np.array_equal(p["boundaries"][v], p2["boundaries"][v])
+    assert np.array_equal(p["resample_rates"], p2["resample_rates"])
+
+
+def test_model_file_invariants(model_dir):
+    """Counts and shapes stated in SURVEY.md section 8c / Appendix B, computed from the shipped files."""
+    expect = {"uncor_1200code_v2p1": (146516, 74480, False), "uncor_1200only_fwse_v1p2": (183145, 74480, False),
+              "cor_v1": (21193, 8100, True), "haa_v1": (1633348, 1472, False), "glider_v1": (9156, 51744, True),
+              "uncor_1200code_v1": (36628, 22344, True), "littoral_cor_v1": (21193, 324, False),
+              "dueregard_v1": (143898, 11620, False), "terminal_v3_radar_encounter_model": (311650, 0, False)}
+    for name, (ni, nt, dep) in expect.items():
+        m = native.NativeModel.load_txt(em_io.materialize_model(name, model_dir))
+        assert (m.info.n_N_initial, m.info.n_N_transition, m.is_dynvar_depend) == (ni, nt, dep), name
+    m = native.NativeModel.load_txt(em_io.materialize_model("terminal_v3_radar_encounter_model", model_dir))
+    assert m.get_i32(L.F_R_INITIAL).tolist() == [4, 2, 3, 2, 4, 7, 36, 7, 5, 36, 7, 36, 7, 5, 36]
+    m = native.NativeModel.load_txt(em_io.materialize_model("cor_v1", model_dir))
+    order = m.get_i32(L.F_ORDER_INITIAL).tolist()     # not upper-triangular: L is a parent of A
+    assert order.index(2) < order.index(1) and sorted(order) == list(range(1, 17))
+    assert m.get_i32(L.F_TEMPORAL_MAP).reshape(-1, 2).tolist() == [[11, 17], [12, 18], [13, 19], [14, 20]]
+    assert m.get_i32(L.F_ZERO_BINS).tolist() == [0, 0, 0, 0, 0, 0, 0, 0, 3, 3, 5, 5, 5, 5, 0, 0]
+
+
+def test_overwrite_zero_boundaries(model_dir):
+    path = em_io.materialize_model("uncor_1200code_v2p1", model_dir)
+    p = E.em_read(path, isOverwriteZeroBoundaries=True)              # em_read.m:119-121
+    assert [len(b) for b in p["boundaries"][:4]] == [0, 0, 0, 9]
+    p = E.em_read(path)
+    assert [len(b) for b in p["boundaries"][:4]] == [0, 0, 5, 9]
+    assert p["cutpoints_initial"][2].tolist() == [1200, 3000, 5000] and p["bounds_initial"][2].tolist() == [500, 12500]
+    assert p["cutpoints_initial"][0].tolist() == [2, 3, 4]          # '*' -> 2:n  (em_read.m:130-132)
+
+
+def test_loader_errors(tmp_path, model_dir):
+    with pytest.raises(E.EmgpuError) as ei:
+        E.em_read(str(tmp_path / "missing.txt"))
+    assert ei.value.code == L.ERR_IO
+    bad = tmp_path / "bad.txt"
+    bad.write_text("# labels_initial\n\"a\" \n# G_initial\n0 \n# r_initial\n2 \n# N_initial\n1 2 \n# bogus\n1 \n")
+    with pytest.raises(E.EmgpuError) as ei:
+        E.em_read(str(bad))
+    assert ei.value.code == L.ERR_PARSE and "Unknown field" in str(ei.value)   # em_read.m:104
+    short = tmp_path / "short.txt"
+    short.write_text("# labels_initial\n\"a\", \"b\" \n# G_initial\n0 1 \n0 0 \n# r_initial\n2 3 \n# N_initial\n1 2 3 \n")
+    with pytest.raises(E.EmgpuError) as ei:
+        E.em_read(str(short))
+    assert ei.value.code == L.ERR_PARSE
+    cyc = tmp_path / "cyc.txt"
+    cyc.write_text("# labels_initial\n\"a\", \"b\" \n# G_initial\n0 1 \n1 0 \n# r_initial\n2 2 \n# N_initial\n1 2 3 4 1 2 3 4 \n")
+    with pytest.raises(E.EmgpuError) as ei:
+        E.em_read(str(cyc))
+    assert ei.value.code == L.ERR_SORT                                           # bn_sort.m:23
+
+
+def test_priors_and_start(model_dir):
+    m = native.NativeModel.load_txt(em_io.materialize_model("uncor_1200code_v2p1", model_dir))
+    assert np.all(m.get_f64(L.F_ALPHA_INITIAL, 7) == 0)
+    m.set_prior("dbe")
+    assert np.all(m.get_f64(L.F_ALPHA_TRANSITION, 8) == 1.0 / 39200)            # 5 x 7840 node
+    m.set_prior(0.5)
+    assert np.all(m.get_f64(L.F_ALPHA_INITIAL, 1) == 0.5)
+    with pytest.raises(E.EmgpuError) as ei:
+        m.set_prior("constant")                                                  # em_sample.m:50 is broken in the reference too
+    assert ei.value.identifier == "prior:notdbe"
+    m.set_transition_stay_prior(1.0)
+    a = m.get_f64(L.F_ALPHA_TRANSITION, 10).reshape(-1, 7).T                     # 7 x 1120
+    expect = np.zeros((7, 1120))
+    for kk in range(7):
+        expect[kk, 160 * kk: 160 * (kk + 1)] = 1
+    assert np.array_equal(a, expect)
+    assert np.array_equal(a, E.setTransitionPriors(E.em_read(em_io.materialize_model("uncor_1200code_v2p1", model_dir))["G_transition"],
+                                                   m.get_i32(L.F_R_TRANSITION), m.get_i32(L.F_TEMPORAL_MAP).reshape(-1, 2), 1)[9])
+    m.set_start([1, 4, 2, None, [], float("nan"), None])                          # RUN_uncor.m:43-45
+    assert m.get_i32(L.F_START).tolist() == [1, 4, 2, 0, 0, 0, 0]
+    with pytest.raises(E.EmgpuError):
+        m.set_start([9, 0, 0, 0, 0, 0, 0])
+
+
+def test_from_arrays_equals_load_txt(model_dir):
+    p = E.em_read(em_io.materialize_model("glider_v1", model_dir))
+    m = native.NativeModel.from_arrays(p["G_initial"], p["r_initial"], p["N_initial"], p["G_transition"], p["r_transition"],
+                                       p["N_transition"], p["temporal_map"], p["boundaries"], p["zero_bins"], p["resample_rates"],
+                                       p["labels_initial"], p["labels_transition"])
+    for f in (L.F_ORDER_INITIAL, L.F_ORDER_TRANSITION, L.F_ZERO_BINS, L.F_TEMPORAL_MAP):
+        assert np.array_equal(m.get_i32(f), p["native"].get_i32(f))
+    assert m.get_i32(L.F_ORDER_TRANSITION).tolist() == [1, 2, 3, 4, 5, 7, 8, 6]   # edges among the (t+1) nodes
+    assert np.array_equal(m.get_f64(L.F_N_TRANSITION, 6), p["native"].get_f64(L.F_N_TRANSITION, 6))
+
+
+def _oracle_bin(w, u):
+    w = np.ascontiguousarray(np.asarray(w, dtype=np.float64))
+    return O.lib().em_select_random_r(w.ctypes.data_as(C.c_void_p), len(w), C.c_double(u))
+
+
+def test_integer_thresholds_reproduce_the_f64_compare(model_dir):
+    """select_random.m:17-20 in f64 (oracle) == count of u32 thresholds (what the kernels do)."""
+    lib = L.lib()
+    rng = np.random.RandomState(5)
+    pp = O.parse_model_txt(em_io.materialize_model("dueregard_v1", model_dir))      # largest counts (1.56e9)
+    cols = [pp["N_transition"][8][:, j] for j in rng.randint(0, 378, 40)]
+    cols += [pp["N_initial"][6][:, j] for j in rng.randint(0, pp["N_initial"][6].shape[1], 40)]
+    cols += [np.array([0., 0, 0, 0]), np.array([0., 5, 0, 5]), np.array([1., 0, 0, 0]), np.array([0., 0, 0, 7]),
+             np.array([1e-5, 2.5e-5, 1e9]), np.full(5, 1 / 39200.0) + np.array([3, 0, 1, 0, 0.])]
+    u32 = O.lib().em_uniform32
+    for w in cols:
+        r = len(w)
+        thr = np.zeros(max(r - 1, 1), dtype=np.uint32)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        assert lib.emgpu_debug_column_thresholds(w.ctypes.data, r, thr.ctypes.data) == 0
+        assert np.all(np.diff(thr[: r - 1].astype(np.int64)) >= 0)
+        xs = set(int(x) for x in rng.randint(0, 2**32, 300, dtype=np.uint64))
+        xs |= {0, 1, 2**32 - 1, 2**32 - 2, 2**31}
+        for t in thr[: r - 1]:
+            xs |= {int(t), max(int(t) - 1, 0), min(int(t) + 1, 2**32 - 1)}
+        for x in xs:
+            xp = min(x, 2**32 - 2)
+            got = 1 + int(np.sum(xp >= thr[: r - 1].astype(np.uint64)))
+            assert got == _oracle_bin(w, u32(x)), (w, x)
+    for rate in [0.0, 0.0127706, 0.0771499, 0.5, 1e-9, 2.0 ** -32, 0.999999]:
+        R = lib.emgpu_debug_bernoulli_threshold(rate)
+        for x in {0, 1, max(R - 1, 0), R, min(R + 1, 2**32 - 1), 2**32 - 1, 12345678}:
+            assert (min(x, 2**32 - 2) < R) == (u32(x) < rate), (rate, x)
+
+
+def test_shard_ranges_cover_exactly():
+    for n, w in [(10, 3), (50_000_000, 8), (7, 8), (0, 2), (1, 1)]:
+        ranges = [sharding.shard_range(n, r, w) for r in range(w)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        assert max(hi - lo for lo, hi in ranges) - min(hi - lo for lo, hi in ranges) <= 1
+    firsts = sorted(sharding.step_first_index(k, r, 4, 100) for k in range(3) for r in range(4))
+    assert firsts == [100 * i for i in range(12)]
+
+
+def test_class_surface(model_dir):
+    mdl = E.UncorEncounterModel(parameters_filename=em_io.materialize_model("uncor_1200only_fwse_v1p2", model_dir))
+    assert mdl.n_initial == 7 and mdl.n_transition == 10 and not mdl.isRotorcraft
+    assert mdl.r_initial.tolist() == [5, 4, 4, 8, 5, 7, 7] and mdl.r_transition.tolist() == [5, 4, 4, 8, 5, 7, 7, 5, 7, 7]
+    assert mdl.order_transition.tolist() == list(range(1, 11))
+    assert mdl.dediscretize_parameters[0].size == 0 and mdl.dediscretize_parameters[6].tolist() == [-8, -6, -4.5, -1.5, 1.5, 4.5, 6, 8]
+    assert [len(c) for c in mdl.cutpoints_fine[4]] == [2] * 5
+    s = mdl.struct()
+    for k in ("G_initial", "G_transition", "temporal_map", "r_transition", "n_initial", "N_initial", "N_transition",
+              "order_initial", "order_transition"):                               # dbn_sample.m:25-33
+        assert k in s
+    start = [None] * 7
+    start[0], start[1], start[2] = 1, 4, 2
+    mdl.start = start
+    assert mdl.native.get_i32(L.F_START).tolist() == [1, 4, 2, 0, 0, 0, 0]
+    ev = E.EncounterModelEvents()
+    assert ev.event.tolist() == [[0, 0, 0, 0]]
+    ev = E.EncounterModelEvents(event=[[0, 1, 2, 3], [5, 4, 3, 2]])
+    assert ev.time_s.tolist() == [0, 5] and ev.longitudeAccel_ftpss.tolist() == [3, 2]
+    t = E.CorTerminalModel(parameters_directory=None)
+    assert t.n_initial == 15 and t.getDynamicLimits(2)["maxVel_ft_s"] == 506 and t.bounds_sample.shape == (15, 2)
+    with pytest.raises(NotImplementedError):
+        mdl.track(1, 10)
