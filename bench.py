@@ -136,11 +136,33 @@ def main():
                          "kernel": kernel_name, "avg_launch_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": bytes_per_traj * n},
         }
+        out["roofline"].update(recorded_traffic(kernel_name, bytes_per_traj * n))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(path, args.cpu_sample, args.per_step)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def recorded_traffic(kernel_name, algorithmic_bytes):
+    """roofline.traffic: HBM bytes per launch from the PMC passes (WRITE_SIZE + 2 x FETCH_SIZE, the
+    gfx950 correction of MI355X_MICROARCH.md) of the newest committed profile of the SAME kernel and
+    launch size (profiles/*_summary.json, produced by tools/profile_bench.sh: counters need their
+    own rocprofv3 passes and cannot be read from inside this process).  null if none matches."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            s = json.load(open(f))
+        except Exception:
+            continue
+        line = s.get("bench_line", {})
+        same = kernel_name in s.get("kernel", "") and line.get("roofline", {}).get("algorithmic_bytes_per_launch") == algorithmic_bytes
+        if same and "hbm_traffic_bytes_per_launch" in s:
+            best = (s["hbm_traffic_bytes_per_launch"], os.path.basename(f))
+    if best is None:
+        return {"traffic": None}
+    return {"traffic": best[0], "traffic_source": "profiles/" + best[1]}
 
 
 def cpu_baseline(model_txt, n_cpu, per_step):

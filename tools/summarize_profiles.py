@@ -1,0 +1,59 @@
+"""tools/summarize_profiles.py TAG -- condense gpurun_out/prof_TAG (rocprofv3 CSVs) into
+profiles/TAG_*: the kernel-stats table, per-launch PMC values of the dominant kernel and a JSON
+summary that bench.py reads for roofline.traffic."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+summary = {"tag": tag}
+# kernel stats (rocprofv3 --kernel-trace --stats)
+for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as o:
+        w = csv.writer(o)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+    top = rows[0]
+    summary["kernel"] = top["Name"]
+    summary["kernel_calls"] = int(top["Calls"])
+    summary["kernel_avg_ms"] = float(top["AverageNs"]) / 1e6
+    summary["kernel_pct_of_gpu_time"] = float(top["Percentage"])
+# per-dispatch resource usage from the kernel trace
+for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        if "k_uncor_fast" in r["Kernel_Name"] or "k_dbn_generic" in r["Kernel_Name"]:
+            summary["dispatch"] = {k: r[k] for k in ("Workgroup_Size", "Grid_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in r}
+            break
+# PMC passes
+pmc = collections.defaultdict(list)
+for d in ("pmc_write", "pmc_fetch", "pmc_sq1", "pmc_sq2"):
+    for f in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "k_uncor_fast" in r["Kernel_Name"] or "k_dbn_generic" in r["Kernel_Name"]:
+                pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary["pmc_per_launch"] = {k: sum(v) / len(v) for k, v in pmc.items()}
+if "WRITE_SIZE" in pmc:
+    # MI355X_MICROARCH.md "HBM": WRITE_SIZE (KiB) is exact for 16-B-per-lane streaming stores;
+    # FETCH_SIZE (KiB) reports 1/2 of the bytes of wide coalesced reads on gfx950 -> doubled.
+    wr = summary["pmc_per_launch"]["WRITE_SIZE"] * 1024
+    rd = summary["pmc_per_launch"].get("FETCH_SIZE", 0.0) * 1024 * 2
+    summary["hbm_write_bytes_per_launch"] = wr
+    summary["hbm_read_bytes_per_launch_corrected"] = rd
+    summary["hbm_traffic_bytes_per_launch"] = wr + rd
+for f in glob.glob(os.path.join(src, "bench_plain.json")):
+    try:
+        summary["bench_line"] = json.loads(open(f).read().strip().split("\n")[-1])
+    except Exception:
+        pass
+json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps({k: v for k, v in summary.items() if k != "bench_line"}, indent=1)[:3000])
