@@ -63,7 +63,7 @@ __device__ __forceinline__ void load_thr(uint32_t (&th)[R - 1], const uint32_t *
 // EXACT = false: decide from the high halfwords only and report `amb` when some compare could
 // flip with the low halfword; EXACT = true: full 32-bit draws.  Every flag is accumulated with
 // x = x + x + carry so that one v_cmp + one v_addc serve per flag and second.
-template <int R, bool EXACT>
+template <int R, bool EXACT, bool EDGE>
 __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 &rh, const uint4 &tl, const uint4 &rl, int g8, int T,
                                                    const uint32_t (&thr)[R - 1], uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
                                                    uint32_t &cur_out, uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
@@ -75,7 +75,7 @@ __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 
     for (int j = 0; j < 8; j++) {
         const int c = 8 * g8 + j; // absolute event time == column produced
         uint32_t h = 0u, ch = 0u, z = 0u;
-        if (c >= 1 && c < T) {   // wave-uniform
+        if (!EDGE || (c >= 1 && c < T)) {   // wave-uniform; interior blocks need no guard
             uint32_t xr = half_hi(rh, j), xt = half_hi(th, j);
             if (EXACT) { xr |= half_lo(rl, j); xt = clamp32(xt | half_lo(tl, j)); }
             h = (xr < Rres) ? 1u : 0u;
@@ -95,7 +95,7 @@ __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 
         hit8 = hit8 + hit8 + h;
         chg8 = chg8 + chg8 + ch;
         zer8 = zer8 + zer8 + z;
-        const uint32_t b = (c < T) ? (c1 << (8 * (j & 3))) : 0u;
+        const uint32_t b = (!EDGE || c < T) ? (c1 << (8 * (j & 3))) : 0u;
         if (j < 4) pbA |= b; else pbB |= b;
     }
     cur_out = c1;
@@ -115,7 +115,7 @@ __device__ __attribute__((noinline)) void eight_seconds_exact(uint32_t c0, uint3
 #pragma unroll
     for (int t = 0; t < R - 1; t++) thr[t] = thr_in[t];
     uint32_t cur, a, b, h, c, z;
-    eight_seconds_pass<R, true>(th, rh, tl, rl, g8, T, thr, Rres, zbin1, cur_in, cur, a, b, h, c, z);
+    eight_seconds_pass<R, true, true>(th, rh, tl, rl, g8, T, thr, Rres, zbin1, cur_in, cur, a, b, h, c, z);
     out[0] = cur; out[1] = a; out[2] = b; out[3] = h; out[4] = c; out[5] = z;
 }
 
@@ -126,11 +126,18 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
     const uint4 th = rng.block(EMGPU_SEC_TRANS, tvar, (uint32_t)g8);
     const uint4 rh = rng.block(EMGPU_SEC_RES, ivar, (uint32_t)g8);
     const uint4 z4 = make_uint4(0, 0, 0, 0);
-    uint32_t cur_out;
-    const bool amb = eight_seconds_pass<R, false>(th, rh, z4, z4, g8, T, thr, Rres, zbin1, cur1, cur_out, pbA, pbB, hit8, chg8, zer8);
-    // If ANY lane of the wave met a tie, every lane recomputes exactly from the full 32-bit draws
-    // (lanes without a tie get the same answers again): control flow stays wave-uniform.
-    if (__ballot(amb) != 0ull) {
+    uint32_t cur_out = cur1;
+    // Interior blocks (every second 1 <= c < T) run the unguarded high-halfword pass inline.  The
+    // first and last block of a trajectory, and any block in which SOME lane of the wave met a tie,
+    // take the out-of-line exact pass (full 32-bit draws, guarded): lanes without a tie get the
+    // same answers again, so control flow stays wave-uniform.
+    const bool edge = (g8 == 0) || (8 * g8 + 7 >= T);
+    bool redo = edge;
+    if (!edge) {
+        const bool amb = eight_seconds_pass<R, false, false>(th, rh, z4, z4, g8, T, thr, Rres, zbin1, cur1, cur_out, pbA, pbB, hit8, chg8, zer8);
+        redo = __ballot(amb) != 0ull;
+    }
+    if (redo) {
         uint32_t tmp[R - 1], out[6];
 #pragma unroll
         for (int t = 0; t < R - 1; t++) tmp[t] = thr[t];

@@ -38,8 +38,10 @@ __device__ __forceinline__ uint4 threefry(uint32_t x0, uint32_t x1, uint32_t x2,
     return make_uint4(x0, x1, x2, x3);
 }
 
-template <int KIND, int ROUNDS, int ITER>
+template <int KIND, int ROUNDS, int ITER, int LDSB = 0>
 __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t k0, uint32_t k1) {
+    __shared__ uint32_t pad[LDSB / 4 + 1];
+    if (LDSB > 0 && k0 == 0xdeadbeefu) pad[threadIdx.x] = k1;   // keep the allocation (occupancy limiter)
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t acc = 0;
 #pragma unroll 4
@@ -47,20 +49,20 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t k0, uint32_t k1
         uint4 v = KIND == 0 ? philox<ROUNDS>(i, 0, 0, it, k0, k1) : threefry<ROUNDS>(i, 0, 0, it, k0, k1);
         acc += (v.x < 0x1234567u) + (v.y < 0x2345678u) + (v.z < 0x3456789u) + (v.w < 0x456789Au);
     }
-    out[i] = acc;
+    out[i] = acc + ((LDSB > 0 && k0 == 0xdeadbeefu) ? pad[(threadIdx.x + 1) & 255] : 0u);
 }
 
-template <int KIND, int ROUNDS>
+template <int KIND, int ROUNDS, int LDSB = 0>
 void run(const char *name) {
     const int ITER = 512, blocks = 256 * 16;
     uint32_t *d;
     hipMalloc(&d, blocks * 256 * 4);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    k<KIND, ROUNDS, ITER><<<blocks, 256>>>(d, 1, 2);
+    k<KIND, ROUNDS, ITER, LDSB><<<blocks, 256>>>(d, 1, 2);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    for (int r = 0; r < 5; r++) k<KIND, ROUNDS, ITER><<<blocks, 256>>>(d, 1, 2);
+    for (int r = 0; r < 5; r++) k<KIND, ROUNDS, ITER, LDSB><<<blocks, 256>>>(d, 1, 2);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
@@ -74,6 +76,10 @@ void run(const char *name) {
 
 int main() {
     run<0, 10>("philox4x32-10");
+    run<0, 10, 20000>("philox-10 8blk/CU");   // 8 waves/SIMD
+    run<0, 10, 40000>("philox-10 4blk/CU");   // 4 waves/SIMD
+    run<0, 10, 80000>("philox-10 2blk/CU");   // 2 waves/SIMD
+    run<0, 10, 160000>("philox-10 1blk/CU");  // 1 wave/SIMD
     run<0, 7>("philox4x32-7");
     run<1, 20>("threefry4x32-20");
     run<1, 12>("threefry4x32-12");
