@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 MODEL = "uncor_1200code_v2p1"
 N_PER_GPU = 10_000_000
-T = 240
+DEFAULT_T = 240
 SEED = 0x5EED0002
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=N_PER_GPU, help="trajectories per GPU per step")
     ap.add_argument("--model", default=MODEL)
+    ap.add_argument("--seconds", type=int, default=DEFAULT_T, help="trajectory length (the headline metric is quoted at 240)")
     ap.add_argument("--per-step", action="store_true", help="PER_STEP transition semantics instead of REFERENCE_AUTO")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="minimum trajectories timed on the CPU oracle (scaled up to ~15 s)")
@@ -69,6 +70,7 @@ def main():
         q = '"%s"' % name
         return labels.index(q) + 1 if q in labels else 0
 
+    T = args.seconds
     n, ni, nd = args.n, model.n_initial, model.n_dyn
     G4 = (T + 3) // 4
     init_bin = torch.empty((ni, n), dtype=torch.uint8, device=dev)
@@ -138,7 +140,7 @@ def main():
         }
         out["roofline"].update(recorded_traffic(kernel_name, bytes_per_traj * n))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(path, args.cpu_sample, args.per_step)
+            out["cpu_baseline"] = cpu_baseline(path, args.cpu_sample, args.per_step, T)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -165,7 +167,7 @@ def recorded_traffic(kernel_name, algorithmic_bytes):
     return {"traffic": best[0], "traffic_source": "profiles/" + best[1]}
 
 
-def cpu_baseline(model_txt, n_cpu, per_step):
+def cpu_baseline(model_txt, n_cpu, per_step, T):
     """The CPU oracle (a faithful scalar port of the reference algorithm) on the same workload,
     bounded sample, one thread.  Reported baseline, not the target."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))

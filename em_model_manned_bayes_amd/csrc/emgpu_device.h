@@ -16,8 +16,9 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     for (int r = 0; r < 10; r++) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ (k0 + (uint32_t)r * 0x9E3779B9u);
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ (k1 + (uint32_t)r * 0xBB67AE85u);
+        // three-input XOR in one v_bitop3_b32 (truth table 0x96), gfx950
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0 + (uint32_t)r * 0x9E3779B9u, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1 + (uint32_t)r * 0xBB67AE85u, 0x96);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;

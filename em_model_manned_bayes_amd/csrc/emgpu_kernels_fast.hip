@@ -19,6 +19,8 @@
 // (DESIGN.md section 5).  No MFMA: there is no contraction on this path.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "emgpu_device.h"
 #include "emgpu_launch.h"
 
@@ -325,7 +327,9 @@ bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
 template <int NI, int R0, int R1, int R2>
 static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs &F, hipStream_t s) {
     const int64_t blocks = (A.n + 255) / 256;
-    hipLaunchKernelGGL((k_uncor_fast<NI, R0, R1, R2>), dim3((unsigned)blocks), dim3(256), 0, s, P, A, F);
+    // EMGPU_DEBUG_EXTRA_LDS: bytes of unused dynamic LDS per workgroup, to study occupancy sensitivity
+    static const int extra_lds = getenv("EMGPU_DEBUG_EXTRA_LDS") ? atoi(getenv("EMGPU_DEBUG_EXTRA_LDS")) : 0;
+    hipLaunchKernelGGL((k_uncor_fast<NI, R0, R1, R2>), dim3((unsigned)blocks), dim3(256), (size_t)extra_lds, s, P, A, F);
     return hipGetLastError();
 }
 
