@@ -176,13 +176,20 @@ def cpu_baseline(model_txt, n_cpu, per_step, T):
     t0 = time.perf_counter()
     O.uncor_sample(om, 2000, T, SEED, mode=O.RNG_PHILOX, want_events=False, want_dense=True)  # warm + calibrate
     rate = 2000 / (time.perf_counter() - t0)
-    n_cpu = int(min(max(n_cpu, rate * 15.0), 2_000_000))  # about 15 s of CPU work
+    n_cpu = int(min(max(n_cpu, rate * 10.0), 2_000_000))  # about 10 s of CPU work per leg
     t0 = time.perf_counter()
     O.uncor_sample(om, n_cpu, T, SEED, mode=O.RNG_PHILOX, per_step=per_step, want_events=False, want_dense=True)
-    dt = time.perf_counter() - t0
-    return {"value": n_cpu / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
-            "sample": "%d trajectories x %d s of the same workload, oracle/em_oracle.c Philox mode, 1 thread, %.1f s; "
-                      "MATLAB itself is not installed and cannot be timed" % (n_cpu, T, dt)}
+    dt1 = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_mt = int(min(n_cpu * cores, 4_000_000))
+    t0 = time.perf_counter()
+    O.uncor_sample_mt(om, n_mt, T, SEED, cores, per_step=per_step)
+    dtm = time.perf_counter() - t0
+    return {"value": n_mt / dtm, "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "single_thread_value": n_cpu / dt1,
+            "sample": "oracle/em_oracle.c (scalar port of the reference algorithm), Philox mode, same workload: %d trajectories x %d s "
+                      "on %d threads in %.1f s; 1 thread: %d trajectories in %.1f s; MATLAB itself is not installed and cannot be timed"
+                      % (n_mt, T, cores, dtm, n_cpu, dt1)}
 
 
 if __name__ == "__main__":

@@ -662,6 +662,30 @@ int64_t em_uncor_sample_batch(const em_model_t *m, int mode, uint64_t seed, uint
     return rc;
 }
 
+/* The same batch split over `threads` OpenMP threads (Philox mode only: trajectories are keyed by
+ * their global index, so any split gives identical results).  Used by bench.py's all-cores
+ * cpu_baseline leg.  Dense outputs only. */
+int64_t em_uncor_sample_batch_mt(const em_model_t *m, uint64_t seed, uint64_t first_index, int64_t n,
+                                 int sample_time, const em_uncor_opts_t *o, int threads,
+                                 uint8_t *dense_bin, double *dense_val, int32_t *init_bin, double *init_val) {
+    int64_t rc_all = 0;
+    const int ni = m->n_initial, nd = m->n_dyn, T = sample_time;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int t = 0; t < threads; t++) {
+        const int64_t lo = n * t / threads, hi = n * (t + 1) / threads;
+        int64_t rc = em_uncor_sample_batch(m, EM_RNG_PHILOX, seed, first_index + (uint64_t)lo, hi - lo, T, o,
+                                           init_bin ? init_bin + lo * ni : NULL, init_val ? init_val + lo * ni : NULL,
+                                           NULL, NULL, NULL, NULL, NULL, 0,
+                                           dense_bin ? dense_bin + (size_t)lo * T * nd : NULL,
+                                           dense_val ? dense_val + (size_t)lo * T * nd : NULL, NULL, NULL);
+        if (rc != 0) {
+#pragma omp critical
+            rc_all = rc;
+        }
+    }
+    return rc_all;
+}
+
 /* ------------------------------------------------------------------------- */
 /* a14 @CorTerminalModel/sample.m:29-77 -- geometry BN, one sample with its   */
 /* rejection loop: bn_sample + dediscretize (:34-42), bounds box (:45-53),    */

@@ -366,6 +366,23 @@ def uncor_sample(om, n, T, seed, mode=RNG_PHILOX, first_index=0, per_step=False,
     return out
 
 
+def uncor_sample_mt(om, n, T, seed, threads, first_index=0, per_step=False, max_attempts=1000):
+    """Dense-only batch over `threads` OpenMP threads (Philox mode); returns (dense_bin, dense_val)."""
+    L = lib()
+    nd = om.temporal_map.shape[0]
+    o = _UncorOpts()
+    o.idxL, o.idxV, o.idxDH = om.label_index("L"), om.label_index("v"), om.label_index("\\dot h")
+    o.max_attempts, o.per_step = int(max_attempts), int(bool(per_step))
+    db = np.zeros((n, T, nd), dtype=np.uint8)
+    dv = np.zeros((n, T, nd), dtype=np.float64)
+    L.em_uncor_sample_batch_mt.restype = C.c_int64
+    rc = L.em_uncor_sample_batch_mt(C.byref(om.c), C.c_uint64(seed), C.c_uint64(first_index), C.c_int64(n), C.c_int(T),
+                                    C.byref(o), C.c_int(int(threads)), _ptr(db), _ptr(dv), None, None)
+    if rc != 0:
+        raise RuntimeError("em_uncor_sample_batch_mt failed rc=%d" % rc)
+    return db, dv
+
+
 def dbn_sample(om, n, t_max, seed, mode=RNG_PHILOX, first_index=0, per_step=False):
     """dbn_sample.m restated: returns init_bin [n,ni], list of raw events [K,3] (dt, var, bin)."""
     L = lib()

@@ -74,7 +74,42 @@ void run(const char *name) {
     hipFree(d);
 }
 
+// xoshiro128++ (Blackman & Vigna 2018): sequential, 4 words of state, ~10 full-rate VALU ops per word
+template <int ITER>
+__global__ void __launch_bounds__(256) kx(uint32_t *out, uint32_t k0, uint32_t k1) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint4 st = philox<10>(i, 0, 0, 0, k0, k1);
+    uint32_t s0 = st.x, s1 = st.y, s2 = st.z, s3 = st.w, acc = 0;
+#pragma unroll 8
+    for (int it = 0; it < ITER * 4; it++) {
+        const uint32_t r = rotl(s0 + s3, 7) + s0;
+        const uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t; s3 = rotl(s3, 11);
+        acc += (r < 0x1234567u);
+    }
+    out[i] = acc;
+}
+void runx(const char *name) {
+    const int ITER = 512, blocks = 256 * 16;
+    uint32_t *d;
+    hipMalloc(&d, blocks * 256 * 4);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    kx<ITER><<<blocks, 256>>>(d, 1, 2);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int r = 0; r < 5; r++) kx<ITER><<<blocks, 256>>>(d, 1, 2);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    double words = 5.0 * blocks * 256.0 * ITER * 4;
+    printf("%-18s %8.3f ms  %.3e words/s  ~%.1f lane-slots/word\n", name, ms / 5, words / (ms * 1e-3), 78.6e12 / (words / (ms * 1e-3)));
+    hipFree(d);
+}
+
 int main() {
+    runx("xoshiro128++");
     run<0, 10>("philox4x32-10");
     run<0, 10, 20000>("philox-10 8blk/CU");   // 8 waves/SIMD
     run<0, 10, 40000>("philox-10 4blk/CU");   // 4 waves/SIMD
