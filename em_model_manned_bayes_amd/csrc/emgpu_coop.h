@@ -1,0 +1,120 @@
+// emgpu_coop.h -- wave-cooperative dediscretize and the dense-trace store, shared by the
+// 8-second-block kernels (k_uncor_fast, k_dbn_step).
+//
+// A dediscretize draw (dediscretize.m:39) is due only at an event (~0.3 per lane and 8-second
+// block), but a per-lane `if (event) philox()` makes the whole wave pay for a Philox call whenever
+// ANY of its 64 lanes has an event.  Instead the flagged positions s = 8k + j of all lanes are
+// compacted into a per-wave LDS queue (ballot + mbcnt ranks, no atomics), lanes 0..R-1 each serve
+// one request (one Philox call per wave serves up to 64 events), and the f32 results go back
+// through LDS to the owners.  Everything is wave-local: no __syncthreads, only a wave fence.
+#pragma once
+#include "emgpu_device.h"
+
+namespace emgpu {
+
+constexpr int kQueueCap = 192; // request descriptors per wave and compaction round
+
+template <int ND>
+struct CoopLds {
+    static constexpr int kStride = 8 * ND + 4; // floats per lane; +4 keeps the b128 reads conflict-free
+    uint32_t queue[kQueueCap];
+    float res[64 * kStride];
+    uint32_t attempt[64];
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int ND>
+__device__ __forceinline__ uint32_t pick_word(const uint32_t (&a)[ND], uint32_t k) {
+    uint32_t r = 0u; // bit masks, not ?: -- see pick() in emgpu_device.h
+#pragma unroll
+    for (int q = 0; q < ND; q++) r |= pick_bits(a[q], k == (uint32_t)q);
+    return r;
+}
+
+// needmask / kindmask: bit (8k + j) for dynamic variable k, second j of the block.
+// pbA / pbB: packed 1-based bins of seconds 0-3 / 4-7.  s_bnd[k][]: boundaries of variable k.
+template <int ND>
+__device__ __forceinline__ void coop_dedisc(CoopLds<ND> &W, int lane, uint64_t gidx, const Rng &rng, int g8,
+                                            uint32_t needmask, uint32_t kindmask, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND],
+                                            const uint32_t (&ivar)[ND], const double (*s_bnd)[16]) {
+    uint32_t m = needmask;
+    unsigned long long bal = __ballot(m != 0u);
+    while (bal != 0ull) {
+        uint32_t base = 0u; // wave-uniform number of queued requests in this round
+        while (bal != 0ull && base + 64u <= (uint32_t)kQueueCap) {
+            if (m != 0u) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                const uint32_t s = (uint32_t)__ffs((int)m) - 1u;
+                const uint32_t k = s >> 3, j = s & 7u;
+                const uint32_t wA = pick_word<ND>(pbA, k), wB = pick_word<ND>(pbB, k);
+                const uint32_t b1 = (((j & 4u) ? wB : wA) >> (8u * (j & 3u))) & 0xFFu;
+                W.queue[base + rank] = (uint32_t)lane | (s << 6) | (((kindmask >> s) & 1u) << 11) | (b1 << 12);
+                m &= m - 1u;
+            }
+            base += (uint32_t)__popcll(bal);
+            bal = __ballot(m != 0u);
+        }
+        wave_sync();
+        for (uint32_t q0 = 0u; q0 < base; q0 += 64u) {
+            const uint32_t q = q0 + (uint32_t)lane;
+            if (q < base) {
+                const uint32_t d = W.queue[q];
+                const uint32_t owner = d & 63u, s = (d >> 6) & 31u, kind = (d >> 11) & 1u, b1 = (d >> 12) & 63u;
+                const uint32_t k = s >> 3, j = s & 7u;
+                const uint64_t go = gidx - (uint64_t)lane + (uint64_t)owner;
+                const uint32_t iv = pick_word<ND>(ivar, k);
+                const uint32_t sec = kind ? EMGPU_SEC_DEDISC_TRANS : EMGPU_SEC_DEDISC_RES;
+                const uint4 r4 = philox4x32_10((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner],
+                                               (sec << 28) | (iv << 20) | (uint32_t)(2 * g8 + (int)(j >> 2)), rng.k0, rng.k1);
+                const uint32_t w = j & 3u;
+                const uint32_t x = w == 0 ? r4.x : (w == 1 ? r4.y : (w == 2 ? r4.z : r4.w));
+                double v;
+                {
+#pragma clang fp contract(off)
+                    const double a = s_bnd[k][b1 - 1u], b = s_bnd[k][b1];
+                    const double dd = b - a;
+                    const double mm = dd * uniform32(x);
+                    v = a + mm;
+                }
+                W.res[owner * CoopLds<ND>::kStride + s] = (float)v;
+            }
+        }
+        wave_sync();
+        bal = __ballot(m != 0u);
+    }
+}
+
+// Forward fill of variable k across the 8 seconds of the block (value changes only where a draw was
+// due or the bin became the zero bin) and the two 4-second output blocks of the time-blocked SoA.
+template <int ND>
+__device__ __forceinline__ void coop_fill_store(const CoopLds<ND> &W, int lane, int k, int g8, int T, int G4, bool valid,
+                                                uint32_t need8, uint32_t zero8, float &cval, uint32_t pbA, uint32_t pbB,
+                                                uint32_t nd, uint32_t slot, int64_t i, int64_t n, uint32_t *dyn_bin, float *dyn_val) {
+    const float4 *rp = reinterpret_cast<const float4 *>(&W.res[lane * CoopLds<ND>::kStride]);
+    const float4 ra = rp[2 * k], rb = rp[2 * k + 1];
+    const float r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+    float pv[8];
+    float v = cval;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        v = ((need8 >> j) & 1u) ? r[j] : (((zero8 >> j) & 1u) ? 0.f : v);
+        pv[j] = (8 * g8 + j < T) ? v : 0.f;
+    }
+    cval = v;
+    if (valid) {
+        const size_t o = ((size_t)(2 * g8) * nd + slot) * (size_t)n + (size_t)i;
+        if (dyn_bin) dyn_bin[o] = pbA;
+        if (dyn_val) reinterpret_cast<float4 *>(dyn_val)[o] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        if (2 * g8 + 1 < G4) {
+            const size_t o2 = o + (size_t)nd * (size_t)n;
+            if (dyn_bin) dyn_bin[o2] = pbB;
+            if (dyn_val) reinterpret_cast<float4 *>(dyn_val)[o2] = make_float4(pv[4], pv[5], pv[6], pv[7]);
+        }
+    }
+}
+
+} // namespace emgpu

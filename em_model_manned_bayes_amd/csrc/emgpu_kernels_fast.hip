@@ -21,6 +21,7 @@
 
 #include <cstdlib>
 
+#include "emgpu_coop.h"
 #include "emgpu_device.h"
 #include "emgpu_launch.h"
 
@@ -31,25 +32,9 @@ struct FastArgs {
     uint32_t slot[3]; // output row of dynamic variable k
 };
 
-constexpr int kQueueCap = 192; // request descriptors per wave and compaction round
 #ifndef EMGPU_FAST_WAVES
-#define EMGPU_FAST_WAVES 4
+#define EMGPU_FAST_WAVES 4 // waves per SIMD the register budget is set for (LDS allows 4 workgroups per CU)
 #endif
-#ifndef EMGPU_RES_STRIDE
-#define EMGPU_RES_STRIDE 28
-#endif
-constexpr int kResStride = EMGPU_RES_STRIDE; // floats per lane in the result area (24 used; 28 keeps b128 reads conflict-free)
-
-struct WaveLds {
-    uint32_t queue[kQueueCap];
-    float res[64 * kResStride];
-    uint32_t attempt[64];
-};
-
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 
 template <int R>
 __device__ __forceinline__ void load_thr(uint32_t (&th)[R - 1], const uint32_t *__restrict__ p) {
@@ -151,10 +136,10 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
 
 template <int NI, int R0, int R1, int R2>
 __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
-    __shared__ WaveLds s_wave[4];
+    __shared__ CoopLds<3> s_wave[4];
     __shared__ double s_bnd[3][16];
     const int tid = threadIdx.x, lane = tid & 63;
-    WaveLds &W = s_wave[tid >> 6];
+    CoopLds<3> &W = s_wave[tid >> 6];
     const int64_t i = (int64_t)blockIdx.x * 256 + tid;
     const bool valid = i < A.n; // lanes past the end stay alive: they serve as workers for their wave
     const uint64_t gidx = A.first_index + (uint64_t)i;
@@ -209,6 +194,7 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
         load_thr<R2>(th2, P.thr + P.d_off[2] + (size_t)col[2] * (R2 - 1));
     }
     const uint32_t iv0 = P.d_ivar[0], iv1 = P.d_ivar[1], iv2 = P.d_ivar[2];
+    const uint32_t ivs[3] = {iv0, iv1, iv2};
 
     const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
     for (int g8 = 0; g8 < G8; g8++) {
@@ -229,81 +215,11 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
         }
         const uint32_t need24 = valid ? (need8[0] | (need8[1] << 8) | (need8[2] << 16)) : 0u;
         const uint32_t kind24 = kind8[0] | (kind8[1] << 8) | (kind8[2] << 16);
-
-        // ---- wave-cooperative dediscretize (dediscretize.m:39) of the flagged positions s = 8k + j
-        uint32_t m = need24;
-        unsigned long long bal = __ballot(m != 0u);
-        while (bal != 0ull) {
-            uint32_t base = 0u; // wave-uniform number of queued requests in this round
-            while (bal != 0ull && base + 64u <= (uint32_t)kQueueCap) {
-                if (m != 0u) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    const uint32_t s = (uint32_t)__ffs((int)m) - 1u;
-                    const uint32_t k = s >> 3, j = s & 7u;
-                    const uint32_t wA = k == 0 ? pbA[0] : (k == 1 ? pbA[1] : pbA[2]);
-                    const uint32_t wB = k == 0 ? pbB[0] : (k == 1 ? pbB[1] : pbB[2]);
-                    const uint32_t b1 = (((j & 4u) ? wB : wA) >> (8u * (j & 3u))) & 0xFFu;
-                    W.queue[base + rank] = (uint32_t)lane | (s << 6) | (((kind24 >> s) & 1u) << 11) | (b1 << 12);
-                    m &= m - 1u;
-                }
-                base += (uint32_t)__popcll(bal);
-                bal = __ballot(m != 0u);
-            }
-            wave_sync();
-            for (uint32_t q0 = 0u; q0 < base; q0 += 64u) {
-                const uint32_t q = q0 + (uint32_t)lane;
-                if (q < base) {
-                    const uint32_t d = W.queue[q];
-                    const uint32_t owner = d & 63u, s = (d >> 6) & 31u, kind = (d >> 11) & 1u, b1 = (d >> 12) & 63u;
-                    const uint32_t k = s >> 3, j = s & 7u;
-                    const uint64_t go = gidx - (uint64_t)lane + (uint64_t)owner;
-                    const uint32_t ivar = k == 0 ? iv0 : (k == 1 ? iv1 : iv2);
-                    const uint32_t sec = kind ? EMGPU_SEC_DEDISC_TRANS : EMGPU_SEC_DEDISC_RES;
-                    const uint4 r4 = philox4x32_10((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner],
-                                                   (sec << 28) | (ivar << 20) | (uint32_t)(2 * g8 + (int)(j >> 2)), rng.k0, rng.k1);
-                    const uint32_t w = j & 3u;
-                    const uint32_t x = w == 0 ? r4.x : (w == 1 ? r4.y : (w == 2 ? r4.z : r4.w));
-                    double v;
-                    {
-#pragma clang fp contract(off)
-                        const double a = s_bnd[k][b1 - 1u], b = s_bnd[k][b1];
-                        const double dd = b - a;
-                        const double mm = dd * uniform32(x);
-                        v = a + mm;
-                    }
-                    W.res[owner * kResStride + s] = (float)v;
-                }
-            }
-            wave_sync();
-            bal = __ballot(m != 0u);
-        }
-
-        // ---- values: forward fill across the 8 seconds, then the two 4-second output blocks
-        const float4 *rp = reinterpret_cast<const float4 *>(&W.res[lane * kResStride]);
+        coop_dedisc<3>(W, lane, gidx, rng, g8, need24, kind24, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float4 ra = rp[2 * k], rb = rp[2 * k + 1];
-            const float r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-            float pv[8];
-            float v = cval[k];
-            const uint32_t nd8 = valid ? need8[k] : 0u, z8 = zero8[k];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                v = ((nd8 >> j) & 1u) ? r[j] : (((z8 >> j) & 1u) ? 0.f : v);
-                pv[j] = (8 * g8 + j < T) ? v : 0.f;
-            }
-            cval[k] = v;
-            if (valid) {
-                const size_t o = ((size_t)(2 * g8) * 3 + F.slot[k]) * (size_t)A.n + (size_t)i;
-                if (A.dyn_bin) A.dyn_bin[o] = pbA[k];
-                if (A.dyn_val) reinterpret_cast<float4 *>(A.dyn_val)[o] = make_float4(pv[0], pv[1], pv[2], pv[3]);
-                if (2 * g8 + 1 < G4) {
-                    const size_t o2 = o + (size_t)3 * (size_t)A.n;
-                    if (A.dyn_bin) A.dyn_bin[o2] = pbB[k];
-                    if (A.dyn_val) reinterpret_cast<float4 *>(A.dyn_val)[o2] = make_float4(pv[4], pv[5], pv[6], pv[7]);
-                }
-            }
-        }
+        for (int k = 0; k < 3; k++)
+            coop_fill_store<3>(W, lane, k, g8, T, G4, valid, valid ? need8[k] : 0u, zero8[k], cval[k], pbA[k], pbB[k],
+                               3u, F.slot[k], i, A.n, A.dyn_bin, A.dyn_val);
         wave_sync(); // results of this block are consumed before the next block's workers overwrite them
     }
 }
