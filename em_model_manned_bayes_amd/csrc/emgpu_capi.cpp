@@ -406,6 +406,7 @@ int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sa
     const char *name = "";
     hipError_t e;
     if (emgpu::fast_uncor_eligible(u.cp.plan, A)) e = emgpu::launch_uncor_fast(u.cp.plan, A, ctx->stream, &name);
+    else if (emgpu::step_eligible(u.cp.plan, A)) e = emgpu::launch_dbn_step(u.cp.plan, A, ctx->stream, &name);
     else e = emgpu::launch_dbn_generic(u.cp.plan, A, ctx->stream, &name);
     ctx->last_kernel = name;
     if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

@@ -10,4 +10,7 @@ hipError_t launch_bn(const EmgpuPlan &P, const EmgpuBnRun &A, hipStream_t s, con
 // Returns false when the (plan, run) pair is outside what the specialised kernel covers.
 bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A);
 hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
+// The per-timestep DBN with dense output (dependent-branch models, EMGPU_TRANSITION_PER_STEP).
+bool step_eligible(const EmgpuPlan &P, const EmgpuRun &A);
+hipError_t launch_dbn_step(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
 } // namespace emgpu

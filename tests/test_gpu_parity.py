@@ -273,3 +273,33 @@ def test_full_size_properties(gpu_ctx, model_dir):
     gb = native.unpack_dyn_bin(db[:, :, lo_i: lo_i + m].contiguous().cpu().numpy().view(np.uint32), T)
     gv = native.unpack_dyn_val(dv[:, :, lo_i: lo_i + m].contiguous().cpu().numpy(), T)
     assert np.array_equal(gb, ref["dense_bin"]) and np.array_equal(gv, ref["dense_val"].astype(np.float32))
+
+
+@pytest.mark.parametrize("name", DEP_MODELS + ["cor_v1"])
+@pytest.mark.parametrize("T,n", [(240, 3000), (61, 700), (2, 130), (9, 257)])
+def test_dense_only_step_kernel_matches_oracle(name, T, n, gpu_ctx, model_dir):
+    """Dense-only output of dependent-branch models takes k_dbn_step."""
+    nm, pp, _ = load_pair(name, model_dir)
+    om = O.OracleModel(pp)
+    seed, first = 0xFEEDFACE, 2**35 + 5
+    idx = uncor_indices(pp)
+    ref = O.uncor_sample(om, n, T, seed, mode=O.RNG_PHILOX, first_index=first, want_events=False)
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, first_index=first, want_dense=True, want_events=False, **idx)
+    assert got["kernel"].startswith("k_dbn_step"), got["kernel"]
+    assert_uncor_parity(got, ref, T)
+
+
+@pytest.mark.parametrize("name", ["uncor_1200code_v2p1", "uncor_1200only_fwme_v1p2", "dueregard_v1", "haa_v1", "littoral_cor_v1"])
+def test_dense_only_per_step_mode_matches_oracle(name, gpu_ctx, model_dir):
+    """EMGPU_TRANSITION_PER_STEP on fast-branch models: the true DBN instead of the frozen parents."""
+    nm, pp, _ = load_pair(name, model_dir)
+    om = O.OracleModel(pp)
+    n, T, seed = 2500, 120, 4242
+    idx = uncor_indices(pp)
+    ref = O.uncor_sample(om, n, T, seed, per_step=True, want_events=False)
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, want_dense=True, want_events=False,
+                                 transition_mode=L.TRANSITION_PER_STEP, **idx)
+    assert got["kernel"].startswith("k_dbn_step"), got["kernel"]
+    assert_uncor_parity(got, ref, T)
+    frozen = O.uncor_sample(om, n, T, seed, per_step=False, want_events=False)
+    assert not np.array_equal(frozen["dense_bin"], ref["dense_bin"])   # the two semantics really differ
