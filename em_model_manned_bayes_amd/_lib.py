@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libemgpu.so")
+# EMGPU_LIB: alternative build of the same library (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("EMGPU_LIB") or os.path.join(_HERE, "libemgpu.so")
 
 OK = 0
 ERR_ARG, ERR_IO, ERR_PARSE, ERR_PRESET, ERR_HIP = -1, -2, -3, -4, -5
@@ -68,6 +69,11 @@ class SampleOut(C.Structure):
                 ("ev_count", C.c_void_p), ("events", C.c_void_p), ("attempts", C.c_void_p)]
 
 
+class TermParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("tmax_s", C.c_double),
+                ("max_resample", C.c_int32), ("cap", C.c_int32), ("dyn_limits", C.c_double * 10)]
+
+
 class BnParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("flags", C.c_uint32),
                 ("max_attempts", C.c_int32), ("bounds_sample", C.c_void_p),
@@ -84,6 +90,7 @@ SYMBOLS = [
     "emgpu_sample_dbn_device", "emgpu_sample_dbn_host", "emgpu_sample_bn_device", "emgpu_sample_bn_host",
     "emgpu_last_kernel_name", "emgpu_discretize_bayes", "emgpu_asub2ind",
     "emgpu_debug_column_thresholds", "emgpu_debug_bernoulli_threshold",
+    "emgpu_propagate_terminal_device", "emgpu_propagate_terminal_host",
 ]
 
 _lib = None
@@ -135,6 +142,8 @@ def lib():
     L.emgpu_debug_column_thresholds.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.emgpu_debug_bernoulli_threshold.argtypes = [C.c_double]
     L.emgpu_debug_bernoulli_threshold.restype = C.c_uint32
+    for f in (L.emgpu_propagate_terminal_device, L.emgpu_propagate_terminal_host):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(TermParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

@@ -2,6 +2,7 @@
 // No CPU fallback anywhere: without a HIP device emgpu_ctx_create fails with EMGPU_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -42,6 +43,7 @@ int fail(int code, const std::string &msg) {
 
 struct Uploaded {
     uint64_t version = 0;
+    uint64_t last_use = 0;
     CompiledPlan cp;
     uint32_t *d_thr = nullptr;
     double *d_bnd = nullptr;
@@ -54,10 +56,13 @@ struct emgpu_ctx {
     hipStream_t own_stream = nullptr;
     uint32_t *d_status = nullptr;
     uint32_t *h_status = nullptr; // pinned
-    std::map<const emgpu_model *, Uploaded> cache;
+    std::map<uint64_t, Uploaded> cache; // by Model::uid
+    uint64_t use_clock = 0;
     std::string last_kernel;
     double *d_layers = nullptr;
     size_t d_layers_cap = 0;
+    const uint32_t **d_thr_base = nullptr; // terminal propagation: per-model table pointers
+    size_t d_thr_base_cap = 0;
 };
 
 template <typename T, typename V>
@@ -326,6 +331,7 @@ void emgpu_ctx_free(emgpu_ctx *ctx) {
     for (auto &kv : ctx->cache) { (void)hipFree(kv.second.d_thr); (void)hipFree(kv.second.d_bnd); }
     (void)hipFree(ctx->d_status);
     (void)hipFree(ctx->d_layers);
+    (void)hipFree(ctx->d_thr_base);
     (void)hipHostFree(ctx->h_status);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -337,7 +343,20 @@ const char *emgpu_last_kernel_name(const emgpu_ctx *ctx) { return ctx ? ctx->las
 
 // ------------------------------------------------------------------------------------------------
 static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h) {
-    Uploaded &u = ctx->cache[h];
+    if (ctx->cache.size() > 48 && ctx->cache.find(h->m.uid) == ctx->cache.end()) {
+        // models come and go (their tables stay uploaded): drop the least recently used half
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        std::vector<std::pair<uint64_t, uint64_t>> byuse;
+        for (auto &kv : ctx->cache) byuse.push_back({kv.second.last_use, kv.first});
+        std::sort(byuse.begin(), byuse.end());
+        for (size_t q = 0; q < byuse.size() / 2; q++) {
+            Uploaded &old = ctx->cache[byuse[q].second];
+            (void)hipFree(old.d_thr); (void)hipFree(old.d_bnd);
+            ctx->cache.erase(byuse[q].second);
+        }
+    }
+    Uploaded &u = ctx->cache[h->m.uid];
+    u.last_use = ++ctx->use_clock;
     if (u.version == h->m.version && u.d_thr) return u;
     // (re)compile: tables depend on N, alpha, start, boundaries, rates
     CompiledPlan cp = emgpu::compile_plan(h->m);
@@ -535,6 +554,96 @@ int emgpu_debug_column_thresholds(const double *weights, int32_t r, uint32_t *ou
 }
 
 uint32_t emgpu_debug_bernoulli_threshold(double rate) { return emgpu::bernoulli_threshold(rate); }
+
+int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
+                                    const emgpu_term_params *p, const double *geo, const int32_t *model_of,
+                                    float *out, int32_t *rows) {
+    EMGPU_TRY
+    if (!ctx || !models || n_models < 1 || !p || !geo || !model_of || !out || !rows) return fail(EMGPU_ERR_ARG, "null argument");
+    if (p->n < 0 || p->cap < 2 || p->max_resample < 1) return fail(EMGPU_ERR_ARG, "bad n / cap / max_resample");
+    HIP_OK(hipSetDevice(ctx->device));
+    std::vector<const uint32_t *> bases;
+    const Uploaded *first = nullptr;
+    for (int i = 0; i < n_models; i++) {
+        if (!models[i]) return fail(EMGPU_ERR_ARG, "null model");
+        Uploaded &u = get_uploaded(ctx, models[i]);
+        const EmgpuPlan &P = u.cp.plan;
+        if (P.ni != 6 || P.nd != 3 || P.depend) return fail(EMGPU_ERR_UNSUPPORTED, "trajectory model must have 6 initial and 3 independent dynamic variables");
+        for (int q = 0; q < 6; q++)
+            if (P.i_var[q] != q) return fail(EMGPU_ERR_UNSUPPORTED, "trajectory model initial network must be in index order");
+        if (P.d_ivar[0] > 5 || P.i_nb[1] < 3 || P.i_nb[2] < 3 || P.i_nb[3] < 3 || P.i_nb[4] < 3 || P.i_nb[5] < 3)
+            return fail(EMGPU_ERR_UNSUPPORTED, "distance, bearing, heading, altitude and speed need boundaries");
+        if (!first) first = &u;
+        else {
+            const EmgpuPlan &Q = first->cp.plan;
+            // the initial networks may differ (2 or 3 intents): only the dynamic tables' relative layout must agree
+            bool same = (P.d_off[1] - P.d_off[0]) == (Q.d_off[1] - Q.d_off[0]) && (P.d_off[2] - P.d_off[0]) == (Q.d_off[2] - Q.d_off[0]) &&
+                        memcmp(P.d_r, Q.d_r, sizeof P.d_r) == 0 &&
+                        memcmp(P.d_stride_static, Q.d_stride_static, sizeof P.d_stride_static) == 0 &&
+                        memcmp(P.d_stride_cur, Q.d_stride_cur, sizeof P.d_stride_cur) == 0 && u.cp.bnd == first->cp.bnd && memcmp(P.i_boff, Q.i_boff, sizeof P.i_boff) == 0 &&
+                        memcmp(P.d_ivar, Q.d_ivar, sizeof P.d_ivar) == 0 && memcmp(P.d_tvar, Q.d_tvar, sizeof P.d_tvar) == 0;
+            if (!same) return fail(EMGPU_ERR_UNSUPPORTED, "trajectory models differ in shape or boundaries");
+        }
+        bases.push_back(u.d_thr + P.d_off[0]); // tables of the dynamic variables, relative to the first one
+    }
+    first = &get_uploaded(ctx, models[0]); // (the map may have rehashed nothing: std::map keeps references valid)
+    if (ctx->d_thr_base_cap < bases.size()) {
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_thr_base) HIP_OK(hipFree(ctx->d_thr_base));
+        HIP_OK(hipMalloc((void **)&ctx->d_thr_base, bases.size() * sizeof(void *)));
+        ctx->d_thr_base_cap = bases.size();
+    }
+    HIP_OK(hipMemcpyAsync(ctx->d_thr_base, bases.data(), bases.size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    EmgpuTermRun A;
+    memset(&A, 0, sizeof A);
+    A.seed = p->seed; A.first_index = p->first_index; A.n = p->n; A.geo = geo; A.model_of = model_of; A.thr_base = ctx->d_thr_base;
+    A.tmax_s = p->tmax_s; A.max_resample = p->max_resample; A.cap = p->cap;
+    memcpy(A.dl, p->dyn_limits, sizeof A.dl);
+    A.out = out; A.rows = rows; A.status = ctx->d_status;
+    const char *name = "";
+    hipError_t e = emgpu::launch_terminal_propagate(first->cp.plan, A, ctx->stream, &name);
+    ctx->last_kernel = name;
+    if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_propagate_terminal_host(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
+                                  const emgpu_term_params *p, const double *geo, const int32_t *model_of,
+                                  float *out, int32_t *rows) {
+    EMGPU_TRY
+    if (!ctx || !p || !geo || !model_of || !out || !rows) return fail(EMGPU_ERR_ARG, "null argument");
+    HIP_OK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)(p->n > 0 ? p->n : 0), nl = 4 * n;
+    double *dg = nullptr; int32_t *dm = nullptr, *dr = nullptr; float *dout = nullptr;
+    int rc;
+    try {
+        HIP_OK(hipMalloc((void **)&dg, n * 12 * sizeof(double) + 8));
+        HIP_OK(hipMalloc((void **)&dm, nl * 4 + 4));
+        HIP_OK(hipMalloc((void **)&dr, nl * 4 + 4));
+        HIP_OK(hipMalloc((void **)&dout, (size_t)6 * p->cap * nl * 4 + 4));
+        if (n) {
+            HIP_OK(hipMemcpyAsync(dg, geo, n * 12 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_OK(hipMemcpyAsync(dm, model_of, nl * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIP_OK(hipMemsetAsync(dout, 0, (size_t)6 * p->cap * nl * 4, ctx->stream));
+        }
+        rc = emgpu_propagate_terminal_device(ctx, models, n_models, p, dg, dm, dout, dr);
+        if (rc == EMGPU_OK && n) {
+            HIP_OK(hipMemcpyAsync(out, dout, (size_t)6 * p->cap * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_OK(hipMemcpyAsync(rows, dr, nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (rc == EMGPU_OK) rc = emgpu_ctx_sync(ctx);
+    } catch (...) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(dg); (void)hipFree(dm); (void)hipFree(dr); (void)hipFree(dout);
+        throw;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dg); (void)hipFree(dm); (void)hipFree(dr); (void)hipFree(dout);
+    return rc;
+    EMGPU_CATCH
+}
 
 int32_t emgpu_discretize_bayes(double x, const double *thresholds, int32_t n) {
     // discretize_bayes.m:17-21

@@ -4,6 +4,7 @@
 #include "emgpu_model.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -154,6 +155,8 @@ void Model::set_transition_stay_prior(double prior) {
 }
 
 void Model::finalize() {
+    static std::atomic<uint64_t> next_uid{1};
+    uid = next_uid.fetch_add(1);
     if (n_initial <= 0) throw Error(EMGPU_ERR_PARSE, "model has no initial network");
     if ((int)r_initial.size() != n_initial) throw Error(EMGPU_ERR_PARSE, "r_initial size mismatch");
     order_initial = bn_sort(G_initial, n_initial);

@@ -34,6 +34,7 @@ struct Model {
     std::vector<double> resample_rates;
     std::vector<int> start; // 0 = unset
     uint64_t version = 1;   // bumped by every setter: invalidates uploaded plans
+    uint64_t uid = 0;       // process-unique id (a freed model's address can be reused: never key a cache by pointer)
 
     int n_dyn() const { return (int)temporal_map.size(); }
     bool is_dynvar_depend() const;

@@ -105,3 +105,17 @@ struct EmgpuBnRun {
     int32_t *attempts;
     uint32_t *status;
 };
+
+struct EmgpuTermRun {
+    uint64_t seed, first_index;
+    int64_t n;                       // encounters; 4 lanes each
+    const double *geo;               // [n][12]: x0 y0 z0 v0 heading0 intent for aircraft 1, then aircraft 2
+    const int32_t *model_of;         // [4n]: index into thr_base for lane 4e + role
+    const uint32_t *const *thr_base; // [n_models] first dynamic-variable table of each trajectory model (same shapes)
+    double tmax_s;
+    double dl[2][5];                 // minVel, maxVel, maxTurnRate, maxAltitude, maxVertRate per aircraft
+    int32_t max_resample, cap;
+    float *out;                      // [6][cap][4n]: t_s x_nm y_nm z_ft heading_deg v_ft_s
+    int32_t *rows;                   // [4n] rows written; < 0: failed (cap / resample cap)
+    uint32_t *status;
+};

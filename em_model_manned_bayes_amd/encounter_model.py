@@ -368,8 +368,13 @@ class CorTerminalModel(EncounterModel):
     reference mount (.MISSING_LARGE_BLOBS), so only the geometry model is loaded; .track needs them
     and em-core and raises NotImplementedError."""
 
-    def __init__(self, srcData="terminalradar", parameters_directory=None):
+    def __init__(self, srcData="terminalradar", parameters_directory=None, compatBackwardModels=True):
+        """compatBackwardModels: CorTerminalModel.m:97,100 load the intruder LANDING reverse file as the
+        backward model of the intruder take-off and transit intents as well (a copy-paste slip in the
+        reference).  True reproduces that; False uses the file each intent names."""
         self.srcData = srcData
+        self.compatBackwardModels = bool(compatBackwardModels)
+        self._traj = None
         name = {"terminalradar": "terminal_v3_radar_encounter_model", "opensky": "terminal_v3_opensky_encounter_model"}.get(srcData)
         if parameters_directory is None:
             base = os.environ.get("AEM_DIR_BAYES")
@@ -391,6 +396,26 @@ class CorTerminalModel(EncounterModel):
         self.bounds_sample = np.column_stack([-np.inf * np.ones(self.n_initial), np.inf * np.ones(self.n_initial)])
         self.acType1 = "GENERIC"
         self.acType2 = "GENERIC"
+        # trajectory models (CorTerminalModel.m:84-100), present only when the directory holds them
+        if parameters_directory is not None:
+            import glob
+
+            def find(stem):
+                hits = glob.glob(os.path.join(parameters_directory, "*_" + stem + ".txt"))
+                return hits[0] if hits else None
+            bck_to = "intruder_landing_model_reverse" if self.compatBackwardModels else None
+            stems = ["ownship_landing_model", "ownship_landing_model_reverse", "ownship_takeoff_model", "ownship_takeoff_model_reverse",
+                     "intruder_landing_model", "intruder_landing_model_reverse", "intruder_takeoff_model",
+                     bck_to or "intruder_takeoff_model_reverse", "intruder_transit_model", bck_to or "intruder_transit_model_reverse"]
+            files = [find(s) for s in stems]
+            if all(files):
+                names = ["mdlFwd1_1", "mdlBck1_1", "mdlFwd1_2", "mdlBck1_2", "mdlFwd2_1", "mdlBck2_1", "mdlFwd2_2", "mdlBck2_2", "mdlFwd2_3", "mdlBck2_3"]
+                self._traj = []
+                for nm_, f in zip(names, files):
+                    mdl = EncounterModel(parameters_filename=f, idxZeroBoundaries=(1, 2, 3), isOverwriteZeroBoundaries=False)
+                    mdl.native.set_transition_stay_prior(1.0)      # createEncounter.m:128-129
+                    setattr(self, nm_, mdl)
+                    self._traj.append(mdl)
 
     def getDynamicLimits(self, acId):
         if acId not in (1, 2):
@@ -431,6 +456,64 @@ class CorTerminalModel(EncounterModel):
         names = [lab.replace('"', "") for lab in labs]
         outSamples = [dict(zip(names, row)) for row in outInits]
         return outInits, outSamples
+
+    # ---- createEncounter.m:1-91 without em-core's local_smooth (:88-89)
+    @staticmethod
+    def _sincosd(deg):
+        r = np.fmod(np.asarray(deg, dtype=np.float64), 360.0)
+        s, c = np.sin(np.deg2rad(r)), np.cos(np.deg2rad(r))
+        for ang, sv, cv in ((0, 0, 1), (90, 1, 0), (-270, 1, 0), (180, 0, -1), (-180, 0, -1), (270, -1, 0), (-90, -1, 0)):
+            m = r == ang
+            s = np.where(m, sv, s); c = np.where(m, cv, c)
+        return s, c
+
+    def _geo_rows(self, samples):
+        """x0 y0 z0 v0 heading0 intent for aircraft 1 and 2 (createEncounter.m:41-49) and the model of each of the 4 tracks."""
+        g = np.zeros((len(samples), 12))
+        mo = np.zeros((len(samples), 4), dtype=np.int32)
+        for e_, sg in enumerate(samples):
+            for a, pre in enumerate(("own", "int")):
+                s, c = self._sincosd(sg[pre + "_bearing"])
+                g[e_, 6 * a: 6 * a + 6] = [sg[pre + "_distance"] * c, sg[pre + "_distance"] * s, sg[pre + "_alt"], sg[pre + "_speed"],
+                                           sg[pre + "_heading"], sg[pre + "_intent"]]
+            oi, ii_ = int(sg["own_intent"]), int(sg["int_intent"])
+            if oi not in (1, 2) or ii_ not in (1, 2, 3):
+                raise ValueError("Unknown intent")      # createEncounter.m:21,38
+            mo[e_] = [2 * (oi - 1), 2 * (oi - 1) + 1, 4 + 2 * (ii_ - 1), 4 + 2 * (ii_ - 1) + 1]
+        return g, mo
+
+    def _dyn_rows(self):
+        keys = ("minVel_ft_s", "maxVel_ft_s", "maxTurnRate_deg_s", "maxAltitude_ft", "maxVertRate_ft_s")
+        return np.array([[self.dynLimits1[k] for k in keys], [self.dynLimits2[k] for k in keys]], dtype=np.float64)
+
+    def createEncounter(self, sample_geo, tmax_s=120, seed=None, first_index=None, ctx=None):
+        """traj = createEncounter(self, sample_geo, tmax_s)  (createEncounter.m:1): a list of two dicts with
+        t_s, x_nm, y_nm, z_ft, heading_deg, v_ft_s sorted in time.  sample_geo may be one dict or a list of
+        dicts (then a list of pairs is returned).  em-core's local_smooth of speed and altitude (:88-89) is
+        not applied."""
+        if self._traj is None:
+            raise NotImplementedError("the terminal trajectory-model files are not in parameters_directory (they are absent from the "
+                                      "reference mount); synthetic.write_terminal_directory builds stand-ins")
+        single = isinstance(sample_geo, dict)
+        samples = [sample_geo] if single else list(sample_geo)
+        s, first = _take(seed, len(samples))
+        if first_index is not None:
+            first = int(first_index)
+        g, mo = self._geo_rows(samples)
+        out, rows = native.propagate_terminal_host(ctx or native.default_context(), [m.native for m in self._traj], g, mo, s,
+                                                   first_index=first, tmax_s=float(tmax_s), dyn_limits=self._dyn_rows())
+        res = []
+        fields = ("t_s", "x_nm", "y_nm", "z_ft", "heading_deg", "v_ft_s")
+        for e_ in range(len(samples)):
+            pair = []
+            for a in range(2):
+                fwd = out[4 * e_ + 2 * a, : rows[4 * e_ + 2 * a]].astype(np.float64)
+                bck = out[4 * e_ + 2 * a + 1, 1: rows[4 * e_ + 2 * a + 1]].astype(np.float64)   # bck(1, 2:end)  :77
+                both = np.concatenate([fwd, bck], axis=0)
+                both = both[np.argsort(both[:, 0], kind="stable")]                              # :81-84
+                pair.append({f: both[:, k].copy() for k, f in enumerate(fields)})
+            res.append(pair)
+        return res[0] if single else res
 
     def track(self, *a, **k):
         raise NotImplementedError("CorTerminalModel.track needs the terminal trajectory-model files (absent from the reference "

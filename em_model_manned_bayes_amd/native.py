@@ -269,3 +269,26 @@ def sample_bn_host(ctx, model, n, seed, first_index=0, dediscretize=False, max_a
     att = np.zeros(n, dtype=np.int32)
     L.check(L.lib().emgpu_sample_bn_host(ctx._h, model._h, C.byref(p), _p(ob), _p(ov), _p(att)))
     return ob.T.copy(), ov.T.copy(), att
+
+
+def propagate_terminal_host(ctx, models, geo, model_of, seed, first_index=0, tmax_s=120.0, dyn_limits=None,
+                            max_resample=100000, cap=None):
+    """emgpu_propagate_terminal_host: PropagateTrajectory for 4 tracks per encounter (createEncounter.m:52-72).
+    models: list of NativeModel (stay prior already applied); geo [n, 12]; model_of [n, 4].
+    Returns (out [4n, rows<=cap, 6] f32 as t_s x_nm y_nm z_ft heading_deg v_ft_s, rows [4n])."""
+    geo = np.ascontiguousarray(np.asarray(geo, dtype=np.float64).reshape(-1, 12))
+    n = geo.shape[0]
+    model_of = np.ascontiguousarray(np.asarray(model_of, dtype=np.int32).reshape(-1))
+    assert model_of.size == 4 * n
+    cap = int(cap or (int(tmax_s) + 3))
+    p = L.TermParams()
+    p.seed, p.first_index, p.n, p.tmax_s = int(seed) & (2**64 - 1), int(first_index), n, float(tmax_s)
+    p.max_resample, p.cap = int(max_resample), cap
+    dl = np.asarray(dyn_limits, dtype=np.float64).reshape(10)
+    for i in range(10):
+        p.dyn_limits[i] = float(dl[i])
+    handles = (C.c_void_p * len(models))(*[m._h for m in models])
+    out = np.zeros((6, cap, 4 * n), dtype=np.float32)
+    rows = np.zeros(4 * n, dtype=np.int32)
+    L.check(L.lib().emgpu_propagate_terminal_host(ctx._h, handles, len(models), C.byref(p), _p(geo), _p(model_of), _p(out), _p(rows)))
+    return np.ascontiguousarray(out.transpose(2, 1, 0)), rows

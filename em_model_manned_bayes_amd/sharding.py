@@ -20,3 +20,18 @@ def shard_range(n_total, rank, world):
 def step_first_index(step, rank, world, n_per_rank):
     """Weak-scaling benchmark layout: step k of rank r samples indices [(k*world + r)*n, ... + n)."""
     return (int(step) * int(world) + int(rank)) * int(n_per_rank)
+
+
+def mixed_batch_blocks(n_total, n_models, lo=0, hi=None):
+    """Mixed-model batch (BASELINE.json configs[3]): the global index range [0, n_total) is cut into
+    n_models contiguous blocks, block m sampled from model m.  Returns, for the sub-range [lo, hi)
+    owned by one rank, the list of (model, first_index, count) calls to make -- each call is one
+    kernel launch touching one table set."""
+    hi = n_total if hi is None else hi
+    out = []
+    for m in range(n_models):
+        a, b = shard_range(n_total, m, n_models)
+        a2, b2 = max(a, lo), min(b, hi)
+        if b2 > a2:
+            out.append((m, a2, b2 - a2))
+    return out

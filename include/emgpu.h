@@ -202,6 +202,34 @@ int emgpu_sample_bn_device(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_bn_
 int emgpu_sample_bn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_bn_params *p,
                          uint8_t *out_bin, float *out_val, int32_t *attempts);
 
+/* ------------------------------------------------------------------------------------------------
+ * Terminal trajectory propagation: replaces PropagateTrajectory (@CorTerminalModel/createEncounter.m:
+ * 93-265) for both aircraft and both directions of n encounters (createEncounter.m:52-72), without
+ * em-core's local_smooth (:88-89).  models[]: trajectory models with the 6 initial variables
+ * {intent, distance, bearing, heading, altitude, speed} and 3 dynamic ones, all of the same shapes and
+ * boundaries; the caller has applied setTransitionPriors(...,1) (createEncounter.m:129) through
+ * emgpu_model_set_transition_stay_prior.
+ *   geo      [n][12] f64: x0_nm y0_nm z0_ft v0_ft_s heading0_deg intent for aircraft 1, then 2
+ *            (createEncounter.m:41-49)
+ *   model_of [4n] i32: index into models[] for lane 4e + role, role = 2*(aircraft-1) + (backward)
+ *   out      [6][cap][4n] f32: t_s x_nm y_nm z_ft heading_deg v_ft_s per second (createEncounter.m:162-167)
+ *   rows     [4n] i32: seconds written (<= tmax_s + 2); negative => cap / resample cap exceeded
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t seed, first_index;
+    int64_t n;
+    double tmax_s;               /* 120 in @CorTerminalModel/track.m:33                            */
+    int32_t max_resample, cap;   /* inner re-draw cap (reference: unbounded); rows per track       */
+    double dyn_limits[2][5];     /* per aircraft: minVel_ft_s maxVel_ft_s maxTurnRate_deg_s
+                                    maxAltitude_ft maxVertRate_ft_s (getDynamicLimits.m:15-62)     */
+} emgpu_term_params;
+int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
+                                    const emgpu_term_params *p, const double *geo, const int32_t *model_of,
+                                    float *out, int32_t *rows);
+int emgpu_propagate_terminal_host(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
+                                  const emgpu_term_params *p, const double *geo, const int32_t *model_of,
+                                  float *out, int32_t *rows);
+
 /* Introspection for benchmarks/tests: name of the kernel variant the last *_device call used and
  * the algorithmic output bytes per trajectory of that call (5*n_i + 5*T*n_d for dense output). */
 const char *emgpu_last_kernel_name(const emgpu_ctx *ctx);

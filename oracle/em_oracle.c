@@ -119,7 +119,11 @@ enum {
      * odd, lower 16 bits when h is even.  (A kernel can decide almost every compare from H alone
      * and fetch L lazily; the value drawn is the same full 32-bit uniform either way.) */
     EM_SEC_TRANS_LO = 9,
-    EM_SEC_RES_LO = 10
+    EM_SEC_RES_LO = 10,
+    /* terminal trajectory propagation (createEncounter.m:93-265): counter word 2 ("attempt") carries
+     * role + 4*resample_attempt with role = 2*(aircraft-1) + (direction == backward); idx = step ii */
+    EM_SEC_TERM_TRANS = 11,  /* dbn_sample(...,2,start) transition draw: a = tvar-1, idx = ii   */
+    EM_SEC_TERM_DEDISC = 12  /* dediscretize of an accepted event:       a = var-1,  idx = ii   */
 };
 
 enum { EM_RNG_MT19937 = 0, EM_RNG_PHILOX = 1 };
@@ -777,6 +781,171 @@ void em_transition_prior_node(int r_jj, int64_t q, double prior, double *alpha) 
     for (int kk = 1; kk <= r_jj; kk++)
         for (int64_t c = n * (kk - 1) + 1; c <= n * kk; c++)
             alpha[(c - 1) * r_jj + (kk - 1)] = prior;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a15 PropagateTrajectory  @CorTerminalModel/createEncounter.m:93-265 with   */
+/* CreateStartDistribution :268-294 and CheckTrajectoryConditions :296-329.   */
+/* The trajectory model m has the 6 initial variables {intent, distance,       */
+/* bearing, heading, altitude, speed} (:107-109,:293) and A_transition must    */
+/* hold setTransitionPriors(G, r, temporal_map, 1) (:129).  em-core's          */
+/* local_smooth (:88-89) is NOT applied (un-vendored dependency).             */
+/* out: rows [t_s x_nm y_nm z_ft heading_deg v_ft_s]; returns the row count.  */
+/* ------------------------------------------------------------------------- */
+typedef struct { double minVel_ft_s, maxVel_ft_s, maxTurnRate_deg_s, maxAltitude_ft, maxVertRate_ft_s; } em_dynlims_t;
+
+static double em_wrapTo360(double lon) {   /* Mapping Toolbox wrapTo360 */
+    const int positive = lon > 0;
+    lon = lon - floor(lon / 360.0) * 360.0; /* mod(lon, 360) */
+    if (lon == 0 && positive) lon = 360.0;
+    return lon;
+}
+static double em_atan2d(double y, double x) { return atan2(y, x) * (180.0 / 3.14159265358979323846); }
+static void em_sincosd(double deg, double *s, double *c) {
+    /* cosd / sind: exact at multiples of 90 degrees like MATLAB, otherwise radians */
+    double r = fmod(deg, 360.0);
+    if (r == 0) { *s = 0; *c = 1; return; }
+    if (r == 90 || r == -270) { *s = 1; *c = 0; return; }
+    if (r == 180 || r == -180) { *s = 0; *c = -1; return; }
+    if (r == 270 || r == -90) { *s = -1; *c = 0; return; }
+    const double rad = r * (3.14159265358979323846 / 180.0);
+    *s = sin(rad); *c = cos(rad);
+}
+static double em_round2(double x) { return round(x * 100.0) / 100.0; } /* round(x, 2) */
+static double em_sign(double x) { return (x > 0) - (x < 0); }
+
+int em_propagate_trajectory(const em_model_t *m, em_rng_t *g, int role, int is_ownship, double dt_s,
+                            double x0_nm, double y0_nm, double z0_ft, double v0_ft_s, double heading0_deg, int intent,
+                            double tmax_s, const em_dynlims_t *dl, int max_resample, double *out, int cap) {
+    const int ni = m->n_initial, nt = m->n_transition;
+    const int IDX_DIST = 2, IDX_BEAR = 3, IDX_HEAD = 4, IDX_ALT = 5, IDX_SPD = 6;
+    if (ni != 6 || m->n_dyn != 3) return -1;
+    const double *bnd[7]; int nb[7];
+    for (int v = 1; v <= 6; v++) { bnd[v] = m->boundaries + m->bnd_off[v - 1]; nb[v] = m->bnd_len[v - 1]; }
+    /* discreteValidAlt / discreteValidV  (:121-127) */
+    int alt_last = 0, spd_first = 0, spd_last = 0;
+    for (int q = 0; q < nb[IDX_ALT]; q++) if (bnd[IDX_ALT][q] <= dl->maxAltitude_ft) alt_last = q + 1;
+    for (int q = 0; q < nb[IDX_SPD]; q++) { if (!(bnd[IDX_SPD][q] >= dl->minVel_ft_s)) spd_first = q + 1; if (bnd[IDX_SPD][q] <= dl->maxVel_ft_s) spd_last = q + 1; }
+    const double bounds_dist_hi = bnd[IDX_DIST][nb[IDX_DIST] - 1]; /* mdl.bounds_initial(idx.dist, 2) = max(boundaries) */
+
+    double xy[2] = {x0_nm, y0_nm}, sh, chh;
+    em_sincosd(heading0_deg, &sh, &chh);
+    double v[2] = {chh * v0_ft_s - sh * 0.0, sh * v0_ft_s + chh * 0.0}; /* rotationmatrix(heading0)*[v0;0]  :145 */
+    double z_ft = z0_ft, heading_deg = heading0_deg, t_s = 0;
+    double prev_z_rec = 0;
+    int ii = 1, rows = 0;
+    int is_resample = 1;
+    double w[EM_MAX_R];
+    while (is_resample) {                                                           /* :160 */
+        if (rows >= cap) return -2;
+        double *row = out + (size_t)rows * 6;
+        row[0] = t_s; row[1] = xy[0]; row[2] = xy[1]; row[3] = z_ft; row[4] = heading_deg; row[5] = sqrt(v[0] * v[0] + v[1] * v[1]);
+        xy[0] += v[0] * dt_s / 6076.1154855643;                                     /* :171-173 */
+        xy[1] += v[1] * dt_s / 6076.1154855643;
+        const double curr_hdg_deg = em_wrapTo360(em_atan2d(v[1], v[0]));            /* :176-177 */
+        row[4] = curr_hdg_deg;
+        if (ii > 1) {                                                               /* :180-184 */
+            const double alt_diff_ft = z_ft - prev_z_rec;
+            row[3] = prev_z_rec + em_sign(alt_diff_ft) * fmin(dl->maxVertRate_ft_s, fabs(alt_diff_ft));
+        }
+        prev_z_rec = row[3];
+        rows++;
+        /* CreateStartDistribution :268-294 */
+        int32_t start[6];
+        start[0] = intent;
+        start[1] = em_discretize_bayes(sqrt(xy[0] * xy[0] + xy[1] * xy[1]), bnd[IDX_DIST] + 1, nb[IDX_DIST] - 2);
+        start[2] = em_discretize_bayes(em_wrapTo360(em_atan2d(xy[1], xy[0])), bnd[IDX_BEAR] + 1, nb[IDX_BEAR] - 2);
+        const int heading_discrete = em_discretize_bayes(heading_deg, bnd[IDX_HEAD] + 1, nb[IDX_HEAD] - 2);
+        start[3] = heading_discrete;
+        start[4] = em_discretize_bayes(z_ft, bnd[IDX_ALT] + 1, nb[IDX_ALT] - 2);
+        start[5] = em_discretize_bayes(sqrt(v[0] * v[0] + v[1] * v[1]), bnd[IDX_SPD] + 1, nb[IDX_SPD] - 2);
+        int att = 0;
+        is_resample = 1;
+        while (is_resample) {                                                       /* :192 */
+            if (att >= max_resample) return -3;
+            g->attempt = (uint32_t)role + 4u * (uint32_t)att;
+            att++;
+            /* dbn_sample(mdl, prior_initial, prior_transition, 2, start) (:193): every initial variable is
+             * preset, so bn_sample draws nothing; fast branch: rand(2,1) per dynamic variable, row 2 used */
+            int32_t x[16], newbin[3];
+            for (int q = 0; q < 6; q++) x[q] = start[q];
+            for (int q = 6; q < nt; q++) x[q] = 0;
+            for (int k = 0; k < 3; k++) {
+                const int tv = m->temporal_map[2 * k + 1];
+                const int r = m->r_transition[tv - 1];
+                const int64_t j = parent_config(m->G_transition, nt, m->r_transition, x, tv);
+                column_weights(m->N_transition, m->A_transition, m->off_transition[tv - 1], r, j, w);
+                if (g->mode == EM_RNG_MT19937) (void)em_rand(g, EM_SEC_TERM_TRANS, (uint32_t)(tv - 1), 0);
+                newbin[k] = em_select_random_r(w, r, em_rand(g, EM_SEC_TERM_TRANS, (uint32_t)(tv - 1), (uint32_t)ii));
+            }
+            is_resample = 0;
+            /* events rows in ascending variable id: 4 heading, 5 altitude, 6 speed (:198-238) */
+            for (int k = 0; k < 3 && !is_resample; k++) {
+                const int var = m->temporal_map[2 * k];
+                if (newbin[k] == start[var - 1]) continue;   /* no event (dbn_sample.m:151-161) */
+                const int d = newbin[k];
+                if (var == IDX_HEAD) {
+                    if (d != heading_discrete) {
+                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, (uint32_t)(var - 1), (uint32_t)ii);
+                        heading_deg = bnd[var][d - 1] + (bnd[var][d] - bnd[var][d - 1]) * u;
+                    }
+                } else if (var == IDX_ALT) {
+                    if (alt_last >= 1 && d >= 1 && d <= alt_last) {      /* 1:[] is empty in MATLAB */
+                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, (uint32_t)(var - 1), (uint32_t)ii);
+                        z_ft = bnd[var][d - 1] + (bnd[var][d] - bnd[var][d - 1]) * u;
+                    } else is_resample = 1;
+                } else if (var == IDX_SPD) {
+                    if (spd_first >= 1 && d >= spd_first && d <= spd_last) { /* []:1:e is empty: no speed event is ever valid */
+                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, (uint32_t)(var - 1), (uint32_t)ii);
+                        double s1 = bnd[var][d - 1] + (bnd[var][d] - bnd[var][d - 1]) * u;
+                        if (s1 < dl->minVel_ft_s) s1 = dl->minVel_ft_s;
+                        if (s1 > dl->maxVel_ft_s) s1 = dl->maxVel_ft_s;
+                        em_sincosd(heading_deg, &sh, &chh);
+                        v[0] = chh * s1; v[1] = sh * s1;                              /* rotationmatrix(heading_deg)*[v;0] */
+                    } else is_resample = 1;
+                }
+            }
+        }
+        /* turn toward the desired heading at no more than maxTurnRate (:241-256) */
+        const double turn1 = em_round2(heading_deg - curr_hdg_deg);
+        const double delta = fmin(fabs(turn1), dl->maxTurnRate_deg_s) * em_sign(turn1);
+        em_sincosd(delta, &sh, &chh);
+        const double vx = chh * v[0] - sh * v[1], vy = sh * v[0] + chh * v[1];
+        v[0] = vx; v[1] = vy;
+        t_s += dt_s; ii++;
+        /* CheckTrajectoryConditions :296-329 */
+        const double d_nm = sqrt(xy[0] * xy[0] + xy[1] * xy[1]);
+        const int violate_time = fabs(t_s) > tmax_s;
+        const int violate_far = d_nm > bounds_dist_hi;
+        const int violate_intent = (intent == 1 || intent == 2) ? (d_nm <= 0.25) : 0;
+        const int violate_ownship = is_ownship && xy[1] > 0.25;
+        is_resample = !(violate_time || violate_far || violate_intent || violate_ownship);
+    }
+    return rows;
+}
+
+/* Batch driver: encounter e, role = 2*aircraft + (backward), gidx = first_index + e.
+ * geo: n x 12 doubles [x0 y0 z0 v0 heading0 intent] for aircraft 1 then 2 (what createEncounter.m:41-49
+ * derives from the geometry sample).  models: 4 per-role model pointers are chosen by the caller
+ * through model_of[e*4 + role] (index into the models array).  out: [n][4][cap][6], rows[n][4]. */
+int64_t em_propagate_batch(const em_model_t *const *models, const int32_t *model_of, int mode, uint64_t seed, uint64_t first_index,
+                           int64_t n, const double *geo, const em_dynlims_t *dl /* [2] */, double tmax_s, int max_resample,
+                           double *out, int32_t *rows, int cap) {
+    em_rng_t g;
+    em_rng_init(&g, mode, seed);
+    for (int64_t e = 0; e < n; e++) {
+        g.gidx = first_index + (uint64_t)e;
+        for (int role = 0; role < 4; role++) {
+            const int ac = role >> 1, bck = role & 1;
+            const double *q = geo + e * 12 + ac * 6;
+            int r = em_propagate_trajectory(models[model_of[e * 4 + role]], &g, role, ac == 0, bck ? -1.0 : 1.0,
+                                            q[0], q[1], q[2], q[3], q[4], (int)q[5], tmax_s, &dl[ac], max_resample,
+                                            out + ((size_t)(e * 4 + role) * cap) * 6, cap);
+            if (r < 0) return r;
+            rows[e * 4 + role] = r;
+        }
+    }
+    return 0;
 }
 
 /* MT19937 helpers for tests */

@@ -467,3 +467,49 @@ def events2controls(om, initial, events):
     ctl = np.zeros((max(K, 1), 1 + nd))
     r = lib().em_events2controls(C.byref(om.c), _ptr(initial), arr, C.c_int(K), _ptr(ctl))
     return ctl[:r].copy()
+
+
+class _DynLims(C.Structure):
+    _fields_ = [("minVel_ft_s", C.c_double), ("maxVel_ft_s", C.c_double), ("maxTurnRate_deg_s", C.c_double),
+                ("maxAltitude_ft", C.c_double), ("maxVertRate_ft_s", C.c_double)]
+
+
+def propagate(oms, model_of, geo, seed, dyn_limits, mode=RNG_PHILOX, first_index=0, tmax_s=120.0, max_resample=100000, cap=None):
+    """PropagateTrajectory restated (createEncounter.m:93-265) for 4 tracks per encounter.
+    oms: list of OracleModel whose alpha_transition holds setTransitionPriors(...,1).
+    Returns (out [4n, cap, 6] f64, rows [4n])."""
+    L = lib()
+    L.em_propagate_batch.restype = C.c_int64
+    geo = np.ascontiguousarray(np.asarray(geo, dtype=np.float64).reshape(-1, 12))
+    n = geo.shape[0]
+    model_of = np.ascontiguousarray(np.asarray(model_of, dtype=np.int32).reshape(-1))
+    cap = int(cap or (int(tmax_s) + 3))
+    ptrs = (C.c_void_p * len(oms))(*[C.addressof(om.c) for om in oms])
+    dl = (_DynLims * 2)()
+    d = np.asarray(dyn_limits, dtype=np.float64).reshape(2, 5)
+    for a in range(2):
+        dl[a].minVel_ft_s, dl[a].maxVel_ft_s, dl[a].maxTurnRate_deg_s, dl[a].maxAltitude_ft, dl[a].maxVertRate_ft_s = [float(x) for x in d[a]]
+    out = np.zeros((4 * n, cap, 6))
+    rows = np.zeros(4 * n, dtype=np.int32)
+    rc = L.em_propagate_batch(ptrs, _ptr(model_of), C.c_int(mode), C.c_uint64(seed), C.c_uint64(first_index), C.c_int64(n),
+                              _ptr(geo), dl, C.c_double(tmax_s), C.c_int(max_resample), _ptr(out), _ptr(rows), C.c_int(cap))
+    if rc != 0:
+        raise RuntimeError("em_propagate_batch failed rc=%d" % rc)
+    return out, rows
+
+
+def stay_prior_alpha(parms, prior=1.0):
+    """setTransitionPriors.m:12-33 through em_oracle.c, as {var0: r x q} for OracleModel(alpha_transition=...)."""
+    L = lib()
+    out = {}
+    G = np.asarray(parms["G_transition"], dtype=bool)
+    r = np.asarray(parms["r_transition"])
+    for tm in np.asarray(parms["temporal_map"]).reshape(-1, 2):
+        ii, jj = int(tm[1]) - 1, int(tm[0]) - 1
+        if not G[:, ii].any():
+            continue
+        q = int(np.prod(r[G[:, ii]]))
+        a = np.zeros(int(r[jj]) * q)
+        L.em_transition_prior_node(C.c_int(int(r[jj])), C.c_int64(q), C.c_double(prior), _ptr(a))
+        out[ii] = a.reshape(q, int(r[jj])).T.copy()
+    return out

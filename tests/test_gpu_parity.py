@@ -303,3 +303,75 @@ def test_dense_only_per_step_mode_matches_oracle(name, gpu_ctx, model_dir):
     assert_uncor_parity(got, ref, T)
     frozen = O.uncor_sample(om, n, T, seed, per_step=False, want_events=False)
     assert not np.array_equal(frozen["dense_bin"], ref["dense_bin"])   # the two semantics really differ
+
+
+def test_mixed_model_batch_matches_oracle(gpu_ctx, model_dir):
+    """BASELINE.json configs[3] in miniature: the six uncor_*_v1p2 files (same shapes, different CPTs)
+    plus two models of other shapes, contiguous index blocks per model, one launch per block into
+    ONE shared output buffer; two 'ranks' own half the index range each."""
+    import torch
+    from em_model_manned_bayes_amd import sharding
+    names = ["uncor_1200only_fwse_v1p2", "uncor_1200only_fwme_v1p2", "uncor_1200only_rotorcraft_v1p2",
+             "uncor_1200exclude_fwse_v1p2", "uncor_1200exclude_fwme_v1p2", "uncor_1200exclude_rotorcraft_v1p2",
+             "uncor_1200code_v2p1", "uncor_allcode_rotorcraft_v1"]
+    pairs = [load_pair(nm_, model_dir) for nm_ in names]
+    n_total, T, seed = 4000, 64, 0x5EED0004
+    dev = torch.device("cuda", 0)
+    ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    G4 = T // 4
+    db = torch.zeros((G4, 3, n_total), dtype=torch.int32, device=dev)
+    dv = torch.zeros((G4, 3, n_total, 4), dtype=torch.float32, device=dev)
+    for rank in range(2):
+        lo, hi = sharding.shard_range(n_total, rank, 2)
+        for m, first, cnt in sharding.mixed_batch_blocks(n_total, len(names), lo, hi):
+            nm, pp, _ = pairs[m]
+            p, _ = native.make_params(cnt, T, seed, first_index=first, **uncor_indices(pp))
+            # column offset `first` into the shared [.., n_total] buffers: element strides are n_total, so use views
+            sub_b = db[:, :, first: first + cnt].contiguous(); sub_v = dv[:, :, first: first + cnt].contiguous()
+            native.sample_dbn_device(ctx, nm, p, dyn_bin=sub_b.data_ptr(), dyn_val=sub_v.data_ptr())
+            ctx.sync()
+            db[:, :, first: first + cnt] = sub_b; dv[:, :, first: first + cnt] = sub_v
+    gb = native.unpack_dyn_bin(db.cpu().numpy().view(np.uint32), T)
+    gv = native.unpack_dyn_val(dv.cpu().numpy(), T)
+    for m, first, cnt in sharding.mixed_batch_blocks(n_total, len(names)):
+        ref = O.uncor_sample(O.OracleModel(pairs[m][1]), cnt, T, seed, first_index=first, want_events=False)
+        assert np.array_equal(gb[first: first + cnt], ref["dense_bin"]), names[m]
+        assert np.array_equal(gv[first: first + cnt], ref["dense_val"].astype(np.float32)), names[m]
+
+
+@pytest.fixture(scope="module")
+def terminal_dir(tmp_path_factory):
+    from em_model_manned_bayes_amd import synthetic
+    return synthetic.write_terminal_directory(str(tmp_path_factory.mktemp("terminal")))
+
+
+@pytest.mark.parametrize("actypes", [("GENERIC", "GENERIC"), ("RTCA228_A1", "RTCA228_A2"), ("RTCA228_A3", "TEST")])
+def test_terminal_propagation_matches_oracle(actypes, terminal_dir, gpu_ctx):
+    """PropagateTrajectory (createEncounter.m:93-265) for both aircraft and both directions, on synthetic
+    trajectory models (the trained files are absent from the reference mount) and real geometry samples."""
+    t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=terminal_dir)
+    t.acType1, t.acType2 = actypes
+    n, seed = 600, 0x5EED0005
+    _, samples = t.sample(n, seed=seed, ctx=gpu_ctx)
+    geo, mo = t._geo_rows(samples)
+    dl = t._dyn_rows()
+    files = [m.parameters_filename for m in t._traj]
+    oms = []
+    for f in files:
+        pp = O.parse_model_txt(f)
+        oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
+    ref, ref_rows = O.propagate(oms, mo, geo, seed, dl, tmax_s=120.0)
+    got, rows = native.propagate_terminal_host(gpu_ctx, [m.native for m in t._traj], geo, mo, seed, tmax_s=120.0, dyn_limits=dl)
+    assert np.array_equal(rows, ref_rows)
+    assert rows.min() >= 1 and rows.max() <= 122
+    for L_ in range(4 * n):
+        r = rows[L_]
+        np.testing.assert_allclose(got[L_, :r], ref[L_, :r], rtol=1e-6, atol=1e-6)
+    # the class method: forward + backward combined and ordered in time (createEncounter.m:74-84)
+    traj = t.createEncounter(samples[:5], 120, seed=seed, ctx=gpu_ctx)
+    for e_, pair in enumerate(traj):
+        for a in range(2):
+            tt = pair[a]["t_s"]
+            assert np.all(np.diff(tt) == 1) and tt[0] <= 0 <= tt[-1]
+            k0 = int(np.nonzero(tt == 0)[0][0])
+            assert abs(pair[a]["v_ft_s"][k0] - samples[e_][("own", "int")[a] + "_speed"]) < 1e-3

