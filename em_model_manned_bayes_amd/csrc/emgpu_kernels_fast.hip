@@ -115,14 +115,23 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
     const uint4 z4 = make_uint4(0, 0, 0, 0);
     uint32_t cur_out = cur1;
     // Interior blocks (every second 1 <= c < T) run the unguarded high-halfword pass inline.  The
-    // first and last block of a trajectory, and any block in which SOME lane of the wave met a tie,
+    // last (partial) block of a trajectory, and any block in which SOME lane of the wave met a tie,
     // take the out-of-line exact pass (full 32-bit draws, guarded): lanes without a tie get the
     // same answers again, so control flow stays wave-uniform.
-    const bool edge = (g8 == 0) || (8 * g8 + 7 >= T);
+    const bool edge = 8 * g8 + 7 >= T; // the block runs past the end of the trajectory
     bool redo = edge;
     if (!edge) {
         const bool amb = eight_seconds_pass<R, false, false>(th, rh, z4, z4, g8, T, thr, Rres, zbin1, cur1, cur_out, pbA, pbB, hit8, chg8, zer8);
         redo = __ballot(amb) != 0ull;
+        if (g8 == 0) {
+            // Second 0 of a trajectory is the initial state, not a draw (slot 0 is never used,
+            // dbn_sample.m:133,138).  The unguarded pass treated it as one: put the initial bin back,
+            // clear its flags (streams are MSB-first: second j is bit 7-j) and re-derive "changed" of second 1.
+            const uint32_t nb_1 = (pbA >> 8) & 0xFFu;
+            pbA = (pbA & 0xFFFFFF00u) | cur1;
+            hit8 &= 0x7Fu; zer8 &= 0x7Fu;
+            chg8 = (chg8 & 0x3Fu) | ((nb_1 != cur1) ? 0x40u : 0u);
+        }
     }
     if (redo) {
         uint32_t tmp[R - 1], out[6];

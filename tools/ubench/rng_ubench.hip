@@ -108,7 +108,49 @@ void runx(const char *name) {
     hipFree(d);
 }
 
+// three interleaved xoshiro128++ streams per lane (one per dynamic variable): ILP for the serial chains
+struct Xo { uint32_t s0, s1, s2, s3; };
+__device__ __forceinline__ uint32_t xo_next(Xo &x) {
+    const uint32_t r = rotl(x.s0 + x.s3, 7) + x.s0;
+    const uint32_t t = x.s1 << 9;
+    x.s2 ^= x.s0; x.s3 ^= x.s1; x.s1 ^= x.s2; x.s0 ^= x.s3; x.s2 ^= t; x.s3 = rotl(x.s3, 11);
+    return r;
+}
+template <int ITER>
+__global__ void __launch_bounds__(256) kx3(uint32_t *out, uint32_t k0, uint32_t k1) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint4 a = philox<10>(i, 0, 0, 0, k0, k1), b = philox<10>(i, 0, 0, 1, k0, k1), c = philox<10>(i, 0, 0, 2, k0, k1);
+    Xo x0{a.x, a.y, a.z, a.w}, x1{b.x, b.y, b.z, b.w}, x2{c.x, c.y, c.z, c.w};
+    uint32_t acc = 0;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) {   // one 8-second block: 8 words per variable
+            acc += (xo_next(x0) < 0x1234567u) + (xo_next(x1) < 0x2345678u) + (xo_next(x2) < 0x3456789u);
+        }
+    }
+    out[i] = acc;
+}
+void runx3(const char *name) {
+    const int ITER = 128, blocks = 256 * 16;
+    uint32_t *d;
+    hipMalloc(&d, blocks * 256 * 4);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    kx3<ITER><<<blocks, 256>>>(d, 1, 2);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int r = 0; r < 5; r++) kx3<ITER><<<blocks, 256>>>(d, 1, 2);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    double words = 5.0 * blocks * 256.0 * ITER * 24;
+    printf("%-18s %8.3f ms  %.3e words/s  ~%.1f lane-slots/word\n", name, ms / 5, words / (ms * 1e-3), 78.6e12 / (words / (ms * 1e-3)));
+    hipFree(d);
+}
+
 int main() {
+    runx3("xoshiro128++ x3");
     runx("xoshiro128++");
     run<0, 10>("philox4x32-10");
     run<0, 10, 20000>("philox-10 8blk/CU");   // 8 waves/SIMD

@@ -1,0 +1,78 @@
+// tools/ubench/valu_ubench.hip -- issue cost of the integer VALU instructions the sampler leans on (gfx950),
+// measured with inline asm so that the compiler cannot fold anything.  8 independent chains per lane,
+// 8 waves per SIMD.  Prints SIMD-cycles per wave-instruction at the clock measured with s_memtime.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t a0, uint32_t b0, int iters) {
+    uint32_t x0, x1, x2, x3, x4, x5, x6, x7;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    x0 = i + a0; x1 = i * 3 + a0; x2 = i * 5 + a0; x3 = i * 7 + a0; x4 = i * 9 + a0; x5 = i * 11 + a0; x6 = i * 13 + a0; x7 = i * 15 + a0;
+    uint32_t c = b0 ^ i, d = a0 + i * 17;
+    uint32_t cnt = 0;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#define XOR(n) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x##n) : "v"(c));
+#define BITOP(n) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x##n) : "v"(c), "s"(b0));
+#define ALIGN(n) asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(x##n));
+#define ADD3(n) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x##n) : "v"(c), "v"(d));
+#define LSHLOR(n) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(x##n) : "v"(c));
+#define MAX3(n) asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(x##n) : "v"(c), "v"(d));
+#define SUBCO(n) asm volatile("v_sub_co_u32 %0, vcc, %1, %2\n\ts_nop 1\n\tv_subbrev_co_u32 %3, vcc, 0, %3, vcc" : "=v"(x##n), "+v"(cnt) : "v"(c), "v"(d) : "vcc"); asm volatile("" : "+v"(cnt));
+#define CMPCND(n) asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x##n) : "v"(c), "v"(d) : "vcc");
+#define SUB(n) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x##n) : "v"(c));
+#define MAD(n) { uint64_t p; asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, 0" : "=v"(p) : "v"(x##n), "s"(b0) : "s10", "s11"); x##n = (uint32_t)(p >> 32); }
+            if (KIND == 0) { REP8(XOR) }
+            if (KIND == 1) { REP8(BITOP) }
+            if (KIND == 2) { REP8(ALIGN) }
+            if (KIND == 3) { REP8(ADD3) }
+            if (KIND == 4) { REP8(MAD) }
+            if (KIND == 5) { REP8(SUBCO) }
+            if (KIND == 6) { REP8(LSHLOR) }
+            if (KIND == 7) { REP8(MAX3) }
+            if (KIND == 8) { REP8(CMPCND) }
+            if (KIND == 9) { REP8(SUB) }
+        }
+    }
+    out[i] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + cnt;
+}
+
+template <int KIND>
+void run(const char *name, int instr_per_op) {
+    const int blocks = 256 * 8, iters = 256;
+    uint32_t *d;
+    hipMalloc(&d, blocks * 256 * 4);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    k<KIND><<<blocks, 256>>>(d, 1, 2, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int r = 0; r < 5; r++) k<KIND><<<blocks, 256>>>(d, 1, 2, iters);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    const double wave_instr = 5.0 * blocks * 4.0 * iters * 8 * 8 * instr_per_op;
+    const double cyc = (ms * 1e-3) * 2.4e9 * 1024.0 / wave_instr;
+    printf("%-34s %7.3f ms  %.2f SIMD-cycles per wave-instruction (at 2.4 GHz)\n", name, ms / 5, cyc);
+    hipFree(d);
+}
+
+int main() {
+    run<0>("v_xor_b32 (VOP2)", 1);
+    run<9>("v_sub_u32 (VOP2)", 1);
+    run<1>("v_bitop3_b32 (VOP3, 1 sgpr)", 1);
+    run<2>("v_alignbit_b32", 1);
+    run<3>("v_add3_u32", 1);
+    run<6>("v_lshl_or_b32", 1);
+    run<7>("v_max3_u32", 1);
+    run<4>("v_mad_u64_u32", 1);
+    run<5>("v_sub_co + s_nop 1 + v_subbrev_co", 2);
+    run<8>("v_cmp_lt + s_nop 1 + v_cndmask", 2);
+    return 0;
+}
