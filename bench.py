@@ -181,7 +181,7 @@ def cpu_baseline(model_txt, n_cpu, per_step, T):
     O.uncor_sample(om, n_cpu, T, SEED, mode=O.RNG_PHILOX, per_step=per_step, want_events=False, want_dense=True)
     dt1 = time.perf_counter() - t0
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n_mt = int(min(n_cpu * cores, 4_000_000))
+    n_mt = int(min(n_cpu * cores, 1_000_000))  # dense f64 outputs: 6.5 GB of host memory at 1 M
     t0 = time.perf_counter()
     O.uncor_sample_mt(om, n_mt, T, SEED, cores, per_step=per_step)
     dtm = time.perf_counter() - t0
