@@ -457,6 +457,31 @@ class CorTerminalModel(EncounterModel):
         outSamples = [dict(zip(names, row)) for row in outInits]
         return outInits, outSamples
 
+    def InitStartTerminal(self, nSamples=1000000, airspace_class=(False, True, True, True), own_intent=(True, True),
+                          int_intent=(True, True, True), isVerbose=False):
+        """out_start = InitStartTerminal(self, nSamples, airspace_class, own_intent, int_intent)
+        (@CorTerminalModel/InitStartTerminal.m:1-92): a grid of start distributions, one row per encounter,
+        the first three variables preset to every kept (airspace class, ownship intent, intruder intent)
+        combination in turn.  Rows are lists usable as `self.start`."""
+        assert self.labels_initial[0] == '"airspace_class"' and self.labels_initial[1] == '"own_intent"' and self.labels_initial[2] == '"int_intent"'
+        r = self.r_initial
+        assert len(airspace_class) == r[0] and len(own_intent) == r[1] and len(int_intent) == r[2]
+        idx_class = [i + 1 for i, k in enumerate(airspace_class) if k]
+        idx_own = [i + 1 for i, k in enumerate(own_intent) if k]
+        idx_int = [i + 1 for i, k in enumerate(int_intent) if k]
+        n_combs = len(idx_class) * len(idx_own) * len(idx_int)
+        n_samples = int(nSamples)
+        if n_combs > n_samples:
+            n_samples = n_combs                                          # :50-53
+        per = -(-n_samples // n_combs)                                   # ceil, :56
+        out = []
+        for ii in idx_class:
+            for jj in idx_own:
+                for kk in idx_int:
+                    for _ in range(per):
+                        out.append([ii, jj, kk] + [None] * (self.n_initial - 3))
+        return out
+
     # ---- createEncounter.m:1-91 without em-core's local_smooth (:88-89)
     @staticmethod
     def _sincosd(deg):

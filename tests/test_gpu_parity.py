@@ -375,3 +375,46 @@ def test_terminal_propagation_matches_oracle(actypes, terminal_dir, gpu_ctx):
             assert np.all(np.diff(tt) == 1) and tt[0] <= 0 <= tt[-1]
             k0 = int(np.nonzero(tt == 0)[0][0])
             assert abs(pair[a]["v_ft_s"][k0] - samples[e_][("own", "int")[a] + "_speed"]) < 1e-3
+
+
+def test_edge_cases_and_error_paths(gpu_ctx, model_dir):
+    nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
+    idx = uncor_indices(pp)
+    om = O.OracleModel(pp)
+    # empty batch
+    got = native.sample_dbn_host(gpu_ctx, nm, 0, 16, 1, want_dense=True, want_events=True, **idx)
+    assert got["init_bin"].shape == (0, 7) and got["dyn_bin"].shape == (0, 16, 3) and got["events"] == []
+    # a single trajectory, a single second (no transition at all: dbn_sample.m:66,138 loops run 2:t_max)
+    for want_events in (False, True):
+        got = native.sample_dbn_host(gpu_ctx, nm, 1, 1, 9, want_dense=True, want_events=want_events, **idx)
+        ref = O.uncor_sample(om, 1, 1, 9)
+        assert_uncor_parity(got, ref, 1)
+    if True:
+        assert ref["events"][0].shape[0] >= 1 and ref["events"][0][-1, 1] == 0     # only resample rows + the terminator
+    # long trajectories, ragged batch sizes around the 64 / 256 lane boundaries
+    for n, T in ((63, 1000), (65, 999), (255, 17), (257, 16), (1, 4001)):
+        ref = O.uncor_sample(om, n, T, 123, first_index=2**40, want_events=False)
+        got = native.sample_dbn_host(gpu_ctx, nm, n, T, 123, first_index=2**40, want_dense=True, want_events=False, **idx)
+        assert_uncor_parity(got, ref, T)
+    # event lists that do not fit event_cap: deferred EMGPU_ERR_EVENT_CAP (the counts are still reported)
+    with pytest.raises(E.EmgpuError) as ei:
+        native.sample_dbn_host(gpu_ctx, nm, 500, 240, 5, want_dense=False, want_events=True, event_cap=8, **idx)
+    assert ei.value.code == L.ERR_EVENT_CAP
+    # rejection cap: preset a start that can never satisfy v*1.68781 > |dh|/60 often enough within 1 attempt
+    nm.set_start([1, 4, 2, 1, 2, 1, 0])          # slowest speed bin with the steepest descent bin (parents preset too)
+    try:
+        with pytest.raises(E.EmgpuError) as ei:
+            native.sample_dbn_host(gpu_ctx, nm, 4000, 8, 5, want_dense=True, max_attempts=1, **idx)
+        assert ei.value.code == L.ERR_REJECT_CAP
+        ref = O.uncor_sample(O.OracleModel(pp, start=[1, 4, 2, 1, 2, 1, 0]), 300, 8, 5, max_attempts=100000)
+        got = native.sample_dbn_host(gpu_ctx, nm, 300, 8, 5, want_dense=True, want_events=True, max_attempts=100000, **idx)
+        assert ref["attempts"].max() > 3
+        assert_uncor_parity(got, ref, 8)
+    finally:
+        nm.set_start([0] * 7)
+    # arguments
+    for bad in (dict(sample_time=0), dict(sample_time=70000)):
+        with pytest.raises(E.EmgpuError):
+            native.sample_dbn_host(gpu_ctx, nm, 4, bad["sample_time"], 1, **idx)
+    with pytest.raises(E.EmgpuError):
+        native.sample_dbn_host(gpu_ctx, nm, 4, 8, 1, layers=np.array([[0, 1]] * 4), **idx)   # L is not a bin index here

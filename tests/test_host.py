@@ -231,3 +231,15 @@ def test_class_surface(model_dir):
     assert t.n_initial == 15 and t.getDynamicLimits(2)["maxVel_ft_s"] == 506 and t.bounds_sample.shape == (15, 2)
     with pytest.raises(NotImplementedError):
         mdl.track(1, 10)
+
+
+def test_init_start_terminal_grid():
+    t = E.CorTerminalModel()
+    grid = t.InitStartTerminal(nSamples=36)                               # InitStartTerminal.m defaults: class B excluded
+    assert len(grid) == 36 and len(grid[0]) == 15
+    combos = sorted({tuple(g[:3]) for g in grid})
+    assert len(combos) == 3 * 2 * 3 and all(c[0] in (2, 3, 4) for c in combos)
+    assert all(v is None for v in grid[0][3:])
+    assert len(t.InitStartTerminal(nSamples=5)) == 18                     # fewer samples than combinations -> one each (:50-53)
+    t.start = grid[0]
+    assert t.native.get_i32(L.F_START).tolist()[:3] == list(grid[0][:3])
