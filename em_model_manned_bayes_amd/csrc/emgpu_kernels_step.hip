@@ -10,6 +10,8 @@
 // Bound: VALU + L1/L2 gather latency; HBM writes are 4 880 B (cor) / 3 635 B (uncor) per trajectory.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "emgpu_coop.h"
 #include "emgpu_device.h"
 #include "emgpu_launch.h"
@@ -21,8 +23,11 @@ struct StepArgs {
     uint32_t slot[EMGPU_MAX_ND]; // output row of dynamic variable k
 };
 
-template <int NI, int ND, int RM1>
+// LDS_T: the dynamic variables' threshold tables are staged in (dynamic) LDS by the workgroup
+// (cor_v1: 29 KB); otherwise they are gathered from global memory (L1/L2).
+template <int NI, int ND, int RM1, bool LDS_T>
 __global__ void __launch_bounds__(256, 2) k_dbn_step(const EmgpuPlan P, const EmgpuRun A, const StepArgs F) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_thr[];
     __shared__ CoopLds<ND> s_wave[4];
     __shared__ double s_bnd[ND][16];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -54,7 +59,10 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step(const EmgpuPlan P, const Em
         }
     }
     W.attempt[lane] = rng.attempt;
+    if (LDS_T)
+        for (uint32_t q = (uint32_t)tid; q < P.thr_total - P.d_off[0]; q += 256u) s_thr[q] = P.thr[P.d_off[0] + q];
     __syncthreads();
+    const uint32_t *__restrict__ tbase = LDS_T ? (const uint32_t *)s_thr - P.d_off[0] : P.thr;
 
     uint32_t cur1[ND], basecol[ND], ivs[ND];
     float cval[ND];
@@ -108,7 +116,7 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step(const EmgpuPlan P, const Em
 #pragma unroll
                     for (int q = 0; q < k; q++) col += P.d_stride_new[k][q] * (nb1[q] - 1u);
                     const int rm1 = (int)P.d_r[k] - 1;
-                    const uint32_t *__restrict__ t = P.thr + P.d_off[k] + (size_t)col * (uint32_t)rm1;
+                    const uint32_t *__restrict__ t = tbase + P.d_off[k] + (size_t)col * (uint32_t)rm1;
                     const uint32_t x = clamp32(split_draw(th[k], tl[k], j));
                     uint32_t borrows = 0u;
 #pragma unroll
@@ -163,9 +171,14 @@ bool step_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
 }
 
 template <int NI, int ND, int RM1>
-static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const StepArgs &F, hipStream_t s) {
+static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const StepArgs &F, hipStream_t s, bool lds) {
     const int64_t blocks = (A.n + 255) / 256;
-    hipLaunchKernelGGL((k_dbn_step<NI, ND, RM1>), dim3((unsigned)blocks), dim3(256), 0, s, P, A, F);
+    if (lds) {
+        const size_t bytes = (size_t)(P.thr_total - P.d_off[0]) * sizeof(uint32_t);
+        hipLaunchKernelGGL((k_dbn_step<NI, ND, RM1, true>), dim3((unsigned)blocks), dim3(256), bytes, s, P, A, F);
+    } else {
+        hipLaunchKernelGGL((k_dbn_step<NI, ND, RM1, false>), dim3((unsigned)blocks), dim3(256), 0, s, P, A, F);
+    }
     return hipGetLastError();
 }
 
@@ -177,10 +190,13 @@ hipError_t launch_dbn_step(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s,
         for (int a = 0; a < P.nact; a++)
             if (P.a_dyn[a] == k) F.Rk[k] = P.a_R[a];
     }
-    if (P.ni <= 7 && P.nd <= 3) { *name = "k_dbn_step<7,3,8>"; return launch_t<7, 3, 8>(P, A, F, s); }
-    if (P.ni <= 9 && P.nd <= 3) { *name = "k_dbn_step<9,3,8>"; return launch_t<9, 3, 8>(P, A, F, s); }
-    *name = "k_dbn_step<16,4,8>";
-    return launch_t<16, 4, 8>(P, A, F, s);
+    // stage the dynamic tables in LDS when two workgroups per CU still fit beside the cooperative area
+    static const bool no_lds = getenv("EMGPU_DEBUG_STEP_NO_LDS") != nullptr;
+    const bool lds = !no_lds && (size_t)(P.thr_total - P.d_off[0]) * sizeof(uint32_t) <= 32768;
+    if (P.ni <= 7 && P.nd <= 3) { *name = lds ? "k_dbn_step<7,3,8,lds>" : "k_dbn_step<7,3,8>"; return launch_t<7, 3, 8>(P, A, F, s, lds); }
+    if (P.ni <= 9 && P.nd <= 3) { *name = lds ? "k_dbn_step<9,3,8,lds>" : "k_dbn_step<9,3,8>"; return launch_t<9, 3, 8>(P, A, F, s, lds); }
+    *name = lds ? "k_dbn_step<16,4,8,lds>" : "k_dbn_step<16,4,8>";
+    return launch_t<16, 4, 8>(P, A, F, s, lds);
 }
 
 } // namespace emgpu

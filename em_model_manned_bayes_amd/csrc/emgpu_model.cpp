@@ -475,6 +475,7 @@ CompiledPlan compile_plan(const Model &m) {
         na++;
     }
     P.nact = na;
+    P.thr_total = (uint32_t)cp.thr.size();
     return cp;
 }
 
