@@ -1,5 +1,5 @@
 """Deterministic synthetic stand-ins for model files that are absent from the reference mount
-(/root/reference/.MISSING_LARGE_BLOBS): the 20 terminal trajectory models
+(the reference repository's .MISSING_LARGE_BLOBS): the 20 terminal trajectory models
 terminal_v3_*_{ownship,intruder}_{landing,takeoff,transit}_model[_reverse].txt.
 
 Structure from doc/model_terminal_traj_fwd.png / _bck.png and createEncounter.m:107-109,:293

@@ -243,3 +243,21 @@ def test_init_start_terminal_grid():
     assert len(t.InitStartTerminal(nSamples=5)) == 18                     # fewer samples than combinations -> one each (:50-53)
     t.start = grid[0]
     assert t.native.get_i32(L.F_START).tolist()[:3] == list(grid[0][:3])
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under the package (Python or C++/HIP) may import,
+    link or open it, and nothing may read /root/reference at run time."""
+    pkg = os.path.join(ROOT, "em_model_manned_bayes_amd")
+    offenders = []
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".c", ".m")) and f != "Makefile":
+                continue
+            text = open(os.path.join(base, f), errors="replace").read()
+            if re.search(r"(import\s+oracle|from\s+oracle|em_oracle|libem_oracle|oracle/|/root/reference)", text):
+                offenders.append(os.path.relpath(os.path.join(base, f), ROOT))
+    assert offenders == [], offenders
+    for f in ("bench.py", "__graft_entry__.py"):
+        text = open(os.path.join(ROOT, f)).read()
+        assert "/root/reference" not in text
