@@ -418,3 +418,51 @@ def test_edge_cases_and_error_paths(gpu_ctx, model_dir):
             native.sample_dbn_host(gpu_ctx, nm, 4, bad["sample_time"], 1, **idx)
     with pytest.raises(E.EmgpuError):
         native.sample_dbn_host(gpu_ctx, nm, 4, 8, 1, layers=np.array([[0, 1]] * 4), **idx)   # L is not a bin index here
+
+
+def test_large_sample_frequencies_match_the_cpts(gpu_ctx, model_dir):
+    """4 M trajectories from the HIP path: empirical frequencies of the root node, of A | G and of the
+    first transition of \\dot\\psi given the most common initial configuration against the normalised CPT
+    columns (chi-square), i.e. the distribution is the reference's, not just the oracle's."""
+    import torch
+    from scipy import stats
+    nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
+    idx = uncor_indices(pp)
+    n, T = 4_000_000, 8
+    dev = torch.device("cuda", 0)
+    ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    ib = torch.empty((7, n), dtype=torch.uint8, device=dev)
+    db = torch.empty((2, 3, n), dtype=torch.int32, device=dev)
+    p, _ = native.make_params(n, T, 20261003, **idx)
+    native.sample_dbn_device(ctx, nm, p, init_bin=ib.data_ptr(), dyn_bin=db.data_ptr())
+    ctx.sync()
+    ibc = ib.cpu().numpy()
+    # root node G
+    w = pp["N_initial"][0][:, 0]
+    obs = np.bincount(ibc[0], minlength=5)[1:]
+    assert stats.chisquare(obs, w / w.sum() * n).pvalue > 1e-4
+    # A | G = 1.  (The rejection test v*1.68781 > |dh|/60 removes <1e-4 of the samples: no visible bias here.)
+    sel = ibc[0] == 1
+    w = pp["N_initial"][1][:, 0]
+    obs = np.bincount(ibc[1][sel], minlength=5)[1:]
+    assert obs[w == 0].sum() == 0
+    assert stats.chisquare(obs[w > 0], w[w > 0] / w.sum() * sel.sum()).pvalue > 1e-4
+    # first transition of \dot\psi for the most common initial configuration (frozen-parent column, dbn_sample.m:110-135)
+    keys = (ibc.astype(np.int64) * (10 ** np.arange(7))[:, None]).sum(axis=0)
+    vals, counts = np.unique(keys, return_counts=True)
+    common = vals[np.argmax(counts)]
+    sel = keys == common
+    cfg = [(common // 10 ** k) % 10 for k in range(7)]
+    G = pp["G_transition"]; r = pp["r_transition"]
+    par = np.nonzero(G[:, 9])[0]
+    j, kk = 0, 1
+    for q in par:
+        j += kk * (cfg[q] - 1); kk *= r[q]
+    w = pp["N_transition"][9][:, j]
+    col1 = (db[0, 2].cpu().numpy().view(np.uint32) >> 8) & 0xFF          # second 1 of \dot\psi
+    obs = np.bincount(col1[sel], minlength=8)[1:]
+    assert obs[w == 0].sum() == 0
+    exp = w[w > 0] / w.sum() * sel.sum()
+    keep = exp >= 5
+    o, e_ = obs[w > 0][keep], exp[keep]
+    assert stats.chisquare(o, e_ * o.sum() / e_.sum()).pvalue > 1e-4
