@@ -46,6 +46,7 @@ struct Uploaded {
     uint64_t last_use = 0;
     CompiledPlan cp;
     uint32_t *d_thr = nullptr;
+    uint32_t *d_cthr = nullptr;
     double *d_bnd = nullptr;
 };
 } // namespace
@@ -328,7 +329,7 @@ int emgpu_ctx_sync(emgpu_ctx *ctx) {
 void emgpu_ctx_free(emgpu_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (auto &kv : ctx->cache) { (void)hipFree(kv.second.d_thr); (void)hipFree(kv.second.d_bnd); }
+    for (auto &kv : ctx->cache) { (void)hipFree(kv.second.d_thr); (void)hipFree(kv.second.d_cthr); (void)hipFree(kv.second.d_bnd); }
     (void)hipFree(ctx->d_status);
     (void)hipFree(ctx->d_layers);
     (void)hipFree(ctx->d_thr_base);
@@ -351,7 +352,7 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h) {
         std::sort(byuse.begin(), byuse.end());
         for (size_t q = 0; q < byuse.size() / 2; q++) {
             Uploaded &old = ctx->cache[byuse[q].second];
-            (void)hipFree(old.d_thr); (void)hipFree(old.d_bnd);
+            (void)hipFree(old.d_thr); (void)hipFree(old.d_cthr); (void)hipFree(old.d_bnd);
             ctx->cache.erase(byuse[q].second);
         }
     }
@@ -363,14 +364,18 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h) {
     HIP_OK(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read the old tables
     if (u.d_thr) { HIP_OK(hipFree(u.d_thr)); u.d_thr = nullptr; }
     if (u.d_bnd) { HIP_OK(hipFree(u.d_bnd)); u.d_bnd = nullptr; }
+    if (u.d_cthr) { HIP_OK(hipFree(u.d_cthr)); u.d_cthr = nullptr; }
     const size_t nthr = cp.thr.size() ? cp.thr.size() : 1;
     HIP_OK(hipMalloc((void **)&u.d_thr, nthr * sizeof(uint32_t)));
     HIP_OK(hipMalloc((void **)&u.d_bnd, cp.bnd.size() * sizeof(double)));
     if (!cp.thr.empty()) HIP_OK(hipMemcpy(u.d_thr, cp.thr.data(), cp.thr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(u.d_bnd, cp.bnd.data(), cp.bnd.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc((void **)&u.d_cthr, (cp.cthr.size() ? cp.cthr.size() : 1) * sizeof(uint32_t)));
+    if (!cp.cthr.empty()) HIP_OK(hipMemcpy(u.d_cthr, cp.cthr.data(), cp.cthr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     u.cp = std::move(cp);
     u.cp.plan.thr = u.d_thr;
     u.cp.plan.bnd = u.d_bnd;
+    u.cp.plan.cthr = u.d_cthr;
     u.version = h->m.version;
     return u;
 }

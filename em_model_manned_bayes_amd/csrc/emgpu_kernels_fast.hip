@@ -36,10 +36,23 @@ struct FastArgs {
 #define EMGPU_FAST_WAVES 4 // waves per SIMD the register budget is set for (LDS allows 4 workgroups per CU)
 #endif
 
-template <int R>
-__device__ __forceinline__ void load_thr(uint32_t (&th)[R - 1], const uint32_t *__restrict__ p) {
+// One compacted CPT column (EmgpuPlan::cthr): meff distinct thresholds, then the nibble map
+// bin(n) = (map >> 4n) & 15 with n = #{t : x' >= threshold t}.  The kernel instance may be built for
+// M >= meff thresholds: the extra ones are "never".  The map is returned re-indexed by the number of
+// BORROWS b = M - n (what the compare chain counts): bin = (bmap >> 4b) & 15.
+template <int M>
+__device__ __forceinline__ void load_cthr(uint32_t (&th)[M], uint32_t &bmap, const uint32_t *__restrict__ p, int meff) {
 #pragma unroll
-    for (int j = 0; j < R - 1; j++) th[j] = p[j];
+    for (int t = 0; t < M; t++) th[t] = (t < meff) ? p[t] : 0xFFFFFFFFu;
+    const uint32_t map = p[meff];
+    uint32_t r = 0u;
+#pragma unroll
+    for (int b = 0; b <= M; b++) {
+        const int n = M - b;                       // thresholds that fired
+        const int nn = n < meff ? n : meff;        // the padded ones never fire
+        r |= ((map >> (4 * nn)) & 15u) << (4 * b);
+    }
+    bmap = r;
 }
 
 // Eight seconds of one dynamic variable.  Outputs: bins packed 1-based 4 per word (pbA: seconds
@@ -50,9 +63,9 @@ __device__ __forceinline__ void load_thr(uint32_t (&th)[R - 1], const uint32_t *
 // EXACT = false: decide from the high halfwords only and report `amb` when some compare could
 // flip with the low halfword; EXACT = true: full 32-bit draws.  Every flag is accumulated with
 // x = x + x + carry so that one v_cmp + one v_addc serve per flag and second.
-template <int R, bool EXACT, bool EDGE>
+template <int M, bool EXACT, bool EDGE>
 __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 &rh, const uint4 &tl, const uint4 &rl, int g8, int T,
-                                                   const uint32_t (&thr)[R - 1], uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
+                                                   const uint32_t (&thr)[M], uint32_t bmap, uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
                                                    uint32_t &cur_out, uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
     bool amb = false;
     uint32_t c1 = cur_in;
@@ -68,13 +81,13 @@ __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 
             h = (xr < Rres) ? 1u : 0u;
             uint32_t borrows = 0u, dmax = 0u;
 #pragma unroll
-            for (int t = 0; t < R - 1; t++) {                 // select_random.m:19-20 on thresholds
+            for (int t = 0; t < M; t++) {                     // select_random.m:19-20 on the distinct thresholds
                 borrows += (xt < thr[t]) ? 1u : 0u;
                 const uint32_t d = xt - thr[t];
                 dmax = d > dmax ? d : dmax;
             }
             if (!EXACT) amb = amb | (xr == Rhi) | (dmax >= 0xFFFF0001u);
-            const uint32_t nb1 = (uint32_t)R - borrows;       // 1 + #{t : xt >= thr[t]}  (dbn_sample.m:144)
+            const uint32_t nb1 = (bmap >> (borrows << 2)) & 15u; // the bin of "M - borrows thresholds fired"  (dbn_sample.m:144)
             ch = (nb1 != c1) ? 1u : 0u;
             c1 = nb1;                                         // map back, dbn_sample.m:149
             z = (nb1 == zbin1) ? 1u : 0u;
@@ -90,25 +103,25 @@ __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 
 }
 
 // rare path, kept out of line so that the hot loop stays small in the instruction cache
-template <int R>
+template <int M>
 __device__ __attribute__((noinline)) void eight_seconds_exact(uint32_t c0, uint32_t c1r, uint32_t attempt, uint32_t k0, uint32_t k1,
                                                               uint4 th, uint4 rh, uint32_t tvar, uint32_t ivar, int g8, int T,
-                                                              const uint32_t *thr_in, uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
+                                                              const uint32_t *thr_in, uint32_t bmap, uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
                                                               uint32_t *out /* cur, pbA, pbB, hit8, chg8, zer8 */) {
     const Rng rng{c0, c1r, attempt, k0, k1};
     const uint4 tl = rng.block(EMGPU_SEC_TRANS_LO, tvar, (uint32_t)g8);
     const uint4 rl = rng.block(EMGPU_SEC_RES_LO, ivar, (uint32_t)g8);
-    uint32_t thr[R - 1];
+    uint32_t thr[M];
 #pragma unroll
-    for (int t = 0; t < R - 1; t++) thr[t] = thr_in[t];
+    for (int t = 0; t < M; t++) thr[t] = thr_in[t];
     uint32_t cur, a, b, h, c, z;
-    eight_seconds_pass<R, true, true>(th, rh, tl, rl, g8, T, thr, Rres, zbin1, cur_in, cur, a, b, h, c, z);
+    eight_seconds_pass<M, true, true>(th, rh, tl, rl, g8, T, thr, bmap, Rres, zbin1, cur_in, cur, a, b, h, c, z);
     out[0] = cur; out[1] = a; out[2] = b; out[3] = h; out[4] = c; out[5] = z;
 }
 
-template <int R>
+template <int M>
 __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uint32_t ivar, int g8, int T,
-                                              const uint32_t (&thr)[R - 1], uint32_t Rres, uint32_t zbin1, uint32_t &cur1,
+                                              const uint32_t (&thr)[M], uint32_t bmap, uint32_t Rres, uint32_t zbin1, uint32_t &cur1,
                                               uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
     const uint4 th = rng.block(EMGPU_SEC_TRANS, tvar, (uint32_t)g8);
     const uint4 rh = rng.block(EMGPU_SEC_RES, ivar, (uint32_t)g8);
@@ -121,7 +134,7 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
     const bool edge = 8 * g8 + 7 >= T; // the block runs past the end of the trajectory
     bool redo = edge;
     if (!edge) {
-        const bool amb = eight_seconds_pass<R, false, false>(th, rh, z4, z4, g8, T, thr, Rres, zbin1, cur1, cur_out, pbA, pbB, hit8, chg8, zer8);
+        const bool amb = eight_seconds_pass<M, false, false>(th, rh, z4, z4, g8, T, thr, bmap, Rres, zbin1, cur1, cur_out, pbA, pbB, hit8, chg8, zer8);
         redo = __ballot(amb) != 0ull;
         if (g8 == 0) {
             // Second 0 of a trajectory is the initial state, not a draw (slot 0 is never used,
@@ -134,16 +147,16 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
         }
     }
     if (redo) {
-        uint32_t tmp[R - 1], out[6];
+        uint32_t tmp[M], out[6];
 #pragma unroll
-        for (int t = 0; t < R - 1; t++) tmp[t] = thr[t];
-        eight_seconds_exact<R>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, tmp, Rres, zbin1, cur1, out);
+        for (int t = 0; t < M; t++) tmp[t] = thr[t];
+        eight_seconds_exact<M>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, tmp, bmap, Rres, zbin1, cur1, out);
         cur_out = out[0]; pbA = out[1]; pbB = out[2]; hit8 = out[3]; chg8 = out[4]; zer8 = out[5];
     }
     cur1 = cur_out;
 }
 
-template <int NI, int R0, int R1, int R2>
+template <int NI, int M0, int M1, int M2>
 __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
     __shared__ CoopLds<3> s_wave[4];
     __shared__ double s_bnd[3][16];
@@ -186,7 +199,7 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
         cur1[k] = (uint32_t)pick<NI>(bin, P.d_ipos[k]) + 1u;
         cval[k] = (float)pick<NI>(val, P.d_ipos[k]);
     }
-    uint32_t th0[R0 - 1], th1[R1 - 1], th2[R2 - 1];
+    uint32_t th0[M0], th1[M1], th2[M2], bm0, bm1, bm2;
     {
         uint32_t col[3];
 #pragma unroll
@@ -198,9 +211,9 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
             for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)(cur1[q] - 1);
             col[k] = c;
         }
-        load_thr<R0>(th0, P.thr + P.d_off[0] + (size_t)col[0] * (R0 - 1));
-        load_thr<R1>(th1, P.thr + P.d_off[1] + (size_t)col[1] * (R1 - 1));
-        load_thr<R2>(th2, P.thr + P.d_off[2] + (size_t)col[2] * (R2 - 1));
+        load_cthr<M0>(th0, bm0, P.cthr + P.d_coff[0] + (size_t)col[0] * (uint32_t)(P.d_meff[0] + 1), P.d_meff[0]);
+        load_cthr<M1>(th1, bm1, P.cthr + P.d_coff[1] + (size_t)col[1] * (uint32_t)(P.d_meff[1] + 1), P.d_meff[1]);
+        load_cthr<M2>(th2, bm2, P.cthr + P.d_coff[2] + (size_t)col[2] * (uint32_t)(P.d_meff[2] + 1), P.d_meff[2]);
     }
     const uint32_t iv0 = P.d_ivar[0], iv1 = P.d_ivar[1], iv2 = P.d_ivar[2];
     const uint32_t ivs[3] = {iv0, iv1, iv2};
@@ -210,9 +223,9 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
         uint32_t pbA[3], pbB[3], need8[3], kind8[3], zero8[3];
         {
             uint32_t hit8[3], chg8[3], zer8[3];
-            eight_seconds<R0>(rng, P.d_tvar[0], iv0, g8, T, th0, F.Rk[0], (uint32_t)P.d_zero[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
-            eight_seconds<R1>(rng, P.d_tvar[1], iv1, g8, T, th1, F.Rk[1], (uint32_t)P.d_zero[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
-            eight_seconds<R2>(rng, P.d_tvar[2], iv2, g8, T, th2, F.Rk[2], (uint32_t)P.d_zero[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
+            eight_seconds<M0>(rng, P.d_tvar[0], iv0, g8, T, th0, bm0, F.Rk[0], (uint32_t)P.d_zero[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
+            eight_seconds<M1>(rng, P.d_tvar[1], iv1, g8, T, th1, bm1, F.Rk[1], (uint32_t)P.d_zero[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
+            eight_seconds<M2>(rng, P.d_tvar[2], iv2, g8, T, th2, bm2, F.Rk[2], (uint32_t)P.d_zero[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 // flag streams are MSB-first: bit (7-j) <-> second j; turn them into bit j <-> second j
@@ -233,28 +246,39 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
     }
 }
 
+// Kernel instances by the number of DISTINCT thresholds per column of the three dynamic variables
+// (EmgpuPlan::d_meff).  A model runs on the first instance that covers it.
+struct FastShape { int ni, m0, m1, m2; };
+static const FastShape kFastShapes[] = {
+    {7, 2, 2, 2}, {7, 2, 4, 2}, {7, 2, 4, 4}, {7, 4, 2, 4}, {7, 4, 6, 4}, {7, 4, 6, 6}, {7, 6, 6, 6}, {9, 6, 6, 6},
+};
+
+static int fast_shape_of(const EmgpuPlan &P) {
+    for (size_t q = 0; q < sizeof kFastShapes / sizeof kFastShapes[0]; q++) {
+        const FastShape &f = kFastShapes[q];
+        if (P.ni <= f.ni && P.d_meff[0] <= f.m0 && P.d_meff[1] <= f.m1 && P.d_meff[2] <= f.m2) return (int)q;
+    }
+    return -1;
+}
+
 bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     if (P.nd != 3 || P.depend || A.per_step) return false;
     if (A.ev_count != nullptr || A.events != nullptr) return false;
     if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
     for (int k = 0; k < 3; k++) {
-        if (P.d_nb[k] == 0 || P.d_nb[k] > 16) return false;
+        if (P.d_nb[k] == 0 || P.d_nb[k] > 16 || P.d_meff[k] == 0) return false;
         for (int a = 0; a < P.nact; a++)
             if (P.a_dyn[a] == k && P.a_R[a] == 0xFFFFFFFFu) return false; // rate ~ 1: generic path
     }
-    const int r0 = P.d_r[0], r1 = P.d_r[1], r2 = P.d_r[2];
-    if (P.ni <= 7 && r0 == 5 && r1 == 7 && r2 == 7) return true;
-    if (P.ni <= 7 && r0 == 5 && r1 == 9 && r2 == 7) return true;
-    if (P.ni <= 9 && r0 == 7 && r1 == 7 && r2 == 5) return true;
-    return false;
+    return fast_shape_of(P) >= 0;
 }
 
-template <int NI, int R0, int R1, int R2>
+template <int NI, int M0, int M1, int M2>
 static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs &F, hipStream_t s) {
     const int64_t blocks = (A.n + 255) / 256;
     // EMGPU_DEBUG_EXTRA_LDS: bytes of unused dynamic LDS per workgroup, to study occupancy sensitivity
     static const int extra_lds = getenv("EMGPU_DEBUG_EXTRA_LDS") ? atoi(getenv("EMGPU_DEBUG_EXTRA_LDS")) : 0;
-    hipLaunchKernelGGL((k_uncor_fast<NI, R0, R1, R2>), dim3((unsigned)blocks), dim3(256), (size_t)extra_lds, s, P, A, F);
+    hipLaunchKernelGGL((k_uncor_fast<NI, M0, M1, M2>), dim3((unsigned)blocks), dim3(256), (size_t)extra_lds, s, P, A, F);
     return hipGetLastError();
 }
 
@@ -266,11 +290,17 @@ hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t 
         for (int a = 0; a < P.nact; a++)
             if (P.a_dyn[a] == k) F.Rk[k] = P.a_R[a];
     }
-    const int r0 = P.d_r[0], r1 = P.d_r[1];
-    if (r0 == 5 && r1 == 7) { *name = "k_uncor_fast<7,5,7,7>"; return launch_t<7, 5, 7, 7>(P, A, F, s); }
-    if (r0 == 5 && r1 == 9) { *name = "k_uncor_fast<7,5,9,7>"; return launch_t<7, 5, 9, 7>(P, A, F, s); }
-    *name = "k_uncor_fast<9,7,7,5>";
-    return launch_t<9, 7, 7, 5>(P, A, F, s);
+    switch (fast_shape_of(P)) {
+    case 0: *name = "k_uncor_fast<7,2,2,2>"; return launch_t<7, 2, 2, 2>(P, A, F, s);
+    case 1: *name = "k_uncor_fast<7,2,4,2>"; return launch_t<7, 2, 4, 2>(P, A, F, s);
+    case 2: *name = "k_uncor_fast<7,2,4,4>"; return launch_t<7, 2, 4, 4>(P, A, F, s);
+    case 3: *name = "k_uncor_fast<7,4,2,4>"; return launch_t<7, 4, 2, 4>(P, A, F, s);
+    case 4: *name = "k_uncor_fast<7,4,6,4>"; return launch_t<7, 4, 6, 4>(P, A, F, s);
+    case 5: *name = "k_uncor_fast<7,4,6,6>"; return launch_t<7, 4, 6, 6>(P, A, F, s);
+    case 6: *name = "k_uncor_fast<7,6,6,6>"; return launch_t<7, 6, 6, 6>(P, A, F, s);
+    case 7: *name = "k_uncor_fast<9,6,6,6>"; return launch_t<9, 6, 6, 6>(P, A, F, s);
+    default: *name = "none"; return hipErrorNotSupported;
+    }
 }
 
 } // namespace emgpu

@@ -463,6 +463,46 @@ CompiledPlan compile_plan(const Model &m) {
             }
             P.d_off[k] = emit_node(m.N_transition[tv], m.A_transition[tv], m.r_transition[tv], m.q_transition[tv]);
         }
+        // Compacted tables: per column keep only the distinct thresholds that can fire (0 < X < 2^32-1)
+        // and a nibble map from "how many fired" to the bin.  bin(x') = 1 + #{X == 0} + sum of the
+        // multiplicities of the distinct thresholds <= x' -- exactly the full table's answer.
+        for (k = 0; k < nd; k++) {
+            const int r = P.d_r[k], rm1 = r - 1;
+            const int64_t q = m.q_transition[P.d_tvar[k]];
+            const uint32_t *X = cp.thr.data() + P.d_off[k];
+            int meff = 0;
+            for (int64_t j = 0; j < q; j++) {
+                int d = 0;
+                uint32_t prev = 0u;
+                for (int t = 0; t < rm1; t++) {
+                    const uint32_t x = X[(size_t)j * rm1 + t];
+                    if (x != 0u && x != 0xFFFFFFFFu && x != prev) { d++; prev = x; }
+                }
+                meff = d > meff ? d : meff;
+            }
+            if (meff < 1) meff = 1;
+            if (meff > 7 || r > 15) { P.d_meff[k] = 0; continue; } // the map has 8 nibbles
+            P.d_meff[k] = (uint8_t)meff;
+            P.d_coff[k] = (uint32_t)cp.cthr.size();
+            cp.cthr.resize(cp.cthr.size() + (size_t)q * (meff + 1));
+            uint32_t *C = cp.cthr.data() + P.d_coff[k];
+            for (int64_t j = 0; j < q; j++) {
+                uint32_t *c = C + (size_t)j * (meff + 1);
+                int d = 0, bin = 1;
+                uint32_t prev = 0u, map = 0u;
+                for (int t = 0; t < rm1; t++) bin += X[(size_t)j * rm1 + t] == 0u;   // thresholds that always fire
+                map = (uint32_t)bin;
+                for (int t = 0; t < rm1; t++) {
+                    const uint32_t x = X[(size_t)j * rm1 + t];
+                    if (x == 0u || x == 0xFFFFFFFFu) continue;
+                    if (x != prev) { c[d++] = x; prev = x; }
+                    bin++;
+                    map = (map & ~(0xFu << (4 * d))) | ((uint32_t)bin << (4 * d));
+                }
+                for (int t = d; t < meff; t++) { c[t] = 0xFFFFFFFFu; map |= (uint32_t)bin << (4 * (t + 1)); }
+                c[meff] = map;
+            }
+        }
     }
     // resample_events.m:24
     int na = 0;

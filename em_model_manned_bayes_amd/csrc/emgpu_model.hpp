@@ -59,6 +59,7 @@ inline double uniform32(uint32_t x) {
 struct CompiledPlan {
     EmgpuPlan plan{};             // thr / bnd pointers are filled at upload time
     std::vector<uint32_t> thr;
+    std::vector<uint32_t> cthr;   // compacted tables of the dynamic variables
     std::vector<double> bnd;
     std::vector<int> pos_of_var;  // variable id (0-based) -> topological position
 };

@@ -67,6 +67,14 @@ struct EmgpuPlan {
     uint8_t a_pos[EMGPU_MAX_NI];  // topological position
     int8_t a_dyn[EMGPU_MAX_NI];   // k if dynamic else -1
     uint32_t a_R[EMGPU_MAX_NI];   // hit  <=>  x' < R
+    // ---- compacted tables of the dynamic variables (see compile_plan): column j of variable k is
+    // cthr[d_coff[k] + j*(d_meff[k]+1) ...]: d_meff[k] DISTINCT real thresholds (padded with "never")
+    // followed by one word of nibbles, bin(n) = (map >> 4n) & 15 for n = #{t : x' >= threshold t}.
+    // Zero-count bins make most of a column's r-1 thresholds coincide, so d_meff is often far below
+    // r-1 (uncor_1200code_v2p1: 2, 4, 2 instead of 4, 6, 6).  d_meff[k] == 0 => not compacted.
+    uint8_t d_meff[EMGPU_MAX_ND];
+    uint32_t d_coff[EMGPU_MAX_ND];
+    const uint32_t *cthr;
     // ---- device tables
     const uint32_t *thr; // quantile thresholds, node after node, column after column, r-1 each
     const double *bnd;   // boundaries

@@ -5,7 +5,7 @@ src = os.path.join(ROOT, "em_model_manned_bayes_amd", "csrc", "emgpu_kernels_fas
 extra = sys.argv[1:]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", "/tmp/fast.s", src] + extra, stderr=subprocess.DEVNULL)
 s = open("/tmp/fast.s").read()
-k = s[s.index("_ZN5emgpu12k_uncor_fastILi7ELi5ELi7ELi7EEEv9EmgpuPlan8EmgpuRunNS_8FastArgsE:"):]
+k = s[s.index("_ZN5emgpu12k_uncor_fastILi7ELi2ELi4ELi2EEEv9EmgpuPlan8EmgpuRunNS_8FastArgsE:"):]
 k = k[:k.index(".Lfunc_end")]
 # find the main loop header: the loop with most mads
 loops = collections.defaultdict(collections.Counter)
@@ -42,6 +42,6 @@ print(c.most_common(28))
 for line in s.split("\n"):
     if re.search(r"\.(vgpr_count|sgpr_count|group_segment_fixed_size|private_segment_fixed_size|sgpr_spill_count|vgpr_spill_count):", line):
         print(line.strip(), end="; ")
-    if "k_uncor_fastILi7ELi5ELi9" in line and ".name" in line:
+    if "k_uncor_fastILi7ELi2ELi4ELi4" in line and ".name" in line:
         break
 print()
