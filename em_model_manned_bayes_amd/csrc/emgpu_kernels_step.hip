@@ -24,8 +24,9 @@ struct StepArgs {
 };
 
 // LDS_T: the dynamic variables' threshold tables are staged in (dynamic) LDS by the workgroup
-// (cor_v1: 29 KB); otherwise they are gathered from global memory (L1/L2).
-template <int NI, int ND, int RM1, bool LDS_T>
+// (cor_v1: 18 KB compacted); otherwise they are gathered from global memory (L1/L2).
+// CT: the tables are the compacted ones (EmgpuPlan::cthr: distinct thresholds + bin map per column).
+template <int NI, int ND, int RM1, bool LDS_T, bool CT>
 __global__ void __launch_bounds__(256, 2) k_dbn_step(const EmgpuPlan P, const EmgpuRun A, const StepArgs F) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_thr[];
     __shared__ CoopLds<ND> s_wave[4];
@@ -59,10 +60,12 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step(const EmgpuPlan P, const Em
         }
     }
     W.attempt[lane] = rng.attempt;
+    const uint32_t *__restrict__ gtab = CT ? P.cthr : P.thr + P.d_off[0];
+    const uint32_t ntab = CT ? P.cthr_total : P.thr_total - P.d_off[0];
     if (LDS_T)
-        for (uint32_t q = (uint32_t)tid; q < P.thr_total - P.d_off[0]; q += 256u) s_thr[q] = P.thr[P.d_off[0] + q];
+        for (uint32_t q = (uint32_t)tid; q < ntab; q += 256u) s_thr[q] = gtab[q];
     __syncthreads();
-    const uint32_t *__restrict__ tbase = LDS_T ? (const uint32_t *)s_thr - P.d_off[0] : P.thr;
+    const uint32_t *__restrict__ tbase = LDS_T ? (const uint32_t *)s_thr : gtab;
 
     uint32_t cur1[ND], basecol[ND], ivs[ND];
     float cval[ND];
@@ -115,14 +118,16 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step(const EmgpuPlan P, const Em
                     for (int q = 0; q < ND; q++) col += P.d_stride_cur[k][q] * (cur1[q] - 1u);
 #pragma unroll
                     for (int q = 0; q < k; q++) col += P.d_stride_new[k][q] * (nb1[q] - 1u);
-                    const int rm1 = (int)P.d_r[k] - 1;
-                    const uint32_t *__restrict__ t = tbase + P.d_off[k] + (size_t)col * (uint32_t)rm1;
+                    const int rm1 = CT ? (int)P.d_meff[k] : (int)P.d_r[k] - 1;               // thresholds per column
+                    const uint32_t *__restrict__ t = tbase + (CT ? P.d_coff[k] + (size_t)col * (uint32_t)(rm1 + 1)
+                                                                 : (P.d_off[k] - P.d_off[0]) + (size_t)col * (uint32_t)rm1);
                     const uint32_t x = clamp32(split_draw(th[k], tl[k], j));
                     uint32_t borrows = 0u;
 #pragma unroll
                     for (int q = 0; q < RM1; q++)
                         if (q < rm1) borrows += (x < t[q]) ? 1u : 0u;                        // select_random.m:19-20
-                    nb1[k] = (uint32_t)(rm1 + 1) - borrows;                                  // dbn_sample.m:77
+                    const uint32_t fired = (uint32_t)rm1 - borrows;
+                    nb1[k] = CT ? ((t[rm1] >> (fired << 2)) & 15u) : fired + 1u;             // dbn_sample.m:77
                 }
 #pragma unroll
                 for (int k = 0; k < ND; k++) {
@@ -170,15 +175,26 @@ bool step_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     return true;
 }
 
+static bool step_compact(const EmgpuPlan &P) {
+    static const bool off = getenv("EMGPU_DEBUG_STEP_NO_COMPACT") != nullptr;
+    if (off) return false;
+    for (int k = 0; k < P.nd; k++)
+        if (P.d_meff[k] == 0) return false;
+    return true;
+}
+static size_t step_table_bytes(const EmgpuPlan &P) {
+    return (size_t)(step_compact(P) ? P.cthr_total : P.thr_total - P.d_off[0]) * sizeof(uint32_t);
+}
+
 template <int NI, int ND, int RM1>
 static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const StepArgs &F, hipStream_t s, bool lds) {
     const int64_t blocks = (A.n + 255) / 256;
-    if (lds) {
-        const size_t bytes = (size_t)(P.thr_total - P.d_off[0]) * sizeof(uint32_t);
-        hipLaunchKernelGGL((k_dbn_step<NI, ND, RM1, true>), dim3((unsigned)blocks), dim3(256), bytes, s, P, A, F);
-    } else {
-        hipLaunchKernelGGL((k_dbn_step<NI, ND, RM1, false>), dim3((unsigned)blocks), dim3(256), 0, s, P, A, F);
-    }
+    const bool ct = step_compact(P);
+    const size_t bytes = lds ? step_table_bytes(P) : 0;
+    if (lds && ct) hipLaunchKernelGGL((k_dbn_step<NI, ND, RM1, true, true>), dim3((unsigned)blocks), dim3(256), bytes, s, P, A, F);
+    else if (lds) hipLaunchKernelGGL((k_dbn_step<NI, ND, RM1, true, false>), dim3((unsigned)blocks), dim3(256), bytes, s, P, A, F);
+    else if (ct) hipLaunchKernelGGL((k_dbn_step<NI, ND, RM1, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, P, A, F);
+    else hipLaunchKernelGGL((k_dbn_step<NI, ND, RM1, false, false>), dim3((unsigned)blocks), dim3(256), 0, s, P, A, F);
     return hipGetLastError();
 }
 
@@ -192,7 +208,7 @@ hipError_t launch_dbn_step(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s,
     }
     // stage the dynamic tables in LDS when two workgroups per CU still fit beside the cooperative area
     static const bool no_lds = getenv("EMGPU_DEBUG_STEP_NO_LDS") != nullptr;
-    const bool lds = !no_lds && (size_t)(P.thr_total - P.d_off[0]) * sizeof(uint32_t) <= 32768;
+    const bool lds = !no_lds && step_table_bytes(P) <= 32768;
     if (P.ni <= 7 && P.nd <= 3) { *name = lds ? "k_dbn_step<7,3,8,lds>" : "k_dbn_step<7,3,8>"; return launch_t<7, 3, 8>(P, A, F, s, lds); }
     if (P.ni <= 9 && P.nd <= 3) { *name = lds ? "k_dbn_step<9,3,8,lds>" : "k_dbn_step<9,3,8>"; return launch_t<9, 3, 8>(P, A, F, s, lds); }
     *name = lds ? "k_dbn_step<16,4,8,lds>" : "k_dbn_step<16,4,8>";

@@ -516,6 +516,7 @@ CompiledPlan compile_plan(const Model &m) {
     }
     P.nact = na;
     P.thr_total = (uint32_t)cp.thr.size();
+    P.cthr_total = (uint32_t)cp.cthr.size();
     return cp;
 }
 

@@ -37,7 +37,8 @@
 
 struct EmgpuPlan {
     int32_t ni, nd, nact, depend; // depend: is_dynvar_depend (dbn_sample.m:55)
-    uint32_t thr_total, _pad0;    // entries in thr[]; the dynamic variables' tables are thr[d_off[0] .. thr_total)
+    uint32_t thr_total;           // entries in thr[]; the dynamic variables' tables are thr[d_off[0] .. thr_total)
+    uint32_t cthr_total;          // entries in cthr[]
     // ---- initial network, by topological position p
     uint8_t i_var[EMGPU_MAX_NI];   // 0-based variable id
     uint8_t i_r[EMGPU_MAX_NI];     // bins
