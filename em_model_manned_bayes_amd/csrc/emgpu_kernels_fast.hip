@@ -38,21 +38,25 @@ struct FastArgs {
 
 // One compacted CPT column (EmgpuPlan::cthr): meff distinct thresholds, then the nibble map
 // bin(n) = (map >> 4n) & 15 with n = #{t : x' >= threshold t}.  The kernel instance may be built for
-// M >= meff thresholds: the extra ones are "never".  The map is returned re-indexed by the number of
-// BORROWS b = M - n (what the compare chain counts): bin = (bmap >> 4b) & 15.
+// M >= meff thresholds: the extra ones are "never".  The map is returned as a BYTE table indexed by
+// the number of BORROWS b = M - n (what the compare chain counts), entries 0-3 in bml and 4-7 in
+// bmh, so that one v_perm_b32 with selector kSelBase + b yields the 1-based bin.
+constexpr uint32_t kSelBase = 0x0c0c0c00u; // v_perm_b32 selector: bytes 1-3 constant zero, byte 0 <- table[b]
 template <int M>
-__device__ __forceinline__ void load_cthr(uint32_t (&th)[M], uint32_t &bmap, const uint32_t *__restrict__ p, int meff) {
+__device__ __forceinline__ void load_cthr(uint32_t (&th)[M], uint32_t &bml, uint32_t &bmh, const uint32_t *__restrict__ p, int meff) {
+    static_assert(M >= 1 && M <= 7, "the byte table has 8 entries");
 #pragma unroll
     for (int t = 0; t < M; t++) th[t] = (t < meff) ? p[t] : 0xFFFFFFFFu;
     const uint32_t map = p[meff];
-    uint32_t r = 0u;
+    uint32_t lo = 0u, hi = 0u;
 #pragma unroll
     for (int b = 0; b <= M; b++) {
         const int n = M - b;                       // thresholds that fired
         const int nn = n < meff ? n : meff;        // the padded ones never fire
-        r |= ((map >> (4 * nn)) & 15u) << (4 * b);
+        const uint32_t e = (map >> (4 * nn)) & 15u;
+        if (b < 4) lo |= e << (8 * b); else hi |= e << (8 * (b - 4));
     }
-    bmap = r;
+    bml = lo; bmh = hi;
 }
 
 // Eight seconds of one dynamic variable.  Outputs: bins packed 1-based 4 per word (pbA: seconds
@@ -61,52 +65,61 @@ __device__ __forceinline__ void load_cthr(uint32_t (&th)[M], uint32_t &bmap, con
 //   chg8  -- the transition draw changed the bin (dbn_sample.m:151-161)
 //   zer8  -- the bin after the draw is the zero bin (dediscretize.m:24-25)
 // EXACT = false: decide from the high halfwords only and report `amb` when some compare could
-// flip with the low halfword; EXACT = true: full 32-bit draws.  Every flag is accumulated with
-// x = x + x + carry so that one v_cmp + one v_addc serve per flag and second.
+// flip with the low halfword; EXACT = true: full 32-bit draws.
+//
+// The compare chains are written as carry arithmetic (two VOP2 instructions per compare, no
+// select, no merge): a borrow out of x - X is "x < X"; flag streams take it with f = f + f + carry;
+// the borrow count starts at kSelBase and feeds v_perm_b32 directly.  The differences x - X are
+// kept: a compare decided from the high halfword can only flip if x - X lies in [-0xFFFF, -1].
+// gfx950 needs two wait states between a VALU write of VCC and a VALU read of it (the assembler
+// does not look inside asm blocks), hence the s_nop 1 in every pair; all asm operands are VGPRs so
+// that no SGPR freshly written by a VALU (v_readlane of a spilled SGPR) can be read too early.
 template <int M, bool EXACT, bool EDGE>
 __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 &rh, const uint4 &tl, const uint4 &rl, int g8, int T,
-                                                   const uint32_t (&thr)[M], uint32_t bmap, uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
+                                                   const uint32_t (&thr)[M], uint32_t bml, uint32_t bmh, uint32_t selbase,
+                                                   uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
                                                    uint32_t &cur_out, uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
-    bool amb = false;
-    uint32_t c1 = cur_in;
+    uint32_t c1 = cur_in, dmax = 0u;
     pbA = pbB = hit8 = chg8 = zer8 = 0u;
-    const uint32_t Rhi = Rres & 0xFFFF0000u;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int c = 8 * g8 + j; // absolute event time == column produced
-        uint32_t h = 0u, ch = 0u, z = 0u;
         if (!EDGE || (c >= 1 && c < T)) {   // wave-uniform; interior blocks need no guard
             uint32_t xr = half_hi(rh, j), xt = half_hi(th, j);
             if (EXACT) { xr |= half_lo(rl, j); xt = clamp32(xt | half_lo(tl, j)); }
-            h = (xr < Rres) ? 1u : 0u;
-            uint32_t borrows = 0u, dmax = 0u;
+            uint32_t d[M + 1], sel;
+            asm("v_sub_co_u32 %0, vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                : "=&v"(d[M]), "+v"(hit8) : "v"(xr), "v"(Rres) : "vcc");                       // resample_events.m:24
+            asm("v_sub_co_u32 %0, vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %4, vcc"
+                : "=&v"(d[0]), "=v"(sel) : "v"(xt), "v"(thr[0]), "v"(selbase) : "vcc");         // select_random.m:19-20
 #pragma unroll
-            for (int t = 0; t < M; t++) {                     // select_random.m:19-20 on the distinct thresholds
-                borrows += (xt < thr[t]) ? 1u : 0u;
-                const uint32_t d = xt - thr[t];
-                dmax = d > dmax ? d : dmax;
+            for (int t = 1; t < M; t++)
+                asm("v_sub_co_u32 %0, vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+                    : "=&v"(d[t]), "+v"(sel) : "v"(xt), "v"(thr[t]) : "vcc");
+            if (!EXACT) {
+#pragma unroll
+                for (int t = 0; t + 1 <= M; t += 2) dmax = max(max(dmax, d[t]), d[t + 1]);
+                if (!(M & 1)) dmax = max(dmax, d[M]);
             }
-            if (!EXACT) amb = amb | (xr == Rhi) | (dmax >= 0xFFFF0001u);
-            const uint32_t nb1 = (bmap >> (borrows << 2)) & 15u; // the bin of "M - borrows thresholds fired"  (dbn_sample.m:144)
-            ch = (nb1 != c1) ? 1u : 0u;
-            c1 = nb1;                                         // map back, dbn_sample.m:149
-            z = (nb1 == zbin1) ? 1u : 0u;
+            const uint32_t nb1 = __builtin_amdgcn_perm(bmh, bml, sel);                          // dbn_sample.m:144
+            asm("v_cmp_ne_u32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(chg8) : "v"(nb1), "v"(c1) : "vcc");
+            asm("v_cmp_eq_u32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(zer8) : "v"(zbin1), "v"(nb1) : "vcc");
+            c1 = nb1;                                                                           // map back, dbn_sample.m:149
+        } else {
+            hit8 += hit8; chg8 += chg8; zer8 += zer8;
         }
-        hit8 = hit8 + hit8 + h;
-        chg8 = chg8 + chg8 + ch;
-        zer8 = zer8 + zer8 + z;
         const uint32_t b = (!EDGE || c < T) ? (c1 << (8 * (j & 3))) : 0u;
         if (j < 4) pbA |= b; else pbB |= b;
     }
     cur_out = c1;
-    return amb;
+    return !EXACT && dmax >= 0xFFFF0001u;
 }
 
 // rare path, kept out of line so that the hot loop stays small in the instruction cache
 template <int M>
 __device__ __attribute__((noinline)) void eight_seconds_exact(uint32_t c0, uint32_t c1r, uint32_t attempt, uint32_t k0, uint32_t k1,
                                                               uint4 th, uint4 rh, uint32_t tvar, uint32_t ivar, int g8, int T,
-                                                              const uint32_t *thr_in, uint32_t bmap, uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
+                                                              const uint32_t *thr_in, uint32_t bml, uint32_t bmh, uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
                                                               uint32_t *out /* cur, pbA, pbB, hit8, chg8, zer8 */) {
     const Rng rng{c0, c1r, attempt, k0, k1};
     const uint4 tl = rng.block(EMGPU_SEC_TRANS_LO, tvar, (uint32_t)g8);
@@ -115,13 +128,13 @@ __device__ __attribute__((noinline)) void eight_seconds_exact(uint32_t c0, uint3
 #pragma unroll
     for (int t = 0; t < M; t++) thr[t] = thr_in[t];
     uint32_t cur, a, b, h, c, z;
-    eight_seconds_pass<M, true, true>(th, rh, tl, rl, g8, T, thr, bmap, Rres, zbin1, cur_in, cur, a, b, h, c, z);
+    eight_seconds_pass<M, true, true>(th, rh, tl, rl, g8, T, thr, bml, bmh, kSelBase, Rres, zbin1, cur_in, cur, a, b, h, c, z);
     out[0] = cur; out[1] = a; out[2] = b; out[3] = h; out[4] = c; out[5] = z;
 }
 
 template <int M>
 __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uint32_t ivar, int g8, int T,
-                                              const uint32_t (&thr)[M], uint32_t bmap, uint32_t Rres, uint32_t zbin1, uint32_t &cur1,
+                                              const uint32_t (&thr)[M], uint32_t bml, uint32_t bmh, uint32_t selbase, uint32_t Rres, uint32_t zbin1, uint32_t &cur1,
                                               uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
     const uint4 th = rng.block(EMGPU_SEC_TRANS, tvar, (uint32_t)g8);
     const uint4 rh = rng.block(EMGPU_SEC_RES, ivar, (uint32_t)g8);
@@ -134,7 +147,7 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
     const bool edge = 8 * g8 + 7 >= T; // the block runs past the end of the trajectory
     bool redo = edge;
     if (!edge) {
-        const bool amb = eight_seconds_pass<M, false, false>(th, rh, z4, z4, g8, T, thr, bmap, Rres, zbin1, cur1, cur_out, pbA, pbB, hit8, chg8, zer8);
+        const bool amb = eight_seconds_pass<M, false, false>(th, rh, z4, z4, g8, T, thr, bml, bmh, selbase, Rres, zbin1, cur1, cur_out, pbA, pbB, hit8, chg8, zer8);
         redo = __ballot(amb) != 0ull;
         if (g8 == 0) {
             // Second 0 of a trajectory is the initial state, not a draw (slot 0 is never used,
@@ -150,7 +163,7 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
         uint32_t tmp[M], out[6];
 #pragma unroll
         for (int t = 0; t < M; t++) tmp[t] = thr[t];
-        eight_seconds_exact<M>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, tmp, bmap, Rres, zbin1, cur1, out);
+        eight_seconds_exact<M>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, tmp, bml, bmh, Rres, zbin1, cur1, out);
         cur_out = out[0]; pbA = out[1]; pbB = out[2]; hit8 = out[3]; chg8 = out[4]; zer8 = out[5];
     }
     cur1 = cur_out;
@@ -199,7 +212,7 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
         cur1[k] = (uint32_t)pick<NI>(bin, P.d_ipos[k]) + 1u;
         cval[k] = (float)pick<NI>(val, P.d_ipos[k]);
     }
-    uint32_t th0[M0], th1[M1], th2[M2], bm0, bm1, bm2;
+    uint32_t th0[M0], th1[M1], th2[M2], bl0, bl1, bl2, bh0, bh1, bh2;
     {
         uint32_t col[3];
 #pragma unroll
@@ -211,21 +224,23 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
             for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)(cur1[q] - 1);
             col[k] = c;
         }
-        load_cthr<M0>(th0, bm0, P.cthr + P.d_coff[0] + (size_t)col[0] * (uint32_t)(P.d_meff[0] + 1), P.d_meff[0]);
-        load_cthr<M1>(th1, bm1, P.cthr + P.d_coff[1] + (size_t)col[1] * (uint32_t)(P.d_meff[1] + 1), P.d_meff[1]);
-        load_cthr<M2>(th2, bm2, P.cthr + P.d_coff[2] + (size_t)col[2] * (uint32_t)(P.d_meff[2] + 1), P.d_meff[2]);
+        load_cthr<M0>(th0, bl0, bh0, P.cthr + P.d_coff[0] + (size_t)col[0] * (uint32_t)(P.d_meff[0] + 1), P.d_meff[0]);
+        load_cthr<M1>(th1, bl1, bh1, P.cthr + P.d_coff[1] + (size_t)col[1] * (uint32_t)(P.d_meff[1] + 1), P.d_meff[1]);
+        load_cthr<M2>(th2, bl2, bh2, P.cthr + P.d_coff[2] + (size_t)col[2] * (uint32_t)(P.d_meff[2] + 1), P.d_meff[2]);
     }
     const uint32_t iv0 = P.d_ivar[0], iv1 = P.d_ivar[1], iv2 = P.d_ivar[2];
     const uint32_t ivs[3] = {iv0, iv1, iv2};
+    uint32_t selbase; // kSelBase held in a VGPR (the first v_addc of every compare chain reads it)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(selbase) : "s"(kSelBase));
 
     const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
     for (int g8 = 0; g8 < G8; g8++) {
         uint32_t pbA[3], pbB[3], need8[3], kind8[3], zero8[3];
         {
             uint32_t hit8[3], chg8[3], zer8[3];
-            eight_seconds<M0>(rng, P.d_tvar[0], iv0, g8, T, th0, bm0, F.Rk[0], (uint32_t)P.d_zero[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
-            eight_seconds<M1>(rng, P.d_tvar[1], iv1, g8, T, th1, bm1, F.Rk[1], (uint32_t)P.d_zero[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
-            eight_seconds<M2>(rng, P.d_tvar[2], iv2, g8, T, th2, bm2, F.Rk[2], (uint32_t)P.d_zero[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
+            eight_seconds<M0>(rng, P.d_tvar[0], iv0, g8, T, th0, bl0, bh0, selbase, F.Rk[0], (uint32_t)P.d_zero[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
+            eight_seconds<M1>(rng, P.d_tvar[1], iv1, g8, T, th1, bl1, bh1, selbase, F.Rk[1], (uint32_t)P.d_zero[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
+            eight_seconds<M2>(rng, P.d_tvar[2], iv2, g8, T, th2, bl2, bh2, selbase, F.Rk[2], (uint32_t)P.d_zero[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 // flag streams are MSB-first: bit (7-j) <-> second j; turn them into bit j <-> second j
