@@ -560,6 +560,30 @@ int emgpu_debug_column_thresholds(const double *weights, int32_t r, uint32_t *ou
 
 uint32_t emgpu_debug_bernoulli_threshold(double rate) { return emgpu::bernoulli_threshold(rate); }
 
+int emgpu_debug_dynamic_column(const emgpu_model *m, int32_t k, int64_t col, int32_t *tvar, int32_t *r, int64_t *q,
+                               uint32_t *thr, int32_t *meff, uint32_t *cthr, uint32_t *map) {
+    EMGPU_TRY
+    if (!m || !tvar || !r || !q || !thr || !meff || !cthr || !map) return fail(EMGPU_ERR_ARG, "null argument");
+    const emgpu::CompiledPlan cp = emgpu::compile_plan(m->m);
+    const EmgpuPlan &P = cp.plan;
+    if (k < 0 || k >= P.nd) return fail(EMGPU_ERR_ARG, "no such dynamic variable");
+    *tvar = (int32_t)P.d_tvar[k] + 1;
+    *r = (int32_t)P.d_r[k];
+    *q = m->m.q_transition[P.d_tvar[k]];
+    if (col < 0 || col >= *q) return fail(EMGPU_ERR_ARG, "no such column");
+    const int rm1 = *r - 1;
+    for (int t = 0; t < rm1 && t < 15; t++) thr[t] = cp.thr[P.d_off[k] + (size_t)col * rm1 + t];
+    *meff = (int32_t)P.d_meff[k];
+    *map = 0u;
+    if (*meff > 0) {
+        const uint32_t *c = cp.cthr.data() + P.d_coff[k] + (size_t)col * (*meff + 1);
+        for (int t = 0; t < *meff; t++) cthr[t] = c[t];
+        *map = c[*meff];
+    }
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
 int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
                                     const emgpu_term_params *p, const double *geo, const int32_t *model_of,
                                     float *out, int32_t *rows) {

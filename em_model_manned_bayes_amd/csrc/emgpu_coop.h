@@ -35,9 +35,10 @@ __device__ __forceinline__ uint32_t pick_word(const uint32_t (&a)[ND], uint32_t 
     return r;
 }
 
-// needmask / kindmask: bit (8k + j) for dynamic variable k, second j of the block.
+// needmask / kindmask: bit (8k + j) for dynamic variable k, second j of the block; with MSBFIRST
+// the byte of a variable is an MSB-first stream instead: bit (8k + 7 - j).
 // pbA / pbB: packed 1-based bins of seconds 0-3 / 4-7.  s_bnd[k][]: boundaries of variable k.
-template <int ND>
+template <int ND, bool MSBFIRST = false>
 __device__ __forceinline__ void coop_dedisc(CoopLds<ND> &W, int lane, uint64_t gidx, const Rng &rng, int g8,
                                             uint32_t needmask, uint32_t kindmask, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND],
                                             const uint32_t (&ivar)[ND], const double (*s_bnd)[16]) {
@@ -48,11 +49,12 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND> &W, int lane, uint64_t g
         while (bal != 0ull && base + 64u <= (uint32_t)kQueueCap) {
             if (m != 0u) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                const uint32_t s = (uint32_t)__ffs((int)m) - 1u;
+                const uint32_t sb = (uint32_t)__ffs((int)m) - 1u;
+                const uint32_t s = MSBFIRST ? (sb ^ 7u) : sb;
                 const uint32_t k = s >> 3, j = s & 7u;
                 const uint32_t wA = pick_word<ND>(pbA, k), wB = pick_word<ND>(pbB, k);
                 const uint32_t b1 = (((j & 4u) ? wB : wA) >> (8u * (j & 3u))) & 0xFFu;
-                W.queue[base + rank] = (uint32_t)lane | (s << 6) | (((kindmask >> s) & 1u) << 11) | (b1 << 12);
+                W.queue[base + rank] = (uint32_t)lane | (s << 6) | (((kindmask >> sb) & 1u) << 11) | (b1 << 12);
                 m &= m - 1u;
             }
             base += (uint32_t)__popcll(bal);
@@ -105,6 +107,48 @@ __device__ __forceinline__ void coop_fill_store(const CoopLds<ND> &W, int lane, 
         pv[j] = (8 * g8 + j < T) ? v : 0.f;
     }
     cval = v;
+    if (valid) {
+        const size_t o = ((size_t)(2 * g8) * nd + slot) * (size_t)n + (size_t)i;
+        if (dyn_bin) dyn_bin[o] = pbA;
+        if (dyn_val) reinterpret_cast<float4 *>(dyn_val)[o] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        if (2 * g8 + 1 < G4) {
+            const size_t o2 = o + (size_t)nd * (size_t)n;
+            if (dyn_bin) dyn_bin[o2] = pbB;
+            if (dyn_val) reinterpret_cast<float4 *>(dyn_val)[o2] = make_float4(pv[4], pv[5], pv[6], pv[7]);
+        }
+    }
+}
+
+// The same for MSB-first flag streams, written as carry arithmetic: fill8 (bit 7-j <-> second j) marks
+// the seconds whose value is replaced by the lane's result slot -- a dediscretize draw, or 0 for a
+// change into the zero bin (coop_zero_results cleared the slots before the workers wrote).
+// One v_add_co (shift the stream, carry = the flag) + one v_cndmask per second; two wait states
+// between the VCC write and its read (see emgpu_kernels_fast.hip).
+template <int ND>
+__device__ __forceinline__ void coop_zero_results(CoopLds<ND> &W, int lane) {
+    float4 *rp = reinterpret_cast<float4 *>(&W.res[lane * CoopLds<ND>::kStride]);
+#pragma unroll
+    for (int q = 0; q < 2 * ND; q++) rp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int ND>
+__device__ __forceinline__ void coop_fill_store_msb(const CoopLds<ND> &W, int lane, int k, int g8, int T, int G4, bool valid,
+                                                    uint32_t fill8, float &cval, uint32_t pbA, uint32_t pbB,
+                                                    uint32_t nd, uint32_t slot, int64_t i, int64_t n, uint32_t *dyn_bin, float *dyn_val) {
+    const float4 *rp = reinterpret_cast<const float4 *>(&W.res[lane * CoopLds<ND>::kStride]);
+    const float4 ra = rp[2 * k], rb = rp[2 * k + 1];
+    const float r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+    float pv[8];
+    uint32_t f = fill8 << 24;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        asm("v_add_co_u32 %0, vcc, %0, %0\n\ts_nop 1\n\tv_cndmask_b32 %1, %2, %3, vcc"
+            : "+v"(f), "=v"(pv[j]) : "v"(j ? pv[j - 1] : cval), "v"(r[j]) : "vcc");
+    cval = pv[7];
+    if (8 * g8 + 7 >= T) { // the last block of the trajectory: nothing past T
+#pragma unroll
+        for (int j = 0; j < 8; j++) pv[j] = (8 * g8 + j < T) ? pv[j] : 0.f;
+    }
     if (valid) {
         const size_t o = ((size_t)(2 * g8) * nd + slot) * (size_t)n + (size_t)i;
         if (dyn_bin) dyn_bin[o] = pbA;

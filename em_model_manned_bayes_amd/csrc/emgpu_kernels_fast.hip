@@ -72,8 +72,8 @@ __device__ __forceinline__ void load_cthr(uint32_t (&th)[M], uint32_t &bml, uint
 // the borrow count starts at kSelBase and feeds v_perm_b32 directly.  The differences x - X are
 // kept: a compare decided from the high halfword can only flip if x - X lies in [-0xFFFF, -1].
 // gfx950 needs two wait states between a VALU write of VCC and a VALU read of it (the assembler
-// does not look inside asm blocks), hence the s_nop 1 in every pair; all asm operands are VGPRs so
-// that no SGPR freshly written by a VALU (v_readlane of a spilled SGPR) can be read too early.
+// does not look inside asm blocks), hence the s_nop 1 in every pair; an SGPR operand is only read
+// three wait states into a block, in case a VALU (v_readlane of a spilled SGPR) wrote it just before.
 template <int M, bool EXACT, bool EDGE>
 __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 &rh, const uint4 &tl, const uint4 &rl, int g8, int T,
                                                    const uint32_t (&thr)[M], uint32_t bml, uint32_t bmh, uint32_t selbase,
@@ -88,10 +88,10 @@ __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 
             uint32_t xr = half_hi(rh, j), xt = half_hi(th, j);
             if (EXACT) { xr |= half_lo(rl, j); xt = clamp32(xt | half_lo(tl, j)); }
             uint32_t d[M + 1], sel;
-            asm("v_sub_co_u32 %0, vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
-                : "=&v"(d[M]), "+v"(hit8) : "v"(xr), "v"(Rres) : "vcc");                       // resample_events.m:24
-            asm("v_sub_co_u32 %0, vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %4, vcc"
-                : "=&v"(d[0]), "=v"(sel) : "v"(xt), "v"(thr[0]), "v"(selbase) : "vcc");         // select_random.m:19-20
+            // first threshold, then the resample Bernoulli: the SGPR operand is read three wait states into the block
+            asm("v_sub_co_u32 %0, vcc, %4, %5\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %6, vcc\n\t"       // select_random.m:19-20
+                "v_subrev_co_u32 %2, vcc, %8, %7\n\ts_nop 1\n\tv_addc_co_u32 %3, vcc, %3, %3, vcc"         // resample_events.m:24
+                : "=&v"(d[0]), "=&v"(sel), "=&v"(d[M]), "+v"(hit8) : "v"(xt), "v"(thr[0]), "v"(selbase), "v"(xr), "s"(Rres) : "vcc");
 #pragma unroll
             for (int t = 1; t < M; t++)
                 asm("v_sub_co_u32 %0, vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
@@ -102,8 +102,9 @@ __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 
                 if (!(M & 1)) dmax = max(dmax, d[M]);
             }
             const uint32_t nb1 = __builtin_amdgcn_perm(bmh, bml, sel);                          // dbn_sample.m:144
-            asm("v_cmp_ne_u32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(chg8) : "v"(nb1), "v"(c1) : "vcc");
-            asm("v_cmp_eq_u32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(zer8) : "v"(zbin1), "v"(nb1) : "vcc");
+            asm("v_cmp_ne_u32 vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                "v_cmp_eq_u32 vcc, %4, %2\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                : "+v"(chg8), "+v"(zer8) : "v"(nb1), "v"(c1), "s"(zbin1) : "vcc");
             c1 = nb1;                                                                           // map back, dbn_sample.m:149
         } else {
             hit8 += hit8; chg8 += chg8; zer8 += zer8;
@@ -235,28 +236,27 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
 
     const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
     for (int g8 = 0; g8 < G8; g8++) {
-        uint32_t pbA[3], pbB[3], need8[3], kind8[3], zero8[3];
+        uint32_t pbA[3], pbB[3], need8[3], kind8[3], fill8[3];
         {
             uint32_t hit8[3], chg8[3], zer8[3];
             eight_seconds<M0>(rng, P.d_tvar[0], iv0, g8, T, th0, bl0, bh0, selbase, F.Rk[0], (uint32_t)P.d_zero[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
             eight_seconds<M1>(rng, P.d_tvar[1], iv1, g8, T, th1, bl1, bh1, selbase, F.Rk[1], (uint32_t)P.d_zero[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
             eight_seconds<M2>(rng, P.d_tvar[2], iv2, g8, T, th2, bl2, bh2, selbase, F.Rk[2], (uint32_t)P.d_zero[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                // flag streams are MSB-first: bit (7-j) <-> second j; turn them into bit j <-> second j
-                const uint32_t h = __brev(hit8[k]) >> 24, c = __brev(chg8[k]) >> 24, z = __brev(zer8[k]) >> 24;
-                need8[k] = (h | c) & ~z;   // a dediscretize draw is due (dediscretize.m:24-39)
-                kind8[k] = c;              // 1 = transition event (it hides a resample event of the same second)
-                zero8[k] = c & z;          // changed into the zero bin: value 0, no draw
+            for (int k = 0; k < 3; k++) {      // the streams stay MSB-first: bit (7-j) <-> second j
+                need8[k] = (hit8[k] | chg8[k]) & ~zer8[k];   // a dediscretize draw is due (dediscretize.m:24-39)
+                kind8[k] = chg8[k];                          // 1 = transition event (it hides a resample event of the same second)
+                fill8[k] = need8[k] | chg8[k];               // the value changes: a draw, or 0 on a change into the zero bin
             }
         }
         const uint32_t need24 = valid ? (need8[0] | (need8[1] << 8) | (need8[2] << 16)) : 0u;
         const uint32_t kind24 = kind8[0] | (kind8[1] << 8) | (kind8[2] << 16);
-        coop_dedisc<3>(W, lane, gidx, rng, g8, need24, kind24, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
+        coop_zero_results<3>(W, lane);
+        coop_dedisc<3, true>(W, lane, gidx, rng, g8, need24, kind24, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
 #pragma unroll
         for (int k = 0; k < 3; k++)
-            coop_fill_store<3>(W, lane, k, g8, T, G4, valid, valid ? need8[k] : 0u, zero8[k], cval[k], pbA[k], pbB[k],
-                               3u, F.slot[k], i, A.n, A.dyn_bin, A.dyn_val);
+            coop_fill_store_msb<3>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
+                                   3u, F.slot[k], i, A.n, A.dyn_bin, A.dyn_val);
         wave_sync(); // results of this block are consumed before the next block's workers overwrite them
     }
 }

@@ -240,6 +240,13 @@ const char *emgpu_last_kernel_name(const emgpu_ctx *ctx);
  * (hit <=> min(x, 2^32-2) < R reproduces `u < rate`, resample_events.m:24). */
 int emgpu_debug_column_thresholds(const double *weights, int32_t r, uint32_t *out);
 uint32_t emgpu_debug_bernoulli_threshold(double rate);
+/* Column `col` (0-based, asub2ind order) of the k-th dynamic variable's transition table as the
+ * kernels read it: the r-1 quantile thresholds (thr, room for 15) and the compacted form -- *meff
+ * distinct thresholds (cthr, room for 7) plus the nibble map, bin = (map >> 4n) & 15 with
+ * n = #{t < meff : min(x, 2^32-2) >= cthr[t]}.  *meff = 0: this variable is not compacted.
+ * k counts the temporal_map rows in plan order; *tvar receives the 1-based transition variable. */
+int emgpu_debug_dynamic_column(const emgpu_model *m, int32_t k, int64_t col, int32_t *tvar, int32_t *r, int64_t *q,
+                               uint32_t *thr, int32_t *meff, uint32_t *cthr, uint32_t *map);
 
 /* Host helpers that mirror small reference functions (used by the class layer and tests). */
 int32_t emgpu_discretize_bayes(double x, const double *thresholds, int32_t n); /* discretize_bayes.m:14-22 */

@@ -185,6 +185,53 @@ def test_integer_thresholds_reproduce_the_f64_compare(model_dir):
             assert (min(x, 2**32 - 2) < R) == (u32(x) < rate), (rate, x)
 
 
+@pytest.mark.parametrize("name", ["uncor_1200code_v2p1", "uncor_1200only_fwse_v1p2", "cor_v1", "haa_v1", "glider_v1"])
+def test_compacted_columns_select_the_same_bin(name, model_dir):
+    """EmgpuPlan::cthr (distinct thresholds + bin map) against the plain r-1 thresholds, on sampled and
+    on every adjacent x, and both against select_random on the Dirichlet-smoothed column (prior 0)."""
+    p = E.em_read(em_io.materialize_model(name, model_dir))
+    pp = O.parse_model_txt(em_io.materialize_model(name, model_dir))
+    lib = L.lib()
+    h = p["native"]._h
+    rng = np.random.RandomState(11)
+    u32 = O.lib().em_uniform32
+    nd = len(pp["temporal_map"])
+    seen_meff = []
+    for k in range(nd):
+        tvar, r, q, meff, mp = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32(), C.c_uint32()
+        thr = np.zeros(15, dtype=np.uint32); cthr = np.zeros(7, dtype=np.uint32)
+        args = lambda col: (h, k, col, C.byref(tvar), C.byref(r), C.byref(q), thr.ctypes.data, C.byref(meff), cthr.ctypes.data, C.byref(mp))
+        assert lib.emgpu_debug_dynamic_column(*args(0)) == 0
+        N = pp["N_transition"][tvar.value - 1]
+        assert N.shape == (r.value, q.value)
+        cols = sorted(set(int(c) for c in rng.randint(0, q.value, 60)) | {0, q.value - 1})
+        worst = 0
+        for col in cols:
+            assert lib.emgpu_debug_dynamic_column(*args(col)) == 0
+            if meff.value == 0:
+                continue
+            t = thr[: r.value - 1].astype(np.uint64)
+            ct = cthr[: meff.value].astype(np.uint64)
+            real = sorted(set(int(x) for x in t if 0 < x < 2**32 - 1))
+            assert len(real) <= meff.value and [int(x) for x in ct[: len(real)]] == real
+            assert all(int(x) == 2**32 - 1 for x in ct[len(real):])
+            worst = max(worst, len(real))
+            xs = set(int(x) for x in rng.randint(0, 2**32, 40, dtype=np.uint64)) | {0, 1, 2**32 - 1, 2**32 - 2}
+            for x in t:
+                xs |= {int(x), max(int(x) - 1, 0), min(int(x) + 1, 2**32 - 1)}
+            w = np.ascontiguousarray(N[:, col], dtype=np.float64)   # all-zero columns: select_random.m:17-20 gives bin 1
+            for x in xs:
+                xp = min(x, 2**32 - 2)
+                full = 1 + int(np.sum(xp >= t))
+                n = int(np.sum(xp >= ct))
+                assert (mp.value >> (4 * n)) & 15 == full, (name, k, col, x)
+                assert full == _oracle_bin(w, u32(x)), (name, k, col, x)
+        seen_meff.append(meff.value)
+    if name == "uncor_1200code_v2p1":
+        assert seen_meff == [2, 4, 2]                    # what k_uncor_fast<7,2,4,2> is built for
+    assert lib.emgpu_debug_dynamic_column(h, nd, 0, *([C.byref(C.c_int64())] * 7)) == L.ERR_ARG   # no such variable
+
+
 def test_shard_ranges_cover_exactly():
     for n, w in [(10, 3), (50_000_000, 8), (7, 8), (0, 2), (1, 1)]:
         ranges = [sharding.shard_range(n, r, w) for r in range(w)]
