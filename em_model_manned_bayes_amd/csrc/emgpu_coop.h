@@ -12,11 +12,15 @@
 
 namespace emgpu {
 
-constexpr int kQueueCap = 192; // request descriptors per wave and compaction round
+constexpr int kQueueCap = 128; // request descriptors per wave and compaction round
 
-template <int ND>
+// LB: the lanes also publish the packed bins of the block (2 words per variable, after the 8*ND result
+// slots) so that a worker looks the bin of a request up itself instead of the owner encoding it.
+template <int ND, bool LB = false>
 struct CoopLds {
-    static constexpr int kStride = 8 * ND + 4; // floats per lane; +4 keeps the b128 reads conflict-free
+    static constexpr int kBins = 8 * ND;                          // word offset of the published bins
+    static constexpr int kStride = 8 * ND + (LB ? 2 * ND + 6 : 4); // words per lane; = 4 (mod 8) keeps the b128 reads conflict-free
+    static_assert(kStride % 8 == 4, "lane stride");
     uint32_t queue[kQueueCap];
     float res[64 * kStride];
     uint32_t attempt[64];
@@ -38,10 +42,13 @@ __device__ __forceinline__ uint32_t pick_word(const uint32_t (&a)[ND], uint32_t 
 // needmask / kindmask: bit (8k + j) for dynamic variable k, second j of the block; with MSBFIRST
 // the byte of a variable is an MSB-first stream instead: bit (8k + 7 - j).
 // pbA / pbB: packed 1-based bins of seconds 0-3 / 4-7.  s_bnd[k][]: boundaries of variable k.
-template <int ND, bool MSBFIRST = false>
-__device__ __forceinline__ void coop_dedisc(CoopLds<ND> &W, int lane, uint64_t gidx, const Rng &rng, int g8,
+template <int ND, bool MSBFIRST = false, bool LB = false>
+__device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64_t gidx, const Rng &rng, int g8,
                                             uint32_t needmask, uint32_t kindmask, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND],
                                             const uint32_t (&ivar)[ND], const double (*s_bnd)[16]) {
+    uint32_t ivpack = 0u; // wave-uniform byte table of the variables' RNG ids
+#pragma unroll
+    for (int q = 0; q < ND; q++) ivpack |= ivar[q] << (8 * q);
     uint32_t m = needmask;
     unsigned long long bal = __ballot(m != 0u);
     while (bal != 0ull) {
@@ -51,9 +58,12 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND> &W, int lane, uint64_t g
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                 const uint32_t sb = (uint32_t)__ffs((int)m) - 1u;
                 const uint32_t s = MSBFIRST ? (sb ^ 7u) : sb;
-                const uint32_t k = s >> 3, j = s & 7u;
-                const uint32_t wA = pick_word<ND>(pbA, k), wB = pick_word<ND>(pbB, k);
-                const uint32_t b1 = (((j & 4u) ? wB : wA) >> (8u * (j & 3u))) & 0xFFu;
+                uint32_t b1 = 0u;
+                if (!LB) {
+                    const uint32_t k = s >> 3, j = s & 7u;
+                    const uint32_t wA = pick_word<ND>(pbA, k), wB = pick_word<ND>(pbB, k);
+                    b1 = (((j & 4u) ? wB : wA) >> (8u * (j & 3u))) & 0xFFu;
+                }
                 W.queue[base + rank] = (uint32_t)lane | (s << 6) | (((kindmask >> sb) & 1u) << 11) | (b1 << 12);
                 m &= m - 1u;
             }
@@ -65,10 +75,12 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND> &W, int lane, uint64_t g
             const uint32_t q = q0 + (uint32_t)lane;
             if (q < base) {
                 const uint32_t d = W.queue[q];
-                const uint32_t owner = d & 63u, s = (d >> 6) & 31u, kind = (d >> 11) & 1u, b1 = (d >> 12) & 63u;
+                const uint32_t owner = d & 63u, s = (d >> 6) & 31u, kind = (d >> 11) & 1u;
+                const uint32_t b1 = LB ? reinterpret_cast<const uint8_t *>(&W.res[owner * CoopLds<ND, LB>::kStride + CoopLds<ND, LB>::kBins])[s]
+                                       : ((d >> 12) & 63u);
                 const uint32_t k = s >> 3, j = s & 7u;
                 const uint64_t go = gidx - (uint64_t)lane + (uint64_t)owner;
-                const uint32_t iv = pick_word<ND>(ivar, k);
+                const uint32_t iv = (ivpack >> (8u * k)) & 0xFFu;
                 const uint32_t sec = kind ? EMGPU_SEC_DEDISC_TRANS : EMGPU_SEC_DEDISC_RES;
                 const uint4 r4 = philox4x32_10((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner],
                                                (sec << 28) | (iv << 20) | (uint32_t)(2 * g8 + (int)(j >> 2)), rng.k0, rng.k1);
@@ -82,7 +94,7 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND> &W, int lane, uint64_t g
                     const double mm = dd * uniform32(x);
                     v = a + mm;
                 }
-                W.res[owner * CoopLds<ND>::kStride + s] = (float)v;
+                W.res[owner * CoopLds<ND, LB>::kStride + s] = (float)v;
             }
         }
         wave_sync();
@@ -124,18 +136,27 @@ __device__ __forceinline__ void coop_fill_store(const CoopLds<ND> &W, int lane, 
 // change into the zero bin (coop_zero_results cleared the slots before the workers wrote).
 // One v_add_co (shift the stream, carry = the flag) + one v_cndmask per second; two wait states
 // between the VCC write and its read (see emgpu_kernels_fast.hip).
-template <int ND>
-__device__ __forceinline__ void coop_zero_results(CoopLds<ND> &W, int lane) {
-    float4 *rp = reinterpret_cast<float4 *>(&W.res[lane * CoopLds<ND>::kStride]);
+template <int ND, bool LB>
+__device__ __forceinline__ void coop_zero_results(CoopLds<ND, LB> &W, int lane) {
+    float4 *rp = reinterpret_cast<float4 *>(&W.res[lane * CoopLds<ND, LB>::kStride]);
 #pragma unroll
     for (int q = 0; q < 2 * ND; q++) rp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// publish the packed bins of this lane's block for the workers (CoopLds<ND, true>)
 template <int ND>
-__device__ __forceinline__ void coop_fill_store_msb(const CoopLds<ND> &W, int lane, int k, int g8, int T, int G4, bool valid,
+__device__ __forceinline__ void coop_publish_bins(CoopLds<ND, true> &W, int lane, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND]) {
+    uint2 *bp = reinterpret_cast<uint2 *>(&W.res[lane * CoopLds<ND, true>::kStride + CoopLds<ND, true>::kBins]);
+#pragma unroll
+    for (int k = 0; k < ND; k++) bp[k] = make_uint2(pbA[k], pbB[k]);
+}
+
+template <int ND, bool LB>
+__device__ __forceinline__ void coop_fill_store_msb(const CoopLds<ND, LB> &W, int lane, int k, int g8, int T, int G4, bool valid,
                                                     uint32_t fill8, float &cval, uint32_t pbA, uint32_t pbB,
-                                                    uint32_t nd, uint32_t slot, int64_t i, int64_t n, uint32_t *dyn_bin, float *dyn_val) {
-    const float4 *rp = reinterpret_cast<const float4 *>(&W.res[lane * CoopLds<ND>::kStride]);
+                                                    uint32_t nd, uint32_t slot, int64_t i_wg, uint32_t tid, int64_t n,
+                                                    uint32_t *dyn_bin, float *dyn_val) {
+    const float4 *rp = reinterpret_cast<const float4 *>(&W.res[lane * CoopLds<ND, LB>::kStride]);
     const float4 ra = rp[2 * k], rb = rp[2 * k + 1];
     const float r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
     float pv[8];
@@ -150,13 +171,16 @@ __device__ __forceinline__ void coop_fill_store_msb(const CoopLds<ND> &W, int la
         for (int j = 0; j < 8; j++) pv[j] = (8 * g8 + j < T) ? pv[j] : 0.f;
     }
     if (valid) {
-        const size_t o = ((size_t)(2 * g8) * nd + slot) * (size_t)n + (size_t)i;
-        if (dyn_bin) dyn_bin[o] = pbA;
-        if (dyn_val) reinterpret_cast<float4 *>(dyn_val)[o] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        // wave-uniform base (scalar registers) + the thread's 32-bit offset: no per-store 64-bit vector arithmetic
+        const size_t o = ((size_t)(2 * g8) * nd + slot) * (size_t)n + (size_t)i_wg;
+        uint32_t *__restrict__ bb = dyn_bin ? dyn_bin + o : nullptr;
+        float4 *__restrict__ vb = dyn_val ? reinterpret_cast<float4 *>(dyn_val) + o : nullptr;
+        if (bb) bb[tid] = pbA;
+        if (vb) vb[tid] = make_float4(pv[0], pv[1], pv[2], pv[3]);
         if (2 * g8 + 1 < G4) {
-            const size_t o2 = o + (size_t)nd * (size_t)n;
-            if (dyn_bin) dyn_bin[o2] = pbB;
-            if (dyn_val) reinterpret_cast<float4 *>(dyn_val)[o2] = make_float4(pv[4], pv[5], pv[6], pv[7]);
+            const size_t o2 = (size_t)nd * (size_t)n;
+            if (bb) bb[o2 + tid] = pbB;
+            if (vb) vb[o2 + tid] = make_float4(pv[4], pv[5], pv[6], pv[7]);
         }
     }
 }

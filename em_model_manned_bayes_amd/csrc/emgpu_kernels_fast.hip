@@ -69,8 +69,8 @@ __device__ __forceinline__ void load_cthr(uint32_t (&th)[M], uint32_t &bml, uint
 //
 // The compare chains are written as carry arithmetic (two VOP2 instructions per compare, no
 // select, no merge): a borrow out of x - X is "x < X"; flag streams take it with f = f + f + carry;
-// the borrow count starts at kSelBase and feeds v_perm_b32 directly.  The differences x - X are
-// kept: a compare decided from the high halfword can only flip if x - X lies in [-0xFFFF, -1].
+// the borrow count starts at kSelBase and feeds v_perm_b32 directly.  The differences x_h - X_h of
+// the high halfwords are kept: a compare decided from them can only flip if the difference is 0.
 // gfx950 needs two wait states between a VALU write of VCC and a VALU read of it (the assembler
 // does not look inside asm blocks), hence the s_nop 1 in every pair; an SGPR operand is only read
 // three wait states into a block, in case a VALU (v_readlane of a spilled SGPR) wrote it just before.
@@ -79,27 +79,51 @@ __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 
                                                    const uint32_t (&thr)[M], uint32_t bml, uint32_t bmh, uint32_t selbase,
                                                    uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
                                                    uint32_t &cur_out, uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
-    uint32_t c1 = cur_in, dmax = 0u;
+    uint32_t c1 = cur_in, dmin = 0xFFFFFFFFu;
     pbA = pbB = hit8 = chg8 = zer8 = 0u;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int c = 8 * g8 + j; // absolute event time == column produced
         if (!EDGE || (c >= 1 && c < T)) {   // wave-uniform; interior blocks need no guard
-            uint32_t xr = half_hi(rh, j), xt = half_hi(th, j);
-            if (EXACT) { xr |= half_lo(rl, j); xt = clamp32(xt | half_lo(tl, j)); }
             uint32_t d[M + 1], sel;
-            // first threshold, then the resample Bernoulli: the SGPR operand is read three wait states into the block
-            asm("v_sub_co_u32 %0, vcc, %4, %5\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %6, vcc\n\t"       // select_random.m:19-20
-                "v_subrev_co_u32 %2, vcc, %8, %7\n\ts_nop 1\n\tv_addc_co_u32 %3, vcc, %3, %3, vcc"         // resample_events.m:24
-                : "=&v"(d[0]), "=&v"(sel), "=&v"(d[M]), "+v"(hit8) : "v"(xt), "v"(thr[0]), "v"(selbase), "v"(xr), "s"(Rres) : "vcc");
+            if (EXACT) {
+                const uint32_t xr = half_hi(rh, j) | half_lo(rl, j), xt = clamp32(half_hi(th, j) | half_lo(tl, j));
+                // first threshold, then the resample Bernoulli: the SGPR operand is read three wait states into the block
+                asm("v_sub_co_u32 %0, vcc, %4, %5\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %6, vcc\n\t"       // select_random.m:19-20
+                    "v_subrev_co_u32 %2, vcc, %8, %7\n\ts_nop 1\n\tv_addc_co_u32 %3, vcc, %3, %3, vcc"         // resample_events.m:24
+                    : "=&v"(d[0]), "=&v"(sel), "=&v"(d[M]), "+v"(hit8) : "v"(xt), "v"(thr[0]), "v"(selbase), "v"(xr), "s"(Rres) : "vcc");
 #pragma unroll
-            for (int t = 1; t < M; t++)
-                asm("v_sub_co_u32 %0, vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-                    : "=&v"(d[t]), "+v"(sel) : "v"(xt), "v"(thr[t]) : "vcc");
-            if (!EXACT) {
+                for (int t = 1; t < M; t++)
+                    asm("v_sub_co_u32 %0, vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+                        : "=&v"(d[t]), "+v"(sel) : "v"(xt), "v"(thr[t]) : "vcc");
+            } else {
+                // High halfwords only, read in place through SDWA operand selects (no extraction):
+                // x_h - X_h borrows <=> x_h < X_h; the difference is 0 exactly when the low halfword decides.
+                const uint32_t wt = word_of(th, j >> 1), wr = word_of(rh, j >> 1);
+#define EMGPU_PAIR0(SELX)                                                                                                        \
+                asm("v_sub_co_u32_sdwa %0, vcc, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:WORD_1\n\t"   \
+                    "s_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %6, vcc\n\t"                                                           \
+                    "v_subrev_co_u32_sdwa %2, vcc, %8, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:" SELX "\n\t" \
+                    "s_nop 1\n\tv_addc_co_u32 %3, vcc, %3, %3, vcc"                                                               \
+                    : "=&v"(d[0]), "=&v"(sel), "=&v"(d[M]), "+v"(hit8) : "v"(wt), "v"(thr[0]), "v"(selbase), "v"(wr), "s"(Rres) : "vcc")
+#define EMGPU_PAIRT(SELX)                                                                                                        \
+                asm("v_sub_co_u32_sdwa %0, vcc, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:WORD_1\n\t"   \
+                    "s_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"                                                                \
+                    : "=&v"(d[t]), "+v"(sel) : "v"(wt), "v"(thr[t]) : "vcc")
+                if (j & 1) {
+                    EMGPU_PAIR0("WORD_1");
 #pragma unroll
-                for (int t = 0; t + 1 <= M; t += 2) dmax = max(max(dmax, d[t]), d[t + 1]);
-                if (!(M & 1)) dmax = max(dmax, d[M]);
+                    for (int t = 1; t < M; t++) EMGPU_PAIRT("WORD_1");
+                } else {
+                    EMGPU_PAIR0("WORD_0");
+#pragma unroll
+                    for (int t = 1; t < M; t++) EMGPU_PAIRT("WORD_0");
+                }
+#undef EMGPU_PAIR0
+#undef EMGPU_PAIRT
+#pragma unroll
+                for (int t = 0; t + 1 <= M; t += 2) dmin = min(min(dmin, d[t]), d[t + 1]);
+                if (!(M & 1)) dmin = min(dmin, d[M]);
             }
             const uint32_t nb1 = __builtin_amdgcn_perm(bmh, bml, sel);                          // dbn_sample.m:144
             asm("v_cmp_ne_u32 vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
@@ -113,7 +137,7 @@ __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 
         if (j < 4) pbA |= b; else pbB |= b;
     }
     cur_out = c1;
-    return !EXACT && dmax >= 0xFFFF0001u;
+    return !EXACT && dmin == 0u;
 }
 
 // rare path, kept out of line so that the hot loop stays small in the instruction cache
@@ -172,10 +196,13 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
 
 template <int NI, int M0, int M1, int M2>
 __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
-    __shared__ CoopLds<3> s_wave[4];
+    // workers look the bin of a request up in LDS only where the registers allow it (the instances with
+    // many thresholds would spill)
+    constexpr bool LB = (M0 + M1 + M2) <= 10;
+    __shared__ CoopLds<3, LB> s_wave[4];
     __shared__ double s_bnd[3][16];
     const int tid = threadIdx.x, lane = tid & 63;
-    CoopLds<3> &W = s_wave[tid >> 6];
+    CoopLds<3, LB> &W = s_wave[tid >> 6];
     const int64_t i = (int64_t)blockIdx.x * 256 + tid;
     const bool valid = i < A.n; // lanes past the end stay alive: they serve as workers for their wave
     const uint64_t gidx = A.first_index + (uint64_t)i;
@@ -251,12 +278,13 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
         }
         const uint32_t need24 = valid ? (need8[0] | (need8[1] << 8) | (need8[2] << 16)) : 0u;
         const uint32_t kind24 = kind8[0] | (kind8[1] << 8) | (kind8[2] << 16);
-        coop_zero_results<3>(W, lane);
-        coop_dedisc<3, true>(W, lane, gidx, rng, g8, need24, kind24, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
+        coop_zero_results<3, LB>(W, lane);
+        if constexpr (LB) coop_publish_bins<3>(W, lane, pbA, pbB);
+        coop_dedisc<3, true, LB>(W, lane, gidx, rng, g8, need24, kind24, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
 #pragma unroll
         for (int k = 0; k < 3; k++)
-            coop_fill_store_msb<3>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
-                                   3u, F.slot[k], i, A.n, A.dyn_bin, A.dyn_val);
+            coop_fill_store_msb<3, LB>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
+                                   3u, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.n, A.dyn_bin, A.dyn_val);
         wave_sync(); // results of this block are consumed before the next block's workers overwrite them
     }
 }
