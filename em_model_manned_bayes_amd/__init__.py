@@ -13,9 +13,10 @@ from .functions import (rng, asub2ind, aind2sub, bn_sort, bn_sample, dbn_sample,
                         hierarchical_discretize, events2samples, events2controls)
 from .encounter_model import EncounterModel, EncounterModelEvents, UncorEncounterModel, CorTerminalModel  # noqa: F401
 from .native import Context, NativeModel, default_context  # noqa: F401
+from .legacy import em_sample, sample2track  # noqa: F401
 
 __all__ = ["em_read", "em_write", "rng", "asub2ind", "aind2sub", "bn_sort", "bn_sample", "dbn_sample",
            "dbn_hierarchical_sample", "bn_dirichlet_prior", "setTransitionPriors", "discretize_bayes",
            "hierarchical_cutpoints", "hierarchical_discretize", "events2samples", "events2controls",
            "EncounterModel", "EncounterModelEvents", "UncorEncounterModel", "CorTerminalModel",
-           "Context", "NativeModel", "EmgpuError"]
+           "em_sample", "sample2track", "Context", "NativeModel", "EmgpuError"]

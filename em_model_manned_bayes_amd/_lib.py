@@ -69,6 +69,12 @@ class SampleOut(C.Structure):
                 ("ev_count", C.c_void_p), ("events", C.c_void_p), ("attempts", C.c_void_p)]
 
 
+class TrackParams(C.Structure):   # emgpu_track_params
+    _fields_ = [("n", C.c_int64), ("T", C.c_int32), ("nd", C.c_int32), ("slot_vertrate", C.c_int32), ("slot_acc", C.c_int32),
+                ("slot_turnrate", C.c_int32), ("reserved", C.c_int32), ("ur_speed", C.c_double), ("ur_vertrate", C.c_double),
+                ("ur_heading", C.c_double), ("min_speed", C.c_double), ("max_speed", C.c_double)]
+
+
 class TermParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("tmax_s", C.c_double),
                 ("max_resample", C.c_int32), ("cap", C.c_int32), ("dyn_limits", C.c_double * 10)]
@@ -91,6 +97,7 @@ SYMBOLS = [
     "emgpu_last_kernel_name", "emgpu_discretize_bayes", "emgpu_asub2ind",
     "emgpu_debug_column_thresholds", "emgpu_debug_bernoulli_threshold", "emgpu_debug_dynamic_column",
     "emgpu_propagate_terminal_device", "emgpu_propagate_terminal_host",
+    "emgpu_sample2track_device", "emgpu_sample2track_host",
 ]
 
 _lib = None
@@ -145,6 +152,8 @@ def lib():
     L.emgpu_debug_bernoulli_threshold.restype = C.c_uint32
     for f in (L.emgpu_propagate_terminal_device, L.emgpu_propagate_terminal_host):
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(TermParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for f in (L.emgpu_sample2track_device, L.emgpu_sample2track_host):
+        f.argtypes = [C.c_void_p, C.POINTER(TrackParams)] + [C.c_void_p] * 6
     _lib = L
     return L
 

@@ -674,6 +674,98 @@ int emgpu_propagate_terminal_host(emgpu_ctx *ctx, const emgpu_model *const *mode
     EMGPU_CATCH
 }
 
+static int track_params_ok(const emgpu_track_params *p) {
+    if (p->n < 0 || p->T < 1) return fail(EMGPU_ERR_ARG, "bad n / T");
+    return EMGPU_OK;
+}
+
+int emgpu_sample2track_device(emgpu_ctx *ctx, const emgpu_track_params *p, const float *alt0, const float *speed0,
+                              const float *dyn_val, double *xyz, uint8_t *flags, double *speed_minmax) {
+    EMGPU_TRY
+    if (!ctx || !p || !alt0 || !speed0 || !dyn_val) return fail(EMGPU_ERR_ARG, "null argument");
+    if (int rc = track_params_ok(p)) return rc;
+    if (p->nd < 1 || p->slot_vertrate < 0 || p->slot_vertrate >= p->nd || p->slot_acc < 0 || p->slot_acc >= p->nd ||
+        p->slot_turnrate < 0 || p->slot_turnrate >= p->nd)
+        return fail(EMGPU_ERR_ARG, "bad dense-trace rows");
+    HIP_OK(hipSetDevice(ctx->device));
+    EmgpuTrackRun A{};
+    A.n = p->n; A.T = p->T;
+    A.ur_speed = p->ur_speed; A.ur_vertrate = p->ur_vertrate; A.ur_heading = p->ur_heading;
+    A.min_speed = p->min_speed; A.max_speed = p->max_speed;
+    A.alt0_f = alt0; A.speed0_f = speed0; A.dyn_val = dyn_val;
+    A.nd = p->nd; A.s_vr = p->slot_vertrate; A.s_acc = p->slot_acc; A.s_tr = p->slot_turnrate;
+    A.xyz = xyz; A.flags = flags; A.vmm = speed_minmax;
+    const char *name = "";
+    const hipError_t e = emgpu::launch_sample2track(A, true, ctx->stream, &name);
+    ctx->last_kernel = name;
+    if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_sample2track_host(emgpu_ctx *ctx, const emgpu_track_params *p, const double *alt0, const double *speed0,
+                            const double *updates, double *xyz, uint8_t *flags, double *speed_minmax) {
+    EMGPU_TRY
+    if (!ctx || !p || !alt0 || !speed0 || !updates) return fail(EMGPU_ERR_ARG, "null argument");
+    if (int rc = track_params_ok(p)) return rc;
+    HIP_OK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)p->n, T = (size_t)p->T;
+    if (n == 0) return EMGPU_OK;
+    // [n][T][3] -> [T][3][n] so that a wave reads 64 consecutive doubles
+    std::vector<double> planar(T * 3 * n), hx;
+    for (size_t i = 0; i < n; i++)
+        for (size_t t = 0; t < T; t++)
+            for (size_t c = 0; c < 3; c++) planar[(t * 3 + c) * n + i] = updates[(i * T + t) * 3 + c];
+    double *d_in = nullptr, *d_xyz = nullptr, *d_vmm = nullptr; uint8_t *d_fl = nullptr;
+    int rc = EMGPU_OK;
+    try {
+        HIP_OK(hipMalloc((void **)&d_in, (planar.size() + 2 * n) * sizeof(double)));
+        HIP_OK(hipMalloc((void **)&d_xyz, (T + 1) * 3 * n * sizeof(double)));
+        HIP_OK(hipMalloc((void **)&d_vmm, 2 * n * sizeof(double)));
+        HIP_OK(hipMalloc((void **)&d_fl, n));
+        HIP_OK(hipMemcpyAsync(d_in, planar.data(), planar.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipMemcpyAsync(d_in + planar.size(), alt0, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipMemcpyAsync(d_in + planar.size() + n, speed0, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        EmgpuTrackRun A{};
+        A.n = p->n; A.T = p->T;
+        A.ur_speed = p->ur_speed; A.ur_vertrate = p->ur_vertrate; A.ur_heading = p->ur_heading;
+        A.min_speed = p->min_speed; A.max_speed = p->max_speed;
+        A.upd = d_in; A.alt0_d = d_in + planar.size(); A.speed0_d = d_in + planar.size() + n;
+        A.xyz = d_xyz; A.flags = d_fl; A.vmm = d_vmm;
+        const char *name = "";
+        const hipError_t e = emgpu::launch_sample2track(A, false, ctx->stream, &name);
+        ctx->last_kernel = name;
+        if (e != hipSuccess) rc = fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+        if (rc == EMGPU_OK) {
+            if (xyz) {
+                hx.resize((T + 1) * 3 * n);
+                HIP_OK(hipMemcpyAsync(hx.data(), d_xyz, hx.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            }
+            if (flags) HIP_OK(hipMemcpyAsync(flags, d_fl, n, hipMemcpyDeviceToHost, ctx->stream));
+            std::vector<double> hv;
+            if (speed_minmax) {
+                hv.resize(2 * n);
+                HIP_OK(hipMemcpyAsync(hv.data(), d_vmm, 2 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            }
+            rc = emgpu_ctx_sync(ctx);
+            if (rc == EMGPU_OK && xyz)
+                for (size_t i = 0; i < n; i++)
+                    for (size_t t = 0; t <= T; t++)
+                        for (size_t c = 0; c < 3; c++) xyz[(i * (T + 1) + t) * 3 + c] = hx[(t * 3 + c) * n + i];
+            if (rc == EMGPU_OK && speed_minmax)
+                for (size_t i = 0; i < n; i++) { speed_minmax[2 * i] = hv[i]; speed_minmax[2 * i + 1] = hv[n + i]; }
+        }
+    } catch (...) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_in); (void)hipFree(d_xyz); (void)hipFree(d_vmm); (void)hipFree(d_fl);
+        throw;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in); (void)hipFree(d_xyz); (void)hipFree(d_vmm); (void)hipFree(d_fl);
+    return rc;
+    EMGPU_CATCH
+}
+
 int32_t emgpu_discretize_bayes(double x, const double *thresholds, int32_t n) {
     // discretize_bayes.m:17-21
     if (n <= 0 || !thresholds) return 1;

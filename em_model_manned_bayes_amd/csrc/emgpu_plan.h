@@ -129,3 +129,22 @@ struct EmgpuTermRun {
     int32_t *rows;                   // [4n] rows written; < 0: failed (cap / resample cap)
     uint32_t *status;
 };
+
+// sample2track.m:183-237 for n trajectories (k_sample2track).  Exactly one input form is set.
+struct EmgpuTrackRun {
+    int64_t n;
+    int32_t T;                              // transition rows per id (= num_transition_samples of em_sample)
+    double ur_speed, ur_vertrate, ur_heading; // sample2track.m:113-123
+    double min_speed, max_speed;            // boundaries{speed}([1 end]) in model units (sample2track.m:104-105)
+    // DENSE: the sampler's device output
+    const float *alt0_f, *speed0_f;         // [n]: rows of init_val
+    const float *dyn_val;                   // [ceil(T/4)][nd][n][4]
+    int32_t nd, s_vr, s_acc, s_tr;          // rows of vertical rate, acceleration, turn rate
+    // PLANAR: f64 columns parsed from the files
+    const double *alt0_d, *speed0_d;        // [n]
+    const double *upd;                      // [T][3][n]: vertical rate, acceleration, turn rate in model units
+    // outputs (each may be null)
+    double *xyz;                            // [T+1][3][n] feet
+    uint8_t *flags;                         // [n]: bit 0 = below ground (CFIT), bit 1 = speed outside (min, max)
+    double *vmm;                            // [2][n]: min and max speed (ft/s)
+};

@@ -292,3 +292,36 @@ def propagate_terminal_host(ctx, models, geo, model_of, seed, first_index=0, tma
     rows = np.zeros(4 * n, dtype=np.int32)
     L.check(L.lib().emgpu_propagate_terminal_host(ctx._h, handles, len(models), C.byref(p), _p(geo), _p(model_of), _p(out), _p(rows)))
     return np.ascontiguousarray(out.transpose(2, 1, 0)), rows
+
+
+def track_params(n, T, ur_speed, ur_vertrate, ur_heading, min_speed, max_speed, nd=0, slot_vertrate=0, slot_acc=0, slot_turnrate=0):
+    p = L.TrackParams()
+    p.n, p.T, p.nd = int(n), int(T), int(nd)
+    p.slot_vertrate, p.slot_acc, p.slot_turnrate = int(slot_vertrate), int(slot_acc), int(slot_turnrate)
+    p.ur_speed, p.ur_vertrate, p.ur_heading = float(ur_speed), float(ur_vertrate), float(ur_heading)
+    p.min_speed, p.max_speed = float(min_speed), float(max_speed)
+    return p
+
+
+def sample2track_host(ctx, alt0, speed0, updates, ur_speed, ur_vertrate, ur_heading, min_speed, max_speed):
+    """emgpu_sample2track_host: sample2track.m:183-243 on the GPU for values parsed from the em_sample files.
+    alt0, speed0 [n]; updates [n, T, 3] = vertical rate, acceleration, turn rate (model units).
+    Returns (xyz [n, T+1, 3] f64 feet, flags [n] u8 (bit 0 CFIT, bit 1 speed), speed_minmax [n, 2])."""
+    alt0 = np.ascontiguousarray(alt0, dtype=np.float64).reshape(-1)
+    speed0 = np.ascontiguousarray(speed0, dtype=np.float64).reshape(-1)
+    updates = np.ascontiguousarray(updates, dtype=np.float64)
+    n, T = updates.shape[0], updates.shape[1]
+    assert updates.shape == (n, T, 3) and alt0.size == n and speed0.size == n
+    p = track_params(n, T, ur_speed, ur_vertrate, ur_heading, min_speed, max_speed)
+    xyz = np.zeros((n, T + 1, 3))
+    flags = np.zeros(n, dtype=np.uint8)
+    vmm = np.zeros((n, 2))
+    L.check(L.lib().emgpu_sample2track_host(ctx._h, C.byref(p), _p(alt0), _p(speed0), _p(updates), _p(xyz), _p(flags), _p(vmm)))
+    return xyz, flags, vmm
+
+
+def sample2track_device(ctx, params, alt0, speed0, dyn_val, xyz=0, flags=0, speed_minmax=0):
+    """emgpu_sample2track_device with raw device pointers (ints, 0 = skip an output): consumes the sampler's
+    device output in place (alt0 / speed0 = rows of init_val, dyn_val = the dense trace).  Asynchronous."""
+    L.check(L.lib().emgpu_sample2track_device(ctx._h, C.byref(params), alt0, speed0, dyn_val, xyz or None, flags or None,
+                                              speed_minmax or None))

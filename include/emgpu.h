@@ -230,6 +230,32 @@ int emgpu_propagate_terminal_host(emgpu_ctx *ctx, const emgpu_model *const *mode
                                   const emgpu_term_params *p, const double *geo, const int32_t *model_of,
                                   float *out, int32_t *rows);
 
+/* sample2track.m:183-237 -- the 1 Hz dead-reckoning track `sample2track` builds from the em_sample
+ * files, and its rejection tests, for n trajectories in one launch:
+ *   z += vertrate*ur_vertrate; speed += acc*ur_speed; heading += turnrate*ur_heading;
+ *   x += speed*cosd(heading); y += speed*sind(heading)            (:201-212, previous speed/heading)
+ * flags[i] bit 0: some z < 0 (CFIT, :234-237); bit 1: some speed <= min or >= max (:240); the
+ * reference keeps a track iff flags[i] == 0 (:243).  speed, min_speed, max_speed are in model
+ * units (knots) and are converted with ur_speed like :126-139.
+ * _device: consumes the sampler's device output in place -- alt0/speed0 = rows of init_val,
+ *   dyn_val = the time-blocked dense trace with nd rows per block, slot_* = the rows holding
+ *   \dot h, \dot v, \dot\psi; xyz f64 [T+1][3][n], speed_minmax f64 [2][n] (either may be NULL).
+ * _host: values as parsed from initial.txt / transition.txt: updates [n][T][3] = vertical rate,
+ *   acceleration, turn rate; xyz [n][T+1][3], speed_minmax [n][2] (either may be NULL). */
+typedef struct {
+    int64_t n;
+    int32_t T;                 /* transition rows per id */
+    int32_t nd;                /* _device: rows per dense block */
+    int32_t slot_vertrate, slot_acc, slot_turnrate;
+    int32_t reserved;
+    double ur_speed, ur_vertrate, ur_heading;
+    double min_speed, max_speed;
+} emgpu_track_params;
+int emgpu_sample2track_device(emgpu_ctx *ctx, const emgpu_track_params *p, const float *alt0, const float *speed0,
+                              const float *dyn_val, double *xyz, uint8_t *flags, double *speed_minmax);
+int emgpu_sample2track_host(emgpu_ctx *ctx, const emgpu_track_params *p, const double *alt0, const double *speed0,
+                            const double *updates, double *xyz, uint8_t *flags, double *speed_minmax);
+
 /* Introspection for benchmarks/tests: name of the kernel variant the last *_device call used and
  * the algorithmic output bytes per trajectory of that call (5*n_i + 5*T*n_d for dense output). */
 const char *emgpu_last_kernel_name(const emgpu_ctx *ctx);

@@ -948,6 +948,40 @@ int64_t em_propagate_batch(const em_model_t *const *models, const int32_t *model
     return 0;
 }
 
+/* sample2track.m:183-243 -- the 1 Hz dead-reckoning track and its rejection tests.
+ * alt0/speed0 [n] and updates [n][T][3] (vertical rate, acceleration, turn rate) in model units, as
+ * read from initial.txt / transition.txt; unit ratios as :113-123; min/max speed = boundaries{v}([1 end]).
+ * xyz [n][T+1][3], flags[n] (bit 0 CFIT :234-237, bit 1 speed :240), vmm [n][2] = min, max speed. */
+void em_sample2track_batch(int64_t n, int T, double ur_speed, double ur_vertrate, double ur_heading, double min_speed, double max_speed,
+                           const double *alt0, const double *speed0, const double *updates, double *xyz, uint8_t *flags, double *vmm) {
+    const double vmin = min_speed * ur_speed, vmax = max_speed * ur_speed;         /* :138-139 */
+    for (int64_t i = 0; i < n; i++) {
+        double x = 0, y = 0, z = alt0[i], sp = speed0[i] * ur_speed, hd = 0;      /* :184-189, :126 */
+        double lo = sp, hi = sp;
+        unsigned fl = 0;
+        if (z < 0) fl |= 1u;
+        if (sp <= vmin || sp >= vmax) fl |= 2u;
+        double *o = xyz ? xyz + (size_t)i * (T + 1) * 3 : NULL;
+        if (o) { o[0] = x; o[1] = y; o[2] = z; }
+        for (int t = 0; t < T; t++) {
+            const double *u = updates + ((size_t)i * T + t) * 3;
+            const double dz = u[0] * ur_vertrate, dsp = u[1] * ur_speed, dhd = u[2] * ur_heading;  /* :131-133 */
+            double sh, ch;
+            em_sincosd(hd, &sh, &ch);
+            const double xn = x + sp * ch, yn = y + sp * sh;                        /* :211-212 use the previous speed and heading */
+            z = z + dz; sp = sp + dsp; hd = hd + dhd;                               /* :207-209 */
+            x = xn; y = yn;
+            if (z < 0) fl |= 1u;
+            if (sp <= vmin || sp >= vmax) fl |= 2u;
+            if (sp < lo) lo = sp;
+            if (sp > hi) hi = sp;
+            if (o) { o[(t + 1) * 3] = x; o[(t + 1) * 3 + 1] = y; o[(t + 1) * 3 + 2] = z; }
+        }
+        if (flags) flags[i] = (uint8_t)fl;
+        if (vmm) { vmm[2 * i] = lo; vmm[2 * i + 1] = hi; }
+    }
+}
+
 /* MT19937 helpers for tests */
 void em_mt_doubles(uint32_t seed, int n, double *out) {
     em_mt_t s; mt_seed(&s, seed);

@@ -498,6 +498,23 @@ def propagate(oms, model_of, geo, seed, dyn_limits, mode=RNG_PHILOX, first_index
     return out, rows
 
 
+def sample2track(alt0, speed0, updates, ur_speed, ur_vertrate, ur_heading, min_speed, max_speed):
+    """sample2track.m:183-243 restated: (xyz [n, T+1, 3], flags [n], speed_minmax [n, 2])."""
+    L = lib()
+    L.em_sample2track_batch.restype = None
+    alt0 = np.ascontiguousarray(alt0, dtype=np.float64)
+    speed0 = np.ascontiguousarray(speed0, dtype=np.float64)
+    updates = np.ascontiguousarray(updates, dtype=np.float64)
+    n, T = updates.shape[0], updates.shape[1]
+    xyz = np.zeros((n, T + 1, 3))
+    flags = np.zeros(n, dtype=np.uint8)
+    vmm = np.zeros((n, 2))
+    L.em_sample2track_batch(C.c_int64(n), C.c_int(T), C.c_double(ur_speed), C.c_double(ur_vertrate), C.c_double(ur_heading),
+                            C.c_double(min_speed), C.c_double(max_speed), _ptr(alt0), _ptr(speed0), _ptr(updates),
+                            _ptr(xyz), _ptr(flags), _ptr(vmm))
+    return xyz, flags, vmm
+
+
 def stay_prior_alpha(parms, prior=1.0):
     """setTransitionPriors.m:12-33 through em_oracle.c, as {var0: r x q} for OracleModel(alpha_transition=...)."""
     L = lib()

@@ -466,3 +466,113 @@ def test_large_sample_frequencies_match_the_cpts(gpu_ctx, model_dir):
     keep = exp >= 5
     o, e_ = obs[w > 0][keep], exp[keep]
     assert stats.chisquare(o, e_ * o.sum() / e_.sum()).pvalue > 1e-4
+
+
+def test_sample2track_kernel_matches_oracle(gpu_ctx):
+    """emgpu_sample2track_host (f64 planar input) against sample2track.m:183-243 restated."""
+    rng = np.random.RandomState(3)
+    n, T = 3000, 61
+    alt0 = rng.uniform(-50, 12000, n)
+    v0 = rng.uniform(20, 320, n)
+    upd = np.stack([rng.normal(0, 800, (n, T)), rng.normal(0, 1.0, (n, T)), rng.normal(0, 3.0, (n, T))], axis=2)
+    upd[::7, :, 2] = 22.5                      # headings that pass through exact multiples of 90 degrees
+    upd[::11] = 0.0
+    ur = ((1852.0 / 0.3048) / 3600.0, 1.0 / 60.0, 1.0)
+    ref_xyz, ref_fl, ref_vmm = O.sample2track(alt0, v0, upd, *ur, 30.0, 300.0)
+    xyz, fl, vmm = native.sample2track_host(gpu_ctx, alt0, v0, upd, *ur, 30.0, 300.0)
+    assert gpu_ctx.last_kernel() == "k_sample2track<planar>"
+    assert np.array_equal(fl, ref_fl) and 0 < (fl == 0).sum() < n and (fl & 1).any() and (fl & 2).any()
+    np.testing.assert_allclose(xyz, ref_xyz, rtol=1e-12, atol=1e-7)      # f64 on both sides; sin/cos differ by ulps
+    np.testing.assert_allclose(vmm, ref_vmm, rtol=1e-14)
+    assert np.array_equal(xyz[::11][:, :, 1], np.zeros_like(xyz[::11][:, :, 1]))
+    # T not a multiple of 4, n not a multiple of 256, single row
+    for n2, T2 in [(1, 1), (257, 2), (130, 7)]:
+        a, b = native.sample2track_host(gpu_ctx, alt0[:n2], v0[:n2], upd[:n2, :T2], *ur, 30.0, 300.0)[:2]
+        ra, rb = O.sample2track(alt0[:n2], v0[:n2], upd[:n2, :T2], *ur, 30.0, 300.0)[:2]
+        np.testing.assert_allclose(a, ra, rtol=1e-12, atol=1e-7)
+        assert np.array_equal(b, rb)
+
+
+def test_sample2track_consumes_the_dense_trace_on_the_device(gpu_ctx, model_dir):
+    """The device consumer: sampler output stays in HBM, k_sample2track<dense> reads it in place."""
+    import torch
+    nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
+    idx = uncor_indices(pp)
+    n, T, seed = 4000, 61, 5
+    ni, nd, G4 = 7, 3, (T + 3) // 4
+    dev = torch.device("cuda:0")
+    iv = torch.zeros((ni, n), dtype=torch.float32, device=dev)
+    dv = torch.zeros((G4, nd, n, 4), dtype=torch.float32, device=dev)
+    xyz = torch.zeros((T + 1, 3, n), dtype=torch.float64, device=dev)
+    fl = torch.zeros(n, dtype=torch.uint8, device=dev)
+    vmm = torch.zeros((2, n), dtype=torch.float64, device=dev)
+    gpu_ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    p, _keep = native.make_params(n, T, seed, **idx)
+    native.sample_dbn_device(gpu_ctx, nm, p, init_val=iv.data_ptr(), dyn_val=dv.data_ptr())
+    tm = np.asarray(pp["temporal_map"]).reshape(-1, 2)
+    lab = [pp["labels_initial"][int(r[0]) - 1] for r in tm]
+    s_acc, s_vr, s_tr = lab.index('"\\dot v"'), lab.index('"\\dot h"'), lab.index('"\\dot \\psi"')
+    b_v = np.asarray(pp["boundaries"][idx["idx_v"] - 1])
+    ur = ((1852.0 / 0.3048) / 3600.0, 1.0 / 60.0, 1.0)
+    tp = native.track_params(n, T, *ur, float(b_v[0]), float(b_v[-1]), nd=nd, slot_vertrate=s_vr, slot_acc=s_acc, slot_turnrate=s_tr)
+    native.sample2track_device(gpu_ctx, tp, iv[idx["idx_L"] - 1].data_ptr(), iv[idx["idx_v"] - 1].data_ptr(), dv.data_ptr(),
+                               xyz.data_ptr(), fl.data_ptr(), vmm.data_ptr())
+    gpu_ctx.sync()
+    assert gpu_ctx.last_kernel() == "k_sample2track<dense>"
+    gpu_ctx.set_stream(None)
+    ref = O.uncor_sample(O.OracleModel(pp), n, T, seed, want_events=False)
+    upd = ref["dense_val"].astype(np.float32).astype(np.float64)[:, :, [s_vr, s_acc, s_tr]]
+    a0 = ref["init_val"][:, idx["idx_L"] - 1].astype(np.float32).astype(np.float64)
+    v0 = ref["init_val"][:, idx["idx_v"] - 1].astype(np.float32).astype(np.float64)
+    rx, rf, rv = O.sample2track(a0, v0, upd, *ur, float(b_v[0]), float(b_v[-1]))
+    np.testing.assert_allclose(xyz.cpu().numpy().transpose(2, 0, 1), rx, rtol=1e-12, atol=1e-7)
+    assert np.array_equal(fl.cpu().numpy(), rf)
+    np.testing.assert_allclose(vmm.cpu().numpy().T, rv, rtol=1e-14)
+
+
+def test_em_sample_and_sample2track_files(gpu_ctx, model_dir, tmp_path):
+    """RUN_1_emsample / RUN_2_sample2track end to end: file formats, values, directories, rejection."""
+    path = em_io.materialize_model("uncor_1200code_v2p1", model_dir)
+    fi, ft = str(tmp_path / "initial.txt"), str(tmp_path / "transition.txt")
+    n, T, seed = 120, 60, 42
+    initial, trace = E.em_sample(path, initial_output_filename=fi, transition_output_filename=ft, num_initial_samples=n,
+                                 num_transition_samples=T, rng_seed=seed, ctx=gpu_ctx)
+    li, lt = open(fi).read().split("\n"), open(ft).read().split("\n")
+    assert li[0] == 'id "G" "A" "L" "v" "\\dot v" "\\dot h" "\\dot \\psi" ' and li[-1] == "" and len(li) == n + 2    # em_sample.m:64-68
+    assert lt[0] == 'initial_id t "\\dot v(t+1)" "\\dot h(t+1)" "\\dot \\psi(t+1)" ' and len(lt) == n * T + 2     # :71-75
+    assert lt[1].split(" ")[:2] == ["1", "0"] and lt[T].split(" ")[:2] == ["1", str(T - 1)] and lt[T + 1].split(" ")[0] == "2"
+    # values: dbn_hierarchical_sample without the rejection test == the oracle's never-rejected samples
+    pp = O.parse_model_txt(path)
+    ref = O.uncor_sample(O.OracleModel(pp), n, T, seed, want_events=False)
+    keep = np.nonzero(ref["attempts"] == 1)[0]
+    assert keep.size > n // 2
+    Ti = np.loadtxt(fi, skiprows=1, ndmin=2)
+    Tt = np.loadtxt(ft, skiprows=1, ndmin=2).reshape(n, T, 5)
+    assert np.array_equal(Ti[:, 0], np.arange(1, n + 1)) and np.array_equal(Tt[0, :, 1], np.arange(T))
+    np.testing.assert_allclose(Ti[keep, 1:], ref["init_val"][keep], rtol=1.1e-5, atol=1e-12)        # %g keeps 6 significant digits
+    np.testing.assert_allclose(Tt[keep][:, :, 2:], ref["dense_val"][keep], rtol=1.1e-5, atol=1e-12)
+    assert np.array_equal(initial[keep].astype(np.float32), ref["init_val"][keep].astype(np.float32))
+    # tracks
+    out = str(tmp_path / "tracks")
+    is_good, T_initial = E.sample2track(path, fi, ft, out_dir_parent=out, verbose=False, ctx=gpu_ctx)
+    ur = ((1852.0 / 0.3048) / 3600.0, 1.0 / 60.0, 1.0)
+    b_v = np.asarray(pp["boundaries"][3])
+    rx, rf, _ = O.sample2track(Ti[:, 3], Ti[:, 4], Tt[:, :, [3, 2, 4]], *ur, float(b_v[0]), float(b_v[-1]))
+    assert np.array_equal(is_good, rf == 0) and is_good.any()
+    np.testing.assert_allclose(T_initial["v"], Ti[:, 4] * ur[0], rtol=1e-15)
+    files = sorted(glob.glob(os.path.join(out, "G*", "A*", "*ft", "BAYES_t%d_id*_alt*_speed*.csv" % T)))
+    assert len(files) == int(is_good.sum())
+    i = int(np.nonzero(is_good)[0][0])
+    mine = [f for f in files if "_id%d_" % (i + 1) in f]
+    assert len(mine) == 1
+    parts = mine[0].split(os.sep)
+    assert parts[-4] == "G%d" % Ti[i, 1] and parts[-3] == "A%d" % Ti[i, 2]
+    alt_dir = int(parts[-2][:-2])
+    assert alt_dir <= Ti[i, 3] < alt_dir + 100 + 1e-9
+    rows = open(mine[0]).read().split("\n")
+    assert rows[0] == "time_s,x_ft,y_ft,z_ft" and len(rows) == T + 3
+    csv = np.array([[float(v) for v in r.split(",")] for r in rows[1:-1]])
+    assert np.array_equal(csv[:, 0], np.arange(T + 1))
+    assert np.max(np.abs(csv[:, 1:] - rx[i])) <= 0.5 + 1e-6           # %0.0f
+    # a track that starts below the speed range is rejected and writes nothing
+    assert not glob.glob(os.path.join(out, "**", "*_id%d_*" % (int(np.nonzero(~is_good)[0][0]) + 1 if (~is_good).any() else 0)), recursive=True)

@@ -308,3 +308,13 @@ def test_product_never_touches_the_oracle_or_the_reference():
     for f in ("bench.py", "__graft_entry__.py"):
         text = open(os.path.join(ROOT, f)).read()
         assert "/root/reference" not in text
+
+
+def test_legacy_label_names_and_number_format():
+    from em_model_manned_bayes_amd import legacy
+    labs = ['"G"', '"A"', '"L"', '"v"', '"\\dot v"', '"\\dot h"', '"\\dot \\psi"']
+    assert [legacy.make_valid_name(legacy._erase(s)) for s in labs] == ["G", "A", "L", "v", "dotV", "dotH", "dotPsi"]   # sample2track.m:27-31
+    tl = ['"\\dot v(t+1)"', '"\\dot h(t+1)"', '"\\dot \\psi(t+1)"']
+    assert [legacy.make_valid_name(legacy._erase(s)) for s in tl] == ["dotV_t_1_", "dotH_t_1_", "dotPsi_t_1_"]          # :38-40
+    assert [legacy._g(x) for x in (3, 0.5, 1234567.0, 1e-7, 145.123456789, -0.0)] == ["3", "0.5", "1.23457e+06", "1e-07", "145.123", "-0"]
+    assert abs(legacy.FT_PER_NM / 3600.0 - 1.68780985710119) < 1e-13

@@ -252,3 +252,29 @@ def test_propagate_trajectory_restatement_properties(tmp_path):
     a, ra = O.propagate(oms, mo[:10], geo[:10], 5, dl, first_index=100)
     b, rb = O.propagate(oms, mo[5:10], geo[5:10], 5, dl, first_index=105)
     assert np.array_equal(ra[20:], rb) and np.array_equal(a[20:], b)
+
+
+def test_sample2track_known_answers():
+    """sample2track.m:183-243 restated: hand-checkable tracks."""
+    ur_s, ur_v = (1852.0 / 0.3048) / 3600.0, 1.0 / 60.0
+    T = 8
+    upd = np.zeros((4, T, 3))
+    upd[1, :, 2] = 90.0 / 4            # quarter turn in 4 s: heading 0, 22.5, 45, 67.5, 90 (exact cosd(90) = 0), ...
+    upd[2, :, 0] = -600.0              # 10 ft/s descent from 35 ft: below ground after 4 s
+    upd[3, 3, 1] = 1000.0              # acceleration spike: leaves the speed range
+    alt0 = np.array([1000.0, 1000.0, 35.0, 1000.0])
+    v0 = np.array([100.0, 100.0, 100.0, 100.0])
+    xyz, flags, vmm = O.sample2track(alt0, v0, upd, ur_s, ur_v, 1.0, 30.0, 300.0)
+    s = 100.0 * ur_s
+    assert np.allclose(xyz[0, :, 0], s * np.arange(T + 1), rtol=1e-15) and np.all(xyz[0, :, 1] == 0) and np.all(xyz[0, :, 2] == 1000.0)
+    hd = 22.5 * np.arange(T)           # heading used for the step t -> t+1 is the one BEFORE the update (:211-212)
+    assert np.allclose(xyz[1, 1:, 0], np.cumsum(s * np.cos(np.deg2rad(hd))), rtol=1e-12, atol=1e-9)
+    assert np.allclose(xyz[1, 1:, 1], np.cumsum(s * np.sin(np.deg2rad(hd))), rtol=1e-12, atol=1e-9)
+    assert xyz[1, 5, 0] == xyz[1, 4, 0]                      # heading exactly 90 degrees: cosd(90) is exactly 0
+    assert xyz[1, 5, 1] == xyz[1, 4, 1] + s                  # and sind(90) exactly 1
+    assert np.allclose(xyz[2, :, 2], 35.0 - 10.0 * np.arange(T + 1))
+    assert flags.tolist() == [0, 0, 1, 2]
+    assert np.allclose(vmm[3], [s, s + 1000.0 * ur_s]) and np.allclose(vmm[0], [s, s])
+    # the bounds are exclusive (<=, >=: sample2track.m:240)
+    _, f2, _ = O.sample2track([10.0], [30.0], np.zeros((1, 2, 3)), ur_s, ur_v, 1.0, 30.0, 300.0)
+    assert f2[0] == 2
