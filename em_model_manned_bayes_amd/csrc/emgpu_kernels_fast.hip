@@ -43,10 +43,20 @@ struct FastArgs {
 // bmh, so that one v_perm_b32 with selector kSelBase + b yields the 1-based bin.
 constexpr uint32_t kSelBase = 0x0c0c0c00u; // v_perm_b32 selector: bytes 1-3 constant zero, byte 0 <- table[b]
 template <int M>
-__device__ __forceinline__ void load_cthr(uint32_t (&th)[M], uint32_t &bml, uint32_t &bmh, const uint32_t *__restrict__ p, int meff) {
-    static_assert(M >= 1 && M <= 7, "the byte table has 8 entries");
+__device__ __forceinline__ void load_cthr_full(uint32_t (&th)[M], const uint32_t *__restrict__ p, int meff) {
 #pragma unroll
     for (int t = 0; t < M; t++) th[t] = (t < meff) ? p[t] : 0xFFFFFFFFu;
+}
+// The hot loop compares high halfwords only, so the registers hold two threshold halves each
+// (threshold 2q in the low word, 2q+1 in the high word: SDWA selects the word); the rare exact pass
+// reloads the full column from the table.
+template <int M>
+__device__ __forceinline__ void load_cthr(uint32_t (&tp)[(M + 1) / 2], uint32_t &bml, uint32_t &bmh, const uint32_t *__restrict__ p, int meff) {
+    static_assert(M >= 1 && M <= 7, "the byte table has 8 entries");
+    uint32_t th[M];
+    load_cthr_full<M>(th, p, meff);
+#pragma unroll
+    for (int q = 0; q < (M + 1) / 2; q++) tp[q] = (th[2 * q] >> 16) | ((2 * q + 1 < M ? th[2 * q + 1] : 0xFFFFFFFFu) & 0xFFFF0000u);
     const uint32_t map = p[meff];
     uint32_t lo = 0u, hi = 0u;
 #pragma unroll
@@ -76,7 +86,7 @@ __device__ __forceinline__ void load_cthr(uint32_t (&th)[M], uint32_t &bml, uint
 // three wait states into a block, in case a VALU (v_readlane of a spilled SGPR) wrote it just before.
 template <int M, bool EXACT, bool EDGE>
 __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 &rh, const uint4 &tl, const uint4 &rl, int g8, int T,
-                                                   const uint32_t (&thr)[M], uint32_t bml, uint32_t bmh, uint32_t selbase,
+                                                   const uint32_t (&thr)[EXACT ? M : (M + 1) / 2], uint32_t bml, uint32_t bmh, uint32_t selbase,
                                                    uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
                                                    uint32_t &cur_out, uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
     uint32_t c1 = cur_in, dmin = 0xFFFFFFFFu;
@@ -101,23 +111,23 @@ __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 
                 // x_h - X_h borrows <=> x_h < X_h; the difference is 0 exactly when the low halfword decides.
                 const uint32_t wt = word_of(th, j >> 1), wr = word_of(rh, j >> 1);
 #define EMGPU_PAIR0(SELX)                                                                                                        \
-                asm("v_sub_co_u32_sdwa %0, vcc, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:WORD_1\n\t"   \
+                asm("v_sub_co_u32_sdwa %0, vcc, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:WORD_0\n\t"   \
                     "s_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %6, vcc\n\t"                                                           \
                     "v_subrev_co_u32_sdwa %2, vcc, %8, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:" SELX "\n\t" \
                     "s_nop 1\n\tv_addc_co_u32 %3, vcc, %3, %3, vcc"                                                               \
                     : "=&v"(d[0]), "=&v"(sel), "=&v"(d[M]), "+v"(hit8) : "v"(wt), "v"(thr[0]), "v"(selbase), "v"(wr), "s"(Rres) : "vcc")
-#define EMGPU_PAIRT(SELX)                                                                                                        \
-                asm("v_sub_co_u32_sdwa %0, vcc, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:WORD_1\n\t"   \
+#define EMGPU_PAIRT(SELX, SELT)                                                                                                  \
+                asm("v_sub_co_u32_sdwa %0, vcc, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:" SELT "\n\t" \
                     "s_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"                                                                \
-                    : "=&v"(d[t]), "+v"(sel) : "v"(wt), "v"(thr[t]) : "vcc")
+                    : "=&v"(d[t]), "+v"(sel) : "v"(wt), "v"(thr[t >> 1]) : "vcc")
                 if (j & 1) {
                     EMGPU_PAIR0("WORD_1");
 #pragma unroll
-                    for (int t = 1; t < M; t++) EMGPU_PAIRT("WORD_1");
+                    for (int t = 1; t < M; t++) { if (t & 1) EMGPU_PAIRT("WORD_1", "WORD_1"); else EMGPU_PAIRT("WORD_1", "WORD_0"); }
                 } else {
                     EMGPU_PAIR0("WORD_0");
 #pragma unroll
-                    for (int t = 1; t < M; t++) EMGPU_PAIRT("WORD_0");
+                    for (int t = 1; t < M; t++) { if (t & 1) EMGPU_PAIRT("WORD_0", "WORD_1"); else EMGPU_PAIRT("WORD_0", "WORD_0"); }
                 }
 #undef EMGPU_PAIR0
 #undef EMGPU_PAIRT
@@ -144,14 +154,14 @@ __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 
 template <int M>
 __device__ __attribute__((noinline)) void eight_seconds_exact(uint32_t c0, uint32_t c1r, uint32_t attempt, uint32_t k0, uint32_t k1,
                                                               uint4 th, uint4 rh, uint32_t tvar, uint32_t ivar, int g8, int T,
-                                                              const uint32_t *thr_in, uint32_t bml, uint32_t bmh, uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
+                                                              const uint32_t *thr_col /* this lane's column in EmgpuPlan::cthr */, int meff,
+                                                              uint32_t bml, uint32_t bmh, uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
                                                               uint32_t *out /* cur, pbA, pbB, hit8, chg8, zer8 */) {
     const Rng rng{c0, c1r, attempt, k0, k1};
     const uint4 tl = rng.block(EMGPU_SEC_TRANS_LO, tvar, (uint32_t)g8);
     const uint4 rl = rng.block(EMGPU_SEC_RES_LO, ivar, (uint32_t)g8);
     uint32_t thr[M];
-#pragma unroll
-    for (int t = 0; t < M; t++) thr[t] = thr_in[t];
+    load_cthr_full<M>(thr, thr_col, meff);
     uint32_t cur, a, b, h, c, z;
     eight_seconds_pass<M, true, true>(th, rh, tl, rl, g8, T, thr, bml, bmh, kSelBase, Rres, zbin1, cur_in, cur, a, b, h, c, z);
     out[0] = cur; out[1] = a; out[2] = b; out[3] = h; out[4] = c; out[5] = z;
@@ -159,7 +169,8 @@ __device__ __attribute__((noinline)) void eight_seconds_exact(uint32_t c0, uint3
 
 template <int M>
 __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uint32_t ivar, int g8, int T,
-                                              const uint32_t (&thr)[M], uint32_t bml, uint32_t bmh, uint32_t selbase, uint32_t Rres, uint32_t zbin1, uint32_t &cur1,
+                                              const uint32_t *ctab /* the variable's compacted table */, int meff, const uint32_t *col_slot /* LDS: this lane's column */,
+                                              const uint32_t (&thr)[(M + 1) / 2], uint32_t bml, uint32_t bmh, uint32_t selbase, uint32_t Rres, uint32_t zbin1, uint32_t &cur1,
                                               uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
     const uint4 th = rng.block(EMGPU_SEC_TRANS, tvar, (uint32_t)g8);
     const uint4 rh = rng.block(EMGPU_SEC_RES, ivar, (uint32_t)g8);
@@ -185,10 +196,9 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
         }
     }
     if (redo) {
-        uint32_t tmp[M], out[6];
-#pragma unroll
-        for (int t = 0; t < M; t++) tmp[t] = thr[t];
-        eight_seconds_exact<M>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, tmp, bml, bmh, Rres, zbin1, cur1, out);
+        uint32_t out[6];
+        const uint32_t *thr_col = ctab + (size_t)(*col_slot) * (uint32_t)(meff + 1);
+        eight_seconds_exact<M>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, thr_col, meff, bml, bmh, Rres, zbin1, cur1, out);
         cur_out = out[0]; pbA = out[1]; pbB = out[2]; hit8 = out[3]; chg8 = out[4]; zer8 = out[5];
     }
     cur1 = cur_out;
@@ -240,7 +250,7 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
         cur1[k] = (uint32_t)pick<NI>(bin, P.d_ipos[k]) + 1u;
         cval[k] = (float)pick<NI>(val, P.d_ipos[k]);
     }
-    uint32_t th0[M0], th1[M1], th2[M2], bl0, bl1, bl2, bh0, bh1, bh2;
+    uint32_t th0[(M0 + 1) / 2], th1[(M1 + 1) / 2], th2[(M2 + 1) / 2], bl0, bl1, bl2, bh0, bh1, bh2;
     {
         uint32_t col[3];
 #pragma unroll
@@ -255,20 +265,24 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
         load_cthr<M0>(th0, bl0, bh0, P.cthr + P.d_coff[0] + (size_t)col[0] * (uint32_t)(P.d_meff[0] + 1), P.d_meff[0]);
         load_cthr<M1>(th1, bl1, bh1, P.cthr + P.d_coff[1] + (size_t)col[1] * (uint32_t)(P.d_meff[1] + 1), P.d_meff[1]);
         load_cthr<M2>(th2, bl2, bh2, P.cthr + P.d_coff[2] + (size_t)col[2] * (uint32_t)(P.d_meff[2] + 1), P.d_meff[2]);
+        // the exact pass finds its column again through the lane's spare LDS words
+#pragma unroll
+        for (int k = 0; k < 3; k++) reinterpret_cast<uint32_t *>(&W.res[lane * CoopLds<3, LB>::kStride + CoopLds<3, LB>::kSpare])[k] = col[k];
     }
     const uint32_t iv0 = P.d_ivar[0], iv1 = P.d_ivar[1], iv2 = P.d_ivar[2];
     const uint32_t ivs[3] = {iv0, iv1, iv2};
     uint32_t selbase; // kSelBase held in a VGPR (the first v_addc of every compare chain reads it)
     asm volatile("v_mov_b32 %0, %1" : "=v"(selbase) : "s"(kSelBase));
 
+    const uint32_t *col_slot = reinterpret_cast<const uint32_t *>(&W.res[lane * CoopLds<3, LB>::kStride + CoopLds<3, LB>::kSpare]);
     const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
     for (int g8 = 0; g8 < G8; g8++) {
         uint32_t pbA[3], pbB[3], need8[3], kind8[3], fill8[3];
         {
             uint32_t hit8[3], chg8[3], zer8[3];
-            eight_seconds<M0>(rng, P.d_tvar[0], iv0, g8, T, th0, bl0, bh0, selbase, F.Rk[0], (uint32_t)P.d_zero[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
-            eight_seconds<M1>(rng, P.d_tvar[1], iv1, g8, T, th1, bl1, bh1, selbase, F.Rk[1], (uint32_t)P.d_zero[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
-            eight_seconds<M2>(rng, P.d_tvar[2], iv2, g8, T, th2, bl2, bh2, selbase, F.Rk[2], (uint32_t)P.d_zero[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
+            eight_seconds<M0>(rng, P.d_tvar[0], iv0, g8, T, P.cthr + P.d_coff[0], P.d_meff[0], col_slot + 0, th0, bl0, bh0, selbase, F.Rk[0], (uint32_t)P.d_zero[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
+            eight_seconds<M1>(rng, P.d_tvar[1], iv1, g8, T, P.cthr + P.d_coff[1], P.d_meff[1], col_slot + 1, th1, bl1, bh1, selbase, F.Rk[1], (uint32_t)P.d_zero[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
+            eight_seconds<M2>(rng, P.d_tvar[2], iv2, g8, T, P.cthr + P.d_coff[2], P.d_meff[2], col_slot + 2, th2, bl2, bh2, selbase, F.Rk[2], (uint32_t)P.d_zero[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
 #pragma unroll
             for (int k = 0; k < 3; k++) {      // the streams stay MSB-first: bit (7-j) <-> second j
                 need8[k] = (hit8[k] | chg8[k]) & ~zer8[k];   // a dediscretize draw is due (dediscretize.m:24-39)
