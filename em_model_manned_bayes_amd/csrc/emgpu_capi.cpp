@@ -47,6 +47,7 @@ struct Uploaded {
     CompiledPlan cp;
     uint32_t *d_thr = nullptr;
     uint32_t *d_cthr = nullptr;
+    uint32_t *d_pthr = nullptr;
     double *d_bnd = nullptr;
 };
 } // namespace
@@ -329,7 +330,7 @@ int emgpu_ctx_sync(emgpu_ctx *ctx) {
 void emgpu_ctx_free(emgpu_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (auto &kv : ctx->cache) { (void)hipFree(kv.second.d_thr); (void)hipFree(kv.second.d_cthr); (void)hipFree(kv.second.d_bnd); }
+    for (auto &kv : ctx->cache) { (void)hipFree(kv.second.d_thr); (void)hipFree(kv.second.d_cthr); (void)hipFree(kv.second.d_pthr); (void)hipFree(kv.second.d_bnd); }
     (void)hipFree(ctx->d_status);
     (void)hipFree(ctx->d_layers);
     (void)hipFree(ctx->d_thr_base);
@@ -352,7 +353,7 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h) {
         std::sort(byuse.begin(), byuse.end());
         for (size_t q = 0; q < byuse.size() / 2; q++) {
             Uploaded &old = ctx->cache[byuse[q].second];
-            (void)hipFree(old.d_thr); (void)hipFree(old.d_cthr); (void)hipFree(old.d_bnd);
+            (void)hipFree(old.d_thr); (void)hipFree(old.d_cthr); (void)hipFree(old.d_pthr); (void)hipFree(old.d_bnd);
             ctx->cache.erase(byuse[q].second);
         }
     }
@@ -365,6 +366,7 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h) {
     if (u.d_thr) { HIP_OK(hipFree(u.d_thr)); u.d_thr = nullptr; }
     if (u.d_bnd) { HIP_OK(hipFree(u.d_bnd)); u.d_bnd = nullptr; }
     if (u.d_cthr) { HIP_OK(hipFree(u.d_cthr)); u.d_cthr = nullptr; }
+    if (u.d_pthr) { HIP_OK(hipFree(u.d_pthr)); u.d_pthr = nullptr; }
     const size_t nthr = cp.thr.size() ? cp.thr.size() : 1;
     HIP_OK(hipMalloc((void **)&u.d_thr, nthr * sizeof(uint32_t)));
     HIP_OK(hipMalloc((void **)&u.d_bnd, cp.bnd.size() * sizeof(double)));
@@ -376,6 +378,9 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h) {
     u.cp.plan.thr = u.d_thr;
     u.cp.plan.bnd = u.d_bnd;
     u.cp.plan.cthr = u.d_cthr;
+    HIP_OK(hipMalloc((void **)&u.d_pthr, (u.cp.pthr.size() ? u.cp.pthr.size() : 4) * sizeof(uint32_t)));
+    if (!u.cp.pthr.empty()) HIP_OK(hipMemcpy(u.d_pthr, u.cp.pthr.data(), u.cp.pthr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    u.cp.plan.pthr = u.d_pthr;
     u.version = h->m.version;
     return u;
 }
@@ -430,6 +435,7 @@ int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sa
     const char *name = "";
     hipError_t e;
     if (emgpu::fast_uncor_eligible(u.cp.plan, A)) e = emgpu::launch_uncor_fast(u.cp.plan, A, ctx->stream, &name);
+    else if (emgpu::step2_eligible(u.cp.plan, A)) e = emgpu::launch_dbn_step2(u.cp.plan, A, ctx->stream, &name);
     else if (emgpu::step_eligible(u.cp.plan, A)) e = emgpu::launch_dbn_step(u.cp.plan, A, ctx->stream, &name);
     else e = emgpu::launch_dbn_generic(u.cp.plan, A, ctx->stream, &name);
     ctx->last_kernel = name;

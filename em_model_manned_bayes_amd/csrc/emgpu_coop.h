@@ -19,8 +19,8 @@ constexpr int kQueueCap = 128; // request descriptors per wave and compaction ro
 template <int ND, bool LB = false>
 struct CoopLds {
     static constexpr int kBins = 8 * ND;                          // word offset of the published bins
-    static constexpr int kSpare = 8 * ND + (LB ? 2 * ND : 0);     // word offset of the lane's spare words (>= 4)
-    static constexpr int kStride = 8 * ND + (LB ? 2 * ND + 6 : 4); // words per lane; = 4 (mod 8) keeps the b128 reads conflict-free
+    static constexpr int kSpare = 8 * ND + (LB ? 2 * ND : 0);     // word offset of the lane's spare words (>= 3 of them)
+    static constexpr int kStride = ((kSpare + 3 + 3) / 8) * 8 + 4; // words per lane; = 4 (mod 8) keeps the b128 reads conflict-free
     static_assert(kStride % 8 == 4, "lane stride");
     uint32_t queue[kQueueCap];
     float res[64 * kStride];

@@ -1,0 +1,319 @@
+// emgpu_kernels_step2.hip -- the per-timestep DBN (dbn_sample.m:65-93: dependent-branch models such as
+// cor_v1 and the glider family, and EMGPU_TRANSITION_PER_STEP) with dense output, built like
+// k_uncor_fast: one lane = one trajectory, 8 seconds per loop iteration, carry-arithmetic compare
+// chains on the primary (high) halfwords, MSB-first flag streams, wave-cooperative dediscretize.
+//
+// What differs from the fast-branch kernel: a variable's CPT column changes every second with the
+// dynamic state (asub2ind.m:13-14 as strides over the current and the freshly drawn bins), so the
+// column -- padded to 4 or 8 words (EmgpuPlan::pthr: thresholds + byte map) -- is fetched per draw
+// with one or two 16-byte loads, from LDS when the tables fit (cor_v1: 14 KB) and from L1/L2
+// otherwise.  The secondary (low) halfword block of a variable is generated only at a second where
+// some lane of the wave met a tie between a draw's high halfword and a threshold's (p = 2^-16 per
+// compare); the draw is then redone with the full 32 bits, in place, because later seconds depend on it.
+// Bound: VALU issue (Philox + ~25 instructions per draw) and the dependent LDS round trips.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "emgpu_coop.h"
+#include "emgpu_device.h"
+#include "emgpu_launch.h"
+
+namespace emgpu {
+
+struct Step2Args {
+    uint32_t Rk[EMGPU_MAX_ND];   // resample hit threshold of dynamic variable k (0 = rate 0)
+    uint32_t slot[EMGPU_MAX_ND]; // output row of dynamic variable k
+};
+
+constexpr uint32_t kSelBase2 = 0x0c0c0c00u; // v_perm_b32 selector: bytes 1-3 zero, byte 0 <- table[borrows]
+
+// borrows of x_h - X_h over the thresholds of one padded column (SDWA reads the draw's halfword and the
+// thresholds' high halves in place); d[] receives the differences (0 <=> the low halfword decides).
+// Two wait states separate every VCC write from its read (the assembler does not look into asm blocks).
+#define EMGPU_S2_FIRST(SELX)                                                                                       \
+    asm("v_sub_co_u32_sdwa %0, vcc, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:WORD_1\n\t" \
+        "s_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %4, vcc"                                                              \
+        : "=&v"(d0), "=&v"(sel) : "v"(w), "v"(t0), "v"(selbase) : "vcc")
+#define EMGPU_S2_NEXT(SELX, D, TH)                                                                                 \
+    asm("v_sub_co_u32_sdwa %0, vcc, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:WORD_1\n\t" \
+        "s_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"                                                              \
+        : "=&v"(D), "+v"(sel) : "v"(w), "v"(TH) : "vcc")
+
+template <bool ODD>
+__device__ __forceinline__ uint32_t chain3(uint32_t w, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t selbase, uint32_t &dmin) {
+    uint32_t d0, d1, d2, sel;
+    if (ODD) { EMGPU_S2_FIRST("WORD_1"); EMGPU_S2_NEXT("WORD_1", d1, t1); EMGPU_S2_NEXT("WORD_1", d2, t2); }
+    else { EMGPU_S2_FIRST("WORD_0"); EMGPU_S2_NEXT("WORD_0", d1, t1); EMGPU_S2_NEXT("WORD_0", d2, t2); }
+    dmin = min(min(d0, d1), d2);
+    return sel;
+}
+template <bool ODD>
+__device__ __forceinline__ uint32_t chain6(uint32_t w, const uint4 &a, uint32_t t4, uint32_t t5, uint32_t selbase, uint32_t &dmin) {
+    uint32_t d0, d1, d2, d3, d4, d5, sel;
+    const uint32_t t0 = a.x;
+    if (ODD) {
+        EMGPU_S2_FIRST("WORD_1"); EMGPU_S2_NEXT("WORD_1", d1, a.y); EMGPU_S2_NEXT("WORD_1", d2, a.z);
+        EMGPU_S2_NEXT("WORD_1", d3, a.w); EMGPU_S2_NEXT("WORD_1", d4, t4); EMGPU_S2_NEXT("WORD_1", d5, t5);
+    } else {
+        EMGPU_S2_FIRST("WORD_0"); EMGPU_S2_NEXT("WORD_0", d1, a.y); EMGPU_S2_NEXT("WORD_0", d2, a.z);
+        EMGPU_S2_NEXT("WORD_0", d3, a.w); EMGPU_S2_NEXT("WORD_0", d4, t4); EMGPU_S2_NEXT("WORD_0", d5, t5);
+    }
+    dmin = min(min(min(d0, d1), d2), min(min(d3, d4), d5));
+    return sel;
+}
+#undef EMGPU_S2_FIRST
+#undef EMGPU_S2_NEXT
+
+// resample Bernoulli on the high halfword: hit8 = hit8 + hit8 + (x_h < R_h); returns x_h - R_h.
+// The leading s_nop keeps two wait states between a VALU that may just have written the SGPR
+// (v_readlane of a spilled register) and its read here.
+template <bool ODD>
+__device__ __forceinline__ uint32_t res_hit(uint32_t w, uint32_t R, uint32_t &hit8) {
+    uint32_t d;
+    if (ODD)
+        asm("s_nop 1\n\tv_subrev_co_u32_sdwa %0, vcc, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+            "s_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc" : "=&v"(d), "+v"(hit8) : "v"(w), "s"(R) : "vcc");
+    else
+        asm("s_nop 1\n\tv_subrev_co_u32_sdwa %0, vcc, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
+            "s_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc" : "=&v"(d), "+v"(hit8) : "v"(w), "s"(R) : "vcc");
+    return d;
+}
+
+// The rare exact redo of one draw, out of line so that the 32 copies of the hot per-second body stay small:
+// the secondary block is generated and the compare repeated on the full 32-bit draw (select_random.m:19-20).
+__device__ __attribute__((noinline)) uint32_t exact_borrows(uint32_t c0, uint32_t c1, uint32_t attempt, uint32_t k0, uint32_t k1,
+                                                            uint32_t hi_word, uint32_t tvar, uint32_t g8, uint32_t j,
+                                                            uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t t4, uint32_t t5) {
+    const Rng rng{c0, c1, attempt, k0, k1};
+    const uint4 tl = rng.block(EMGPU_SEC_TRANS_LO, tvar, g8);
+    const uint32_t q = j >> 1;
+    const uint32_t wl = q == 0 ? tl.x : (q == 1 ? tl.y : (q == 2 ? tl.z : tl.w));
+    const uint32_t hi = (j & 1u) ? (hi_word & 0xFFFF0000u) : (hi_word << 16), lo = (j & 1u) ? (wl >> 16) : (wl & 0xFFFFu);
+    const uint32_t x = clamp32(hi | lo);
+    return (x < t0 ? 1u : 0u) + (x < t1 ? 1u : 0u) + (x < t2 ? 1u : 0u) + (x < t3 ? 1u : 0u) + (x < t4 ? 1u : 0u) + (x < t5 ? 1u : 0u);
+}
+__device__ __attribute__((noinline)) uint32_t exact_hit(uint32_t c0, uint32_t c1, uint32_t attempt, uint32_t k0, uint32_t k1,
+                                                        uint32_t hi_word, uint32_t ivar, uint32_t g8, uint32_t j, uint32_t R) {
+    const Rng rng{c0, c1, attempt, k0, k1};
+    const uint4 rl = rng.block(EMGPU_SEC_RES_LO, ivar, g8);
+    const uint32_t q = j >> 1;
+    const uint32_t wl = q == 0 ? rl.x : (q == 1 ? rl.y : (q == 2 ? rl.z : rl.w));
+    const uint32_t hi = (j & 1u) ? (hi_word & 0xFFFF0000u) : (hi_word << 16), lo = (j & 1u) ? (wl >> 16) : (wl & 0xFFFFu);
+    return clamp32(hi | lo) < R ? 1u : 0u;                                                  // resample_events.m:24
+}
+
+// LDS_T: the padded tables of the dynamic variables are staged in (dynamic) LDS by the workgroup.
+template <int NI, int ND, bool LDS_T>
+__global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];
+    __shared__ CoopLds<ND, true> s_wave[4];
+    __shared__ double s_bnd[ND][16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    CoopLds<ND, true> &W = s_wave[tid >> 6];
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    const bool valid = i < A.n; // lanes past the end stay alive: they serve as workers for their wave
+    const uint64_t gidx = A.first_index + (uint64_t)i;
+    Rng rng{(uint32_t)gidx, (uint32_t)(gidx >> 32), 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
+    const int T = A.T;
+#pragma unroll
+    for (int k = 0; k < ND; k++) // k stays a compile-time index into the plan (a per-lane index would force the kernarg struct into scratch)
+        if ((tid >> 4) == k) {
+            const int q = tid & 15;
+            s_bnd[k][q] = (k < P.nd && q < (int)P.d_nb[k]) ? P.bnd[P.d_boff[k] + q] : 0.0;
+        }
+
+    uint32_t cur1[ND], basecol[ND];
+    float cval[ND];
+    {
+        int bin[NI];
+        double val[NI];
+#pragma unroll
+        for (int p = 0; p < NI; p++) { bin[p] = 0; val[p] = 0.0; }
+        const int32_t attempts_used = init_network<NI>(P, A, rng, bin, val);
+        if (valid) {
+            if (attempts_used < 0) atomicOr(A.status, 1u);
+            if (A.attempts) A.attempts[i] = attempts_used;
+#pragma unroll
+            for (int p = 0; p < NI; p++) {
+                if (p < P.ni) {
+                    if (A.init_bin) A.init_bin[(size_t)P.i_var[p] * A.n + i] = (uint8_t)(bin[p] + 1);
+                    if (A.init_val) A.init_val[(size_t)P.i_var[p] * A.n + i] = (float)val[p];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ND; k++) {
+            cur1[k] = 1u; cval[k] = 0.f; basecol[k] = 0u;
+            if (k < P.nd) {
+                cur1[k] = (uint32_t)pick<NI>(bin, P.d_ipos[k]) + 1u;
+                cval[k] = (float)pick<NI>(val, P.d_ipos[k]);
+                uint32_t b = 0;
+#pragma unroll
+                for (int p = 0; p < NI; p++) b += P.d_stride_static[k][p] * (uint32_t)bin[p];
+                // the dynamic parents are added as stride * (1-based bin): take the "-1"s out here
+#pragma unroll
+                for (int q = 0; q < ND; q++) b -= P.d_stride_cur[k][q] + P.d_stride_new[k][q];
+                basecol[k] = b;
+            }
+        }
+    }
+    W.attempt[lane] = rng.attempt;
+    if (LDS_T)
+        for (uint32_t q = (uint32_t)tid; q < P.pthr_total; q += 256u) s_tab[q] = P.pthr[q];
+    __syncthreads();
+    // one 16-byte group of a padded column, from LDS or through L1/L2 (kept in their own address spaces)
+    const uint32_t *__restrict__ gtab = P.pthr;
+#define load4(word_off) (LDS_T ? *reinterpret_cast<const uint4 *>(s_tab + (word_off)) : *reinterpret_cast<const uint4 *>(gtab + (word_off)))
+    uint32_t ivs[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++) ivs[k] = P.d_ivar[k];
+    uint32_t selbase; // kSelBase2 held in a VGPR (the first v_addc of every compare chain reads it)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(selbase) : "s"(kSelBase2));
+
+    const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
+    for (int g8 = 0; g8 < G8; g8++) {
+        uint4 th[ND], rh[ND];
+#pragma unroll
+        for (int k = 0; k < ND; k++) {
+            th[k] = rh[k] = make_uint4(0, 0, 0, 0);
+            if (k < P.nd) {
+                th[k] = rng.block(EMGPU_SEC_TRANS, P.d_tvar[k], (uint32_t)g8);
+                if (F.Rk[k] != 0u) rh[k] = rng.block(EMGPU_SEC_RES, P.d_ivar[k], (uint32_t)g8);
+            }
+        }
+        uint32_t pbA[ND], pbB[ND], hit8[ND], chg8[ND], zer8[ND]; // flag streams MSB-first: bit 7-j <-> second j
+#pragma unroll
+        for (int k = 0; k < ND; k++) pbA[k] = pbB[k] = hit8[k] = chg8[k] = zer8[k] = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = 8 * g8 + j; // absolute event time == column produced
+            if (c >= 1 && c < T) {    // wave-uniform
+                uint32_t nb1[ND];
+#pragma unroll
+                for (int k = 0; k < ND; k++) {
+                    nb1[k] = 1u;
+                    if (k >= P.nd) continue;
+                    // ---- resample_events.m:24
+                    if (F.Rk[k] != 0u) {
+                        const uint32_t wr = word_of(rh[k], j >> 1);
+                        const uint32_t dr = (j & 1) ? res_hit<true>(wr, F.Rk[k], hit8[k]) : res_hit<false>(wr, F.Rk[k], hit8[k]);
+                        if (__ballot(dr == 0u) != 0ull) { // the low halfword decides in some lane: redo with 32 bits
+                            hit8[k] = (hit8[k] & ~1u) | exact_hit(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, wr, P.d_ivar[k], (uint32_t)g8, (uint32_t)j, F.Rk[k]);
+                        }
+                    } else {
+                        hit8[k] += hit8[k];
+                    }
+                    // ---- the column of this second: asub2ind.m:13-14 over the current and the new bins
+                    uint32_t col = basecol[k];
+#pragma unroll
+                    for (int q = 0; q < ND; q++)
+                        if (q < P.nd && P.d_stride_cur[k][q] != 0u) col = __umul24(P.d_stride_cur[k][q], cur1[q]) + col;
+#pragma unroll
+                    for (int q = 0; q < k; q++)
+                        if (P.d_stride_new[k][q] != 0u) col = __umul24(P.d_stride_new[k][q], nb1[q]) + col;
+                    const uint32_t wt = word_of(th[k], j >> 1);
+                    uint32_t sel, dmin, bml, bmh = 0u;
+                    if (P.d_pw[k] == 4) { // wave-uniform
+                        const uint4 a = load4(P.d_poff[k] + col * 4u);
+                        sel = (j & 1) ? chain3<true>(wt, a.x, a.y, a.z, selbase, dmin) : chain3<false>(wt, a.x, a.y, a.z, selbase, dmin);
+                        bml = a.w;
+                        if (__ballot(dmin == 0u) != 0ull) {
+                            sel = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, wt, P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
+                                                            a.x, a.y, a.z, 0u, 0u, 0u);
+                        }
+                    } else {
+                        const uint4 a = load4(P.d_poff[k] + col * 8u), b = load4(P.d_poff[k] + col * 8u + 4u);
+                        sel = (j & 1) ? chain6<true>(wt, a, b.x, b.y, selbase, dmin) : chain6<false>(wt, a, b.x, b.y, selbase, dmin);
+                        bml = b.z; bmh = b.w;
+                        if (__ballot(dmin == 0u) != 0ull) {
+                            sel = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, wt, P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
+                                                            a.x, a.y, a.z, a.w, b.x, b.y);
+                        }
+                    }
+                    nb1[k] = __builtin_amdgcn_perm(bmh, bml, sel);                                  // dbn_sample.m:77
+                }
+#pragma unroll
+                for (int k = 0; k < ND; k++) {
+                    if (k >= P.nd) continue;
+                    asm("v_cmp_ne_u32 vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                        "v_cmp_eq_u32 vcc, %4, %2\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                        : "+v"(chg8[k]), "+v"(zer8[k]) : "v"(nb1[k]), "v"(cur1[k]), "s"((uint32_t)P.d_zero[k]) : "vcc");
+                    cur1[k] = nb1[k];                                                               // map back, dbn_sample.m:82
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < ND; k++) { hit8[k] += hit8[k]; chg8[k] += chg8[k]; zer8[k] += zer8[k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < ND; k++) {
+                const uint32_t b = (c < T) ? (cur1[k] << (8 * (j & 3))) : 0u;
+                if (j < 4) pbA[k] |= b; else pbB[k] |= b;
+            }
+        }
+        uint32_t need = 0u, kind = 0u, fill8[ND];
+#pragma unroll
+        for (int k = 0; k < ND; k++) {
+            const uint32_t n8 = (k < P.nd) ? ((hit8[k] | chg8[k]) & ~zer8[k] & 0xFFu) : 0u; // a dediscretize draw is due
+            fill8[k] = n8 | (chg8[k] & 0xFFu);                                              // ... or 0 on a change into the zero bin
+            need |= n8 << (8 * k);
+            kind |= (chg8[k] & 0xFFu) << (8 * k);
+        }
+        if (!valid) need = 0u;
+        coop_zero_results<ND, true>(W, lane);
+        coop_publish_bins<ND>(W, lane, pbA, pbB);
+        coop_dedisc<ND, true, true>(W, lane, gidx, rng, g8, need, kind, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
+#pragma unroll
+        for (int k = 0; k < ND; k++)
+            if (k < P.nd)
+                coop_fill_store_msb<ND, true>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
+                                              (uint32_t)P.nd, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.n, A.dyn_bin, A.dyn_val);
+        wave_sync();
+    }
+}
+
+#undef load4
+
+bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
+    static const bool off = getenv("EMGPU_DEBUG_NO_STEP2") != nullptr;
+    if (off) return false;
+    if (P.nd < 1 || P.nd > 4) return false;
+    if (!(P.depend || A.per_step)) return false;
+    if (A.ev_count != nullptr || A.events != nullptr) return false;
+    if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
+    for (int k = 0; k < P.nd; k++) {
+        if (P.d_nb[k] == 0 || P.d_nb[k] > 16 || P.d_pw[k] == 0) return false;
+        for (int q = 0; q < P.nd; q++)
+            if (P.d_stride_cur[k][q] >= (1u << 24) || P.d_stride_new[k][q] >= (1u << 24)) return false; // 24-bit multiplies
+        for (int a = 0; a < P.nact; a++)
+            if (P.a_dyn[a] == k && P.a_R[a] == 0xFFFFFFFFu) return false;
+    }
+    return true;
+}
+
+template <int NI, int ND>
+static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args &F, hipStream_t s, bool lds) {
+    const int64_t blocks = (A.n + 255) / 256;
+    if (lds) hipLaunchKernelGGL((k_dbn_step2<NI, ND, true>), dim3((unsigned)blocks), dim3(256), (size_t)P.pthr_total * sizeof(uint32_t), s, P, A, F);
+    else hipLaunchKernelGGL((k_dbn_step2<NI, ND, false>), dim3((unsigned)blocks), dim3(256), 0, s, P, A, F);
+    return hipGetLastError();
+}
+
+hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
+    if (A.n <= 0) return hipSuccess;
+    Step2Args F{};
+    for (int k = 0; k < P.nd; k++) {
+        F.slot[k] = P.d_row[k];
+        for (int a = 0; a < P.nact; a++)
+            if (P.a_dyn[a] == k) F.Rk[k] = P.a_R[a];
+    }
+    // stage the tables in LDS when two workgroups per CU still fit beside the cooperative areas
+    static const bool no_lds = getenv("EMGPU_DEBUG_STEP_NO_LDS") != nullptr;
+    const bool lds = !no_lds && (size_t)P.pthr_total * sizeof(uint32_t) <= 24576;
+    if (P.ni <= 7 && P.nd <= 3) { *name = lds ? "k_dbn_step2<7,3,lds>" : "k_dbn_step2<7,3>"; return launch_t<7, 3>(P, A, F, s, lds); }
+    if (P.ni <= 9 && P.nd <= 3) { *name = lds ? "k_dbn_step2<9,3,lds>" : "k_dbn_step2<9,3>"; return launch_t<9, 3>(P, A, F, s, lds); }
+    *name = lds ? "k_dbn_step2<16,4,lds>" : "k_dbn_step2<16,4>";
+    return launch_t<16, 4>(P, A, F, s, lds);
+}
+
+} // namespace emgpu

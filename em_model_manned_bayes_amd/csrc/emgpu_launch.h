@@ -13,6 +13,8 @@ hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t 
 // The per-timestep DBN with dense output (dependent-branch models, EMGPU_TRANSITION_PER_STEP).
 bool step_eligible(const EmgpuPlan &P, const EmgpuRun &A);
 hipError_t launch_dbn_step(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
+bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A);
+hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
 hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, hipStream_t s, const char **name);
 hipError_t launch_sample2track(const EmgpuTrackRun &A, bool dense, hipStream_t s, const char **name);
 } // namespace emgpu

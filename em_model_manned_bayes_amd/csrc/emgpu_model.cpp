@@ -502,6 +502,30 @@ CompiledPlan compile_plan(const Model &m) {
                 for (int t = d; t < meff; t++) { c[t] = 0xFFFFFFFFu; map |= (uint32_t)bin << (4 * (t + 1)); }
                 c[meff] = map;
             }
+            // the padded form (EmgpuPlan::d_pw)
+            const int mfix = meff <= 3 ? 3 : (meff <= 6 ? 6 : 0);
+            P.d_pw[k] = 0;
+            if (mfix) {
+                const int W = mfix == 3 ? 4 : 8;
+                P.d_pw[k] = (uint8_t)W;
+                P.d_poff[k] = (uint32_t)cp.pthr.size();
+                cp.pthr.resize(cp.pthr.size() + (size_t)q * W);
+                C = cp.cthr.data() + P.d_coff[k]; // (resize above may not move cthr, but stay safe)
+                uint32_t *Pd = cp.pthr.data() + P.d_poff[k];
+                for (int64_t j = 0; j < q; j++) {
+                    const uint32_t *c = C + (size_t)j * (meff + 1);
+                    uint32_t *o = Pd + (size_t)j * W;
+                    for (int t = 0; t < mfix; t++) o[t] = t < meff ? c[t] : 0xFFFFFFFFu;
+                    uint32_t lo = 0u, hi = 0u;
+                    for (int b = 0; b <= mfix; b++) {
+                        const int n = mfix - b, nn = n < meff ? n : meff;
+                        const uint32_t e = (c[meff] >> (4 * nn)) & 15u;
+                        if (b < 4) lo |= e << (8 * b); else hi |= e << (8 * (b - 4));
+                    }
+                    o[mfix] = lo;
+                    if (W == 8) o[7] = hi;
+                }
+            }
         }
     }
     // resample_events.m:24
@@ -517,6 +541,7 @@ CompiledPlan compile_plan(const Model &m) {
     P.nact = na;
     P.thr_total = (uint32_t)cp.thr.size();
     P.cthr_total = (uint32_t)cp.cthr.size();
+    P.pthr_total = (uint32_t)cp.pthr.size();
     return cp;
 }
 

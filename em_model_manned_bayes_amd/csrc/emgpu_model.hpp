@@ -60,6 +60,7 @@ struct CompiledPlan {
     EmgpuPlan plan{};             // thr / bnd pointers are filled at upload time
     std::vector<uint32_t> thr;
     std::vector<uint32_t> cthr;   // compacted tables of the dynamic variables
+    std::vector<uint32_t> pthr;   // ... padded to 4 / 8 words per column (EmgpuPlan::d_pw)
     std::vector<double> bnd;
     std::vector<int> pos_of_var;  // variable id (0-based) -> topological position
 };

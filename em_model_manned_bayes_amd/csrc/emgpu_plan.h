@@ -76,6 +76,15 @@ struct EmgpuPlan {
     uint8_t d_meff[EMGPU_MAX_ND];
     uint32_t d_coff[EMGPU_MAX_ND];
     const uint32_t *cthr;
+    // ---- the same columns padded to a power of two for the per-timestep kernel (one or two 16-byte
+    // loads per draw): d_pw[k] = 4 words {t0, t1, t2, map} (d_meff <= 3) or 8 words {t0..t5, map_lo,
+    // map_hi} (d_meff <= 6); unused thresholds are "never"; the map is a BYTE table indexed by the
+    // number of thresholds that did NOT fire (b = 3 or 6 minus the fired count) -> 1-based bin, ready
+    // for v_perm_b32.  d_pw[k] == 0 => no padded table for this variable.
+    uint8_t d_pw[EMGPU_MAX_ND];
+    uint32_t d_poff[EMGPU_MAX_ND];
+    uint32_t pthr_total, _pad1;
+    const uint32_t *pthr;
     // ---- device tables
     const uint32_t *thr; // quantile thresholds, node after node, column after column, r-1 each
     const double *bnd;   // boundaries
