@@ -6,8 +6,7 @@
 // What differs from the fast-branch kernel: a variable's CPT column changes every second with the
 // dynamic state (asub2ind.m:13-14 as strides over the current and the freshly drawn bins), so the
 // column -- padded to 4 or 8 words (EmgpuPlan::pthr: thresholds + byte map) -- is fetched per draw
-// with one or two 16-byte loads, from LDS when the tables fit (cor_v1: 14 KB) and from L1/L2
-// otherwise.  The secondary (low) halfword block of a variable is generated only at a second where
+// with one or two 16-byte loads through L1/L2 (the tables are small: cor_v1 14 KB).  The secondary (low) halfword block of a variable is generated only at a second where
 // some lane of the wave met a tie between a draw's high halfword and a threshold's (p = 2^-16 per
 // compare); the draw is then redone with the full 32 bits, in place, because later seconds depend on it.
 // Bound: VALU issue (Philox + ~25 instructions per draw) and the dependent LDS round trips.
@@ -307,9 +306,13 @@ hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s
         for (int a = 0; a < P.nact; a++)
             if (P.a_dyn[a] == k) F.Rk[k] = P.a_R[a];
     }
-    // stage the tables in LDS when two workgroups per CU still fit beside the cooperative areas
-    static const bool no_lds = getenv("EMGPU_DEBUG_STEP_NO_LDS") != nullptr;
-    const bool lds = !no_lds && (size_t)P.pthr_total * sizeof(uint32_t) <= 24576;
+    // Staging the tables in LDS is kept for experiments only: random 16-byte gathers from LDS pay bank
+    // conflicts and the extra LDS costs a workgroup of occupancy (cor_v1: 36.9 ms staged, 28.9 ms
+    // through L1/L2), so the columns are gathered from global memory.  Fetching the columns of one
+    // dependency level together was also measured (cor_v1: 53 ms): the extra registers cost more
+    // occupancy than the overlapped round trips give back.
+    static const bool want_lds = getenv("EMGPU_DEBUG_STEP_LDS") != nullptr;
+    const bool lds = want_lds && (size_t)P.pthr_total * sizeof(uint32_t) <= 24576;
     if (P.ni <= 7 && P.nd <= 3) { *name = lds ? "k_dbn_step2<7,3,lds>" : "k_dbn_step2<7,3>"; return launch_t<7, 3>(P, A, F, s, lds); }
     if (P.ni <= 9 && P.nd <= 3) { *name = lds ? "k_dbn_step2<9,3,lds>" : "k_dbn_step2<9,3>"; return launch_t<9, 3>(P, A, F, s, lds); }
     *name = lds ? "k_dbn_step2<16,4,lds>" : "k_dbn_step2<16,4>";
