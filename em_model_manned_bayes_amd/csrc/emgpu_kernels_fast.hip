@@ -218,10 +218,12 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
     const uint64_t gidx = A.first_index + (uint64_t)i;
     Rng rng{(uint32_t)gidx, (uint32_t)(gidx >> 32), 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
     const int T = A.T;
-    if (tid < 48) {
-        const int k = tid >> 4, q = tid & 15;
-        s_bnd[k][q] = (q < (int)P.d_nb[k]) ? P.bnd[P.d_boff[k] + q] : 0.0;
-    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) // k stays a compile-time index into the plan (a per-lane index would force it into scratch)
+        if ((tid >> 4) == k) {
+            const int q = tid & 15;
+            s_bnd[k][q] = (q < (int)P.d_nb[k]) ? P.bnd[P.d_boff[k] + q] : 0.0;
+        }
 
     int bin[NI];
     double val[NI];
