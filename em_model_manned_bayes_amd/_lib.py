@@ -95,7 +95,7 @@ SYMBOLS = [
     "emgpu_ctx_create", "emgpu_ctx_set_stream", "emgpu_ctx_sync", "emgpu_ctx_free",
     "emgpu_sample_dbn_device", "emgpu_sample_dbn_host", "emgpu_sample_bn_device", "emgpu_sample_bn_host",
     "emgpu_last_kernel_name", "emgpu_discretize_bayes", "emgpu_asub2ind",
-    "emgpu_debug_column_thresholds", "emgpu_debug_bernoulli_threshold", "emgpu_debug_dynamic_column",
+    "emgpu_debug_column_thresholds", "emgpu_debug_bernoulli_threshold", "emgpu_debug_dynamic_column", "emgpu_debug_padded_column",
     "emgpu_propagate_terminal_device", "emgpu_propagate_terminal_host",
     "emgpu_sample2track_device", "emgpu_sample2track_host",
 ]
@@ -149,6 +149,7 @@ def lib():
     L.emgpu_debug_column_thresholds.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.emgpu_debug_bernoulli_threshold.argtypes = [C.c_double]
     L.emgpu_debug_dynamic_column.argtypes = [C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 7
+    L.emgpu_debug_padded_column.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
     L.emgpu_debug_bernoulli_threshold.restype = C.c_uint32
     for f in (L.emgpu_propagate_terminal_device, L.emgpu_propagate_terminal_host):
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(TermParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -590,6 +590,19 @@ int emgpu_debug_dynamic_column(const emgpu_model *m, int32_t k, int64_t col, int
     EMGPU_CATCH
 }
 
+int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int32_t *width, uint32_t *words) {
+    EMGPU_TRY
+    if (!m || !width || !words) return fail(EMGPU_ERR_ARG, "null argument");
+    const emgpu::CompiledPlan cp = emgpu::compile_plan(m->m);
+    const EmgpuPlan &P = cp.plan;
+    if (k < 0 || k >= P.nd) return fail(EMGPU_ERR_ARG, "no such dynamic variable");
+    if (col < 0 || col >= m->m.q_transition[P.d_tvar[k]]) return fail(EMGPU_ERR_ARG, "no such column");
+    *width = (int32_t)P.d_pw[k];
+    for (int t = 0; t < *width; t++) words[t] = cp.pthr[P.d_poff[k] + (size_t)col * (size_t)*width + t];
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
 int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
                                     const emgpu_term_params *p, const double *geo, const int32_t *model_of,
                                     float *out, int32_t *rows) {

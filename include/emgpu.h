@@ -273,6 +273,10 @@ uint32_t emgpu_debug_bernoulli_threshold(double rate);
  * k counts the temporal_map rows in plan order; *tvar receives the 1-based transition variable. */
 int emgpu_debug_dynamic_column(const emgpu_model *m, int32_t k, int64_t col, int32_t *tvar, int32_t *r, int64_t *q,
                                uint32_t *thr, int32_t *meff, uint32_t *cthr, uint32_t *map);
+/* The same column in the padded form the per-timestep kernel loads: *width = 4 words {t0, t1, t2, map} or
+ * 8 words {t0..t5, map_lo, map_hi} (0: the variable has no padded table); unused thresholds are 2^32-1;
+ * the map is a byte table: entry b = 1-based bin when b of the 3 (6) thresholds did NOT fire. */
+int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int32_t *width, uint32_t *words);
 
 /* Host helpers that mirror small reference functions (used by the class layer and tests). */
 int32_t emgpu_discretize_bayes(double x, const double *thresholds, int32_t n); /* discretize_bayes.m:14-22 */

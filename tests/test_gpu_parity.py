@@ -60,6 +60,7 @@ import em_model_manned_bayes_amd as E
 from em_model_manned_bayes_amd import em_io
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _unpack_events(cnt, flat):
@@ -576,3 +577,29 @@ def test_em_sample_and_sample2track_files(gpu_ctx, model_dir, tmp_path):
     assert np.max(np.abs(csv[:, 1:] - rx[i])) <= 0.5 + 1e-6           # %0.0f
     # a track that starts below the speed range is rejected and writes nothing
     assert not glob.glob(os.path.join(out, "**", "*_id%d_*" % (int(np.nonzero(~is_good)[0][0]) + 1 if (~is_good).any() else 0)), recursive=True)
+
+
+def test_fallback_per_step_kernel_still_matches_oracle(model_dir):
+    """k_dbn_step (columns of any width up to 9 bins) is the fallback of k_dbn_step2; the dispatch is decided
+    once per process, so the fallback is exercised in a child process with EMGPU_DEBUG_NO_STEP2 set."""
+    import subprocess, sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle as O
+from em_model_manned_bayes_amd import native
+from util import load_pair, uncor_indices, assert_uncor_parity
+ctx = native.Context(0)
+for name, T, n in [("glider_v1", 61, 600), ("cor_v1", 24, 300)]:
+    nm, pp, _ = load_pair(name, %r)
+    idx = uncor_indices(pp) if name != "cor_v1" else {}
+    got = native.sample_dbn_host(ctx, nm, n, T, 11, want_dense=True, want_events=False, **idx)
+    assert got["kernel"].startswith("k_dbn_step<"), got["kernel"]
+    om = O.OracleModel(pp)
+    ref = O.uncor_sample(om, n, T, 11, want_events=False)
+    assert_uncor_parity(got, ref, T, check_events=False)
+print("fallback ok")
+''' % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"), os.path.join(ROOT_DIR, "oracle"), str(model_dir))
+    env = dict(os.environ, EMGPU_DEBUG_NO_STEP2="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr

@@ -220,12 +220,21 @@ def test_compacted_columns_select_the_same_bin(name, model_dir):
             for x in t:
                 xs |= {int(x), max(int(x) - 1, 0), min(int(x) + 1, 2**32 - 1)}
             w = np.ascontiguousarray(N[:, col], dtype=np.float64)   # all-zero columns: select_random.m:17-20 gives bin 1
+            width = C.c_int32()
+            pw = np.zeros(8, dtype=np.uint32)
+            assert lib.emgpu_debug_padded_column(h, k, col, C.byref(width), pw.ctypes.data) == 0
+            assert width.value == (4 if meff.value <= 3 else 8 if meff.value <= 6 else 0)
+            mfix = {4: 3, 8: 6, 0: 0}[width.value]
+            pt = pw[:mfix].astype(np.uint64)
+            table = [int(b) for b in pw[mfix: mfix + (1 if mfix == 3 else 2)].view(np.uint8)] if mfix else []
             for x in xs:
                 xp = min(x, 2**32 - 2)
                 full = 1 + int(np.sum(xp >= t))
                 n = int(np.sum(xp >= ct))
                 assert (mp.value >> (4 * n)) & 15 == full, (name, k, col, x)
                 assert full == _oracle_bin(w, u32(x)), (name, k, col, x)
+                if mfix:                                  # EmgpuPlan::pthr: byte table indexed by the thresholds that did not fire
+                    assert table[int(np.sum(xp < pt))] == full, (name, k, col, x)
         seen_meff.append(meff.value)
     if name == "uncor_1200code_v2p1":
         assert seen_meff == [2, 4, 2]                    # what k_uncor_fast<7,2,4,2> is built for
