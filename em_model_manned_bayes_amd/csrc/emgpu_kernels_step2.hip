@@ -102,10 +102,11 @@ __device__ __attribute__((noinline)) uint32_t exact_hit(uint32_t c0, uint32_t c1
     return clamp32(hi | lo) < R ? 1u : 0u;                                                  // resample_events.m:24
 }
 
-// LDS_T: the padded tables of the dynamic variables are staged in (dynamic) LDS by the workgroup.
-template <int NI, int ND, bool LDS_T>
+// WMODE: 4 / 8 = every variable's columns are 4 / 8 words wide, 0 = decided per variable at run time.
+// REG ("regular"): exactly ND dynamic variables, all with a resample rate > 0.  The specialised
+// instances drop the wave-uniform tests and the code behind them (cor_v1: 25.2 -> 20.8 ms).
+template <int NI, int ND, int WMODE, bool REG>
 __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];
     __shared__ CoopLds<ND, true> s_wave[4];
     __shared__ double s_bnd[ND][16];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -158,12 +159,10 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const E
         }
     }
     W.attempt[lane] = rng.attempt;
-    if (LDS_T)
-        for (uint32_t q = (uint32_t)tid; q < P.pthr_total; q += 256u) s_tab[q] = P.pthr[q];
     __syncthreads();
-    // one 16-byte group of a padded column, from LDS or through L1/L2 (kept in their own address spaces)
+    // one 16-byte group of a padded column, gathered through L1/L2 (the tables are small)
     const uint32_t *__restrict__ gtab = P.pthr;
-#define load4(word_off) (LDS_T ? *reinterpret_cast<const uint4 *>(s_tab + (word_off)) : *reinterpret_cast<const uint4 *>(gtab + (word_off)))
+#define load4(word_off) (*reinterpret_cast<const uint4 *>(gtab + (word_off)))
     uint32_t ivs[ND];
 #pragma unroll
     for (int k = 0; k < ND; k++) ivs[k] = P.d_ivar[k];
@@ -192,9 +191,9 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const E
 #pragma unroll
                 for (int k = 0; k < ND; k++) {
                     nb1[k] = 1u;
-                    if (k >= P.nd) continue;
+                    if (!REG && k >= P.nd) continue;
                     // ---- resample_events.m:24
-                    if (F.Rk[k] != 0u) {
+                    if (REG || F.Rk[k] != 0u) {
                         const uint32_t wr = word_of(rh[k], j >> 1);
                         const uint32_t dr = (j & 1) ? res_hit<true>(wr, F.Rk[k], hit8[k]) : res_hit<false>(wr, F.Rk[k], hit8[k]);
                         if (__ballot(dr == 0u) != 0ull) { // the low halfword decides in some lane: redo with 32 bits
@@ -205,15 +204,14 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const E
                     }
                     // ---- the column of this second: asub2ind.m:13-14 over the current and the new bins
                     uint32_t col = basecol[k];
+                    // (a stride of 0 = not a parent; testing for it would keep 2 SGPRs per pair alive and spill)
 #pragma unroll
-                    for (int q = 0; q < ND; q++)
-                        if (q < P.nd && P.d_stride_cur[k][q] != 0u) col = __umul24(P.d_stride_cur[k][q], cur1[q]) + col;
+                    for (int q = 0; q < ND; q++) col = __umul24(P.d_stride_cur[k][q], cur1[q]) + col;
 #pragma unroll
-                    for (int q = 0; q < k; q++)
-                        if (P.d_stride_new[k][q] != 0u) col = __umul24(P.d_stride_new[k][q], nb1[q]) + col;
+                    for (int q = 0; q < k; q++) col = __umul24(P.d_stride_new[k][q], nb1[q]) + col;
                     const uint32_t wt = word_of(th[k], j >> 1);
                     uint32_t sel, dmin, bml, bmh = 0u;
-                    if (P.d_pw[k] == 4) { // wave-uniform
+                    if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) { // wave-uniform
                         const uint4 a = load4(P.d_poff[k] + col * 4u);
                         sel = (j & 1) ? chain3<true>(wt, a.x, a.y, a.z, selbase, dmin) : chain3<false>(wt, a.x, a.y, a.z, selbase, dmin);
                         bml = a.w;
@@ -234,7 +232,7 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const E
                 }
 #pragma unroll
                 for (int k = 0; k < ND; k++) {
-                    if (k >= P.nd) continue;
+                    if (!REG && k >= P.nd) continue;
                     asm("v_cmp_ne_u32 vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
                         "v_cmp_eq_u32 vcc, %4, %2\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
                         : "+v"(chg8[k]), "+v"(zer8[k]) : "v"(nb1[k]), "v"(cur1[k]), "s"((uint32_t)P.d_zero[k]) : "vcc");
@@ -291,32 +289,41 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
 }
 
 template <int NI, int ND>
-static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args &F, hipStream_t s, bool lds) {
-    const int64_t blocks = (A.n + 255) / 256;
-    if (lds) hipLaunchKernelGGL((k_dbn_step2<NI, ND, true>), dim3((unsigned)blocks), dim3(256), (size_t)P.pthr_total * sizeof(uint32_t), s, P, A, F);
-    else hipLaunchKernelGGL((k_dbn_step2<NI, ND, false>), dim3((unsigned)blocks), dim3(256), 0, s, P, A, F);
+static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args &F, hipStream_t s, int wmode, bool reg) {
+    const dim3 g((unsigned)((A.n + 255) / 256)), b(256);
+    if (reg && wmode == 4) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 4, true>), g, b, 0, s, P, A, F);
+    else if (reg && wmode == 8) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 8, true>), g, b, 0, s, P, A, F);
+    else if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true>), g, b, 0, s, P, A, F);
+    else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false>), g, b, 0, s, P, A, F);
     return hipGetLastError();
 }
 
 hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
     if (A.n <= 0) return hipSuccess;
     Step2Args F{};
+    bool all_res = true;
+    int wmode = P.d_pw[0];
     for (int k = 0; k < P.nd; k++) {
         F.slot[k] = P.d_row[k];
         for (int a = 0; a < P.nact; a++)
             if (P.a_dyn[a] == k) F.Rk[k] = P.a_R[a];
+        all_res = all_res && F.Rk[k] != 0u;
+        if (P.d_pw[k] != wmode) wmode = 0;
     }
-    // Staging the tables in LDS is kept for experiments only: random 16-byte gathers from LDS pay bank
-    // conflicts and the extra LDS costs a workgroup of occupancy (cor_v1: 36.9 ms staged, 28.9 ms
-    // through L1/L2), so the columns are gathered from global memory.  Fetching the columns of one
-    // dependency level together was also measured (cor_v1: 53 ms): the extra registers cost more
-    // occupancy than the overlapped round trips give back.
-    static const bool want_lds = getenv("EMGPU_DEBUG_STEP_LDS") != nullptr;
-    const bool lds = want_lds && (size_t)P.pthr_total * sizeof(uint32_t) <= 24576;
-    if (P.ni <= 7 && P.nd <= 3) { *name = lds ? "k_dbn_step2<7,3,lds>" : "k_dbn_step2<7,3>"; return launch_t<7, 3>(P, A, F, s, lds); }
-    if (P.ni <= 9 && P.nd <= 3) { *name = lds ? "k_dbn_step2<9,3,lds>" : "k_dbn_step2<9,3>"; return launch_t<9, 3>(P, A, F, s, lds); }
-    *name = lds ? "k_dbn_step2<16,4,lds>" : "k_dbn_step2<16,4>";
-    return launch_t<16, 4>(P, A, F, s, lds);
+    // (Staging the tables in LDS was measured and dropped: random 16-byte gathers from LDS pay bank
+    // conflicts and the extra LDS costs a workgroup of occupancy -- cor_v1 36.9 ms staged, 28.9 ms through
+    // L1/L2.  Fetching the columns of one dependency level together: 53 ms, the registers cost more
+    // occupancy than the overlapped round trips give back.)
+    static const char *names[3][4] = {
+        {"k_dbn_step2<7,3,w4,reg>", "k_dbn_step2<7,3,w8,reg>", "k_dbn_step2<7,3,reg>", "k_dbn_step2<7,3>"},
+        {"k_dbn_step2<9,3,w4,reg>", "k_dbn_step2<9,3,w8,reg>", "k_dbn_step2<9,3,reg>", "k_dbn_step2<9,3>"},
+        {"k_dbn_step2<16,4,w4,reg>", "k_dbn_step2<16,4,w8,reg>", "k_dbn_step2<16,4,reg>", "k_dbn_step2<16,4>"}};
+    const int shape = (P.ni <= 7 && P.nd <= 3) ? 0 : ((P.ni <= 9 && P.nd <= 3) ? 1 : 2);
+    const bool reg = all_res && P.nd == (shape == 2 ? 4 : 3);
+    *name = names[shape][reg ? (wmode == 4 ? 0 : (wmode == 8 ? 1 : 2)) : 3];
+    if (shape == 0) return launch_t<7, 3>(P, A, F, s, wmode, reg);
+    if (shape == 1) return launch_t<9, 3>(P, A, F, s, wmode, reg);
+    return launch_t<16, 4>(P, A, F, s, wmode, reg);
 }
 
 } // namespace emgpu
