@@ -603,3 +603,17 @@ print("fallback ok")
     env = dict(os.environ, EMGPU_DEBUG_NO_STEP2="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name", ["uncor_1200code_v2p1", "uncor_1200only_fwme_v1p2", "glider_v1", "cor_v1"])
+def test_every_short_length_matches_oracle(name, gpu_ctx, model_dir):
+    """T = 1 .. 18 (every position of the 8-second block boundary, the 4-second output blocks and the
+    partial last block), n not a multiple of the wave size."""
+    nm, pp, _ = load_pair(name, model_dir)
+    om = O.OracleModel(pp)
+    idx = uncor_indices(pp)
+    for T in range(1, 19):
+        n = 130 + 7 * T
+        ref = O.uncor_sample(om, n, T, 1000 + T, want_events=False)
+        got = native.sample_dbn_host(gpu_ctx, nm, n, T, 1000 + T, want_dense=True, want_events=False, **idx)
+        assert_uncor_parity(got, ref, T, check_events=False)
