@@ -38,14 +38,14 @@ struct FastArgs {
 
 // One compacted CPT column (EmgpuPlan::cthr): meff distinct thresholds, then the nibble map
 // bin(n) = (map >> 4n) & 15 with n = #{t : x' >= threshold t}.  The kernel instance may be built for
-// M >= meff thresholds: the extra ones are "never".  The map is returned as a BYTE table indexed by
+// M >= meff thresholds: the extra ones repeat the last one (no new tie value).  The map is returned as a BYTE table indexed by
 // the number of BORROWS b = M - n (what the compare chain counts), entries 0-3 in bml and 4-7 in
 // bmh, so that one v_perm_b32 with selector kSelBase + b yields the 1-based bin.
 constexpr uint32_t kSelBase = 0x0c0c0c00u; // v_perm_b32 selector: bytes 1-3 constant zero, byte 0 <- table[b]
 template <int M>
 __device__ __forceinline__ void load_cthr_full(uint32_t (&th)[M], const uint32_t *__restrict__ p, int meff) {
 #pragma unroll
-    for (int t = 0; t < M; t++) th[t] = (t < meff) ? p[t] : 0xFFFFFFFFu;
+    for (int t = 0; t < M; t++) th[t] = p[t < meff ? t : meff - 1]; // the instance's extra thresholds repeat the last one
 }
 // The hot loop compares high halfwords only, so the registers hold two threshold halves each
 // (threshold 2q in the low word, 2q+1 in the high word: SDWA selects the word); the rare exact pass
@@ -62,7 +62,7 @@ __device__ __forceinline__ void load_cthr(uint32_t (&tp)[(M + 1) / 2], uint32_t 
 #pragma unroll
     for (int b = 0; b <= M; b++) {
         const int n = M - b;                       // thresholds that fired
-        const int nn = n < meff ? n : meff;        // the padded ones never fire
+        const int nn = n < meff ? n : meff;        // the repeated ones fire with the last real one: n jumps to M
         const uint32_t e = (map >> (4 * nn)) & 15u;
         if (b < 4) lo |= e << (8 * b); else hi |= e << (8 * (b - 4));
     }

@@ -499,7 +499,10 @@ CompiledPlan compile_plan(const Model &m) {
                     bin++;
                     map = (map & ~(0xFu << (4 * d))) | ((uint32_t)bin << (4 * d));
                 }
-                for (int t = d; t < meff; t++) { c[t] = 0xFFFFFFFFu; map |= (uint32_t)bin << (4 * (t + 1)); }
+                // pad with copies of the last real threshold (they fire together with it, so the count jumps to
+                // meff and no new tie value appears: a tie with a high halfword costs the kernels an exact redo);
+                // a column without real thresholds is padded with "never"
+                for (int t = d; t < meff; t++) { c[t] = d > 0 ? c[d - 1] : 0xFFFFFFFFu; map |= (uint32_t)bin << (4 * (t + 1)); }
                 c[meff] = map;
             }
             // the padded form (EmgpuPlan::d_pw)
@@ -515,7 +518,7 @@ CompiledPlan compile_plan(const Model &m) {
                 for (int64_t j = 0; j < q; j++) {
                     const uint32_t *c = C + (size_t)j * (meff + 1);
                     uint32_t *o = Pd + (size_t)j * W;
-                    for (int t = 0; t < mfix; t++) o[t] = t < meff ? c[t] : 0xFFFFFFFFu;
+                    for (int t = 0; t < mfix; t++) o[t] = t < meff ? c[t] : c[meff - 1];
                     uint32_t lo = 0u, hi = 0u;
                     for (int b = 0; b <= mfix; b++) {
                         const int n = mfix - b, nn = n < meff ? n : meff;

@@ -69,7 +69,7 @@ struct EmgpuPlan {
     int8_t a_dyn[EMGPU_MAX_NI];   // k if dynamic else -1
     uint32_t a_R[EMGPU_MAX_NI];   // hit  <=>  x' < R
     // ---- compacted tables of the dynamic variables (see compile_plan): column j of variable k is
-    // cthr[d_coff[k] + j*(d_meff[k]+1) ...]: d_meff[k] DISTINCT real thresholds (padded with "never")
+    // cthr[d_coff[k] + j*(d_meff[k]+1) ...]: d_meff[k] DISTINCT real thresholds (padded with copies of the last one)
     // followed by one word of nibbles, bin(n) = (map >> 4n) & 15 for n = #{t : x' >= threshold t}.
     // Zero-count bins make most of a column's r-1 thresholds coincide, so d_meff is often far below
     // r-1 (uncor_1200code_v2p1: 2, 4, 2 instead of 4, 6, 6).  d_meff[k] == 0 => not compacted.
@@ -78,7 +78,7 @@ struct EmgpuPlan {
     const uint32_t *cthr;
     // ---- the same columns padded to a power of two for the per-timestep kernel (one or two 16-byte
     // loads per draw): d_pw[k] = 4 words {t0, t1, t2, map} (d_meff <= 3) or 8 words {t0..t5, map_lo,
-    // map_hi} (d_meff <= 6); unused thresholds are "never"; the map is a BYTE table indexed by the
+    // map_hi} (d_meff <= 6); unused thresholds repeat the last real one; the map is a BYTE table indexed by the
     // number of thresholds that did NOT fire (b = 3 or 6 minus the fired count) -> 1-based bin, ready
     // for v_perm_b32.  d_pw[k] == 0 => no padded table for this variable.
     uint8_t d_pw[EMGPU_MAX_ND];

@@ -274,7 +274,7 @@ uint32_t emgpu_debug_bernoulli_threshold(double rate);
 int emgpu_debug_dynamic_column(const emgpu_model *m, int32_t k, int64_t col, int32_t *tvar, int32_t *r, int64_t *q,
                                uint32_t *thr, int32_t *meff, uint32_t *cthr, uint32_t *map);
 /* The same column in the padded form the per-timestep kernel loads: *width = 4 words {t0, t1, t2, map} or
- * 8 words {t0..t5, map_lo, map_hi} (0: the variable has no padded table); unused thresholds are 2^32-1;
+ * 8 words {t0..t5, map_lo, map_hi} (0: the variable has no padded table); unused thresholds repeat the last real one (2^32-1 if none);
  * the map is a byte table: entry b = 1-based bin when b of the 3 (6) thresholds did NOT fire. */
 int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int32_t *width, uint32_t *words);
 
