@@ -159,7 +159,7 @@ def recorded_traffic(kernel_name, algorithmic_bytes):
         except Exception:
             continue
         line = s.get("bench_line", {})
-        same = kernel_name in s.get("kernel", "") and line.get("roofline", {}).get("algorithmic_bytes_per_launch") == algorithmic_bytes
+        same = kernel_name.replace(" ", "") in s.get("kernel", "").replace(" ", "") and line.get("roofline", {}).get("algorithmic_bytes_per_launch") == algorithmic_bytes
         if same and "hbm_traffic_bytes_per_launch" in s:
             best = (s["hbm_traffic_bytes_per_launch"], os.path.basename(f))
     if best is None:
