@@ -54,6 +54,7 @@ def test_dense_only_fast_kernel_matches_oracle(name, T, n, gpu_ctx, model_dir):
 
 # ---------------------------------------------------------------------------------------------
 import glob
+import re
 import os
 
 import em_model_manned_bayes_amd as E
@@ -617,3 +618,15 @@ def test_every_short_length_matches_oracle(name, gpu_ctx, model_dir):
         ref = O.uncor_sample(om, n, T, 1000 + T, want_events=False)
         got = native.sample_dbn_host(gpu_ctx, nm, n, T, 1000 + T, want_dense=True, want_events=False, **idx)
         assert_uncor_parity(got, ref, T, check_events=False)
+
+
+def test_plain_c_host_runs_the_abi_end_to_end(model_dir, tmp_path):
+    """examples/c_api_demo.c: model file -> trajectories -> tracks through the C ABI only."""
+    import subprocess
+    from test_host import _build_c_demo
+    exe = _build_c_demo(tmp_path)
+    r = subprocess.run([exe, em_io.materialize_model("uncor_1200code_v2p1", model_dir), "5000", "120", "7"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "7 initial / 3 dynamic variables; 5000 trajectories x 120 s (kernel k_sample2track<planar>)" in r.stdout
+    m = re.search(r"bin changes per trajectory: ([0-9.]+); rejection retries: (\d+); tracks accepted by sample2track: (\d+)", r.stdout)
+    assert m and 2.0 < float(m.group(1)) < 8.0 and int(m.group(2)) < 20 and 3000 < int(m.group(3)) <= 5000

@@ -327,3 +327,26 @@ def test_legacy_label_names_and_number_format():
     assert [legacy.make_valid_name(legacy._erase(s)) for s in tl] == ["dotV_t_1_", "dotH_t_1_", "dotPsi_t_1_"]          # :38-40
     assert [legacy._g(x) for x in (3, 0.5, 1234567.0, 1e-7, 145.123456789, -0.0)] == ["3", "0.5", "1.23457e+06", "1e-07", "145.123", "-0"]
     assert abs(legacy.FT_PER_NM / 3600.0 - 1.68780985710119) < 1e-13
+
+
+def _build_c_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_api_demo")
+    pkg = os.path.join(ROOT, "em_model_manned_bayes_amd")
+    r = subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-std=c99", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "c_api_demo.c"), "-L" + pkg, "-lemgpu", "-Wl,-rpath," + pkg, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_the_demo_fails_cleanly_without_a_device(tmp_path, model_dir):
+    """include/emgpu.h compiles as C99 with -Wall -Werror; the plain-C host reports errors through the ABI."""
+    import subprocess
+    exe = _build_c_demo(tmp_path)
+    r = subprocess.run([exe, str(tmp_path / "missing.txt")], capture_output=True, text=True)
+    assert r.returncode == 1 and "-> -2: cannot open" in r.stderr                      # EMGPU_ERR_IO
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, em_io.materialize_model("uncor_1200code_v2p1", model_dir), "10", "8"], capture_output=True, text=True)
+        assert r.returncode == 1 and "emgpu_ctx_create" in r.stderr and "-> -8" in r.stderr   # EMGPU_ERR_NO_DEVICE: no CPU fallback
