@@ -630,3 +630,32 @@ def test_plain_c_host_runs_the_abi_end_to_end(model_dir, tmp_path):
     assert "7 initial / 3 dynamic variables; 5000 trajectories x 120 s (kernel k_sample2track<planar>)" in r.stdout
     m = re.search(r"bin changes per trajectory: ([0-9.]+); rejection retries: (\d+); tracks accepted by sample2track: (\d+)", r.stdout)
     assert m and 2.0 < float(m.group(1)) < 8.0 and int(m.group(2)) < 20 and 3000 < int(m.group(3)) <= 5000
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_models_match_oracle(seed, gpu_ctx, tmp_path):
+    """Fuzz: generated models (random DAGs, sparse tables with all-zero columns and huge counts, 1-4 dynamic
+    variables, fast and dependent branches, categorical variables, zero bins, zero resample rates) through every
+    kernel family: event lists (k_dbn_generic), dense REFERENCE_AUTO (k_uncor_fast / k_dbn_step2 / generic) and
+    dense PER_STEP."""
+    from util import random_model
+    rs = np.random.RandomState(7000 + seed)
+    # seeds 2, 6, 10, ...: three independent dynamic variables = the shape k_uncor_fast takes
+    parms = random_model(rs, nd=(seed % 4) + 1 if seed < 16 else None, dependent=False if seed % 4 == 2 else None)
+    path = str(tmp_path / "m.txt")
+    em_io.em_write(parms, path)
+    nm = native.NativeModel.load_txt(path)
+    pp = O.parse_model_txt(path)
+    om = O.OracleModel(pp)
+    n, T = 700 + 13 * seed, int(rs.choice([5, 33, 64, 97]))
+    ref = O.uncor_sample(om, n, T, 50 + seed)
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, 50 + seed, want_dense=True, want_events=True)
+    assert_uncor_parity(got, ref, T)
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, 50 + seed, want_dense=True, want_events=False)
+    assert_uncor_parity(got, ref, T, check_events=False)
+    kernels = {got["kernel"].split("<")[0]}
+    refp = O.uncor_sample(om, n, T, 50 + seed, per_step=True, want_events=False)
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, 50 + seed, want_dense=True, want_events=False, transition_mode=L.TRANSITION_PER_STEP)
+    assert_uncor_parity(got, refp, T, check_events=False)
+    kernels.add(got["kernel"].split("<")[0])
+    assert kernels <= {"k_uncor_fast", "k_dbn_step2", "k_dbn_step", "k_dbn_generic"}

@@ -350,3 +350,22 @@ def test_header_is_plain_c_and_the_demo_fails_cleanly_without_a_device(tmp_path,
     if not torch.cuda.is_available():
         r = subprocess.run([exe, em_io.materialize_model("uncor_1200code_v2p1", model_dir), "10", "8"], capture_output=True, text=True)
         assert r.returncode == 1 and "emgpu_ctx_create" in r.stderr and "-> -8" in r.stderr   # EMGPU_ERR_NO_DEVICE: no CPU fallback
+
+
+def test_random_models_parse_identically(tmp_path):
+    """Generated models (tests/util.random_model) through em_write -> the C++ loader and the oracle's parser."""
+    from util import random_model
+    for seed in range(12):
+        parms = random_model(np.random.RandomState(100 + seed))
+        path = str(tmp_path / ("rand%d.txt" % seed))
+        em_io.em_write(parms, path)
+        p = E.em_read(path)
+        pp = O.parse_model_txt(path)
+        assert np.array_equal(np.asarray(p["temporal_map"]).reshape(-1, 2), np.asarray(pp["temporal_map"]).reshape(-1, 2))
+        assert [int(z) if np.size(z) else 0 for z in p["zero_bins"]] == [int(z) for z in pp["zero_bins"]]   # [] (MATLAB) == 0 (none)
+        assert np.array_equal(p["order_transition"], pp["order_transition"])
+        for v in range(parms["n_initial"]):
+            assert np.array_equal(p["N_initial"][v], parms["N_initial"][v]) and np.array_equal(pp["N_initial"][v], parms["N_initial"][v])
+            assert np.array_equal(np.asarray(p["boundaries"][v]), np.asarray(pp["boundaries"][v]))
+        for v in range(parms["n_initial"], parms["n_transition"]):
+            assert np.array_equal(p["N_transition"][v], parms["N_transition"][v]) and np.array_equal(pp["N_transition"][v], parms["N_transition"][v])

@@ -51,3 +51,73 @@ def assert_uncor_parity(got, ref, T, check_events=True, tol_rel=1e-6):
             assert np.array_equal(e["bin"].astype(np.float64), r[:, 3]), "trajectory %d: bin differs" % i
             np.testing.assert_allclose(e["value"], r[:, 2], rtol=tol_rel, atol=0)
             assert np.array_equal(e["value"], r[:, 2].astype(np.float32)), "trajectory %d: values not bit-equal" % i
+
+
+def random_model(rs, dependent=None, nd=None):
+    """A random small model in the em_read dict layout (for em_io.em_write): random DAGs, sparse count tables
+    (zero entries, all-zero columns), categorical and continuous variables, zero-crossing boundaries,
+    zero and non-zero resample rates.  rs: numpy RandomState."""
+    ni = int(rs.randint(3, 8))
+    r = rs.randint(2, 9, ni)
+    if rs.rand() < 0.3:
+        r[rs.randint(ni)] = rs.randint(9, 13)
+    nd = int(nd or rs.randint(1, min(ni, 4) + 1))
+    dyn = sorted(rs.choice(ni, nd, replace=False).tolist())
+    Gi = np.zeros((ni, ni), dtype=np.uint8)
+    for v in range(1, ni):
+        cand = list(range(v))
+        rs.shuffle(cand)
+        q = 1
+        for p in cand[: rs.randint(0, 4)]:
+            if q * r[p] <= 400:
+                Gi[p, v] = 1
+                q *= r[p]
+    nt = ni + nd
+    rt = np.concatenate([r, r[dyn]])
+    Gt = np.zeros((nt, nt), dtype=np.uint8)
+    dependent = (rs.rand() < 0.5) if dependent is None else dependent
+    for k, d in enumerate(dyn):
+        v = ni + k
+        Gt[d, v] = 1
+        q = r[d]
+        cand = [p for p in range(ni) if p != d]
+        rs.shuffle(cand)
+        for p in cand[: rs.randint(0, 3)]:
+            if q * r[p] <= 600:
+                Gt[p, v] = 1
+                q *= r[p]
+        if dependent and k > 0:
+            for kk in range(k):
+                if rs.rand() < 0.6 and q * rt[ni + kk] <= 900:
+                    Gt[ni + kk, v] = 1
+                    q *= rt[ni + kk]
+
+    def counts(rv, parents_r):
+        q = int(np.prod(parents_r)) if len(parents_r) else 1
+        N = rs.randint(1, 2000, (rv, q)).astype(np.float64)
+        N *= rs.rand(rv, q) < rs.choice([0.35, 0.6, 0.9])
+        N[:, rs.rand(q) < 0.05] = 0                      # all-zero columns: select_random gives bin 1
+        if rs.rand() < 0.3:
+            N[:, rs.randint(q)] = 0
+            N[rs.randint(rv), rs.randint(q)] = 1.56e9    # one huge count (dueregard-size)
+        return N
+
+    N_initial = [counts(r[v], r[Gi[:, v] > 0]) for v in range(ni)]
+    N_transition = [np.zeros((0, 0))] * ni + [counts(rt[v], rt[Gt[:, v] > 0]) for v in range(ni, nt)]
+    boundaries = []
+    for v in range(ni):
+        if v not in dyn and rs.rand() < 0.35:
+            boundaries.append(np.zeros(0))               # categorical
+            continue
+        if rs.rand() < 0.6:                              # a bin that straddles 0 => zero bin (em_read.m:143-156)
+            lo, hi = -rs.uniform(1, 50), rs.uniform(1, 50)
+        else:
+            lo = rs.uniform(0, 100); hi = lo + rs.uniform(1, 500)
+        e = np.sort(np.round(rs.uniform(lo, hi, r[v] - 1), 3))
+        boundaries.append(np.unique(np.concatenate([[np.round(lo, 3)], e, [np.round(hi, 3)]])) if len(np.unique(e)) == r[v] - 1 else np.round(np.linspace(lo, hi, r[v] + 1), 3))
+    rates = np.where(rs.rand(ni) < 0.4, 0.0, np.round(rs.uniform(0.001, 0.25, ni), 6))
+    labels_initial = ['"v%d"' % (v + 1) for v in range(ni)]
+    labels_transition = ['"v%d(t)"' % (v + 1) if v in dyn else '"v%d"' % (v + 1) for v in range(ni)] + ['"v%d(t+1)"' % (d + 1) for d in dyn]
+    return {"n_initial": ni, "n_transition": nt, "labels_initial": labels_initial, "labels_transition": labels_transition,
+            "G_initial": Gi, "G_transition": Gt, "r_initial": r, "r_transition": rt, "N_initial": N_initial,
+            "N_transition": N_transition, "boundaries": boundaries, "resample_rates": rates}
