@@ -1,8 +1,9 @@
 /*
  * emgpu_mex.c -- MATLAB gateway to libemgpu.so (include/emgpu.h).
  *
- * UNTESTED: neither MATLAB nor mex.h exists in the build image; this file is the binding a
- * maintainer compiles on a machine that has both:
+ * NOT RUN: neither MATLAB nor mex.h exists in the build image (tests only type-check this file against a
+ * declaration-only stand-in, tests/stubs/mex.h); this is the binding a maintainer compiles on a machine
+ * that has both:
  *     mex -R2018a emgpu_mex.c -I<repo>/include -L<repo>/em_model_manned_bayes_amd -lemgpu
  *
  * One entry point, dispatched on a command string (MATLAB calls are single threaded):
@@ -14,6 +15,10 @@
  *         init_val : n x n_initial double        (out_inits, UncorEncounterModel.m:303)
  *         ev_count : n x 1 double
  *         events   : event_cap x 3 x n double    rows [dt var value] (out_events{i}, :304)
+ *   [xyz, flags, vminmax] = emgpu_mex('sample2track', alt0, speed0, updates, ur, min_speed, max_speed)
+ *         the loop of sample2track.m:182-243 for n trajectories: alt0, speed0 n x 1; updates 3 x T x n
+ *         (vertical rate, acceleration, turn rate per second); ur = [ur_speed ur_vertrate ur_heading];
+ *         xyz 3 x (T+1) x n feet; flags n x 1 (bit 0 CFIT, bit 1 speed); vminmax 2 x n
  *         emgpu_mex('free', h)
  */
 #include <math.h>
@@ -94,6 +99,20 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
             }
         }
         mxFree(iv); mxFree(ec); mxFree(ev); if (layers_rm) mxFree(layers_rm);
+    } else if (!strcmp(cmd, "sample2track")) {
+        if (nrhs < 7) mexErrMsgIdAndTxt("emgpu:usage", "sample2track needs alt0, speed0, updates, ur, min_speed, max_speed");
+        emgpu_track_params tp; memset(&tp, 0, sizeof tp);
+        tp.n = (int64_t)mxGetNumberOfElements(prhs[1]);
+        tp.T = tp.n ? (int32_t)(mxGetNumberOfElements(prhs[3]) / (3 * (size_t)tp.n)) : 1;
+        tp.ur_speed = mxGetPr(prhs[4])[0]; tp.ur_vertrate = mxGetPr(prhs[4])[1]; tp.ur_heading = mxGetPr(prhs[4])[2];
+        tp.min_speed = mxGetScalar(prhs[5]); tp.max_speed = mxGetScalar(prhs[6]);
+        /* column-major 3 x T x n == row-major [n][T][3], 3 x (T+1) x n == [n][T+1][3], 2 x n == [n][2]: no transposes */
+        mwSize dx[3] = {3, (mwSize)tp.T + 1, (mwSize)tp.n};
+        plhs[0] = mxCreateNumericArray(3, dx, mxDOUBLE_CLASS, mxREAL);
+        plhs[1] = mxCreateNumericMatrix((mwSize)tp.n, 1, mxUINT8_CLASS, mxREAL);
+        plhs[2] = mxCreateDoubleMatrix(2, (mwSize)tp.n, mxREAL);
+        check(emgpu_sample2track_host(g_ctx, &tp, mxGetPr(prhs[1]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(plhs[0]),
+                                      (uint8_t *)mxGetData(plhs[1]), mxGetPr(plhs[2])));
     } else if (!strcmp(cmd, "free")) {
         emgpu_model_free(handle_of(prhs[1]));
     } else {

@@ -369,3 +369,13 @@ def test_random_models_parse_identically(tmp_path):
             assert np.array_equal(np.asarray(p["boundaries"][v]), np.asarray(pp["boundaries"][v]))
         for v in range(parms["n_initial"], parms["n_transition"]):
             assert np.array_equal(p["N_transition"][v], parms["N_transition"][v]) and np.array_equal(pp["N_transition"][v], parms["N_transition"][v])
+
+
+def test_mex_gateway_compiles():
+    """The MATLAB gateway cannot be run here (no MATLAB); it is at least type-checked against the C ABI header with a
+    declaration-only stand-in for mex.h (tests/stubs/mex.h)."""
+    import subprocess
+    r = subprocess.run(["gcc", "-fsyntax-only", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "stubs"),
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "em_model_manned_bayes_amd", "matlab", "emgpu_mex.c")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
