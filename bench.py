@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps (the first launches run while the GPU clocks still ramp up)")
     ap.add_argument("--n", type=int, default=N_PER_GPU, help="trajectories per GPU per step")
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--seconds", type=int, default=DEFAULT_T, help="trajectory length (the headline metric is quoted at 240)")

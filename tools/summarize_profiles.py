@@ -28,15 +28,15 @@ for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
     summary["kernel_calls"] = int(top["Calls"])
     summary["kernel_avg_ms"] = float(top["AverageNs"]) / 1e6
     summary["kernel_pct_of_gpu_time"] = float(top["Percentage"])
-# every launch of the dominant kernel, in time order: the first (cold) launches are bench.py's warm-up,
+# every launch of the dominant kernel, in time order: the first five (clocks still ramping) are bench.py's warm-up,
 # the rest are its timed region -- their mean is what bench.py's roofline.avg_launch_ms must agree with
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv")):
     rows = [r for r in csv.DictReader(open(f)) if summary.get("kernel") and r["Kernel_Name"] == summary["kernel"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
     summary["kernel_launch_ms"] = [round(x, 4) for x in ms]
-    if len(ms) > 2:
-        summary["kernel_avg_ms_timed_region"] = sum(ms[2:]) / len(ms[2:])   # bench.py --warmup 2
+    if len(ms) > 5:
+        summary["kernel_avg_ms_timed_region"] = sum(ms[5:]) / len(ms[5:])   # bench.py default --warmup 5
 # per-dispatch resource usage from the kernel trace
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
