@@ -659,3 +659,34 @@ def test_random_models_match_oracle(seed, gpu_ctx, tmp_path):
     assert_uncor_parity(got, refp, T, check_events=False)
     kernels.add(got["kernel"].split("<")[0])
     assert kernels <= {"k_uncor_fast", "k_dbn_step2", "k_dbn_step", "k_dbn_generic"}
+
+
+@pytest.mark.parametrize("name,n,kernel", [("cor_v1", 3_000_000, "k_dbn_step2<16,4,w4,reg>"), ("glider_v1", 4_000_000, "k_dbn_step2<7,3"),
+                                           ("uncor_1200only_rotorcraft_v1p2", 6_000_000, "k_uncor_fast<7,4,6,6>")])
+def test_large_batches_of_the_other_kernels_spot_checked(name, n, kernel, model_dir):
+    """BASELINE configs 3 and 4 at sizes the oracle cannot finish: millions of trajectories x 240 s on the device,
+    slices from the start, the middle and the ragged end of the batch against the oracle (slots are keyed by the
+    global index, so the oracle can produce any slice on its own)."""
+    import torch
+    nm, pp, _ = load_pair(name, model_dir)
+    idx = uncor_indices(pp)
+    n += 77                                     # not a multiple of the workgroup
+    T, seed, first = 240, 99, 2**33 + 11
+    dev = torch.device("cuda", 0)
+    ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    ni, nd, G4 = nm.n_initial, nm.n_dyn, T // 4
+    ib = torch.empty((ni, n), dtype=torch.uint8, device=dev); iv = torch.empty((ni, n), dtype=torch.float32, device=dev)
+    db = torch.empty((G4, nd, n), dtype=torch.int32, device=dev); dv = torch.empty((G4, nd, n, 4), dtype=torch.float32, device=dev)
+    p, _ = native.make_params(n, T, seed, first_index=first, **idx)
+    native.sample_dbn_device(ctx, nm, p, init_bin=ib.data_ptr(), init_val=iv.data_ptr(), dyn_bin=db.data_ptr(), dyn_val=dv.data_ptr())
+    ctx.sync()
+    assert ctx.last_kernel().startswith(kernel), ctx.last_kernel()
+    om = O.OracleModel(pp)
+    m = 1500
+    for lo_i in (0, n // 2 + 13, n - m):
+        ref = O.uncor_sample(om, m, T, seed, first_index=first + lo_i, want_events=False)
+        gb = native.unpack_dyn_bin(db[:, :, lo_i: lo_i + m].contiguous().cpu().numpy().view(np.uint32), T)
+        gv = native.unpack_dyn_val(dv[:, :, lo_i: lo_i + m].contiguous().cpu().numpy(), T)
+        assert np.array_equal(gb, ref["dense_bin"]) and np.array_equal(gv, ref["dense_val"].astype(np.float32))
+        assert np.array_equal(ib[:, lo_i: lo_i + m].cpu().numpy().T.astype(np.int32), ref["init_bin"])
+        assert np.array_equal(iv[:, lo_i: lo_i + m].cpu().numpy().T, ref["init_val"].astype(np.float32))
