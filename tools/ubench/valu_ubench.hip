@@ -27,6 +27,27 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t a0, uint32_t b0
 #define CMPCND(n) asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x##n) : "v"(c), "v"(d) : "vcc");
 #define SUB(n) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x##n) : "v"(c));
 #define MAD(n) { uint64_t p; asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, 0" : "=v"(p) : "v"(x##n), "s"(b0) : "s10", "s11"); x##n = (uint32_t)(p >> 32); }
+#define SDWASUB(n) asm volatile("v_sub_co_u32_sdwa %0, vcc, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\ts_nop 1\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "=v"(x##n), "+v"(cnt) : "v"(c), "v"(d) : "vcc"); asm volatile("" : "+v"(cnt));
+#define PERM(n) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x##n) : "v"(c), "v"(d));
+#define ANDV(n) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(x##n));
+#define LSHL(n) asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(x##n));
+#define ADDC2(n) asm volatile("v_cmp_ne_u32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x##n) : "v"(c), "v"(d) : "vcc");
+#define MIN3(n) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(x##n) : "v"(c), "v"(d));
+#define MINV(n) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x##n) : "v"(c));
+#define PAIRNONOP(n) asm volatile("v_sub_co_u32 %0, vcc, %1, %2\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "=v"(x##n), "+v"(cnt) : "v"(c), "v"(d) : "vcc"); asm volatile("" : "+v"(cnt));
+#define PAIRFILL(n) asm volatile("v_sub_co_u32 %0, vcc, %1, %2\n\tv_xor_b32 %4, %4, %1\n\tv_xor_b32 %5, %5, %2\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "=v"(x##n), "+v"(cnt), "+v"(c) : "v"(c), "v"(d), "v"(e1), "v"(e2) : "vcc");
+#define NOPONLY(n) asm volatile("s_nop 1");
+#define XORNOP(n) asm volatile("v_xor_b32 %0, %0, %1\n\ts_nop 1" : "+v"(x##n) : "v"(c));
+            if (KIND == 17) { REP8(PAIRNONOP) }
+            if (KIND == 19) { REP8(NOPONLY) }
+            if (KIND == 20) { REP8(XORNOP) }
+            if (KIND == 10) { REP8(SDWASUB) }
+            if (KIND == 11) { REP8(PERM) }
+            if (KIND == 12) { REP8(ANDV) }
+            if (KIND == 13) { REP8(LSHL) }
+            if (KIND == 14) { REP8(ADDC2) }
+            if (KIND == 15) { REP8(MIN3) }
+            if (KIND == 16) { REP8(MINV) }
             if (KIND == 0) { REP8(XOR) }
             if (KIND == 1) { REP8(BITOP) }
             if (KIND == 2) { REP8(ALIGN) }
@@ -74,5 +95,15 @@ int main() {
     run<4>("v_mad_u64_u32", 1);
     run<5>("v_sub_co + s_nop 1 + v_subbrev_co", 2);
     run<8>("v_cmp_lt + s_nop 1 + v_cndmask", 2);
+    run<17>("v_sub_co + v_addc (no s_nop; timing only)", 2);
+    run<19>("s_nop 1 alone (per s_nop)", 1);
+    run<20>("v_xor + s_nop 1 (per v_xor)", 1);
+    run<10>("v_sub_co_sdwa + s_nop 1 + v_addc", 2);
+    run<14>("v_cmp_ne + s_nop 1 + v_addc", 2);
+    run<11>("v_perm_b32", 1);
+    run<15>("v_min3_u32", 1);
+    run<16>("v_min_u32 (VOP2)", 1);
+    run<12>("v_and_b32 literal (VOP2)", 1);
+    run<13>("v_lshlrev_b32 (VOP2)", 1);
     return 0;
 }
