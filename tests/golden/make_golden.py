@@ -59,6 +59,27 @@ def main():
                             ev_count=cnt, ev_flat=flat, dense_bin=r["dense_bin"], dense_val=r["dense_val"],
                             attempts=r["attempts"], meta=np.array([n, T, seed, first, int(per_step)], dtype=np.int64))
         print("wrote", tag)
+    # ---- sample2track.m:183-243 (hand-checkable cases first, then random columns); cor_v1 Philox golden
+    rs = np.random.RandomState(20261003)
+    n, T = 48, 40
+    upd = np.stack([rs.normal(0, 700, (n, T)), rs.normal(0, 1.2, (n, T)), rs.normal(0, 3.0, (n, T))], axis=2)
+    upd[0] = 0.0
+    upd[1, :, 2] = 22.5
+    upd[2, :, 0] = -3000.0
+    alt0 = rs.uniform(100, 9000, n); v0 = rs.uniform(40, 250, n)
+    ur = ((1852.0 / 0.3048) / 3600.0, 1.0 / 60.0, 1.0)
+    xyz, flags, vmm = O.sample2track(alt0, v0, upd, *ur, 30.0, 300.0)
+    np.savez_compressed(os.path.join(HERE, "sample2track_48x40.npz"), alt0=alt0, speed0=v0, updates=upd, ur=np.array(ur),
+                        min_speed=np.array([30.0]), max_speed=np.array([300.0]), xyz=xyz, flags=flags, speed_minmax=vmm)
+    print("wrote sample2track_48x40")
+    path = em_io.materialize_model("cor_v1", tmp)
+    om = O.OracleModel(O.parse_model_txt(path))
+    r = O.uncor_sample(om, 48, 40, 0xC0, mode=O.RNG_PHILOX, first_index=9)
+    cnt, flat = pack_events(r["events"])
+    np.savez_compressed(os.path.join(HERE, "cor_v1_philox_seedc0_first9_48x40.npz"), init_bin=r["init_bin"], init_val=r["init_val"],
+                        ev_count=cnt, ev_flat=flat, dense_bin=r["dense_bin"], dense_val=r["dense_val"],
+                        attempts=r["attempts"], meta=np.array([48, 40, 0xC0, 9, 0], dtype=np.int64))
+    print("wrote cor_v1")
 
 
 if __name__ == "__main__":

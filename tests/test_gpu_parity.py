@@ -690,3 +690,11 @@ def test_large_batches_of_the_other_kernels_spot_checked(name, n, kernel, model_
         assert np.array_equal(gb, ref["dense_bin"]) and np.array_equal(gv, ref["dense_val"].astype(np.float32))
         assert np.array_equal(ib[:, lo_i: lo_i + m].cpu().numpy().T.astype(np.int32), ref["init_bin"])
         assert np.array_equal(iv[:, lo_i: lo_i + m].cpu().numpy().T, ref["init_val"].astype(np.float32))
+
+
+def test_sample2track_kernel_reproduces_the_committed_golden(gpu_ctx):
+    g = np.load(os.path.join(GOLD, "sample2track_48x40.npz"))
+    xyz, flags, vmm = native.sample2track_host(gpu_ctx, g["alt0"], g["speed0"], g["updates"], *g["ur"], float(g["min_speed"][0]), float(g["max_speed"][0]))
+    assert np.array_equal(flags, g["flags"])
+    np.testing.assert_allclose(xyz, g["xyz"], rtol=1e-12, atol=1e-7)
+    np.testing.assert_allclose(vmm, g["speed_minmax"], rtol=1e-14)

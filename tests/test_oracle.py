@@ -278,3 +278,11 @@ def test_sample2track_known_answers():
     # the bounds are exclusive (<=, >=: sample2track.m:240)
     _, f2, _ = O.sample2track([10.0], [30.0], np.zeros((1, 2, 3)), ur_s, ur_v, 1.0, 30.0, 300.0)
     assert f2[0] == 2
+
+
+def test_golden_sample2track():
+    g = np.load(os.path.join(GOLD, "sample2track_48x40.npz"))
+    xyz, flags, vmm = O.sample2track(g["alt0"], g["speed0"], g["updates"], *g["ur"], float(g["min_speed"][0]), float(g["max_speed"][0]))
+    assert np.array_equal(xyz, g["xyz"]) and np.array_equal(flags, g["flags"]) and np.array_equal(vmm, g["speed_minmax"])
+    assert flags[0] == 0 and np.all(np.diff(g["xyz"][0, :, 0]) > 0) and np.all(g["xyz"][0, :, 1] == 0)   # straight and level
+    assert flags[2] & 1                                                                                # dives into the ground
