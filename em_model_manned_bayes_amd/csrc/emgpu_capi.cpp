@@ -477,9 +477,25 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_samp
             };
             back(out->init_bin, d.init_bin, b_ib); back(out->init_val, d.init_val, b_iv);
             back(out->dyn_bin, d.dyn_bin, b_db); back(out->dyn_val, d.dyn_val, b_dv);
-            back(out->ev_count, d.ev_count, b_ec); back(out->events, d.events, b_ev);
+            back(out->ev_count, d.ev_count, b_ec);
             back(out->attempts, d.attempts, b_at);
             rc = emgpu_ctx_sync(ctx);
+            if (out->events && b_ev) {
+                // only the used part of every event list crosses PCIe: rows past the longest list (or past
+                // ev_count[i]) are left as the caller passed them
+                const size_t cap = (size_t)p->event_cap;
+                size_t longest = cap;
+                if (out->ev_count) {
+                    longest = 0;
+                    for (size_t i = 0; i < n; i++) longest = out->ev_count[i] > longest ? out->ev_count[i] : longest;
+                    if (longest > cap) longest = cap;
+                }
+                if (longest) {
+                    HIP_OK(hipMemcpy2DAsync(out->events, cap * sizeof(emgpu_event), d.events, cap * sizeof(emgpu_event),
+                                            longest * sizeof(emgpu_event), n, hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_OK(hipStreamSynchronize(ctx->stream));
+                }
+            }
         }
     } catch (...) {
         (void)hipStreamSynchronize(ctx->stream);

@@ -317,7 +317,8 @@ class UncorEncounterModel(EncounterModel):
         out_events, out_samples, out_EME = [None] * n_samples, [None] * n_samples, [None] * n_samples
         tm = self.temporal_map
         idxEME = [int(np.nonzero(tm[:, 0] == v)[0][0]) + 1 for v in (idxDH, idxDPsi, idxDV)]  # :291
-        chunk, cap, pos = 32768, 256, 0
+        vars_dyn = tm[:, 0].astype(np.int64) - 1
+        chunk, cap, pos = max(1, min(32768, (96 << 20) // (8 * ni * T))), 256, 0   # the dense [chunk, ni, T] f64 block stays < 100 MB
         while pos < n_samples:
             nn = min(chunk, n_samples - pos)
             try:
@@ -330,20 +331,42 @@ class UncorEncounterModel(EncounterModel):
                     continue
                 raise
             iv = res["init_val"].astype(np.float64)
+            out_inits[pos: pos + nn] = iv
+            # The whole chunk at once (events2samples.m:9-26, events2controls.m:11-31 restated on flat arrays):
+            # row r of sample i happens at absolute second at = cumsum(dt) and, if it names a variable, sets it
+            # from then on; the state during [t, t+dt) before the row is what the row's control line reports.
+            cnt = res["ev_count"].astype(np.int64)
+            flat = np.concatenate(res["events"]) if nn else np.zeros(0, dtype=native.EVENT_DTYPE)
+            sid = np.repeat(np.arange(nn), cnt)
+            dt = flat["dt"].astype(np.float64); var = flat["var"].astype(np.int64); val = flat["value"].astype(np.float64)
+            ends = np.cumsum(cnt)
+            csum = np.cumsum(dt)
+            base = np.concatenate([[0.0], csum[ends[:-1] - 1]]) if nn > 1 else np.zeros(nn)
+            at = (csum - np.repeat(base, cnt)).astype(np.int64)            # time after the row
+            t0 = at - dt.astype(np.int64)                                  # time before the row
+            ev_all = np.stack([dt, var.astype(np.float64), val], axis=1)
+            D = np.broadcast_to(iv[:, :, None], (nn, ni, T)).copy()
+            ch = (var > 0) & (at < T)
+            if ch.any():
+                last = np.zeros((nn, ni, T), dtype=np.int32)               # index (+1) of the latest change at or before t
+                order = np.flatnonzero(ch)
+                last[sid[order], var[order] - 1, at[order]] = order + 1
+                np.maximum.accumulate(last, axis=2, out=last)
+                hit = last > 0
+                D[hit] = val[last[hit] - 1]
+            crow = dt > 0                                                   # rows that open a control line (:19-24)
+            csid, ct0 = sid[crow], t0[crow]
+            ctrl = np.empty((csid.size, 4))
+            ctrl[:, 0] = ct0
+            ctrl[:, 1] = D[csid, vars_dyn[idxEME[0] - 1], ct0] / 60.0                    # dh: fpm -> fps          :295
+            ctrl[:, 2] = np.deg2rad(D[csid, vars_dyn[idxEME[1] - 1], ct0])               # dpsi: deg/s -> rad/s    :296
+            ctrl[:, 3] = D[csid, vars_dyn[idxEME[2] - 1], ct0] * 1.68780972222222        # dv: kt/s -> ft/s^2      :297
+            ev_split = np.split(ev_all, ends[:-1]) if nn > 1 else [ev_all]
+            ctrl_split = np.split(ctrl, np.cumsum(np.bincount(csid, minlength=nn))[:-1]) if nn > 1 else [ctrl]
             for k in range(nn):
-                e = res["events"][k]
-                ev = np.stack([e["dt"].astype(np.float64), e["var"].astype(np.float64), e["value"].astype(np.float64)], axis=1)
-                initial = iv[k]
-                samples = events2samples(initial, ev)                      # :283
-                controls = events2controls(initial, ev, {"temporal_map": tm})  # :286
-                controls = controls[:, [0] + idxEME]                        # :292
-                controls[:, 1] = controls[:, 1] / 60.0                      # dh: fpm -> fps          :295
-                controls[:, 2] = np.deg2rad(controls[:, 2])                 # dpsi: deg/s -> rad/s    :296
-                controls[:, 3] = controls[:, 3] * 1.68780972222222          # dv: kt/s -> ft/s^2      :297
-                out_inits[pos + k] = initial
-                out_events[pos + k] = ev
-                out_samples[pos + k] = samples
-                out_EME[pos + k] = EncounterModelEvents(event=controls)
+                out_events[pos + k] = ev_split[k]
+                out_samples[pos + k] = D[k]
+                out_EME[pos + k] = EncounterModelEvents(event=ctrl_split[k])
             pos += nn
         return out_inits, out_events, out_samples, out_EME
 

@@ -181,7 +181,8 @@ typedef struct {
 int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_sample_params *p,
                             const emgpu_sample_out *out);
 /* Synchronous convenience for the MATLAB/Python class layer: HOST pointers in `out`; allocates
- * device buffers, runs, copies back (PCIe-inclusive; never the benchmarked path). */
+ * device buffers, runs, copies back (PCIe-inclusive; never the benchmarked path).  Of `events` only
+ * rows [0, ev_count[i]) of list i are defined on return (with ev_count == NULL all event_cap rows are copied). */
 int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_sample_params *p,
                           const emgpu_sample_out *out);
 

@@ -213,6 +213,14 @@ def test_uncor_class_sample_matches_reference_outputs(gpu_ctx, model_dir):
         ctl[:, 1] /= 60.0; ctl[:, 2] = np.deg2rad(ctl[:, 2]); ctl[:, 3] *= 1.68780972222222
         np.testing.assert_allclose(out_EME[i].event, ctl, rtol=1e-6, atol=0)
         assert out_EME[i].event[0, 0] == 0
+    # a call that spans several internal chunks gives the same samples as one-at-a-time calls at the same global index
+    big = mdl.sample(20000, 120, seed=5, ctx=gpu_ctx)
+    for i in (0, 14978, 14979, 14980, 19999):
+        one = mdl.sample(1, 120, seed=5, first_index=i, ctx=gpu_ctx)
+        assert np.array_equal(big[0][i], one[0][0]) and np.array_equal(big[1][i], one[1][0])
+        assert np.array_equal(big[2][i], one[2][0]) and np.array_equal(big[3][i].event, one[3][0].event)
+        r1 = O.uncor_sample(om, 1, 120, 5, first_index=i)
+        np.testing.assert_allclose(big[2][i], O.events2samples(r1["init_val"][0], r1["events"][0][:, :3]), rtol=1e-6, atol=0)
     with pytest.raises(E.EmgpuError) as ei:          # UncorEncounterModel.m:231-234
         E.UncorEncounterModel(parameters_filename=em_io.materialize_model("balloon_v1", model_dir)).sample(1, 10, seed=1, ctx=gpu_ctx)
     assert ei.value.identifier == "dynvar:empty"
