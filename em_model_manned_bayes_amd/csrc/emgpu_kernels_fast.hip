@@ -50,8 +50,12 @@ __device__ __forceinline__ void load_cthr_full(uint32_t (&th)[M], const uint32_t
 // The hot loop compares high halfwords only, so the registers hold two threshold halves each
 // (threshold 2q in the low word, 2q+1 in the high word: SDWA selects the word); the rare exact pass
 // reloads the full column from the table.
+// Entries of the byte table carry bit 7 when the bin is the variable's zero bin: the "zero bin" flag of a second
+// is then bit 7 of its packed byte, and the whole 8-bit stream is gathered from the two packed words with one
+// multiply each (zero_stream below) instead of one compare + carry per second.
+constexpr uint32_t kZeroFlag = 0x80u;
 template <int M>
-__device__ __forceinline__ void load_cthr(uint32_t (&tp)[(M + 1) / 2], uint32_t &bml, uint32_t &bmh, const uint32_t *__restrict__ p, int meff) {
+__device__ __forceinline__ void load_cthr(uint32_t (&tp)[(M + 1) / 2], uint32_t &bml, uint32_t &bmh, const uint32_t *__restrict__ p, int meff, uint32_t zbin1) {
     static_assert(M >= 1 && M <= 7, "the byte table has 8 entries");
     uint32_t th[M];
     load_cthr_full<M>(th, p, meff);
@@ -63,17 +67,24 @@ __device__ __forceinline__ void load_cthr(uint32_t (&tp)[(M + 1) / 2], uint32_t 
     for (int b = 0; b <= M; b++) {
         const int n = M - b;                       // thresholds that fired
         const int nn = n < meff ? n : meff;        // the repeated ones fire with the last real one: n jumps to M
-        const uint32_t e = (map >> (4 * nn)) & 15u;
+        uint32_t e = (map >> (4 * nn)) & 15u;
+        e |= (e == zbin1) ? kZeroFlag : 0u;
         if (b < 4) lo |= e << (8 * b); else hi |= e << (8 * (b - 4));
     }
     bml = lo; bmh = hi;
+}
+
+// bit 7 of the 8 packed bytes (seconds 0-3 in a, 4-7 in b) as an MSB-first stream: bit 7-j <-> second j
+__device__ __forceinline__ uint32_t zero_stream(uint32_t a, uint32_t b) {
+    const uint32_t na = (((a >> 7) & 0x01010101u) * 0x80402010u) >> 28, nb = (((b >> 7) & 0x01010101u) * 0x80402010u) >> 28;
+    return (na << 4) | nb;
 }
 
 // Eight seconds of one dynamic variable.  Outputs: bins packed 1-based 4 per word (pbA: seconds
 // 0-3, pbB: 4-7) and three 8-bit flag streams, MSB-first (bit 7-j belongs to second j):
 //   hit8  -- resample Bernoulli hit (resample_events.m:24)
 //   chg8  -- the transition draw changed the bin (dbn_sample.m:151-161)
-//   zer8  -- the bin after the draw is the zero bin (dediscretize.m:24-25)
+//   zer8  -- the bin after the draw is the zero bin (dediscretize.m:24-25); gathered from bit 7 of the packed bytes
 // EXACT = false: decide from the high halfwords only and report `amb` when some compare could
 // flip with the low halfword; EXACT = true: full 32-bit draws.
 //
@@ -87,10 +98,10 @@ __device__ __forceinline__ void load_cthr(uint32_t (&tp)[(M + 1) / 2], uint32_t 
 template <int M, bool EXACT, bool EDGE>
 __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 &rh, const uint4 &tl, const uint4 &rl, int g8, int T,
                                                    const uint32_t (&thr)[EXACT ? M : (M + 1) / 2], uint32_t bml, uint32_t bmh, uint32_t selbase,
-                                                   uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
-                                                   uint32_t &cur_out, uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
+                                                   uint32_t Rres, uint32_t cur_in,
+                                                   uint32_t &cur_out, uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8) {
     uint32_t c1 = cur_in, dmin = 0xFFFFFFFFu;
-    pbA = pbB = hit8 = chg8 = zer8 = 0u;
+    pbA = pbB = hit8 = chg8 = 0u;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int c = 8 * g8 + j; // absolute event time == column produced
@@ -136,12 +147,10 @@ __device__ __forceinline__ bool eight_seconds_pass(const uint4 &th, const uint4 
                 if (!(M & 1)) dmin = min(dmin, d[M]);
             }
             const uint32_t nb1 = __builtin_amdgcn_perm(bmh, bml, sel);                          // dbn_sample.m:144
-            asm("v_cmp_ne_u32 vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
-                "v_cmp_eq_u32 vcc, %4, %2\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
-                : "+v"(chg8), "+v"(zer8) : "v"(nb1), "v"(c1), "s"(zbin1) : "vcc");
+            asm("v_cmp_ne_u32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(chg8) : "v"(nb1), "v"(c1) : "vcc");
             c1 = nb1;                                                                           // map back, dbn_sample.m:149
         } else {
-            hit8 += hit8; chg8 += chg8; zer8 += zer8;
+            hit8 += hit8; chg8 += chg8;
         }
         const uint32_t b = (!EDGE || c < T) ? (c1 << (8 * (j & 3))) : 0u;
         if (j < 4) pbA |= b; else pbB |= b;
@@ -155,22 +164,22 @@ template <int M>
 __device__ __attribute__((noinline)) void eight_seconds_exact(uint32_t c0, uint32_t c1r, uint32_t attempt, uint32_t k0, uint32_t k1,
                                                               uint4 th, uint4 rh, uint32_t tvar, uint32_t ivar, int g8, int T,
                                                               const uint32_t *thr_col /* this lane's column in EmgpuPlan::cthr */, int meff,
-                                                              uint32_t bml, uint32_t bmh, uint32_t Rres, uint32_t zbin1, uint32_t cur_in,
-                                                              uint32_t *out /* cur, pbA, pbB, hit8, chg8, zer8 */) {
+                                                              uint32_t bml, uint32_t bmh, uint32_t Rres, uint32_t cur_in,
+                                                              uint32_t *out /* cur, pbA, pbB, hit8, chg8 */) {
     const Rng rng{c0, c1r, attempt, k0, k1};
     const uint4 tl = rng.block(EMGPU_SEC_TRANS_LO, tvar, (uint32_t)g8);
     const uint4 rl = rng.block(EMGPU_SEC_RES_LO, ivar, (uint32_t)g8);
     uint32_t thr[M];
     load_cthr_full<M>(thr, thr_col, meff);
-    uint32_t cur, a, b, h, c, z;
-    eight_seconds_pass<M, true, true>(th, rh, tl, rl, g8, T, thr, bml, bmh, kSelBase, Rres, zbin1, cur_in, cur, a, b, h, c, z);
-    out[0] = cur; out[1] = a; out[2] = b; out[3] = h; out[4] = c; out[5] = z;
+    uint32_t cur, a, b, h, c;
+    eight_seconds_pass<M, true, true>(th, rh, tl, rl, g8, T, thr, bml, bmh, kSelBase, Rres, cur_in, cur, a, b, h, c);
+    out[0] = cur; out[1] = a; out[2] = b; out[3] = h; out[4] = c;
 }
 
 template <int M>
 __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uint32_t ivar, int g8, int T,
                                               const uint32_t *ctab /* the variable's compacted table */, int meff, const uint32_t *col_slot /* LDS: this lane's column */,
-                                              const uint32_t (&thr)[(M + 1) / 2], uint32_t bml, uint32_t bmh, uint32_t selbase, uint32_t Rres, uint32_t zbin1, uint32_t &cur1,
+                                              const uint32_t (&thr)[(M + 1) / 2], uint32_t bml, uint32_t bmh, uint32_t selbase, uint32_t Rres, uint32_t &cur1,
                                               uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
     const uint4 th = rng.block(EMGPU_SEC_TRANS, tvar, (uint32_t)g8);
     const uint4 rh = rng.block(EMGPU_SEC_RES, ivar, (uint32_t)g8);
@@ -183,7 +192,7 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
     const bool edge = 8 * g8 + 7 >= T; // the block runs past the end of the trajectory
     bool redo = edge;
     if (!edge) {
-        const bool amb = eight_seconds_pass<M, false, false>(th, rh, z4, z4, g8, T, thr, bml, bmh, selbase, Rres, zbin1, cur1, cur_out, pbA, pbB, hit8, chg8, zer8);
+        const bool amb = eight_seconds_pass<M, false, false>(th, rh, z4, z4, g8, T, thr, bml, bmh, selbase, Rres, cur1, cur_out, pbA, pbB, hit8, chg8);
         redo = __ballot(amb) != 0ull;
         if (g8 == 0) {
             // Second 0 of a trajectory is the initial state, not a draw (slot 0 is never used,
@@ -191,17 +200,19 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
             // clear its flags (streams are MSB-first: second j is bit 7-j) and re-derive "changed" of second 1.
             const uint32_t nb_1 = (pbA >> 8) & 0xFFu;
             pbA = (pbA & 0xFFFFFF00u) | cur1;
-            hit8 &= 0x7Fu; zer8 &= 0x7Fu;
+            hit8 &= 0x7Fu;
             chg8 = (chg8 & 0x3Fu) | ((nb_1 != cur1) ? 0x40u : 0u);
         }
     }
     if (redo) {
-        uint32_t out[6];
+        uint32_t out[5];
         const uint32_t *thr_col = ctab + (size_t)(*col_slot) * (uint32_t)(meff + 1);
-        eight_seconds_exact<M>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, thr_col, meff, bml, bmh, Rres, zbin1, cur1, out);
-        cur_out = out[0]; pbA = out[1]; pbB = out[2]; hit8 = out[3]; chg8 = out[4]; zer8 = out[5];
+        eight_seconds_exact<M>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, thr_col, meff, bml, bmh, Rres, cur1, out);
+        cur_out = out[0]; pbA = out[1]; pbB = out[2]; hit8 = out[3]; chg8 = out[4];
     }
-    cur1 = cur_out;
+    cur1 = cur_out;                      // still carries the zero-bin flag
+    zer8 = zero_stream(pbA, pbB);        // dediscretize.m:24-25 (the bit of second 0 of a trajectory is never consumed)
+    pbA &= 0x7F7F7F7Fu; pbB &= 0x7F7F7F7Fu;
 }
 
 template <int NI, int M0, int M1, int M2>
@@ -264,13 +275,16 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
             for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)(cur1[q] - 1);
             col[k] = c;
         }
-        load_cthr<M0>(th0, bl0, bh0, P.cthr + P.d_coff[0] + (size_t)col[0] * (uint32_t)(P.d_meff[0] + 1), P.d_meff[0]);
-        load_cthr<M1>(th1, bl1, bh1, P.cthr + P.d_coff[1] + (size_t)col[1] * (uint32_t)(P.d_meff[1] + 1), P.d_meff[1]);
-        load_cthr<M2>(th2, bl2, bh2, P.cthr + P.d_coff[2] + (size_t)col[2] * (uint32_t)(P.d_meff[2] + 1), P.d_meff[2]);
+        load_cthr<M0>(th0, bl0, bh0, P.cthr + P.d_coff[0] + (size_t)col[0] * (uint32_t)(P.d_meff[0] + 1), P.d_meff[0], (uint32_t)P.d_zero[0]);
+        load_cthr<M1>(th1, bl1, bh1, P.cthr + P.d_coff[1] + (size_t)col[1] * (uint32_t)(P.d_meff[1] + 1), P.d_meff[1], (uint32_t)P.d_zero[1]);
+        load_cthr<M2>(th2, bl2, bh2, P.cthr + P.d_coff[2] + (size_t)col[2] * (uint32_t)(P.d_meff[2] + 1), P.d_meff[2], (uint32_t)P.d_zero[2]);
         // the exact pass finds its column again through the lane's spare LDS words
 #pragma unroll
         for (int k = 0; k < 3; k++) reinterpret_cast<uint32_t *>(&W.res[lane * CoopLds<3, LB>::kStride + CoopLds<3, LB>::kSpare])[k] = col[k];
     }
+    // from here on the current bin carries the zero-bin flag like the entries of the byte tables
+#pragma unroll
+    for (int k = 0; k < 3; k++) cur1[k] |= (cur1[k] == (uint32_t)P.d_zero[k]) ? kZeroFlag : 0u;
     const uint32_t iv0 = P.d_ivar[0], iv1 = P.d_ivar[1], iv2 = P.d_ivar[2];
     const uint32_t ivs[3] = {iv0, iv1, iv2};
     uint32_t selbase; // kSelBase held in a VGPR (the first v_addc of every compare chain reads it)
@@ -282,9 +296,9 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
         uint32_t pbA[3], pbB[3], need8[3], kind8[3], fill8[3];
         {
             uint32_t hit8[3], chg8[3], zer8[3];
-            eight_seconds<M0>(rng, P.d_tvar[0], iv0, g8, T, P.cthr + P.d_coff[0], P.d_meff[0], col_slot + 0, th0, bl0, bh0, selbase, F.Rk[0], (uint32_t)P.d_zero[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
-            eight_seconds<M1>(rng, P.d_tvar[1], iv1, g8, T, P.cthr + P.d_coff[1], P.d_meff[1], col_slot + 1, th1, bl1, bh1, selbase, F.Rk[1], (uint32_t)P.d_zero[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
-            eight_seconds<M2>(rng, P.d_tvar[2], iv2, g8, T, P.cthr + P.d_coff[2], P.d_meff[2], col_slot + 2, th2, bl2, bh2, selbase, F.Rk[2], (uint32_t)P.d_zero[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
+            eight_seconds<M0>(rng, P.d_tvar[0], iv0, g8, T, P.cthr + P.d_coff[0], P.d_meff[0], col_slot + 0, th0, bl0, bh0, selbase, F.Rk[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
+            eight_seconds<M1>(rng, P.d_tvar[1], iv1, g8, T, P.cthr + P.d_coff[1], P.d_meff[1], col_slot + 1, th1, bl1, bh1, selbase, F.Rk[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
+            eight_seconds<M2>(rng, P.d_tvar[2], iv2, g8, T, P.cthr + P.d_coff[2], P.d_meff[2], col_slot + 2, th2, bl2, bh2, selbase, F.Rk[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
 #pragma unroll
             for (int k = 0; k < 3; k++) {      // the streams stay MSB-first: bit (7-j) <-> second j
                 need8[k] = (hit8[k] | chg8[k]) & ~zer8[k];   // a dediscretize draw is due (dediscretize.m:24-39)

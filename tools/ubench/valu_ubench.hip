@@ -38,6 +38,12 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t a0, uint32_t b0
 #define PAIRFILL(n) asm volatile("v_sub_co_u32 %0, vcc, %1, %2\n\tv_xor_b32 %4, %4, %1\n\tv_xor_b32 %5, %5, %2\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "=v"(x##n), "+v"(cnt), "+v"(c) : "v"(c), "v"(d), "v"(e1), "v"(e2) : "vcc");
 #define NOPONLY(n) asm volatile("s_nop 1");
 #define XORNOP(n) asm volatile("v_xor_b32 %0, %0, %1\n\ts_nop 1" : "+v"(x##n) : "v"(c));
+#define MULLO(n) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x##n) : "v"(c));
+#define MULU24(n) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x##n) : "v"(c));
+#define MADU24(n) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x##n) : "v"(c), "v"(d));
+            if (KIND == 21) { REP8(MULLO) }
+            if (KIND == 22) { REP8(MULU24) }
+            if (KIND == 23) { REP8(MADU24) }
             if (KIND == 17) { REP8(PAIRNONOP) }
             if (KIND == 19) { REP8(NOPONLY) }
             if (KIND == 20) { REP8(XORNOP) }
@@ -101,6 +107,9 @@ int main() {
     run<10>("v_sub_co_sdwa + s_nop 1 + v_addc", 2);
     run<14>("v_cmp_ne + s_nop 1 + v_addc", 2);
     run<11>("v_perm_b32", 1);
+    run<21>("v_mul_lo_u32", 1);
+    run<22>("v_mul_u32_u24 (VOP2)", 1);
+    run<23>("v_mad_u32_u24", 1);
     run<15>("v_min3_u32", 1);
     run<16>("v_min_u32 (VOP2)", 1);
     run<12>("v_and_b32 literal (VOP2)", 1);
