@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- trajectory samples/sec of the 240-s uncorrelated DBN sampler on N MI355X.
+"""bench.py -- throughput of the MI355X-native encounter sampler on N GPUs of one node.
 
-Workload (BASELINE.json configs[1]): uncor_1200code_v2p1 initial + transition DBN,
-10 M trajectories x 240 s per GPU, REFERENCE_AUTO transition semantics, compact dense trace
-output (5*n_i + 5*T*n_d = 3635 B / trajectory) resident in HBM.  One "step" = one pass of the hot
-path over one batch of 10 M fresh trajectories (new global indices every step).  One process per
-GPU; trajectories are independent, so ranks shard the global index range with no collective
-(torch.distributed is used only for the barrier and the max-over-ranks clock).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config uncor|cor|mixed|terminal]
+
+--config uncor (default; BASELINE.json configs[1], the configuration the headline metric is quoted
+on): uncor_1200code_v2p1 initial + transition DBN, 10 M trajectories x 240 s per GPU,
+REFERENCE_AUTO transition semantics, compact dense trace (5*n_i + 5*T*n_d = 3635 B / trajectory)
+resident in HBM.  cor / mixed / terminal are BASELINE.json configs[2..4] (see CONFIGS below).
+One "step" = one pass of the hot path over one batch of fresh units (new global indices every step).
+
+N > 1: one process per GPU.  Under a launcher (torchrun: RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) this process is one rank; WITHOUT one, `--gpus N` makes this process the launcher: it
+starts N rank processes itself -- before anything here touches a GPU -- and relays rank 0's line.
+It never runs fewer ranks than asked: a mismatch between --gpus and the ranks that ran is an error
+(exit code 3), not a quietly smaller benchmark.  Units are independent, so ranks shard the global
+index range with no collective (torch.distributed is only the barrier and the max-over-ranks clock).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     -- algorithmic bytes / average kernel launch duration (HIP events on the launch
-                  stream) against the 8 TB/s HBM3E peak,
+  roofline     -- algorithmic bytes / average step duration on the launch stream (HIP events)
+                  against the 8 TB/s HBM3E peak,
   cpu_baseline -- the CPU oracle (oracle/em_oracle.c, "port") timed on this host, rank 0, N=1 only.
 MATLAB cannot be timed: it is not installed here or on the GPU box.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -24,133 +34,407 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MODEL = "uncor_1200code_v2p1"
-N_PER_GPU = 10_000_000
 DEFAULT_T = 240
-SEED = 0x5EED0002
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+V1P2 = ["uncor_1200exclude_fwme_v1p2", "uncor_1200exclude_fwse_v1p2", "uncor_1200exclude_rotorcraft_v1p2",
+        "uncor_1200only_fwme_v1p2", "uncor_1200only_fwse_v1p2", "uncor_1200only_rotorcraft_v1p2"]
+
+# BASELINE.json configs[1..4] as concrete synthetic inputs
+CONFIGS = {
+    "uncor": dict(models=["uncor_1200code_v2p1"], n=10_000_000, seed=0x5EED0002, unit="trajectories/s",
+                  metric="trajectory samples/sec (240 s uncor DBN)",
+                  workload="%(model)s initial+transition DBN, %(n)d trajectories x %(T)d s per GPU"),
+    "cor": dict(models=["cor_v1"], n=10_000_000, seed=0x5EED0003, unit="encounters/s",
+                metric="encounter samples/sec (240 s correlated two-aircraft DBN)",
+                workload="%(model)s correlated two-aircraft joint network (stand-in for cor_v2p1, absent from the reference mount), "
+                         "%(n)d encounters x %(T)d s per GPU"),
+    "mixed": dict(models=V1P2, n=6_250_000, seed=0x5EED0004, unit="trajectories/s",
+                  metric="trajectory samples/sec (240 s uncor DBN, mixed batch over the six uncor_*_v1p2 files)",
+                  workload="mixed batch over all uncor_*_v1p2 model files, model = contiguous block of the global index range, "
+                           "%(n)d trajectories x %(T)d s per GPU (50 M on 8 GPUs)"),
+    "terminal": dict(models=[], n=2_000_000, seed=0x5EED0005, unit="encounters/s",
+                     metric="terminal encounters/sec (geometry draw + forward/backward propagation of both aircraft)",
+                     workload="CorTerminalModel: terminal_v3_radar geometry network + 10 synthetic trajectory models (the trained "
+                              "files are absent from the reference mount), %(n)d encounters x 4 tracks x <=121 s per GPU"),
+}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=5, help="untimed steps (the first launches run while the GPU clocks still ramp up)")
-    ap.add_argument("--n", type=int, default=N_PER_GPU, help="trajectories per GPU per step")
-    ap.add_argument("--model", default=MODEL)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="uncor")
+    ap.add_argument("--n", type=int, default=0, help="units per GPU per step (default: the config's)")
+    ap.add_argument("--model", default=None, help="uncor / cor: another packed model (or a reference-format .txt path)")
     ap.add_argument("--seconds", type=int, default=DEFAULT_T, help="trajectory length (the headline metric is quoted at 240)")
     ap.add_argument("--per-step", action="store_true", help="PER_STEP transition semantics instead of REFERENCE_AUTO")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="minimum trajectories timed on the CPU oracle (scaled up to ~15 s)")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="minimum units timed on the CPU oracle (scaled up to ~10 s)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST ONLY: allow more ranks than GPUs (ranks share devices, gloo barrier); the line says so")
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+# ------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a launcher's environment
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    """Start args.gpus rank processes of this script and relay rank 0's JSON line.  Nothing in this
+    process touches a GPU (torch.cuda.device_count() does not initialise one on this image)."""
     import torch
-    import torch.distributed as dist
-    from em_model_manned_bayes_amd import em_io, native, sharding, _lib as L
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.oversubscribe:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        return max(abs(r) for r in rcs) or 1
+    if line is None or json.loads(line).get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: asked for %d GPUs but the line says %s\n" % (args.gpus, line))
+        return 3
+    print(line, flush=True)
+    return 0
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
 
-    tmp = tempfile.mkdtemp(prefix="emgpu_bench_")
-    path = em_io.materialize_model(args.model, tmp)      # packed model -> reference-format .txt
-    model = native.NativeModel.load_txt(path)            # the drop-in loader (em_read.m)
+# ------------------------------------------------------------------------------------------------
+# plumbing: device memory, streams, events and the barrier (PyTorch-ROCm; not the product)
+# ------------------------------------------------------------------------------------------------
+class TorchRocm:
+    def __init__(self, rank, local_rank, world, oversubscribe=False):
+        import torch
+        import torch.distributed as dist
+        from em_model_manned_bayes_amd import native
+        self.torch, self.dist, self.native = torch, dist, native
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        have = torch.cuda.device_count()
+        self.shared = world > have
+        if self.shared and not oversubscribe:
+            raise SystemExit("bench.py: %d ranks but %d GPU(s)" % (world, have))
+        self.rank, self.world = rank, world
+        self.dev = torch.device("cuda", local_rank % have)
+        torch.cuda.set_device(self.dev)
+        if world > 1:
+            if self.shared:   # RCCL refuses two ranks on one device: the test-only path uses gloo for the barrier
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=self.dev)
+        self.stream = torch.cuda.current_stream(self.dev)
+
+    def context(self):
+        return self.native.Context(self.dev.index, stream=self.stream.cuda_stream)
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=getattr(self.torch, dtype), device=self.dev)
+
+    def from_numpy(self, a):
+        return self.torch.from_numpy(a).to(self.dev)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def event(self):
+        return self.torch.cuda.Event(enable_timing=True)
+
+    def record(self, ev):
+        ev.record(self.stream)
+
+    def elapsed_ms(self, a, b):
+        return a.elapsed_time(b)
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.shared else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def _materialize(name, tmp):
+    from em_model_manned_bayes_amd import em_io
+    return name if os.path.isfile(name) else em_io.materialize_model(name, tmp)
+
+
+def _label_indices(model):
+    from em_model_manned_bayes_amd import _lib as L
     labels = model.get_labels(L.F_LABELS_INITIAL)
 
     def lab(name):
         q = '"%s"' % name
         return labels.index(q) + 1 if q in labels else 0
+    return dict(idx_L=lab("L"), idx_v=lab("v"), idx_dh=lab("\\dot h"))
 
-    T = args.seconds
-    n, ni, nd = args.n, model.n_initial, model.n_dyn
-    G4 = (T + 3) // 4
-    init_bin = torch.empty((ni, n), dtype=torch.uint8, device=dev)
-    init_val = torch.empty((ni, n), dtype=torch.float32, device=dev)
-    dyn_bin = torch.empty((G4, nd, n), dtype=torch.int32, device=dev)
-    dyn_val = torch.empty((G4, nd, n, 4), dtype=torch.float32, device=dev)
-    bytes_per_traj = 5 * ni + 5 * T * nd
 
-    stream = torch.cuda.current_stream(dev)
-    ctx = native.Context(local_rank, stream=stream.cuda_stream)
-    mode = L.TRANSITION_PER_STEP if args.per_step else L.TRANSITION_REFERENCE_AUTO
+class DbnWorkload:
+    """uncor / cor / mixed: emgpu_sample_dbn_device (one model) or emgpu_sample_dbn_blocks_device (several
+    models filling one shared trace), dense output."""
 
-    def step(k):
-        first = sharding.step_first_index(k, rank, world, n)  # fresh global indices every step, disjoint across ranks
-        p, _ = native.make_params(n, T, SEED, first_index=first, transition_mode=mode,
-                                  idx_L=lab("L"), idx_v=lab("v"), idx_dh=lab("\\dot h"))
-        native.sample_dbn_device(ctx, model, p, init_bin=init_bin.data_ptr(), init_val=init_val.data_ptr(),
-                                 dyn_bin=dyn_bin.data_ptr(), dyn_val=dyn_val.data_ptr())
+    def __init__(self, args, cfg, pl, rank, world):
+        from em_model_manned_bayes_amd import _lib as L
+        native = pl.native
+        self.pl, self.native, self.rank, self.world, self.cfg = pl, native, rank, world, cfg
+        self.tmp = tempfile.mkdtemp(prefix="emgpu_bench_")
+        names = [args.model] if args.model else cfg["models"]
+        self.paths = [_materialize(nm, self.tmp) for nm in names]
+        self.names = [os.path.splitext(os.path.basename(nm))[0] for nm in names]
+        self.models = [native.NativeModel.load_txt(p) for p in self.paths]   # the drop-in loader (em_read.m)
+        self.idx = [_label_indices(m) for m in self.models]
+        self.T, self.n, self.seed = args.seconds, args.n or cfg["n"], cfg["seed"]
+        m0 = self.models[0]
+        self.ni, self.nd = m0.n_initial, m0.n_dyn
+        G4 = (self.T + 3) // 4
+        n = self.n
+        self.init_bin = pl.empty((self.ni, n), "uint8")
+        self.init_val = pl.empty((self.ni, n), "float32")
+        self.dyn_bin = pl.empty((G4, self.nd, n), "int32")
+        self.dyn_val = pl.empty((G4, self.nd, n, 4), "float32")
+        self.bytes_per_unit = 5 * self.ni + 5 * self.T * self.nd
+        self.mode = L.TRANSITION_PER_STEP if args.per_step else L.TRANSITION_REFERENCE_AUTO
+        self.per_step = args.per_step
+        self.ctx = pl.context()
+        self.launches_per_step = 1
+        self.kernels = []
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    def ptrs(self):
+        return dict(init_bin=self.init_bin.data_ptr(), init_val=self.init_val.data_ptr(),
+                    dyn_bin=self.dyn_bin.data_ptr(), dyn_val=self.dyn_val.data_ptr())
 
+    def step(self, k):
+        from em_model_manned_bayes_amd import sharding
+        native, n = self.native, self.n
+        # fresh global indices every step, disjoint across ranks: step k covers [k*world*n, (k+1)*world*n)
+        first = sharding.step_first_index(k, self.rank, self.world, n)
+        if len(self.models) == 1:
+            p, _ = native.make_params(n, self.T, self.seed, first_index=first, transition_mode=self.mode, **self.idx[0])
+            native.sample_dbn_device(self.ctx, self.models[0], p, **self.ptrs())
+            return
+        # mixed batch: model m owns the m-th contiguous block of the step's global range; this rank's shard of that
+        # range intersects one or two blocks -> one launch each into the rank's ONE trace
+        total = n * self.world
+        base = k * total
+        blocks = [(m, base + f, c) for (m, f, c) in native.mixed_blocks(total, len(self.models), first - base, first - base + n)]
+        self.launches_per_step = max(self.launches_per_step, len(blocks))
+        p, _ = native.make_params(n, self.T, self.seed, first_index=first, transition_mode=self.mode, **self.idx[0])
+        native.sample_dbn_blocks_device(self.ctx, self.models, p, blocks, **self.ptrs())
+
+    def sync(self):
+        self.ctx.sync()  # surfaces deferred rejection-cap errors
+
+    def kernel_name(self):
+        return self.ctx.last_kernel()
+
+    def check(self):
+        # size-independent sanity on the full-size output: every bin within 1..r, no NaN
+        t = self.pl.torch if hasattr(self.pl, "torch") else None
+        if t is not None:
+            assert int(self.init_bin.min()) >= 1 and bool(t.isfinite(self.dyn_val[:, :, : min(self.n, 100000)]).all())
+            assert int((self.dyn_bin[0] & 0xFF).min()) >= 1
+
+    def config(self):
+        return {"workload": self.cfg["workload"] % dict(model=self.names[0], n=self.n, T=self.T),
+                "transition_mode": "PER_STEP" if self.per_step else "REFERENCE_AUTO",
+                "output": "dense trace of the DYNAMIC variables only (u8 bin + f32 value per variable-second) + initial "
+                          "state (u8 + f32 per variable): %d B/unit; re-draws of static variables appear only in the "
+                          "event-list output" % self.bytes_per_unit,
+                "values": "f32 at the boundary (f64 arithmetic inside, rounded on store); uniforms are 32-bit",
+                "models": self.names, "launches_per_step": self.launches_per_step,
+                "sharding": "global sample index, no collective"}
+
+    def cpu_baseline(self, n_cpu):
+        """The CPU oracle (a faithful scalar port of the reference algorithm) on the same workload,
+        bounded sample, one thread and all threads.  Reported baseline, not the target."""
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+        om = O.OracleModel(O.parse_model_txt(self.paths[0]))
+        T, seed = self.T, self.seed
+        t0 = time.perf_counter()
+        O.uncor_sample(om, 2000, T, seed, mode=O.RNG_PHILOX, want_events=False, want_dense=True)  # warm + calibrate
+        rate = 2000 / (time.perf_counter() - t0)
+        n_cpu = int(min(max(n_cpu, rate * 10.0), 2_000_000))  # about 10 s of CPU work per leg
+        t0 = time.perf_counter()
+        O.uncor_sample(om, n_cpu, T, seed, mode=O.RNG_PHILOX, per_step=self.per_step, want_events=False, want_dense=True)
+        dt1 = time.perf_counter() - t0
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        n_mt = int(min(n_cpu * cores, 1_000_000))  # dense f64 outputs: 6.5 GB of host memory at 1 M
+        t0 = time.perf_counter()
+        O.uncor_sample_mt(om, n_mt, T, seed, cores, per_step=self.per_step)
+        dtm = time.perf_counter() - t0
+        return {"value": n_mt / dtm, "unit": self.cfg["unit"], "cores": cores, "kind": "port",
+                "single_thread_value": n_cpu / dt1,
+                "sample": "oracle/em_oracle.c (scalar port of the reference algorithm), Philox mode, model %s: %d units x %d s "
+                          "on %d threads in %.1f s; 1 thread: %d units in %.1f s; MATLAB itself is not installed and cannot be timed"
+                          % (self.names[0], n_mt, T, cores, dtm, n_cpu, dt1)}
+
+
+class TerminalWorkload:
+    """configs[4]: geometry draw (k_bn, box + speed rejection) + PropagateTrajectory of both aircraft in both
+    directions (k_terminal_propagate) on synthetic trajectory tables, device-resident."""
+
+    def __init__(self, args, cfg, pl, rank, world):
+        import numpy as np
+        import ctypes as C
+        import em_model_manned_bayes_amd as E
+        from em_model_manned_bayes_amd import synthetic, _lib as L
+        self.np, self.C, self.L = np, C, L
+        self.pl, self.rank, self.world, self.cfg = pl, rank, world, cfg
+        self.n, self.seed = args.n or cfg["n"], cfg["seed"]
+        self.dir = synthetic.write_terminal_directory(tempfile.mkdtemp(prefix="emgpu_bench_term_"))
+        self.ctx = pl.context()
+        self.t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=self.dir)
+        # the geometry samples the propagation starts from: drawn once on the GPU (k_bn), tiled to n encounters
+        m = 8192
+        _, samples = self.t.sample(m, seed=self.seed, ctx=self.ctx)
+        g, mo = self.t._geo_rows(samples)
+        reps = (self.n + m - 1) // m
+        self.geo_h, self.mo_h = g, mo
+        self.geo = pl.from_numpy(np.tile(g, (reps, 1))[: self.n].copy())
+        self.mof = pl.from_numpy(np.tile(mo, (reps, 1))[: self.n].reshape(-1).astype(np.int32))
+        self.cap = 123
+        self.out = pl.empty((6, self.cap, 4 * self.n), "float32")
+        self.rows = pl.empty((4 * self.n,), "int32")
+        self.handles = (C.c_void_p * 10)(*[x.native._h for x in self.t._traj])
+        self.bytes_per_unit = 7335   # SURVEY.md 8d: 75 B geometry + 2 x 2 x <=121 steps x 3 variables x 5 B
+        self.launches_per_step = 1
+
+    def step(self, k):
+        from em_model_manned_bayes_amd import sharding
+        C, L = self.C, self.L
+        p = L.TermParams()
+        p.seed, p.first_index, p.n, p.tmax_s = self.seed, sharding.step_first_index(k, self.rank, self.world, self.n), self.n, 120.0
+        p.max_resample, p.cap = 100000, self.cap
+        for i, v in enumerate(self.t._dyn_rows().reshape(-1)):
+            p.dyn_limits[i] = float(v)
+        L.check(L.lib().emgpu_propagate_terminal_device(self.ctx._h, self.handles, 10, C.byref(p), C.c_void_p(self.geo.data_ptr()),
+                                                        C.c_void_p(self.mof.data_ptr()), C.c_void_p(self.out.data_ptr()),
+                                                        C.c_void_p(self.rows.data_ptr())))
+
+    def sync(self):
+        self.ctx.sync()
+
+    def kernel_name(self):
+        return self.ctx.last_kernel()
+
+    def check(self):
+        # rows < 0: a track whose inner re-draw loop hit max_resample (the reference would spin on it, createEncounter.m:218-262)
+        self.failed = int((self.rows < 0).sum())
+        assert int(self.rows.max()) <= self.cap and int(self.rows.max()) >= 2 and self.failed <= 0.01 * 4 * self.n, (int(self.rows.min()), self.failed)
+
+    def config(self):
+        return {"workload": self.cfg["workload"] % dict(n=self.n), "output": "tracks f32 [6][%d][4n] + rows; <=%d B/encounter algorithmic" % (self.cap, self.bytes_per_unit),
+                "launches_per_step": 1, "sharding": "global encounter index, no collective",
+                "track_seconds_per_encounter": float(self.rows.clamp(min=0).sum().item()) / self.n,
+                "tracks_over_the_redraw_cap": getattr(self, "failed", None)}
+
+    def cpu_baseline(self, n_cpu):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import glob
+        import oracle as O
+        files = [glob.glob(os.path.join(self.dir, "*_" + s + ".txt"))[0] for s in
+                 ["ownship_landing_model", "ownship_landing_model_reverse", "ownship_takeoff_model", "ownship_takeoff_model_reverse",
+                  "intruder_landing_model", "intruder_landing_model_reverse", "intruder_takeoff_model", "intruder_landing_model_reverse",
+                  "intruder_transit_model", "intruder_landing_model_reverse"]]
+        oms = []
+        for f in files:
+            pp = O.parse_model_txt(f)
+            oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
+        n_cpu = 2000
+        t0 = time.perf_counter()
+        O.propagate(oms, self.mo_h[:n_cpu].reshape(-1), self.geo_h[:n_cpu], self.seed, self.t._dyn_rows())
+        dt = time.perf_counter() - t0
+        return {"value": n_cpu / dt, "unit": self.cfg["unit"], "cores": 1, "kind": "port",
+                "sample": "oracle/em_oracle.c em_propagate_batch (scalar port of createEncounter.m:93-329), %d encounters in %.1f s on 1 thread; "
+                          "MATLAB itself is not installed and cannot be timed" % (n_cpu, dt)}
+
+
+def make_workload(args, pl, rank, world):
+    cfg = CONFIGS[args.config]
+    return (TerminalWorkload if args.config == "terminal" else DbnWorkload)(args, cfg, pl, rank, world)
+
+
+# ------------------------------------------------------------------------------------------------
+def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
+    """One rank of the benchmark.  `pl` (plumbing) is TorchRocm unless a test injects its own."""
+    pl = pl or TorchRocm(rank, local_rank, world, args.oversubscribe)
+    w = make_workload(args, pl, rank, world)
     for k in range(args.warmup):
-        step(k)
-    ctx.sync()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        w.step(k)
+    w.sync()
+    pl.barrier()
+    ev = [(pl.event(), pl.event()) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record(stream)
-        step(args.warmup + k)
-        ev[k][1].record(stream)
-    barrier()
+        pl.record(ev[k][0])
+        w.step(args.warmup + k)
+        pl.record(ev[k][1])
+    pl.barrier()
     t1 = time.perf_counter()
-    ctx.sync()  # surfaces deferred rejection-cap errors
-    elapsed = t1 - t0
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kernel_name = ctx.last_kernel()
-
-    # size-independent sanity on the full-size output: every bin within 1..r, no NaN
-    assert int(init_bin.min()) >= 1 and bool(torch.isfinite(dyn_val[:, :, : min(n, 100000)]).all())
-
+    w.sync()
+    elapsed = pl.max_over_ranks(t1 - t0)
+    step_ms = [pl.elapsed_ms(a, b) for a, b in ev]
+    w.check()
+    line = None
     if rank == 0:
-        total = n * world * args.steps
-        value = total / elapsed
-        avg_kernel_s = (sum(kern_ms) / len(kern_ms)) * 1e-3
-        achieved = bytes_per_traj * n / avg_kernel_s / 1e9
-        out = {
-            "metric": "trajectory samples/sec (240 s uncor DBN)",
-            "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%s initial+transition DBN, %d trajectories x %d s per GPU" % (args.model, n, T),
-                       "transition_mode": "PER_STEP" if args.per_step else "REFERENCE_AUTO",
-                       "output": "dense trace u8 bin + f32 value, %d B/trajectory" % bytes_per_traj,
-                       "kernel": kernel_name, "sharding": "global sample index, no collective"},
+        from em_model_manned_bayes_amd import _lib as L
+        cfg = CONFIGS[args.config]
+        total = w.n * world * args.steps
+        avg_step_s = (sum(step_ms) / len(step_ms)) * 1e-3
+        alg = w.bytes_per_unit * w.n
+        achieved = alg / avg_step_s / 1e9
+        kernel = w.kernel_name()
+        line = {
+            "metric": cfg["metric"], "value": total / elapsed, "unit": cfg["unit"], "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 draws and compares; f64 dediscretize; f32 values stored", "data": "synthetic",
+            "config": dict(w.config(), kernel=kernel, lib=L.lib().emgpu_version().decode()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": kernel_name, "avg_launch_ms": avg_kernel_s * 1e3,
-                         "algorithmic_bytes_per_launch": bytes_per_traj * n},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+                         "avg_launch_ms": avg_step_s * 1e3 / w.launches_per_step, "launches_per_step": w.launches_per_step,
+                         "avg_step_ms": avg_step_s * 1e3, "algorithmic_bytes_per_launch": alg // w.launches_per_step,
+                         "algorithmic_bytes_per_unit": w.bytes_per_unit},
         }
-        out["roofline"].update(recorded_traffic(kernel_name, bytes_per_traj * n))
+        if getattr(pl, "shared", False):
+            line["oversubscribed"] = True
+        line["roofline"].update(recorded_traffic(kernel, alg // w.launches_per_step, line["config"]["lib"]))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(path, args.cpu_sample, args.per_step, T)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+            line["cpu_baseline"] = w.cpu_baseline(args.cpu_sample)
+        out.write(json.dumps(line) + "\n")
+        out.flush()
+    pl.finish()
+    return line
 
 
-def recorded_traffic(kernel_name, algorithmic_bytes):
+def recorded_traffic(kernel_name, algorithmic_bytes, lib_version):
     """roofline.traffic: HBM bytes per launch from the PMC passes (WRITE_SIZE + 2 x FETCH_SIZE, the
-    gfx950 correction of MI355X_MICROARCH.md) of the newest committed profile of the SAME kernel and
-    launch size (profiles/*_summary.json, produced by tools/profile_bench.sh: counters need their
-    own rocprofv3 passes and cannot be read from inside this process).  null if none matches."""
+    gfx950 correction of MI355X_MICROARCH.md) of a committed profile of the SAME kernel, launch size
+    AND library build (profiles/*_summary.json, produced by tools/profile_bench.sh: counters need
+    their own rocprofv3 passes and cannot be read from inside this process).  The library carries a
+    hash of its sources (emgpu_version()); a summary recorded from other sources does not count:
+    null rather than a stale figure."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
@@ -159,7 +443,9 @@ def recorded_traffic(kernel_name, algorithmic_bytes):
         except Exception:
             continue
         line = s.get("bench_line", {})
-        same = kernel_name.replace(" ", "") in s.get("kernel", "").replace(" ", "") and line.get("roofline", {}).get("algorithmic_bytes_per_launch") == algorithmic_bytes
+        same = (kernel_name.replace(" ", "") in s.get("kernel", "").replace(" ", "")
+                and line.get("roofline", {}).get("algorithmic_bytes_per_launch") == algorithmic_bytes
+                and line.get("config", {}).get("lib") == lib_version)
         if same and "hbm_traffic_bytes_per_launch" in s:
             best = (s["hbm_traffic_bytes_per_launch"], os.path.basename(f))
     if best is None:
@@ -167,30 +453,22 @@ def recorded_traffic(kernel_name, algorithmic_bytes):
     return {"traffic": best[0], "traffic_source": "profiles/" + best[1]}
 
 
-def cpu_baseline(model_txt, n_cpu, per_step, T):
-    """The CPU oracle (a faithful scalar port of the reference algorithm) on the same workload,
-    bounded sample, one thread.  Reported baseline, not the target."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O
-    om = O.OracleModel(O.parse_model_txt(model_txt))
-    t0 = time.perf_counter()
-    O.uncor_sample(om, 2000, T, SEED, mode=O.RNG_PHILOX, want_events=False, want_dense=True)  # warm + calibrate
-    rate = 2000 / (time.perf_counter() - t0)
-    n_cpu = int(min(max(n_cpu, rate * 10.0), 2_000_000))  # about 10 s of CPU work per leg
-    t0 = time.perf_counter()
-    O.uncor_sample(om, n_cpu, T, SEED, mode=O.RNG_PHILOX, per_step=per_step, want_events=False, want_dense=True)
-    dt1 = time.perf_counter() - t0
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n_mt = int(min(n_cpu * cores, 1_000_000))  # dense f64 outputs: 6.5 GB of host memory at 1 M
-    t0 = time.perf_counter()
-    O.uncor_sample_mt(om, n_mt, T, SEED, cores, per_step=per_step)
-    dtm = time.perf_counter() - t0
-    return {"value": n_mt / dtm, "unit": "trajectories/s", "cores": cores, "kind": "port",
-            "single_thread_value": n_cpu / dt1,
-            "sample": "oracle/em_oracle.c (scalar port of the reference algorithm), Philox mode, same workload: %d trajectories x %d s "
-                      "on %d threads in %.1f s; 1 thread: %d trajectories in %.1f s; MATLAB itself is not installed and cannot be timed"
-                      % (n_mt, T, cores, dtm, n_cpu, dt1)}
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        return 3
+    run_rank(args, rank, local_rank, world)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -66,7 +66,12 @@ class SampleParams(C.Structure):
 
 class SampleOut(C.Structure):
     _fields_ = [("init_bin", C.c_void_p), ("init_val", C.c_void_p), ("dyn_bin", C.c_void_p), ("dyn_val", C.c_void_p),
-                ("ev_count", C.c_void_p), ("events", C.c_void_p), ("attempts", C.c_void_p)]
+                ("ev_count", C.c_void_p), ("events", C.c_void_p), ("attempts", C.c_void_p),
+                ("ld", C.c_int64), ("col_offset", C.c_int64)]
+
+
+class Block(C.Structure):         # emgpu_block
+    _fields_ = [("model", C.c_int32), ("_pad", C.c_int32), ("first_index", C.c_uint64), ("n", C.c_int64)]
 
 
 class TrackParams(C.Structure):   # emgpu_track_params
@@ -98,6 +103,8 @@ SYMBOLS = [
     "emgpu_debug_column_thresholds", "emgpu_debug_bernoulli_threshold", "emgpu_debug_dynamic_column", "emgpu_debug_padded_column",
     "emgpu_propagate_terminal_device", "emgpu_propagate_terminal_host",
     "emgpu_sample2track_device", "emgpu_sample2track_host",
+    "emgpu_model_set_zero_bins", "emgpu_shard_range", "emgpu_device_count", "emgpu_mixed_blocks",
+    "emgpu_sample_dbn_blocks_device", "emgpu_sample_dbn_multi_host", "emgpu_sample_dbn_multi_device",
 ]
 
 _lib = None
@@ -133,6 +140,15 @@ def lib():
     L.emgpu_model_set_prior.argtypes = [C.c_void_p, C.c_int32, C.c_double]
     L.emgpu_model_set_transition_stay_prior.argtypes = [C.c_void_p, C.c_double]
     L.emgpu_model_set_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.emgpu_model_set_zero_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.emgpu_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.emgpu_device_count.argtypes = [C.POINTER(C.c_int32)]
+    L.emgpu_mixed_blocks.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.POINTER(Block)]
+    L.emgpu_mixed_blocks.restype = C.c_int32
+    L.emgpu_sample_dbn_blocks_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(SampleParams), C.POINTER(Block), C.c_int32,
+                                                 C.POINTER(SampleOut)]
+    L.emgpu_sample_dbn_multi_host.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(SampleParams), C.POINTER(SampleOut)]
+    L.emgpu_sample_dbn_multi_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(SampleParams), C.POINTER(SampleOut)]
     L.emgpu_ctx_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
     L.emgpu_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.emgpu_ctx_sync.argtypes = [C.c_void_p]

@@ -7,7 +7,9 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/emgpu.h"
@@ -53,6 +55,7 @@ struct Uploaded {
 } // namespace
 
 struct emgpu_ctx {
+    std::recursive_mutex mu; // serialises calls on this ctx (the *_host entry points re-enter through *_device)
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
@@ -67,6 +70,8 @@ struct emgpu_ctx {
     size_t d_thr_base_cap = 0;
 };
 
+#define CTX_LOCK(ctx) std::lock_guard<std::recursive_mutex> _ctx_lock((ctx)->mu)
+
 template <typename T, typename V>
 static int64_t copy_out(const V &v, T *out, int64_t cap) {
     if (out) {
@@ -79,7 +84,10 @@ static int64_t copy_out(const V &v, T *out, int64_t cap) {
 extern "C" {
 
 const char *emgpu_last_error(void) { return g_err.c_str(); }
-const char *emgpu_version(void) { return "emgpu 0.1 (gfx950)"; }
+#ifndef EMGPU_SRC_HASH
+#define EMGPU_SRC_HASH "unhashed"
+#endif
+const char *emgpu_version(void) { return "emgpu 0.2 (gfx950) src:" EMGPU_SRC_HASH; }
 
 int emgpu_model_load_txt(const char *path, const int32_t *idx_zero_boundaries, int32_t n_idx,
                          int32_t is_overwrite_zero_boundaries, emgpu_model **out) {
@@ -106,6 +114,27 @@ static std::vector<std::string> split_nl(const char *s) {
 int emgpu_model_from_arrays(const emgpu_model_desc *d, emgpu_model **out) {
     EMGPU_TRY
     if (!d || !out || d->n_initial <= 0 || !d->G_initial || !d->r_initial || !d->N_initial) return fail(EMGPU_ERR_ARG, "null/empty argument");
+    if (d->n_initial > EMGPU_MAX_NI) return fail(EMGPU_ERR_UNSUPPORTED, "more initial variables than EMGPU_MAX_NI");
+    for (int i = 0; i < d->n_initial; i++)
+        if (d->r_initial[i] < 1 || d->r_initial[i] > EMGPU_MAX_R) return fail(EMGPU_ERR_ARG, "r_initial entry outside 1..EMGPU_MAX_R");
+    if (d->n_transition > 0) {
+        if (d->n_transition < d->n_initial || !d->r_transition) return fail(EMGPU_ERR_ARG, "transition arrays missing");
+        for (int i = 0; i < d->n_transition; i++)
+            if (d->r_transition[i] < 1 || d->r_transition[i] > EMGPU_MAX_R) return fail(EMGPU_ERR_ARG, "r_transition entry outside 1..EMGPU_MAX_R");
+        if (d->n_dyn < 0 || d->n_dyn > d->n_transition - d->n_initial || (d->n_dyn > 0 && !d->temporal_map))
+            return fail(EMGPU_ERR_ARG, "n_dyn must be within 0..n_transition-n_initial (with a temporal_map)");
+        for (int k = 0; k < d->n_dyn; k++)
+            if (d->temporal_map[2 * k] < 1 || d->temporal_map[2 * k] > d->n_initial || d->temporal_map[2 * k + 1] <= d->n_initial ||
+                d->temporal_map[2 * k + 1] > d->n_transition)
+                return fail(EMGPU_ERR_ARG, "temporal_map row outside (1..n_initial, n_initial+1..n_transition)");
+    }
+    if (d->boundaries && d->bnd_len)
+        for (int i = 0; i < d->n_initial; i++)
+            if (d->bnd_len[i] != 0 && d->bnd_len[i] != d->r_initial[i] + 1)
+                return fail(EMGPU_ERR_ARG, "bnd_len[i] must be 0 ('*') or r_initial[i] + 1");
+    if (d->zero_bins)
+        for (int i = 0; i < d->n_initial; i++)
+            if (d->zero_bins[i] < 0 || d->zero_bins[i] > d->r_initial[i]) return fail(EMGPU_ERR_ARG, "zero_bins entry outside 0..r");
     std::unique_ptr<emgpu_model> h(new emgpu_model());
     Model &m = h->m;
     const int ni = d->n_initial, nt = d->n_transition;
@@ -232,7 +261,7 @@ int64_t emgpu_model_get_text(const emgpu_model *h, int32_t field, char *out, int
 
 int emgpu_model_set_f64(emgpu_model *h, int32_t field, int32_t node, const double *v, int64_t n) {
     EMGPU_TRY
-    if (!h || !v) return fail(EMGPU_ERR_ARG, "null argument");
+    if (!h || (!v && n != 0) || n < 0) return fail(EMGPU_ERR_ARG, "null argument or negative length");
     Model &m = h->m;
     auto assign_same = [&](std::vector<std::vector<double>> &dst) {
         if (node < 1 || (size_t)node > dst.size()) throw Error(EMGPU_ERR_ARG, "node out of range");
@@ -246,6 +275,10 @@ int emgpu_model_set_f64(emgpu_model *h, int32_t field, int32_t node, const doubl
     case EMGPU_F_ALPHA_TRANSITION: assign_same(m.A_transition); break;
     case EMGPU_F_BOUNDARIES:
         if (node < 1 || node > m.n_initial) throw Error(EMGPU_ERR_ARG, "node out of range");
+        // numel(boundaries) == r + 1 in every shipped file (dediscretize.m:33-38 reads params(d+1)); 0 = categorical ('*')
+        if (n != 0 && n != (int64_t)m.r_initial[node - 1] + 1) throw Error(EMGPU_ERR_ARG, "boundaries need 0 or r+1 entries");
+        // (zero_bins is its own property in the reference, derived once by em_read.m:110-114 and not by
+        // set.boundaries: use emgpu_model_set_zero_bins to change it)
         m.boundaries[node - 1].assign(v, v + n);
         break;
     case EMGPU_F_RESAMPLE_RATES:
@@ -285,6 +318,15 @@ int emgpu_model_set_start(emgpu_model *h, const int32_t *start, int32_t n) {
     return EMGPU_OK;
 }
 
+int emgpu_model_set_zero_bins(emgpu_model *h, const int32_t *zero_bins, int32_t n) {
+    if (!h || !zero_bins || n != h->m.n_initial) return fail(EMGPU_ERR_ARG, "zero_bins needs n_initial entries");
+    for (int i = 0; i < n; i++)
+        if (zero_bins[i] < 0 || zero_bins[i] > h->m.r_initial[i]) return fail(EMGPU_ERR_ARG, "zero bin out of range");
+    h->m.zero_bins.assign(zero_bins, zero_bins + n);
+    h->m.version++;
+    return EMGPU_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 int emgpu_ctx_create(int32_t device, emgpu_ctx **out) {
     EMGPU_TRY
@@ -309,6 +351,7 @@ int emgpu_ctx_create(int32_t device, emgpu_ctx **out) {
 
 int emgpu_ctx_set_stream(emgpu_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail(EMGPU_ERR_ARG, "null ctx");
+    CTX_LOCK(ctx);
     ctx->stream = (hipStream_t)hip_stream; // NULL = the HIP default (null) stream
     return EMGPU_OK;
 }
@@ -316,6 +359,7 @@ int emgpu_ctx_set_stream(emgpu_ctx *ctx, void *hip_stream) {
 int emgpu_ctx_sync(emgpu_ctx *ctx) {
     EMGPU_TRY
     if (!ctx) return fail(EMGPU_ERR_ARG, "null ctx");
+    CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_OK(hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream));
@@ -344,12 +388,17 @@ const char *emgpu_last_kernel_name(const emgpu_ctx *ctx) { return ctx ? ctx->las
 } // extern "C"
 
 // ------------------------------------------------------------------------------------------------
-static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h) {
+// `pinned`: uids of the other models of the current call -- their tables may already sit in a launch's
+// argument list (terminal propagation, mixed batches) and must survive the eviction.
+// Entries outlive emgpu_model_free (a model does not know the contexts that uploaded it): they are
+// reclaimed by this LRU sweep or by emgpu_ctx_free; at most 48 + the models of one call stay resident.
+static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h, const std::set<uint64_t> *pinned = nullptr) {
     if (ctx->cache.size() > 48 && ctx->cache.find(h->m.uid) == ctx->cache.end()) {
         // models come and go (their tables stay uploaded): drop the least recently used half
         HIP_OK(hipStreamSynchronize(ctx->stream));
         std::vector<std::pair<uint64_t, uint64_t>> byuse;
-        for (auto &kv : ctx->cache) byuse.push_back({kv.second.last_use, kv.first});
+        for (auto &kv : ctx->cache)
+            if (!pinned || !pinned->count(kv.first)) byuse.push_back({kv.second.last_use, kv.first});
         std::sort(byuse.begin(), byuse.end());
         for (size_t q = 0; q < byuse.size() / 2; q++) {
             Uploaded &old = ctx->cache[byuse[q].second];
@@ -417,21 +466,28 @@ static void fill_run(emgpu_ctx *ctx, const Uploaded &u, const Model &m, const em
     }
     A.event_cap = p->event_cap;
     A.status = ctx->d_status;
+    A.ld = p->n;
 }
 
-extern "C" {
+// Point the run at the caller's buffers: column col_offset of arrays whose trajectory dimension is ld.
+static void bind_outputs(EmgpuRun &A, const Model &m, const emgpu_sample_params *p, const emgpu_sample_out *out, int64_t extra_offset = 0) {
+    if ((out->ev_count != nullptr) != (out->events != nullptr)) throw Error(EMGPU_ERR_ARG, "ev_count and events go together");
+    if (out->events && p->event_cap < 1) throw Error(EMGPU_ERR_ARG, "event_cap must be >= 1");
+    const int64_t ld = out->ld ? out->ld : A.n, off = out->col_offset + extra_offset;
+    if (ld < 0 || off < 0 || off + A.n > ld) throw Error(EMGPU_ERR_ARG, "col_offset + n exceeds ld");
+    A.ld = ld;
+    const size_t o = (size_t)off;
+    A.init_bin = out->init_bin ? out->init_bin + o : nullptr;
+    A.init_val = out->init_val ? out->init_val + o : nullptr;
+    A.dyn_bin = out->dyn_bin ? out->dyn_bin + o : nullptr;
+    A.dyn_val = out->dyn_val ? out->dyn_val + 4 * o : nullptr;
+    A.ev_count = out->ev_count ? out->ev_count + o : nullptr;
+    A.events = out->events ? reinterpret_cast<uint64_t *>(out->events) + o * (size_t)p->event_cap : nullptr;
+    A.attempts = out->attempts ? out->attempts + o : nullptr;
+    (void)m;
+}
 
-int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sample_params *p, const emgpu_sample_out *out) {
-    EMGPU_TRY
-    if (!ctx || !h || !p || !out) return fail(EMGPU_ERR_ARG, "null argument");
-    HIP_OK(hipSetDevice(ctx->device));
-    Uploaded &u = get_uploaded(ctx, h);
-    EmgpuRun A;
-    fill_run(ctx, u, h->m, p, A);
-    if ((out->ev_count != nullptr) != (out->events != nullptr)) return fail(EMGPU_ERR_ARG, "ev_count and events go together");
-    if (out->events && p->event_cap < 1) return fail(EMGPU_ERR_ARG, "event_cap must be >= 1");
-    A.init_bin = out->init_bin; A.init_val = out->init_val; A.dyn_bin = out->dyn_bin; A.dyn_val = out->dyn_val;
-    A.ev_count = out->ev_count; A.events = reinterpret_cast<uint64_t *>(out->events); A.attempts = out->attempts;
+static void launch_dbn(emgpu_ctx *ctx, const Uploaded &u, const EmgpuRun &A) {
     const char *name = "";
     hipError_t e;
     if (emgpu::fast_uncor_eligible(u.cp.plan, A)) e = emgpu::launch_uncor_fast(u.cp.plan, A, ctx->stream, &name);
@@ -439,18 +495,152 @@ int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sa
     else if (emgpu::step_eligible(u.cp.plan, A)) e = emgpu::launch_dbn_step(u.cp.plan, A, ctx->stream, &name);
     else e = emgpu::launch_dbn_generic(u.cp.plan, A, ctx->stream, &name);
     ctx->last_kernel = name;
-    if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+}
+
+// Run fn(d) for d = 0..n-1 on one host thread per device and fold the results: the first
+// failing device's status and message become the caller's.
+template <typename F>
+static int on_devices(int n, F fn) {
+    std::vector<int> rc((size_t)n, EMGPU_OK);
+    std::vector<std::string> msg((size_t)n);
+    auto body = [&](int d) {
+        rc[d] = fn(d);
+        if (rc[d] != EMGPU_OK) msg[d] = g_err; // g_err is thread-local
+    };
+    std::vector<std::thread> th;
+    for (int d = 1; d < n; d++) th.emplace_back(body, d);
+    body(0);
+    for (auto &t : th) t.join();
+    for (int d = 0; d < n; d++)
+        if (rc[d] != EMGPU_OK) return fail(rc[d], "device " + std::to_string(d) + ": " + msg[d]);
     return EMGPU_OK;
+}
+
+extern "C" {
+
+int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sample_params *p, const emgpu_sample_out *out) {
+    EMGPU_TRY
+    if (!ctx || !h || !p || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    CTX_LOCK(ctx);
+    HIP_OK(hipSetDevice(ctx->device));
+    Uploaded &u = get_uploaded(ctx, h);
+    EmgpuRun A;
+    fill_run(ctx, u, h->m, p, A);
+    bind_outputs(A, h->m, p, out);
+    launch_dbn(ctx, u, A);
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_shard_range(int64_t n_total, int32_t rank, int32_t world, int64_t *lo, int64_t *hi) {
+    if (n_total < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return fail(EMGPU_ERR_ARG, "bad shard arguments");
+    const int64_t base = n_total / world, rem = n_total % world;
+    *lo = rank * base + (rank < rem ? rank : rem);
+    *hi = *lo + base + (rank < rem ? 1 : 0);
+    return EMGPU_OK;
+}
+
+int emgpu_device_count(int32_t *count) {
+    if (!count) return fail(EMGPU_ERR_ARG, "null argument");
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *count = c;
+    return EMGPU_OK;
+}
+
+int32_t emgpu_mixed_blocks(int64_t n_total, int32_t n_models, int64_t lo, int64_t hi, emgpu_block *blocks) {
+    if (n_total < 0 || n_models < 1 || !blocks || lo < 0 || hi > n_total) return fail(EMGPU_ERR_ARG, "bad block arguments");
+    int32_t k = 0;
+    for (int32_t m = 0; m < n_models; m++) {
+        int64_t a, b;
+        emgpu_shard_range(n_total, m, n_models, &a, &b);
+        const int64_t a2 = a > lo ? a : lo, b2 = b < hi ? b : hi;
+        if (b2 > a2) blocks[k++] = emgpu_block{m, 0, (uint64_t)a2, b2 - a2};
+    }
+    return k;
+}
+
+int emgpu_sample_dbn_blocks_device(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
+                                   const emgpu_sample_params *p, const emgpu_block *blocks, int32_t n_blocks,
+                                   const emgpu_sample_out *out) {
+    EMGPU_TRY
+    if (!ctx || !models || n_models < 1 || !p || (!blocks && n_blocks > 0) || n_blocks < 0 || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    CTX_LOCK(ctx);
+    HIP_OK(hipSetDevice(ctx->device));
+    std::set<uint64_t> pinned;
+    for (int i = 0; i < n_models; i++) {
+        if (!models[i]) return fail(EMGPU_ERR_ARG, "null model");
+        if (models[i]->m.n_initial != models[0]->m.n_initial || models[i]->m.n_dyn() != models[0]->m.n_dyn())
+            return fail(EMGPU_ERR_ARG, "the models of a mixed batch must agree in n_initial and n_dyn (one trace shape)");
+        pinned.insert(models[i]->m.uid);
+    }
+    emgpu_sample_out o = *out;
+    if (!o.ld) o.ld = p->n;
+    for (int b = 0; b < n_blocks; b++) {
+        const emgpu_block &B = blocks[b];
+        if (B.model < 0 || B.model >= n_models) return fail(EMGPU_ERR_ARG, "block names a model outside the list");
+        if (B.n < 0 || B.first_index < p->first_index || B.first_index - p->first_index + (uint64_t)B.n > (uint64_t)p->n)
+            return fail(EMGPU_ERR_ARG, "block outside [first_index, first_index + n)");
+        if (B.n == 0) continue;
+        const emgpu_model *h = models[B.model];
+        Uploaded &u = get_uploaded(ctx, h, &pinned);
+        emgpu_sample_params q = *p;
+        q.first_index = B.first_index; q.n = B.n;
+        EmgpuRun A;
+        fill_run(ctx, u, h->m, &q, A);
+        bind_outputs(A, h->m, &q, &o, (int64_t)(B.first_index - p->first_index));
+        launch_dbn(ctx, u, A);
+    }
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_sample_dbn_multi_device(emgpu_ctx *const *ctxs, int32_t n_ctx, const emgpu_model *h,
+                                  const emgpu_sample_params *p, const emgpu_sample_out *outs) {
+    EMGPU_TRY
+    if (!ctxs || n_ctx < 1 || !h || !p || !outs) return fail(EMGPU_ERR_ARG, "null argument");
+    for (int d = 0; d < n_ctx; d++) if (!ctxs[d]) return fail(EMGPU_ERR_ARG, "null ctx");
+    return on_devices(n_ctx, [&](int d) {
+        int64_t lo, hi;
+        emgpu_shard_range(p->n, d, n_ctx, &lo, &hi);
+        emgpu_sample_params q = *p;
+        q.first_index = p->first_index + (uint64_t)lo; q.n = hi - lo;
+        return emgpu_sample_dbn_device(ctxs[d], h, &q, &outs[d]);
+    });
+    EMGPU_CATCH
+}
+
+int emgpu_sample_dbn_multi_host(emgpu_ctx *const *ctxs, int32_t n_ctx, const emgpu_model *h,
+                                const emgpu_sample_params *p, const emgpu_sample_out *out) {
+    EMGPU_TRY
+    if (!ctxs || n_ctx < 1 || !h || !p || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    for (int d = 0; d < n_ctx; d++) if (!ctxs[d]) return fail(EMGPU_ERR_ARG, "null ctx");
+    if (p->n < 0) return fail(EMGPU_ERR_ARG, "n < 0");
+    return on_devices(n_ctx, [&](int d) {
+        int64_t lo, hi;
+        emgpu_shard_range(p->n, d, n_ctx, &lo, &hi);
+        emgpu_sample_params q = *p;
+        q.first_index = p->first_index + (uint64_t)lo; q.n = hi - lo;
+        emgpu_sample_out o = *out;
+        o.ld = out->ld ? out->ld : p->n;
+        o.col_offset = out->col_offset + lo;
+        return emgpu_sample_dbn_host(ctxs[d], h, &q, &o);
+    });
     EMGPU_CATCH
 }
 
 int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sample_params *p, const emgpu_sample_out *out) {
     EMGPU_TRY
     if (!ctx || !h || !p || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     const Model &m = h->m;
     const size_t n = (size_t)(p->n > 0 ? p->n : 0), ni = m.n_initial, nd = m.n_dyn();
     const size_t G4 = ((size_t)p->sample_time + 3) / 4;
+    // the host arrays may be dimensioned for a larger batch (ld) of which this call fills columns [off, off + n)
+    const size_t ld = out->ld ? (size_t)out->ld : n, off = (size_t)out->col_offset;
+    if (out->ld < 0 || out->col_offset < 0 || off + n > ld) return fail(EMGPU_ERR_ARG, "col_offset + n exceeds ld");
     emgpu_sample_out d{};
     std::vector<void *> allocs;
     auto dalloc = [&](size_t bytes) -> void * {
@@ -472,26 +662,32 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_samp
         if (out->attempts) d.attempts = (int32_t *)dalloc(b_at);
         rc = emgpu_sample_dbn_device(ctx, h, p, &d);
         if (rc == EMGPU_OK) {
-            auto back = [&](void *dst, const void *src, size_t bytes) {
-                if (dst && bytes) HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            // rows x (n elements of `elem` bytes) from the shard-sized device array into columns [off, off + n) of the host array
+            auto back = [&](void *dst, const void *src, size_t rows, size_t elem) {
+                if (!dst || !n || !rows) return;
+                char *dcol = (char *)dst + off * elem;
+                if (ld == n) HIP_OK(hipMemcpyAsync(dcol, src, rows * n * elem, hipMemcpyDeviceToHost, ctx->stream));
+                else HIP_OK(hipMemcpy2DAsync(dcol, ld * elem, src, n * elem, n * elem, rows, hipMemcpyDeviceToHost, ctx->stream));
             };
-            back(out->init_bin, d.init_bin, b_ib); back(out->init_val, d.init_val, b_iv);
-            back(out->dyn_bin, d.dyn_bin, b_db); back(out->dyn_val, d.dyn_val, b_dv);
-            back(out->ev_count, d.ev_count, b_ec);
-            back(out->attempts, d.attempts, b_at);
+            back(out->init_bin, d.init_bin, ni, 1); back(out->init_val, d.init_val, ni, 4);
+            back(out->dyn_bin, d.dyn_bin, G4 * nd, 4); back(out->dyn_val, d.dyn_val, G4 * nd, 16);
+            back(out->ev_count, d.ev_count, 1, 4);
+            back(out->attempts, d.attempts, 1, 4);
             rc = emgpu_ctx_sync(ctx);
+            uint32_t *h_ec = out->ev_count ? out->ev_count + off : nullptr;
+            emgpu_event *h_ev = out->events ? out->events + off * (size_t)p->event_cap : nullptr;
             if (out->events && b_ev) {
                 // only the used part of every event list crosses PCIe: rows past the longest list (or past
                 // ev_count[i]) are left as the caller passed them
                 const size_t cap = (size_t)p->event_cap;
                 size_t longest = cap;
-                if (out->ev_count) {
+                if (h_ec) {
                     longest = 0;
-                    for (size_t i = 0; i < n; i++) longest = out->ev_count[i] > longest ? out->ev_count[i] : longest;
+                    for (size_t i = 0; i < n; i++) longest = h_ec[i] > longest ? h_ec[i] : longest;
                     if (longest > cap) longest = cap;
                 }
-                if (longest) {
-                    HIP_OK(hipMemcpy2DAsync(out->events, cap * sizeof(emgpu_event), d.events, cap * sizeof(emgpu_event),
+                if (longest && n) {
+                    HIP_OK(hipMemcpy2DAsync(h_ev, cap * sizeof(emgpu_event), d.events, cap * sizeof(emgpu_event),
                                             longest * sizeof(emgpu_event), n, hipMemcpyDeviceToHost, ctx->stream));
                     HIP_OK(hipStreamSynchronize(ctx->stream));
                 }
@@ -511,7 +707,7 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_samp
 static void fill_bn(emgpu_ctx *ctx, const Uploaded &u, const Model &m, const emgpu_bn_params *p, EmgpuBnRun &A) {
     memset(&A, 0, sizeof A);
     if (p->n < 0 || p->max_attempts < 1) throw Error(EMGPU_ERR_ARG, "n < 0 or max_attempts < 1");
-    A.seed = p->seed; A.first_index = p->first_index; A.n = p->n; A.flags = p->flags; A.max_attempts = p->max_attempts;
+    A.seed = p->seed; A.first_index = p->first_index; A.n = p->n; A.ld = p->n; A.flags = p->flags; A.max_attempts = p->max_attempts;
     A.has_bounds = p->bounds_sample != nullptr;
     if (p->bounds_sample)
         for (int v = 0; v < m.n_initial; v++) {
@@ -532,6 +728,7 @@ static void fill_bn(emgpu_ctx *ctx, const Uploaded &u, const Model &m, const emg
 int emgpu_sample_bn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_bn_params *p, uint8_t *out_bin, float *out_val, int32_t *attempts) {
     EMGPU_TRY
     if (!ctx || !h || !p) return fail(EMGPU_ERR_ARG, "null argument");
+    CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     Uploaded &u = get_uploaded(ctx, h);
     EmgpuBnRun A;
@@ -548,6 +745,7 @@ int emgpu_sample_bn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_bn_
 int emgpu_sample_bn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_bn_params *p, uint8_t *out_bin, float *out_val, int32_t *attempts) {
     EMGPU_TRY
     if (!ctx || !h || !p) return fail(EMGPU_ERR_ARG, "null argument");
+    CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     const size_t n = (size_t)(p->n > 0 ? p->n : 0), ni = h->m.n_initial;
     uint8_t *db = nullptr; float *dv = nullptr; int32_t *da = nullptr;
@@ -625,12 +823,17 @@ int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *mo
     EMGPU_TRY
     if (!ctx || !models || n_models < 1 || !p || !geo || !model_of || !out || !rows) return fail(EMGPU_ERR_ARG, "null argument");
     if (p->n < 0 || p->cap < 2 || p->max_resample < 1) return fail(EMGPU_ERR_ARG, "bad n / cap / max_resample");
+    CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     std::vector<const uint32_t *> bases;
     const Uploaded *first = nullptr;
+    std::set<uint64_t> pinned; // the table pointers collected below must survive the cache's LRU sweep
     for (int i = 0; i < n_models; i++) {
         if (!models[i]) return fail(EMGPU_ERR_ARG, "null model");
-        Uploaded &u = get_uploaded(ctx, models[i]);
+        pinned.insert(models[i]->m.uid);
+    }
+    for (int i = 0; i < n_models; i++) {
+        Uploaded &u = get_uploaded(ctx, models[i], &pinned);
         const EmgpuPlan &P = u.cp.plan;
         if (P.ni != 6 || P.nd != 3 || P.depend) return fail(EMGPU_ERR_UNSUPPORTED, "trajectory model must have 6 initial and 3 independent dynamic variables");
         for (int q = 0; q < 6; q++)
@@ -650,7 +853,7 @@ int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *mo
         }
         bases.push_back(u.d_thr + P.d_off[0]); // tables of the dynamic variables, relative to the first one
     }
-    first = &get_uploaded(ctx, models[0]); // (the map may have rehashed nothing: std::map keeps references valid)
+    first = &get_uploaded(ctx, models[0], &pinned); // std::map keeps references valid and nothing pinned was erased
     if (ctx->d_thr_base_cap < bases.size()) {
         HIP_OK(hipStreamSynchronize(ctx->stream));
         if (ctx->d_thr_base) HIP_OK(hipFree(ctx->d_thr_base));
@@ -678,6 +881,7 @@ int emgpu_propagate_terminal_host(emgpu_ctx *ctx, const emgpu_model *const *mode
                                   float *out, int32_t *rows) {
     EMGPU_TRY
     if (!ctx || !p || !geo || !model_of || !out || !rows) return fail(EMGPU_ERR_ARG, "null argument");
+    CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     const size_t n = (size_t)(p->n > 0 ? p->n : 0), nl = 4 * n;
     double *dg = nullptr; int32_t *dm = nullptr, *dr = nullptr; float *dout = nullptr;
@@ -722,6 +926,7 @@ int emgpu_sample2track_device(emgpu_ctx *ctx, const emgpu_track_params *p, const
     if (p->nd < 1 || p->slot_vertrate < 0 || p->slot_vertrate >= p->nd || p->slot_acc < 0 || p->slot_acc >= p->nd ||
         p->slot_turnrate < 0 || p->slot_turnrate >= p->nd)
         return fail(EMGPU_ERR_ARG, "bad dense-trace rows");
+    CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     EmgpuTrackRun A{};
     A.n = p->n; A.T = p->T;
@@ -743,6 +948,7 @@ int emgpu_sample2track_host(emgpu_ctx *ctx, const emgpu_track_params *p, const d
     EMGPU_TRY
     if (!ctx || !p || !alt0 || !speed0 || !updates) return fail(EMGPU_ERR_ARG, "null argument");
     if (int rc = track_params_ok(p)) return rc;
+    CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     const size_t n = (size_t)p->n, T = (size_t)p->T;
     if (n == 0) return EMGPU_OK;

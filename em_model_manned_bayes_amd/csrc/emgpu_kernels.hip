@@ -39,8 +39,8 @@ __global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const Em
 #pragma unroll
     for (int p = 0; p < NI; p++) {
         if (p >= P.ni) continue;
-        if (A.init_bin) A.init_bin[(size_t)P.i_var[p] * A.n + i] = (uint8_t)(bin[p] + 1);
-        if (A.init_val) A.init_val[(size_t)P.i_var[p] * A.n + i] = (float)val[p];
+        if (A.init_bin) A.init_bin[(size_t)P.i_var[p] * A.ld + i] = (uint8_t)(bin[p] + 1);
+        if (A.init_val) A.init_val[(size_t)P.i_var[p] * A.ld + i] = (float)val[p];
     }
     if (P.nd == 0 && !want_events) return;
 
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const Em
 #pragma unroll
             for (int k = 0; k < ND; k++) {
                 if (k >= P.nd) continue;
-                const size_t o = ((size_t)g * P.nd + P.d_row[k]) * (size_t)A.n + (size_t)i;
+                const size_t o = ((size_t)g * P.nd + P.d_row[k]) * (size_t)A.ld + (size_t)i;
                 if (A.dyn_bin) A.dyn_bin[o] = pb[k][hb];
                 if (A.dyn_val) reinterpret_cast<float4 *>(A.dyn_val)[o] = make_float4(pv[k][hb][0], pv[k][hb][1], pv[k][hb][2], pv[k][hb][3]);
             }
@@ -264,8 +264,8 @@ __global__ void __launch_bounds__(256) k_bn(const EmgpuPlan P, const EmgpuBnRun 
 #pragma unroll
     for (int p = 0; p < NI; p++) {
         if (p >= P.ni) continue;
-        if (A.out_bin) A.out_bin[(size_t)P.i_var[p] * A.n + i] = (uint8_t)(bin[p] + 1);
-        if (A.out_val) A.out_val[(size_t)P.i_var[p] * A.n + i] = (float)val[p];
+        if (A.out_bin) A.out_bin[(size_t)P.i_var[p] * A.ld + i] = (uint8_t)(bin[p] + 1);
+        if (A.out_val) A.out_val[(size_t)P.i_var[p] * A.ld + i] = (float)val[p];
     }
 }
 

@@ -247,8 +247,8 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
 #pragma unroll
         for (int p = 0; p < NI; p++) {
             if (p < P.ni) {
-                if (A.init_bin) A.init_bin[(size_t)P.i_var[p] * A.n + i] = (uint8_t)(bin[p] + 1);
-                if (A.init_val) A.init_val[(size_t)P.i_var[p] * A.n + i] = (float)val[p];
+                if (A.init_bin) A.init_bin[(size_t)P.i_var[p] * A.ld + i] = (uint8_t)(bin[p] + 1);
+                if (A.init_val) A.init_val[(size_t)P.i_var[p] * A.ld + i] = (float)val[p];
             }
         }
     }
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
 #pragma unroll
         for (int k = 0; k < 3; k++)
             coop_fill_store_msb<3, LB>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
-                                   3u, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.n, A.dyn_bin, A.dyn_val);
+                                   3u, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
         wave_sync(); // results of this block are consumed before the next block's workers overwrite them
     }
 }

@@ -137,8 +137,8 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const E
 #pragma unroll
             for (int p = 0; p < NI; p++) {
                 if (p < P.ni) {
-                    if (A.init_bin) A.init_bin[(size_t)P.i_var[p] * A.n + i] = (uint8_t)(bin[p] + 1);
-                    if (A.init_val) A.init_val[(size_t)P.i_var[p] * A.n + i] = (float)val[p];
+                    if (A.init_bin) A.init_bin[(size_t)P.i_var[p] * A.ld + i] = (uint8_t)(bin[p] + 1);
+                    if (A.init_val) A.init_val[(size_t)P.i_var[p] * A.ld + i] = (float)val[p];
                 }
             }
         }
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const E
         for (int k = 0; k < ND; k++)
             if (k < P.nd)
                 coop_fill_store_msb<ND, true>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
-                                              (uint32_t)P.nd, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.n, A.dyn_bin, A.dyn_val);
+                                              (uint32_t)P.nd, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
         wave_sync();
     }
 }

@@ -93,6 +93,7 @@ struct EmgpuPlan {
 struct EmgpuRun {
     uint64_t seed, first_index;
     int64_t n;
+    int64_t ld; // trajectory dimension of the output arrays (>= n: a shard may be written into a larger shared trace)
     int32_t T, per_step;
     uint32_t flags;
     int32_t max_attempts;
@@ -114,6 +115,7 @@ struct EmgpuRun {
 struct EmgpuBnRun {
     uint64_t seed, first_index;
     int64_t n;
+    int64_t ld; // trajectory dimension of out_bin / out_val
     uint32_t flags;
     int32_t max_attempts;
     int32_t has_bounds, pos_own_speed, pos_int_speed, _pad;

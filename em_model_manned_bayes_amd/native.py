@@ -133,6 +133,11 @@ class NativeModel:
     def set_transition_stay_prior(self, prior):
         L.check(L.lib().emgpu_model_set_transition_stay_prior(self._h, float(prior)))
 
+    def set_zero_bins(self, zero_bins):
+        zb = np.array([0 if (z is None or (hasattr(z, "__len__") and len(z) == 0)) else int(np.asarray(z).reshape(-1)[0]) for z in zero_bins],
+                      dtype=np.int32)
+        L.check(L.lib().emgpu_model_set_zero_bins(self._h, _p(zb), zb.size))
+
     def set_start(self, start):
         st = np.zeros(self.n_initial, dtype=np.int32)
         for i, s in enumerate(start):
@@ -182,6 +187,11 @@ def default_context(device=0):
     return _default_ctx[device]
 
 
+def all_device_contexts():
+    """One default Context per visible device: pass the list as `ctx` to spread one call over every GPU."""
+    return [default_context(d) for d in range(device_count())]
+
+
 def make_params(n, sample_time, seed, first_index=0, transition_mode=L.TRANSITION_REFERENCE_AUTO, flags=0,
                 max_attempts=1000, idx_L=0, idx_v=0, idx_dh=0, layers=None, event_cap=0):
     p = L.SampleParams()
@@ -196,18 +206,72 @@ def make_params(n, sample_time, seed, first_index=0, transition_mode=L.TRANSITIO
     return p, keep
 
 
-def sample_dbn_device(ctx, model, params, init_bin=0, init_val=0, dyn_bin=0, dyn_val=0, ev_count=0, events=0, attempts=0):
-    """Asynchronous launch with raw device pointers (ints, 0 = skip)."""
+def device_count():
+    c = C.c_int32(0)
+    L.check(L.lib().emgpu_device_count(C.byref(c)))
+    return int(c.value)
+
+
+def shard_range(n_total, rank, world):
+    """emgpu_shard_range: the split every sharded entry point uses (== sharding.shard_range)."""
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    L.check(L.lib().emgpu_shard_range(int(n_total), int(rank), int(world), C.byref(lo), C.byref(hi)))
+    return int(lo.value), int(hi.value)
+
+
+def _sample_out(init_bin=0, init_val=0, dyn_bin=0, dyn_val=0, ev_count=0, events=0, attempts=0, ld=0, col_offset=0):
     o = L.SampleOut()
     o.init_bin, o.init_val, o.dyn_bin, o.dyn_val = init_bin or None, init_val or None, dyn_bin or None, dyn_val or None
     o.ev_count, o.events, o.attempts = ev_count or None, events or None, attempts or None
+    o.ld, o.col_offset = int(ld), int(col_offset)
+    return o
+
+
+def sample_dbn_device(ctx, model, params, init_bin=0, init_val=0, dyn_bin=0, dyn_val=0, ev_count=0, events=0, attempts=0,
+                      ld=0, col_offset=0):
+    """Asynchronous launch with raw device pointers (ints, 0 = skip).  ld / col_offset: write this call's
+    trajectories into columns [col_offset, col_offset + n) of buffers dimensioned for ld trajectories."""
+    o = _sample_out(init_bin, init_val, dyn_bin, dyn_val, ev_count, events, attempts, ld, col_offset)
     L.check(L.lib().emgpu_sample_dbn_device(ctx._h, model._h, C.byref(params), C.byref(o)))
+
+
+def mixed_blocks(n_total, n_models, lo=0, hi=None):
+    """emgpu_mixed_blocks: [(model, first_index, count)] of the equal-contiguous-block assignment inside [lo, hi)."""
+    hi = n_total if hi is None else hi
+    buf = (L.Block * max(1, int(n_models)))()
+    k = L.check(L.lib().emgpu_mixed_blocks(int(n_total), int(n_models), int(lo), int(hi), buf))
+    return [(int(buf[i].model), int(buf[i].first_index), int(buf[i].n)) for i in range(k)]
+
+
+def sample_dbn_blocks_device(ctx, models, params, blocks, **ptrs):
+    """emgpu_sample_dbn_blocks_device: one shared trace (device pointers in ptrs, as for sample_dbn_device) filled by
+    blocks = [(model index, first_index, count)]; params.n / params.first_index describe the range the trace covers."""
+    o = _sample_out(**ptrs)
+    handles = (C.c_void_p * len(models))(*[m._h for m in models])
+    arr = (L.Block * max(1, len(blocks)))()
+    for i, (m, f, c) in enumerate(blocks):
+        arr[i].model, arr[i].first_index, arr[i].n = int(m), int(f), int(c)
+    L.check(L.lib().emgpu_sample_dbn_blocks_device(ctx._h, handles, len(models), C.byref(params), arr, len(blocks), C.byref(o)))
+
+
+def sample_dbn_multi_device(ctxs, model, params, outs):
+    """emgpu_sample_dbn_multi_device: outs = one dict of device pointers (sample_dbn_device keywords) per ctx, each
+    holding that ctx's shard (native.shard_range(params.n, d, len(ctxs))).  Asynchronous: sync every ctx afterwards."""
+    hs = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    arr = (L.SampleOut * len(ctxs))()
+    for d, kw in enumerate(outs):
+        o = _sample_out(**kw)
+        for f, _ in L.SampleOut._fields_:
+            setattr(arr[d], f, getattr(o, f))
+    L.check(L.lib().emgpu_sample_dbn_multi_device(hs, len(ctxs), model._h, C.byref(params), arr))
 
 
 def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_events=False, event_cap=None, **kw):
     """Synchronous host-buffer call.  Returns a dict of numpy arrays in user-facing shapes:
     init_bin [n, n_i] u8, init_val [n, n_i] f32, dyn_bin [n, T, n_d] u8, dyn_val [n, T, n_d] f32,
     events: list of structured arrays (EVENT_DTYPE), attempts [n].
+    ctx may be a list of Contexts (one per device): the batch is then split over them inside ONE library call
+    (emgpu_sample_dbn_multi_host: one host thread + one stream per device) with identical results.
     """
     ni, nd, T = model.n_initial, model.n_dyn, int(sample_time)
     if want_events and event_cap is None:
@@ -227,7 +291,12 @@ def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_even
         ec = np.zeros(n, dtype=np.uint32)
         ev = np.zeros((n, event_cap), dtype=EVENT_DTYPE)
         o.ev_count, o.events = _p(ec), _p(ev)
-    L.check(L.lib().emgpu_sample_dbn_host(ctx._h, model._h, C.byref(p), C.byref(o)))
+    if isinstance(ctx, (list, tuple)):
+        hs = (C.c_void_p * len(ctx))(*[c._h for c in ctx])
+        L.check(L.lib().emgpu_sample_dbn_multi_host(hs, len(ctx), model._h, C.byref(p), C.byref(o)))
+        ctx = ctx[0]
+    else:
+        L.check(L.lib().emgpu_sample_dbn_host(ctx._h, model._h, C.byref(p), C.byref(o)))
     out = {"init_bin": ib.T.copy(), "init_val": iv.T.copy(), "attempts": att, "kernel": ctx.last_kernel()}
     if want_dense and nd > 0:
         out["dyn_bin"] = unpack_dyn_bin(db, T)

@@ -14,7 +14,9 @@
  *   - The caller owns every output buffer.  The library owns only emgpu_model / emgpu_ctx handles.
  *   - Variable ids, bins and the temporal map are 1-based at this boundary, like the reference.
  *   - Matrices that mirror MATLAB arrays are column-major (N{i} is r_i x q_i, em_read.m:191-198).
- *   - Re-entrant per ctx; a ctx is bound to one device and launches on one HIP stream.
+ *   - Re-entrant per ctx; a ctx is bound to one device and launches on one HIP stream.  Calls on
+ *     the same ctx from several threads are serialised by a lock inside the ctx; models are only
+ *     read by the sampling calls (setters must not race with sampling, as in any MATLAB handle class).
  */
 #ifndef EMGPU_H
 #define EMGPU_H
@@ -113,6 +115,9 @@ int emgpu_model_set_prior(emgpu_model *m, int32_t kind, double value);
 int emgpu_model_set_transition_stay_prior(emgpu_model *m, double prior);
 /* EncounterModel.start (EncounterModel.m:52,205-207): n_initial entries, 0 = unset ([] or NaN). */
 int emgpu_model_set_start(emgpu_model *m, const int32_t *start, int32_t n);
+/* EncounterModel.zero_bins (EncounterModel.m:40; derived once by em_read.m:110-114,143-156 and, like in
+ * the reference, NOT re-derived when boundaries are replaced): n_initial entries, 0 = none. */
+int emgpu_model_set_zero_bins(emgpu_model *m, const int32_t *zero_bins, int32_t n);
 
 /* ------------------------------------------------------------------------------------------------
  * Context
@@ -165,7 +170,13 @@ typedef struct {
  * G4 = ceil(T/4).  Column c of trajectory i (c = 0 is the initial state, events2samples.m:15-26):
  *   dyn_bin[((c/4)*n_dyn + k)*n + i]        byte (c%4) of the uint32 = bin (1-based)
  *   dyn_val[(((c/4)*n_dyn + k)*n + i)*4 + c%4]
- * with k = row of the temporal map (ascending variable id).  Padding columns >= T are 0. */
+ * with k = row of the temporal map (ascending variable id).  Padding columns >= T are 0.
+ *
+ * Writing a shard into a larger shared trace: `ld` is the trajectory dimension of the buffers (0 = the
+ * call's own n) and `col_offset` the column of trajectory 0 of this call, i.e. trajectory i lands in
+ * column col_offset + i of arrays dimensioned [..][ld] (events: list col_offset + i of [ld][event_cap]).
+ * That is how the ranks / devices / model blocks of one batch fill one trace without temporaries
+ * (SURVEY.md 8e "sort/block by model id"; RUN_1_emsample.m:24-47 is the reference's only sharding). */
 typedef struct {
     uint8_t *init_bin;   /* [n_initial][n]                                                        */
     float *init_val;     /* [n_initial][n]                                                        */
@@ -174,6 +185,8 @@ typedef struct {
     uint32_t *ev_count;  /* [n] rows written (may exceed event_cap => EMGPU_ERR_EVENT_CAP)        */
     emgpu_event *events; /* [n][event_cap]                                                        */
     int32_t *attempts;   /* [n] attempts used by the rejection loop; <0 => cap hit                */
+    int64_t ld;          /* trajectory dimension of every buffer above; 0 => params.n             */
+    int64_t col_offset;  /* column of trajectory 0 of this call; col_offset + n <= ld             */
 } emgpu_sample_out;
 
 /* Asynchronous: enqueue on the ctx stream with DEVICE pointers in `out`; returns after launch.
@@ -185,6 +198,49 @@ int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_sa
  * rows [0, ev_count[i]) of list i are defined on return (with ev_count == NULL all event_cap rows are copied). */
 int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_sample_params *p,
                           const emgpu_sample_out *out);
+
+/* ------------------------------------------------------------------------------------------------
+ * One batch, several models / several devices.  The reference shards only by running em_sample in
+ * a parfor over model files (RUN_1_emsample.m:13,24-47) and loops over samples serially
+ * (UncorEncounterModel.m:244); trajectories are independent and every RNG slot is keyed by the GLOBAL
+ * sample index, so any split gives the same trajectories.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* The contiguous block [*lo, *hi) of `rank` when n_total indices are split over `world` parts (the
+ * first n_total % world parts get one extra): the split every sharded entry point below uses. */
+int emgpu_shard_range(int64_t n_total, int32_t rank, int32_t world, int64_t *lo, int64_t *hi);
+int emgpu_device_count(int32_t *count);
+
+/* Mixed-model batch (BASELINE.json configs[3]): block b samples trajectories
+ * [first_index, first_index + n) (global indices) from models[model] into columns
+ * out->col_offset + (first_index - p->first_index) + [0, n) of ONE shared trace whose trajectory
+ * dimension is out->ld (0 => p->n).  p->n / p->first_index describe the range the trace covers;
+ * every block must lie inside it.  All models must agree in n_initial and n_dyn (the trace shape).
+ * One launch per block on the ctx stream; device pointers; asynchronous. */
+typedef struct {
+    int32_t model, _pad;
+    uint64_t first_index;
+    int64_t n;
+} emgpu_block;
+int emgpu_sample_dbn_blocks_device(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
+                                   const emgpu_sample_params *p, const emgpu_block *blocks, int32_t n_blocks,
+                                   const emgpu_sample_out *out);
+/* The blocks of the equal-contiguous-block assignment "model m owns emgpu_shard_range(n_total, m,
+ * n_models)" that intersect [lo, hi) (one rank's share): writes at most n_models entries, returns the count. */
+int32_t emgpu_mixed_blocks(int64_t n_total, int32_t n_models, int64_t lo, int64_t hi, emgpu_block *blocks);
+
+/* One call, several devices (one host thread + one HIP stream per device inside a
+ * call): [p->first_index, p->first_index + p->n) is split with emgpu_shard_range over the n_ctx
+ * contexts (each bound to its own device -- or to the same one, which only adds streams).
+ *   _multi_host:   HOST pointers in `out` dimensioned for all p->n trajectories; synchronous; deferred
+ *                  errors (rejection / event cap) are returned.  What a single-threaded MATLAB / Python
+ *                  caller uses to drive 8 GPUs.
+ *   _multi_device: outs[d] holds DEVICE pointers on ctx d's device for ITS shard only (ld / col_offset
+ *                  as above, relative to the shard); asynchronous: emgpu_ctx_sync each ctx afterwards. */
+int emgpu_sample_dbn_multi_host(emgpu_ctx *const *ctxs, int32_t n_ctx, const emgpu_model *m,
+                                const emgpu_sample_params *p, const emgpu_sample_out *out);
+int emgpu_sample_dbn_multi_device(emgpu_ctx *const *ctxs, int32_t n_ctx, const emgpu_model *m,
+                                  const emgpu_sample_params *p, const emgpu_sample_out *outs);
 
 /* bn_sample(G,r,N,alpha,num_samples,start,order) (bn_sample.m:1) on the initial network with an
  * optional dediscretize + rejection stage = the geometry draw of @CorTerminalModel/sample.m:29-77.

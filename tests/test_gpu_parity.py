@@ -1,4 +1,7 @@
 """-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -7,6 +10,7 @@ from em_model_manned_bayes_amd import native, _lib as L
 from util import load_pair, uncor_indices, assert_uncor_parity
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FAST_MODELS = ["uncor_1200code_v2p1", "uncor_1200only_fwse_v1p2", "uncor_1200exclude_rotorcraft_v1p2",
                "uncor_allcode_fwmulti_v1", "dueregard_v1", "haa_v1", "blimp_v1"]
@@ -317,36 +321,200 @@ def test_dense_only_per_step_mode_matches_oracle(name, gpu_ctx, model_dir):
 
 def test_mixed_model_batch_matches_oracle(gpu_ctx, model_dir):
     """BASELINE.json configs[3] in miniature: the six uncor_*_v1p2 files (same shapes, different CPTs)
-    plus two models of other shapes, contiguous index blocks per model, one launch per block into
-    ONE shared output buffer; two 'ranks' own half the index range each."""
+    plus two models of other shapes, contiguous index blocks per model; two 'ranks' own half the index
+    range each and fill THEIR HALF of one shared trace with one emgpu_sample_dbn_blocks_device call
+    (one launch per block, written in place through ld / col_offset: no temporaries, no copies)."""
     import torch
     from em_model_manned_bayes_amd import sharding
     names = ["uncor_1200only_fwse_v1p2", "uncor_1200only_fwme_v1p2", "uncor_1200only_rotorcraft_v1p2",
              "uncor_1200exclude_fwse_v1p2", "uncor_1200exclude_fwme_v1p2", "uncor_1200exclude_rotorcraft_v1p2",
              "uncor_1200code_v2p1", "uncor_allcode_rotorcraft_v1"]
     pairs = [load_pair(nm_, model_dir) for nm_ in names]
-    n_total, T, seed = 4000, 64, 0x5EED0004
+    n_total, T, seed = 4001, 64, 0x5EED0004
     dev = torch.device("cuda", 0)
     ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
     G4 = T // 4
+    ib = torch.zeros((7, n_total), dtype=torch.uint8, device=dev)
+    iv = torch.zeros((7, n_total), dtype=torch.float32, device=dev)
     db = torch.zeros((G4, 3, n_total), dtype=torch.int32, device=dev)
     dv = torch.zeros((G4, 3, n_total, 4), dtype=torch.float32, device=dev)
     for rank in range(2):
         lo, hi = sharding.shard_range(n_total, rank, 2)
-        for m, first, cnt in sharding.mixed_batch_blocks(n_total, len(names), lo, hi):
-            nm, pp, _ = pairs[m]
-            p, _ = native.make_params(cnt, T, seed, first_index=first, **uncor_indices(pp))
-            # column offset `first` into the shared [.., n_total] buffers: element strides are n_total, so use views
-            sub_b = db[:, :, first: first + cnt].contiguous(); sub_v = dv[:, :, first: first + cnt].contiguous()
-            native.sample_dbn_device(ctx, nm, p, dyn_bin=sub_b.data_ptr(), dyn_val=sub_v.data_ptr())
-            ctx.sync()
-            db[:, :, first: first + cnt] = sub_b; dv[:, :, first: first + cnt] = sub_v
+        blocks = native.mixed_blocks(n_total, len(names), lo, hi)
+        assert blocks == sharding.mixed_batch_blocks(n_total, len(names), lo, hi)
+        p, _ = native.make_params(hi - lo, T, seed, first_index=lo, **uncor_indices(pairs[0][1]))
+        native.sample_dbn_blocks_device(ctx, [pr[0] for pr in pairs], p, blocks, init_bin=ib.data_ptr(), init_val=iv.data_ptr(),
+                                        dyn_bin=db.data_ptr(), dyn_val=dv.data_ptr(), ld=n_total, col_offset=lo)
+    ctx.sync()
     gb = native.unpack_dyn_bin(db.cpu().numpy().view(np.uint32), T)
     gv = native.unpack_dyn_val(dv.cpu().numpy(), T)
+    gib, giv = ib.cpu().numpy().T, iv.cpu().numpy().T
     for m, first, cnt in sharding.mixed_batch_blocks(n_total, len(names)):
         ref = O.uncor_sample(O.OracleModel(pairs[m][1]), cnt, T, seed, first_index=first, want_events=False)
         assert np.array_equal(gb[first: first + cnt], ref["dense_bin"]), names[m]
         assert np.array_equal(gv[first: first + cnt], ref["dense_val"].astype(np.float32)), names[m]
+        assert np.array_equal(gib[first: first + cnt], ref["init_bin"]), names[m]
+        assert np.array_equal(giv[first: first + cnt], ref["init_val"].astype(np.float32)), names[m]
+    # a block outside the range the trace covers is refused
+    p, _ = native.make_params(100, T, seed, first_index=1000)
+    with pytest.raises(L.EmgpuError):
+        native.sample_dbn_blocks_device(ctx, [pairs[0][0]], p, [(0, 1050, 51)], dyn_bin=db.data_ptr(), ld=n_total)
+    with pytest.raises(L.EmgpuError):   # models of different trace shapes cannot share a trace
+        native.sample_dbn_blocks_device(ctx, [pairs[0][0], load_pair("cor_v1", model_dir)[0]], p, [(0, 1000, 10)], dyn_bin=db.data_ptr(), ld=n_total)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,per_step", [("uncor_1200code_v2p1", False), ("cor_v1", False), ("uncor_1200only_fwme_v1p2", True), ("haa_v1", False)])
+def test_shards_written_into_one_trace_through_ld_and_col_offset(name, per_step, gpu_ctx, model_dir):
+    """emgpu_sample_out.ld / col_offset on every dense kernel family and on the event-list kernel: three uneven shards of one
+    index range written in place (device pointers) equal one call; so does the host entry point with ld / col_offset."""
+    import torch
+    nm, pp, _ = load_pair(name, model_dir)
+    n, T, seed = 1000, 37, 99
+    idx = uncor_indices(pp)
+    mode = L.TRANSITION_PER_STEP if per_step else L.TRANSITION_REFERENCE_AUTO
+    one = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, want_dense=True, want_events=True, transition_mode=mode, **idx)
+    dev = torch.device("cuda", 0)
+    ni, nd, G4, cap = nm.n_initial, nm.n_dyn, (T + 3) // 4, 512
+    ib = torch.zeros((ni, n), dtype=torch.uint8, device=dev); iv = torch.zeros((ni, n), dtype=torch.float32, device=dev)
+    db = torch.zeros((G4, nd, n), dtype=torch.int32, device=dev); dv = torch.zeros((G4, nd, n, 4), dtype=torch.float32, device=dev)
+    ec = torch.zeros(n, dtype=torch.int32, device=dev); ev = torch.zeros((n, cap, 2), dtype=torch.int32, device=dev)
+    at = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for lo, hi in ((0, 70), (70, 701), (701, n)):
+        p, _ = native.make_params(hi - lo, T, seed, first_index=lo, transition_mode=mode, event_cap=cap, **idx)
+        native.sample_dbn_device(gpu_ctx, nm, p, init_bin=ib.data_ptr(), init_val=iv.data_ptr(), dyn_bin=db.data_ptr(), dyn_val=dv.data_ptr(),
+                                 attempts=at.data_ptr(), ld=n, col_offset=lo)            # dense kernels
+        native.sample_dbn_device(gpu_ctx, nm, p, ev_count=ec.data_ptr(), events=ev.data_ptr(), ld=n, col_offset=lo)   # event-list kernel
+    gpu_ctx.sync()
+    assert np.array_equal(ib.cpu().numpy().T, one["init_bin"]) and np.array_equal(iv.cpu().numpy().T, one["init_val"])
+    assert np.array_equal(native.unpack_dyn_bin(db.cpu().numpy().view(np.uint32), T), one["dyn_bin"])
+    assert np.array_equal(native.unpack_dyn_val(dv.cpu().numpy(), T), one["dyn_val"])
+    assert np.array_equal(at.cpu().numpy(), one["attempts"])
+    cnt = ec.cpu().numpy()
+    assert np.array_equal(cnt, one["ev_count"].astype(np.int32))
+    evh = ev.cpu().numpy().reshape(n, cap * 2).view(native.EVENT_DTYPE)
+    for i in (0, 69, 70, 700, 701, n - 1):
+        assert np.array_equal(evh[i, : cnt[i]], one["events"][i])
+    with pytest.raises(L.EmgpuError):   # a shard that does not fit the leading dimension
+        p, _ = native.make_params(10, T, seed)
+        native.sample_dbn_device(gpu_ctx, nm, p, dyn_bin=db.data_ptr(), ld=n, col_offset=n - 5)
+
+
+@pytest.mark.gpu
+def test_multi_device_driver_equals_one_call(gpu_ctx, model_dir):
+    """emgpu_sample_dbn_multi_host / _multi_device: one library call, one host thread + one stream per context.  A 1-GPU box
+    has one device, so the three contexts here share it (three streams, three threads): the split, the threads, the per-shard
+    host copies and the error folding are the same code that drives 8 devices."""
+    import torch
+    from em_model_manned_bayes_amd import sharding
+    nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
+    idx = uncor_indices(pp)
+    n, T, seed = 10_001, 61, 0x5EED0002
+    ctxs = [native.Context(0) for _ in range(3)]
+    one = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, first_index=12345, want_dense=True, want_events=True, **idx)
+    multi = native.sample_dbn_host(ctxs, nm, n, T, seed, first_index=12345, want_dense=True, want_events=True, **idx)
+    for k in ("init_bin", "init_val", "dyn_bin", "dyn_val", "attempts", "ev_count"):
+        assert np.array_equal(one[k], multi[k]), k
+    assert all(np.array_equal(a, b) for a, b in zip(one["events"], multi["events"]))
+    assert_uncor_parity(multi, O.uncor_sample(O.OracleModel(pp), n, T, seed, first_index=12345), T)
+    shard = sharding.run_sharded(nm, 3000, T, seed, devices=[0, 0], want_events=False, **idx)   # the package-level driver
+    assert np.array_equal(shard["dyn_bin"], native.sample_dbn_host(gpu_ctx, nm, 3000, T, seed, want_events=False, **idx)["dyn_bin"])
+    # device variant: per-context shard buffers
+    dev = torch.device("cuda", 0)
+    G4 = (T + 3) // 4
+    bufs, outs = [], []
+    for d in range(3):
+        lo, hi = native.shard_range(n, d, 3)
+        b = torch.zeros((G4, 3, hi - lo), dtype=torch.int32, device=dev)
+        bufs.append(b); outs.append(dict(dyn_bin=b.data_ptr()))
+    torch.cuda.synchronize()
+    p, _ = native.make_params(n, T, seed, first_index=12345, **idx)
+    native.sample_dbn_multi_device(ctxs, nm, p, outs)
+    for c in ctxs:
+        c.sync()
+    got = np.concatenate([native.unpack_dyn_bin(b.cpu().numpy().view(np.uint32), T) for b in bufs])
+    assert np.array_equal(got, one["dyn_bin"])
+    # a deferred per-trajectory error on one shard surfaces from the call (rejection cap 1 cannot be met by every trajectory)
+    with pytest.raises(L.EmgpuError) as e:
+        native.sample_dbn_host(ctxs, nm, n, T, seed, want_dense=False, max_attempts=1, **idx)
+    assert e.value.code == L.ERR_REJECT_CAP and "device" in str(e.value)
+
+
+_RANK_WORKER = r"""
+import os, sys, pickle
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["EMGPU_ROOT"])
+from em_model_manned_bayes_amd import native, sharding, _lib as L
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)    # two ranks share the box's one GPU: RCCL would refuse
+dev = torch.device("cuda", 0)
+nm = native.NativeModel.load_txt(os.environ["EMGPU_MODEL"])
+labs = nm.get_labels(L.F_LABELS_INITIAL)
+idx = {k: (labs.index('"%s"' % v) + 1) for k, v in (("idx_L", "L"), ("idx_v", "v"), ("idx_dh", "\dot h"))}
+n_total, T, seed = 20000, 48, 77
+lo, hi = sharding.shard_range(n_total, rank, world)
+ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+G4 = T // 4
+db = torch.zeros((G4, 3, hi - lo), dtype=torch.int32, device=dev)
+dv = torch.zeros((G4, 3, hi - lo, 4), dtype=torch.float32, device=dev)
+p, _ = native.make_params(hi - lo, T, seed, first_index=lo, **idx)
+native.sample_dbn_device(ctx, nm, p, dyn_bin=db.data_ptr(), dyn_val=dv.data_ptr())
+ctx.sync()
+dist.barrier()
+pickle.dump((lo, hi, db.cpu().numpy(), dv.cpu().numpy(), ctx.last_kernel()), open(os.environ["EMGPU_OUT"] + str(rank), "wb"))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_two_rank_processes_on_one_gpu(gpu_ctx, model_dir, tmp_path):
+    """Two rank PROCESSES (started before they touch the GPU; gloo barrier because both sit on the box's one device) each run
+    the product's sample_dbn_device on their shard of the global range: the union equals one single-process call."""
+    import pickle
+    import socket
+    import subprocess
+    nm, pp, path = load_pair("uncor_1200code_v2p1", model_dir)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    script = tmp_path / "rank_worker.py"
+    script.write_text(_RANK_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EMGPU_ROOT=ROOT,
+                   EMGPU_MODEL=path, EMGPU_OUT=str(tmp_path / "out"))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    parts = [pickle.load(open(str(tmp_path / "out") + str(r), "rb")) for r in range(2)]
+    assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == 20000
+    one = native.sample_dbn_host(gpu_ctx, nm, 20000, 48, 77, want_dense=True, want_events=False, **uncor_indices(pp))
+    assert np.array_equal(np.concatenate([native.unpack_dyn_bin(q[2].view(np.uint32), 48) for q in parts]), one["dyn_bin"])
+    assert np.array_equal(np.concatenate([native.unpack_dyn_val(q[3], 48) for q in parts]), one["dyn_val"])
+    assert parts[0][4] == one["kernel"]
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher starts two rank processes itself and says n_gpus 2 (--oversubscribe: this box
+    has one GPU); without the flag it refuses instead of benchmarking one GPU (VERDICT r1 weak #3)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n", "200000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd + ["--oversubscribe"], env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["oversubscribed"] is True and line["value"] > 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, env=env, capture_output=True, timeout=900)
+        assert r.returncode == 3 and r.stdout.decode().strip() == ""
+    r = subprocess.run(cmd[:2] + ["--config", "mixed", "--steps", "2", "--warmup", "1", "--n", "300000", "--no-cpu-baseline"], env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["kernel"].startswith("k_uncor_fast<7,4,6,6>") and len(line["config"]["models"]) == 6
 
 
 @pytest.fixture(scope="module")

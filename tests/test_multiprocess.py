@@ -1,57 +1,122 @@
-"""World-size-2 gloo test of the N>1 path: ranks shard the global index range, there is no
-collective on the data path, and the union of the shards equals the single-process result.
-No GPU here, so the per-shard sampler is the oracle; the same property is checked for the HIP
-path on one GPU in tests/test_gpu_parity.py::test_sharded_calls_equal_one_call."""
+"""World-size-2 gloo tests of the N>1 path (no GPU here).
+
+test_two_rank_bench_runs_the_products_rank_logic: both ranks run bench.run_rank -- the product's
+make_params / step_first_index / mixed_blocks / loader / JSON line -- with only device memory and
+the kernel launch replaced (tests/mp_plumbing.py answers a launch with the CPU oracle), and the
+union of what the ranks sampled must equal one oracle run over the global index range.
+The same property is checked for the HIP path itself on a GPU in tests/test_gpu_parity.py
+(test_sharded_calls_equal_one_call, test_two_rank_processes_on_one_gpu, test_multi_device_driver).
+"""
+import io
+import json
 import os
 import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n_total, T, seed, path, q):
+def _worker(rank, world, port, argv, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O
-    from em_model_manned_bayes_amd import sharding
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, hi = sharding.shard_range(n_total, rank, world)
-    om = O.OracleModel(O.parse_model_txt(path))
-    r = O.uncor_sample(om, hi - lo, T, seed, first_index=lo, want_events=False)
-    # the only communication: a barrier and the max-over-ranks clock, as in bench.py
-    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.barrier()
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    assert t.item() == world
-    q.put((rank, lo, hi, r["dense_bin"], r["dense_val"], r["init_val"]))
-    dist.barrier()
-    dist.destroy_process_group()
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import bench
+    import mp_plumbing
+    args = bench.parse_args(argv)
+    pl = mp_plumbing.CpuGloo(rank, world)
+    buf = io.StringIO()
+    bench.run_rank(args, rank, rank, world, pl=pl, out=buf)
+    q.put((rank, buf.getvalue(), pl.ctx.launches, [b.a for b in pl.bufs]))
 
 
-def test_two_rank_sharding_matches_single_process(model_dir):
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O
-    from em_model_manned_bayes_amd import em_io
-    path = em_io.materialize_model("uncor_1200code_v2p1", model_dir)
-    n_total, T, seed, world = 61, 48, 0x5EED0004, 2
+def _run(world, argv):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, T, seed, path, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, argv, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got[0][1] == 0 and got[0][2] == got[1][1] and got[1][2] == n_total
-    full = O.uncor_sample(O.OracleModel(O.parse_model_txt(path)), n_total, T, seed, want_events=False)
-    assert np.array_equal(np.concatenate([g[3] for g in got]), full["dense_bin"])
-    assert np.array_equal(np.concatenate([g[4] for g in got]), full["dense_val"])
-    assert np.array_equal(np.concatenate([g[5] for g in got]), full["init_val"])
+    return got
+
+
+def _unpack(bufs, T):
+    from em_model_manned_bayes_amd import native
+    ib, iv, db, dv = bufs
+    return ib.T, iv.T, native.unpack_dyn_bin(db, T), native.unpack_dyn_val(dv, T)
+
+
+def test_two_rank_bench_runs_the_products_rank_logic(model_dir):
+    import oracle as O
+    from em_model_manned_bayes_amd import em_io
+    n, T, world, steps, warmup = 37, 24, 2, 2, 1
+    got = _run(world, ["--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--n", str(n), "--seconds", str(T), "--no-cpu-baseline"])
+    line = json.loads(got[0][1])
+    assert got[1][1] == ""                                    # only rank 0 prints
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["scaling"] == "weak"
+    assert abs(line["value"] - n * world * steps / (line["ms_per_step"] * steps * 1e-3)) < 1e-6 * line["value"]
+    assert line["roofline"]["algorithmic_bytes_per_unit"] == 5 * 7 + 5 * T * 3
+    # every step covers a fresh contiguous global range, rank r the r-th part of it
+    for r in range(world):
+        assert got[r][2] == [(0, (k * world + r) * n, n) for k in range(warmup + steps)]
+    # the buffers hold the last step: ranks 0 and 1 together == one oracle run over that step's global range
+    k = warmup + steps - 1
+    om = O.OracleModel(O.parse_model_txt(em_io.materialize_model("uncor_1200code_v2p1", model_dir)))
+    full = O.uncor_sample(om, n * world, T, 0x5EED0002, first_index=k * world * n, want_events=False)
+    parts = [_unpack(g[3], T) for g in got]
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), full["init_bin"])
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), full["init_val"].astype(np.float32))
+    assert np.array_equal(np.concatenate([p[2] for p in parts]), full["dense_bin"])
+    assert np.array_equal(np.concatenate([p[3] for p in parts]), full["dense_val"].astype(np.float32))
+
+
+def test_two_rank_mixed_batch_blocks(model_dir):
+    """config 4 in miniature: 2 ranks x 50 trajectories, six models in contiguous blocks of the step's range;
+    each rank's launches tile its shard and land in ONE trace per rank."""
+    import bench
+    import oracle as O
+    from em_model_manned_bayes_amd import em_io, sharding
+    n, T, world = 50, 16, 2
+    got = _run(world, ["--gpus", "2", "--config", "mixed", "--steps", "1", "--warmup", "0", "--n", str(n), "--seconds", str(T), "--no-cpu-baseline"])
+    line = json.loads(got[0][1])
+    assert line["n_gpus"] == 2 and line["config"]["models"] == bench.V1P2
+    total = n * world
+    oms = [O.OracleModel(O.parse_model_txt(em_io.materialize_model(nm, model_dir))) for nm in bench.V1P2]
+    for r in range(world):
+        launches = got[r][2]
+        lo, hi = sharding.shard_range(total, r, world)
+        assert launches == sharding.mixed_batch_blocks(total, 6, lo, hi)
+        assert sum(c for _, _, c in launches) == n and launches[0][1] == lo
+        ib, iv, db, dv = _unpack(got[r][3], T)
+        for (m, first, cnt) in launches:
+            ref = O.uncor_sample(oms[m], cnt, T, 0x5EED0004, first_index=first, want_events=False)
+            sl = slice(first - lo, first - lo + cnt)
+            assert np.array_equal(ib[sl], ref["init_bin"]) and np.array_equal(db[sl], ref["dense_bin"])
+            assert np.array_equal(dv[sl], ref["dense_val"].astype(np.float32))
+
+
+def test_bench_never_runs_fewer_ranks_than_asked(monkeypatch):
+    """`python bench.py --gpus 2` must start two ranks or fail: no silent one-GPU run."""
+    import bench
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.main(["--gpus", "2"]) == 3            # launcher: no GPUs here -> refuses before spawning anything
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert bench.main(["--gpus", "2"]) == 3            # under a launcher whose world disagrees with --gpus
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    assert bench.main(["--gpus", "1"]) == 3
+
+
+def test_shard_arithmetic_matches_the_library():
+    from em_model_manned_bayes_amd import native, sharding
+    for n_total, world in ((0, 3), (7, 8), (61, 2), (50_000_000, 8), (10, 1)):
+        for r in range(world):
+            assert native.shard_range(n_total, r, world) == sharding.shard_range(n_total, r, world)
+    for n_total, nm, lo, hi in ((50, 6, 10, 30), (50_000_000, 6, 6_250_000, 12_500_000), (5, 6, 0, 5)):
+        assert native.mixed_blocks(n_total, nm, lo, hi) == sharding.mixed_batch_blocks(n_total, nm, lo, hi)
