@@ -96,7 +96,15 @@ def launch_ranks(args, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
+    # a rank that dies must not leave the others waiting at a barrier: watch them all, stop the rest (exact PIDs)
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    out0 = procs[0].communicate()[0].decode()   # one short line: the pipe cannot fill up
     rcs = [p.wait() for p in procs]
     line = None
     for ln in out0.splitlines():

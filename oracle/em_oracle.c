@@ -988,3 +988,8 @@ void em_mt_doubles(uint32_t seed, int n, double *out) {
     for (int i = 0; i < n; i++) out[i] = mt_res53(&s);
 }
 int em_sizeof_model(void) { return (int)sizeof(em_model_t); }
+
+/* test hook: the cosd / sind restatement on a table of angles (tests/golden/make_matlab_goldens.py) */
+void em_sincosd_table(const double *deg, int n, double *s, double *c) {
+    for (int i = 0; i < n; i++) em_sincosd(deg[i], &s[i], &c[i]);
+}

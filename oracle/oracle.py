@@ -316,7 +316,7 @@ class OracleModel:
 
 def uncor_sample(om, n, T, seed, mode=RNG_PHILOX, first_index=0, per_step=False,
                  is_quantize500=False, layers=None, max_attempts=1000,
-                 want_events=True, want_dense=True, ev_cap=None):
+                 want_events=True, want_dense=True, ev_cap=None, reject=True):
     """UncorEncounterModel.sample restated (UncorEncounterModel.m:192-313), n samples.
 
     Returns dict: init_bin [n,ni] int32, init_val [n,ni] f64, events (list of
@@ -327,6 +327,8 @@ def uncor_sample(om, n, T, seed, mode=RNG_PHILOX, first_index=0, per_step=False,
     ni, nd = om.n_initial, om.temporal_map.shape[0]
     o = _UncorOpts()
     o.idxL, o.idxV, o.idxDH = om.label_index("L"), om.label_index("v"), om.label_index("\\dot h")
+    if not reject:   # a plain loop of dbn_hierarchical_sample calls on one stream (no UncorEncounterModel.m:275 test)
+        o.idxL = o.idxV = o.idxDH = 0
     o.is_quantize500 = int(bool(is_quantize500))
     lay = None
     if layers is not None:
