@@ -14,6 +14,15 @@ namespace emgpu {
 
 constexpr int kQueueCap = 128; // request descriptors per wave and compaction round
 
+// -DEMGPU_DEBUG_COUNTERS: wave-level event counts of the data-dependent paths (diagnostic builds only, read
+// through emgpu_debug_counters): 0 exact redos, 1 compaction rounds, 2 compaction steps, 3 worker passes, 4 requests, 5 blocks
+#ifdef EMGPU_DEBUG_COUNTERS
+__device__ unsigned long long g_dbg[8];
+#define EMGPU_COUNT(slot, lane, val) do { if ((lane) == 0) atomicAdd(&g_dbg[slot], (unsigned long long)(val)); } while (0)
+#else
+#define EMGPU_COUNT(slot, lane, val) do { } while (0)
+#endif
+
 // LB: the lanes also publish the packed bins of the block (2 words per variable, after the 8*ND result
 // slots) so that a worker looks the bin of a request up itself instead of the owner encoding it.
 template <int ND, bool LB = false>
@@ -54,7 +63,9 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64
     unsigned long long bal = __ballot(m != 0u);
     while (bal != 0ull) {
         uint32_t base = 0u; // wave-uniform number of queued requests in this round
+        EMGPU_COUNT(1, lane, 1);
         while (bal != 0ull && base + 64u <= (uint32_t)kQueueCap) {
+            EMGPU_COUNT(2, lane, 1);
             if (m != 0u) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                 const uint32_t sb = (uint32_t)__ffs((int)m) - 1u;
@@ -72,7 +83,9 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64
             bal = __ballot(m != 0u);
         }
         wave_sync();
+        EMGPU_COUNT(4, lane, base);
         for (uint32_t q0 = 0u; q0 < base; q0 += 64u) {
+            EMGPU_COUNT(3, lane, 1);
             const uint32_t q = q0 + (uint32_t)lane;
             if (q < base) {
                 const uint32_t d = W.queue[q];

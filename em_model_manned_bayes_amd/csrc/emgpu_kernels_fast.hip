@@ -10,7 +10,10 @@
 //     A draw is decided from its high 16 bits alone unless they tie with a threshold's high half
 //     (p ~ 1e-4 per draw); only then are the SECONDARY (low) halfwords fetched and the 8 seconds
 //     of that variable redone exactly -- the value drawn is the same 32-bit uniform either way.
-//   * u32 compares against register-resident quantile thresholds (select_random.m:17-20).
+//   * compares against register-resident quantile thresholds (select_random.m:17-20), two SECONDS per
+//     instruction: the 16-bit primary halfwords of seconds 2p and 2p+1 share a Philox word, and packed
+//     16-bit arithmetic (v_pk_sub_u16 clamp / v_pk_min_u16 / v_pk_add_u16) counts fired thresholds in
+//     both halves at once; ties with a threshold's high half show up as an odd count.
 //   * the rare dediscretize draws (dediscretize.m:39; ~0.3 per lane and block) are compacted
 //     across the 64 lanes of the wave through LDS and computed by "worker" lanes: one Philox call
 //     per wave serves them all instead of one divergent call per event.
@@ -28,8 +31,9 @@
 namespace emgpu {
 
 struct FastArgs {
-    uint32_t Rk[3];   // resample hit threshold of dynamic variable k (0 = rate 0), < 0xFFFFFFFF
+    uint32_t Rk[3];   // resample hit threshold of dynamic variable k (0 = rate 0), < 0xFFFF0000
     uint32_t slot[3]; // output row of dynamic variable k
+    uint32_t RR1[3];  // (Rk >> 16) + 1 in both halfwords: the packed resample compare (eight_seconds_pk)
 };
 
 #ifndef EMGPU_FAST_WAVES
@@ -78,6 +82,99 @@ __device__ __forceinline__ void load_cthr(uint32_t (&tp)[(M + 1) / 2], uint32_t 
 __device__ __forceinline__ uint32_t zero_stream(uint32_t a, uint32_t b) {
     const uint32_t na = (((a >> 7) & 0x01010101u) * 0x80402010u) >> 28, nb = (((b >> 7) & 0x01010101u) * 0x80402010u) >> 28;
     return (na << 4) | nb;
+}
+
+// ---- the packed (two seconds per instruction) form of the same column ------------------------------------
+// For the high-halfword compare every threshold X_t is represented by the 16-bit value T'_t such that
+//     d = sat(x_h - T'_t)   is   0: not fired,   1: the low halfword decides (tie),   >= 2: fired,
+// i.e. T'_t = H_t - 1 for H_t = X_t >> 16.  Two refinements keep "an odd sum of min(d, 2) <=> some tie" exact:
+//   * the T' of a column are made strictly increasing (T'_t = max(H_t - 1, T'_{t-1} + 1)): thresholds that share a
+//     high half would otherwise tie together and leave an even sum.  A shifted threshold can only be mis-decided
+//     at an x_h where its predecessor in the chain reports a tie, so the block is redone exactly anyway;
+//   * H_t = 0 has no T' (it would be -1): it gets T' = 0 and x_h = 0 is treated as a tie by a separate test of the
+//     draws themselves (p = 2^-16 per draw, like any other tie).
+// Thresholds beyond meff (the instance is built for M >= meff) get T' = 0xFFFF: never fired, never a tie.
+// The byte table is indexed by the number of FIRED thresholds n (entries 0-3 in bnl, 4-7 in bnh) and carries the
+// zero-bin flag in bit 7 like the by-borrows table of the exact pass.
+template <int M>
+__device__ __forceinline__ void load_cthr_pk(uint32_t (&tp)[(M + 1) / 2], uint32_t &bnl, uint32_t &bnh, const uint32_t *__restrict__ p, int meff, uint32_t zbin1) {
+    static_assert(M >= 1 && M <= 7, "the byte table has 8 entries");
+    uint32_t tq[M];
+    uint32_t prev = 0u;
+#pragma unroll
+    for (int t = 0; t < M; t++) {
+        uint32_t v = 0xFFFFu;
+        if (t < meff) {
+            const uint32_t h = p[t] >> 16;
+            v = h ? h - 1u : 0u;
+            if (t > 0 && v <= prev) v = prev + 1u;
+            v = v > 0xFFFFu ? 0xFFFFu : v;
+        }
+        tq[t] = v; prev = v;
+    }
+#pragma unroll
+    for (int q = 0; q < (M + 1) / 2; q++) tp[q] = tq[2 * q] | ((2 * q + 1 < M ? tq[2 * q + 1] : 0xFFFFu) << 16);
+    const uint32_t map = p[meff];
+    uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+    for (int n = 0; n <= M; n++) {
+        uint32_t e = (map >> (4 * (n < meff ? n : meff))) & 15u;
+        e |= (e == zbin1) ? kZeroFlag : 0u;
+        if (n < 4) lo |= e << (8 * n); else hi |= e << (8 * (n - 4));
+    }
+    bnl = lo; bnh = hi;
+}
+
+// bit `B` of the 8 packed bytes as an MSB-first stream (see zero_stream)
+template <int B>
+__device__ __forceinline__ uint32_t byte_bit_stream(uint32_t a, uint32_t b) {
+    const uint32_t na = (((a >> B) & 0x01010101u) * 0x80402010u) >> 28, nb = (((b >> B) & 0x01010101u) * 0x80402010u) >> 28;
+    return (na << 4) | nb;
+}
+
+// Eight seconds of one dynamic variable, interior block (every second is a draw), decided from the high halfwords:
+// same outputs as eight_seconds_pass<M, false, false>.  Returns true when some compare of this lane needs the low
+// halfword (the caller then redoes the block exactly).  No carries, no VCC: nothing here needs wait states.
+template <int M>
+__device__ __forceinline__ bool eight_seconds_pk(const uint4 &th, const uint4 &rh, const uint32_t (&tp)[(M + 1) / 2], uint32_t bnl, uint32_t bnh,
+                                                 uint32_t RR1, uint32_t cur_in, uint32_t &cur_out, uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8) {
+    uint32_t nb2[4], par = 0u, hitA = 0u;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const uint32_t w = word_of(th, p), wr = word_of(rh, p);
+        uint32_t acc = 0u;
+#pragma unroll
+        for (int t = 0; t < M; t++) {
+            uint32_t d;                                                                      // select_random.m:19-20 for seconds 2p, 2p+1
+            if (t & 1) asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] clamp" : "=v"(d) : "v"(w), "v"(tp[t >> 1]));
+            else       asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] clamp" : "=v"(d) : "v"(w), "v"(tp[t >> 1]));
+            asm("v_pk_min_u16 %0, %0, 2 op_sel_hi:[1,0]" : "+v"(d));
+            if (t == 0) acc = d; else asm("v_pk_add_u16 %0, %0, %1" : "+v"(acc) : "v"(d));
+        }
+        par |= acc;                                                                          // an odd count in either half: a tie
+        uint32_t cnt;
+        asm("v_pk_lshrrev_b16 %0, 1, %1 op_sel_hi:[0,1]" : "=v"(cnt) : "v"(acc));
+        nb2[p] = __builtin_amdgcn_perm(bnh, bnl, cnt | 0x0c000c00u);                         // dbn_sample.m:144: bins of 2p (byte 0) and 2p+1 (byte 2)
+        uint32_t u;                                                                          // resample_events.m:24: 0 no hit, 1 tie, 2 hit
+        asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(u) : "s"(RR1), "v"(wr));
+        asm("v_pk_min_u16 %0, %0, 2 op_sel_hi:[1,0]" : "+v"(u));
+        hitA = p ? ((hitA << 2) | u) : u;
+    }
+    // x_h = 0 ties with a threshold whose high half is 0 (it has no T'): treat every such draw as a tie
+    uint32_t mz, zt;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(mz) : "v"(th.x), "v"(th.y));
+    asm("v_pk_min_u16 %0, %0, %1" : "+v"(mz) : "v"(th.z));
+    asm("v_pk_min_u16 %0, %0, %1" : "+v"(mz) : "v"(th.w));
+    asm("v_pk_sub_u16 %0, 1, %1 op_sel_hi:[0,1] clamp" : "=v"(zt) : "v"(mz));              // 1 in a half <=> that half of mz is 0
+    pbA = __builtin_amdgcn_perm(nb2[1], nb2[0], 0x06040200u);
+    pbB = __builtin_amdgcn_perm(nb2[3], nb2[2], 0x06040200u);
+    hit8 = (hitA & 0xAAu) | ((hitA >> 17) & 0x55u);                                          // bit 1 of every 2-bit field, MSB-first
+    // changed <=> the bin differs from the second before (dbn_sample.m:151-161); the low nibble alone tells
+    const uint32_t prevA = (pbA << 8) | cur_in, prevB = __builtin_amdgcn_alignbit(pbB, pbA, 24);
+    const uint32_t yA = ((pbA ^ prevA) & 0x0F0F0F0Fu) + 0x0F0F0F0Fu, yB = ((pbB ^ prevB) & 0x0F0F0F0Fu) + 0x0F0F0F0Fu;
+    chg8 = byte_bit_stream<4>(yA, yB);
+    cur_out = pbB >> 24;
+    return (((par & 0x00010001u) | (hitA & 0x00550055u)) | zt) != 0u;
 }
 
 // Eight seconds of one dynamic variable.  Outputs: bins packed 1-based 4 per word (pbA: seconds
@@ -164,12 +261,16 @@ template <int M>
 __device__ __attribute__((noinline)) void eight_seconds_exact(uint32_t c0, uint32_t c1r, uint32_t attempt, uint32_t k0, uint32_t k1,
                                                               uint4 th, uint4 rh, uint32_t tvar, uint32_t ivar, int g8, int T,
                                                               const uint32_t *thr_col /* this lane's column in EmgpuPlan::cthr */, int meff,
-                                                              uint32_t bml, uint32_t bmh, uint32_t Rres, uint32_t cur_in,
+                                                              uint32_t zbin1, uint32_t Rres, uint32_t cur_in,
                                                               uint32_t *out /* cur, pbA, pbB, hit8, chg8 */) {
     const Rng rng{c0, c1r, attempt, k0, k1};
     const uint4 tl = rng.block(EMGPU_SEC_TRANS_LO, tvar, (uint32_t)g8);
     const uint4 rl = rng.block(EMGPU_SEC_RES_LO, ivar, (uint32_t)g8);
-    uint32_t thr[M];
+    uint32_t thr[M], bml, bmh;
+    {   // the column again, in full and with the by-borrows byte table (rare path: nothing of this stays in registers)
+        uint32_t tph[(M + 1) / 2];
+        load_cthr<M>(tph, bml, bmh, thr_col, meff, zbin1);
+    }
     load_cthr_full<M>(thr, thr_col, meff);
     uint32_t cur, a, b, h, c;
     eight_seconds_pass<M, true, true>(th, rh, tl, rl, g8, T, thr, bml, bmh, kSelBase, Rres, cur_in, cur, a, b, h, c);
@@ -179,11 +280,10 @@ __device__ __attribute__((noinline)) void eight_seconds_exact(uint32_t c0, uint3
 template <int M>
 __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uint32_t ivar, int g8, int T,
                                               const uint32_t *ctab /* the variable's compacted table */, int meff, const uint32_t *col_slot /* LDS: this lane's column */,
-                                              const uint32_t (&thr)[(M + 1) / 2], uint32_t bml, uint32_t bmh, uint32_t selbase, uint32_t Rres, uint32_t &cur1,
+                                              const uint32_t (&thr)[(M + 1) / 2], uint32_t bnl, uint32_t bnh, uint32_t zbin1, uint32_t Rres, uint32_t RR1, uint32_t &cur1,
                                               uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8, uint32_t &zer8) {
     const uint4 th = rng.block(EMGPU_SEC_TRANS, tvar, (uint32_t)g8);
     const uint4 rh = rng.block(EMGPU_SEC_RES, ivar, (uint32_t)g8);
-    const uint4 z4 = make_uint4(0, 0, 0, 0);
     uint32_t cur_out = cur1;
     // Interior blocks (every second 1 <= c < T) run the unguarded high-halfword pass inline.  The
     // last (partial) block of a trajectory, and any block in which SOME lane of the wave met a tie,
@@ -192,7 +292,7 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
     const bool edge = 8 * g8 + 7 >= T; // the block runs past the end of the trajectory
     bool redo = edge;
     if (!edge) {
-        const bool amb = eight_seconds_pass<M, false, false>(th, rh, z4, z4, g8, T, thr, bml, bmh, selbase, Rres, cur1, cur_out, pbA, pbB, hit8, chg8);
+        const bool amb = eight_seconds_pk<M>(th, rh, thr, bnl, bnh, RR1, cur1, cur_out, pbA, pbB, hit8, chg8);
         redo = __ballot(amb) != 0ull;
         if (g8 == 0) {
             // Second 0 of a trajectory is the initial state, not a draw (slot 0 is never used,
@@ -205,9 +305,10 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
         }
     }
     if (redo) {
+        EMGPU_COUNT(0, (int)(threadIdx.x & 63), 1);
         uint32_t out[5];
         const uint32_t *thr_col = ctab + (size_t)(*col_slot) * (uint32_t)(meff + 1);
-        eight_seconds_exact<M>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, thr_col, meff, bml, bmh, Rres, cur1, out);
+        eight_seconds_exact<M>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, thr_col, meff, zbin1, Rres, cur1, out);
         cur_out = out[0]; pbA = out[1]; pbB = out[2]; hit8 = out[3]; chg8 = out[4];
     }
     cur1 = cur_out;                      // still carries the zero-bin flag
@@ -275,9 +376,9 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
             for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)(cur1[q] - 1);
             col[k] = c;
         }
-        load_cthr<M0>(th0, bl0, bh0, P.cthr + P.d_coff[0] + (size_t)col[0] * (uint32_t)(P.d_meff[0] + 1), P.d_meff[0], (uint32_t)P.d_zero[0]);
-        load_cthr<M1>(th1, bl1, bh1, P.cthr + P.d_coff[1] + (size_t)col[1] * (uint32_t)(P.d_meff[1] + 1), P.d_meff[1], (uint32_t)P.d_zero[1]);
-        load_cthr<M2>(th2, bl2, bh2, P.cthr + P.d_coff[2] + (size_t)col[2] * (uint32_t)(P.d_meff[2] + 1), P.d_meff[2], (uint32_t)P.d_zero[2]);
+        load_cthr_pk<M0>(th0, bl0, bh0, P.cthr + P.d_coff[0] + (size_t)col[0] * (uint32_t)(P.d_meff[0] + 1), P.d_meff[0], (uint32_t)P.d_zero[0]);
+        load_cthr_pk<M1>(th1, bl1, bh1, P.cthr + P.d_coff[1] + (size_t)col[1] * (uint32_t)(P.d_meff[1] + 1), P.d_meff[1], (uint32_t)P.d_zero[1]);
+        load_cthr_pk<M2>(th2, bl2, bh2, P.cthr + P.d_coff[2] + (size_t)col[2] * (uint32_t)(P.d_meff[2] + 1), P.d_meff[2], (uint32_t)P.d_zero[2]);
         // the exact pass finds its column again through the lane's spare LDS words
 #pragma unroll
         for (int k = 0; k < 3; k++) reinterpret_cast<uint32_t *>(&W.res[lane * CoopLds<3, LB>::kStride + CoopLds<3, LB>::kSpare])[k] = col[k];
@@ -287,18 +388,15 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
     for (int k = 0; k < 3; k++) cur1[k] |= (cur1[k] == (uint32_t)P.d_zero[k]) ? kZeroFlag : 0u;
     const uint32_t iv0 = P.d_ivar[0], iv1 = P.d_ivar[1], iv2 = P.d_ivar[2];
     const uint32_t ivs[3] = {iv0, iv1, iv2};
-    uint32_t selbase; // kSelBase held in a VGPR (the first v_addc of every compare chain reads it)
-    asm volatile("v_mov_b32 %0, %1" : "=v"(selbase) : "s"(kSelBase));
-
     const uint32_t *col_slot = reinterpret_cast<const uint32_t *>(&W.res[lane * CoopLds<3, LB>::kStride + CoopLds<3, LB>::kSpare]);
     const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
     for (int g8 = 0; g8 < G8; g8++) {
         uint32_t pbA[3], pbB[3], need8[3], kind8[3], fill8[3];
         {
             uint32_t hit8[3], chg8[3], zer8[3];
-            eight_seconds<M0>(rng, P.d_tvar[0], iv0, g8, T, P.cthr + P.d_coff[0], P.d_meff[0], col_slot + 0, th0, bl0, bh0, selbase, F.Rk[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
-            eight_seconds<M1>(rng, P.d_tvar[1], iv1, g8, T, P.cthr + P.d_coff[1], P.d_meff[1], col_slot + 1, th1, bl1, bh1, selbase, F.Rk[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
-            eight_seconds<M2>(rng, P.d_tvar[2], iv2, g8, T, P.cthr + P.d_coff[2], P.d_meff[2], col_slot + 2, th2, bl2, bh2, selbase, F.Rk[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
+            eight_seconds<M0>(rng, P.d_tvar[0], iv0, g8, T, P.cthr + P.d_coff[0], P.d_meff[0], col_slot + 0, th0, bl0, bh0, (uint32_t)P.d_zero[0], F.Rk[0], F.RR1[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
+            eight_seconds<M1>(rng, P.d_tvar[1], iv1, g8, T, P.cthr + P.d_coff[1], P.d_meff[1], col_slot + 1, th1, bl1, bh1, (uint32_t)P.d_zero[1], F.Rk[1], F.RR1[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
+            eight_seconds<M2>(rng, P.d_tvar[2], iv2, g8, T, P.cthr + P.d_coff[2], P.d_meff[2], col_slot + 2, th2, bl2, bh2, (uint32_t)P.d_zero[2], F.Rk[2], F.RR1[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
 #pragma unroll
             for (int k = 0; k < 3; k++) {      // the streams stay MSB-first: bit (7-j) <-> second j
                 need8[k] = (hit8[k] | chg8[k]) & ~zer8[k];   // a dediscretize draw is due (dediscretize.m:24-39)
@@ -306,6 +404,7 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
                 fill8[k] = need8[k] | chg8[k];               // the value changes: a draw, or 0 on a change into the zero bin
             }
         }
+        EMGPU_COUNT(5, lane, 1);
         const uint32_t need24 = valid ? (need8[0] | (need8[1] << 8) | (need8[2] << 16)) : 0u;
         const uint32_t kind24 = kind8[0] | (kind8[1] << 8) | (kind8[2] << 16);
         coop_zero_results<3, LB>(W, lane);
@@ -341,7 +440,7 @@ bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     for (int k = 0; k < 3; k++) {
         if (P.d_nb[k] == 0 || P.d_nb[k] > 16 || P.d_meff[k] == 0) return false;
         for (int a = 0; a < P.nact; a++)
-            if (P.a_dyn[a] == k && P.a_R[a] == 0xFFFFFFFFu) return false; // rate ~ 1: generic path
+            if (P.a_dyn[a] == k && P.a_R[a] >= 0xFFFF0000u) return false; // rate ~ 1 (R_h + 1 must fit 16 bits): generic path
     }
     return fast_shape_of(P) >= 0;
 }
@@ -362,6 +461,7 @@ hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t 
         F.slot[k] = P.d_row[k];
         for (int a = 0; a < P.nact; a++)
             if (P.a_dyn[a] == k) F.Rk[k] = P.a_R[a];
+        F.RR1[k] = ((F.Rk[k] >> 16) + 1u) * 0x00010001u;
     }
     switch (fast_shape_of(P)) {
     case 0: *name = "k_uncor_fast<7,2,2,2>"; return launch_t<7, 2, 2, 2>(P, A, F, s);
@@ -375,5 +475,13 @@ hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t 
     default: *name = "none"; return hipErrorNotSupported;
     }
 }
+
+#ifdef EMGPU_DEBUG_COUNTERS
+extern "C" int emgpu_debug_counters(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof z); }
+    return 0;
+}
+#endif
 
 } // namespace emgpu

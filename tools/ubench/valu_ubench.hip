@@ -41,6 +41,47 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t a0, uint32_t b0
 #define MULLO(n) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x##n) : "v"(c));
 #define MULU24(n) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x##n) : "v"(c));
 #define MADU24(n) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x##n) : "v"(c), "v"(d));
+#define PKSUBC(n) asm volatile("v_pk_sub_u16 %0, %0, %1 op_sel_hi:[1,1] clamp" : "+v"(x##n) : "v"(c));
+#define PKSUBSEL(n) asm volatile("v_pk_sub_u16 %0, %0, %1 op_sel:[1,0] op_sel_hi:[1,1] clamp" : "+v"(x##n) : "v"(c));
+#define PKMIN(n) asm volatile("v_pk_min_u16 %0, %0, 2 op_sel_hi:[1,0]" : "+v"(x##n));
+#define PKMINV(n) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(x##n) : "v"(c));
+#define PKADD(n) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(x##n) : "v"(c));
+#define PKLSHR(n) asm volatile("v_pk_lshrrev_b16 %0, 1, %0 op_sel_hi:[0,1]" : "+v"(x##n));
+#define ANDOR(n) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x##n) : "v"(c), "v"(d));
+#define BFE(n) asm volatile("v_bfe_u32 %0, %0, 3, 5" : "+v"(x##n));
+#define BCNT(n) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(x##n) : "v"(c));
+#define ORLIT(n) asm volatile("v_or_b32 %0, 0x0c000c00, %0" : "+v"(x##n));
+#define ADDV(n) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x##n) : "v"(c));
+#define LSHR(n) asm volatile("v_lshrrev_b32 %0, 15, %0" : "+v"(x##n));
+#define ADDDPP(n) asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(x##n));
+#define DOT2(n) asm volatile("v_dot2_u32_u16 %0, %0, %1, %2" : "+v"(x##n) : "v"(c), "v"(d));
+#define ADDSDWA(n) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "+v"(x##n) : "v"(c));
+#define SWAR4(n) asm volatile("v_sub_u32 %0, %1, %0\n\tv_lshrrev_b32 %0, 15, %0\n\tv_and_b32 %0, 0x00010001, %0\n\tv_add_u32 %0, %0, %2" : "+v"(x##n) : "v"(c), "v"(d));
+#define PK3(n) asm volatile("v_pk_sub_u16 %0, %1, %0 clamp\n\tv_pk_min_u16 %0, %0, 2 op_sel_hi:[1,0]\n\tv_pk_add_u16 %0, %0, %2" : "+v"(x##n) : "v"(c), "v"(d));
+#define FFBL(n) asm volatile("v_ffbl_b32 %0, %0" : "+v"(x##n));
+#define MOVV(n) asm volatile("v_mov_b32 %0, %1" : "=v"(x##n) : "v"(c));
+#define CNDM(n) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x##n) : "v"(c) : "vcc");
+#define ADDF64(n) { double q = __longlong_as_double(((long long)x##n << 32) | x##n); asm volatile("v_add_f64 %0, %0, %1" : "+v"(q) : "v"(q)); x##n = (uint32_t)__double_as_longlong(q); }
+            if (KIND == 30) { REP8(PKSUBC) }
+            if (KIND == 31) { REP8(PKSUBSEL) }
+            if (KIND == 32) { REP8(PKMIN) }
+            if (KIND == 33) { REP8(PKMINV) }
+            if (KIND == 34) { REP8(PKADD) }
+            if (KIND == 35) { REP8(PKLSHR) }
+            if (KIND == 36) { REP8(ANDOR) }
+            if (KIND == 37) { REP8(BFE) }
+            if (KIND == 38) { REP8(BCNT) }
+            if (KIND == 39) { REP8(ORLIT) }
+            if (KIND == 40) { REP8(ADDV) }
+            if (KIND == 41) { REP8(LSHR) }
+            if (KIND == 42) { REP8(ADDDPP) }
+            if (KIND == 43) { REP8(DOT2) }
+            if (KIND == 44) { REP8(ADDSDWA) }
+            if (KIND == 45) { REP8(SWAR4) }
+            if (KIND == 46) { REP8(PK3) }
+            if (KIND == 47) { REP8(FFBL) }
+            if (KIND == 48) { REP8(MOVV) }
+            if (KIND == 49) { REP8(CNDM) }
             if (KIND == 21) { REP8(MULLO) }
             if (KIND == 22) { REP8(MULU24) }
             if (KIND == 23) { REP8(MADU24) }
@@ -112,6 +153,26 @@ int main() {
     run<23>("v_mad_u32_u24", 1);
     run<15>("v_min3_u32", 1);
     run<16>("v_min_u32 (VOP2)", 1);
+    run<30>("v_pk_sub_u16 clamp", 1);
+    run<31>("v_pk_sub_u16 clamp op_sel", 1);
+    run<32>("v_pk_min_u16 inline const", 1);
+    run<33>("v_pk_min_u16 vgpr", 1);
+    run<34>("v_pk_add_u16", 1);
+    run<35>("v_pk_lshrrev_b16", 1);
+    run<36>("v_and_or_b32", 1);
+    run<37>("v_bfe_u32", 1);
+    run<38>("v_bcnt_u32_b32", 1);
+    run<39>("v_or_b32 literal (VOP2)", 1);
+    run<40>("v_add_u32 (VOP2)", 1);
+    run<41>("v_lshrrev_b32 (VOP2)", 1);
+    run<42>("v_add_u32_dpp row_shr:1", 1);
+    run<43>("v_dot2_u32_u16", 1);
+    run<44>("v_add_u32_sdwa", 1);
+    run<45>("SWAR4: sub,lshr,and,add (per instr)", 4);
+    run<46>("PK3: pk_sub clamp,pk_min,pk_add (per instr)", 3);
+    run<47>("v_ffbl_b32 (VOP1)", 1);
+    run<48>("v_mov_b32 (VOP1)", 1);
+    run<49>("v_cndmask_b32 vcc (VOP2)", 1);
     run<12>("v_and_b32 literal (VOP2)", 1);
     run<13>("v_lshlrev_b32 (VOP2)", 1);
     return 0;
