@@ -318,9 +318,9 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
 
 template <int NI, int M0, int M1, int M2>
 __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
-    // workers look the bin of a request up in LDS only where the registers allow it (the instances with
-    // many thresholds would spill)
-    constexpr bool LB = (M0 + M1 + M2) <= 10;
+    // workers look the bin of a request up in LDS (the owner does not encode it into the request): -1.8 % on the
+    // <7,4,6,6> instance too since the packed compare pass freed its registers
+    constexpr bool LB = true;
     __shared__ CoopLds<3, LB> s_wave[4];
     __shared__ double s_bnd[3][16];
     const int tid = threadIdx.x, lane = tid & 63;
