@@ -61,13 +61,21 @@ class SampleParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64),
                 ("sample_time", C.c_int32), ("transition_mode", C.c_int32), ("flags", C.c_uint32),
                 ("max_attempts", C.c_int32), ("idx_L", C.c_int32), ("idx_v", C.c_int32), ("idx_dh", C.c_int32),
-                ("n_layers", C.c_int32), ("layers", C.c_void_p), ("event_cap", C.c_int32), ("_pad", C.c_int32)]
+                ("n_layers", C.c_int32), ("layers", C.c_void_p), ("event_cap", C.c_int32), ("_pad", C.c_int32),
+                ("indices", C.c_void_p)]
 
 
 class SampleOut(C.Structure):
     _fields_ = [("init_bin", C.c_void_p), ("init_val", C.c_void_p), ("dyn_bin", C.c_void_p), ("dyn_val", C.c_void_p),
                 ("ev_count", C.c_void_p), ("events", C.c_void_p), ("attempts", C.c_void_p),
                 ("ld", C.c_int64), ("col_offset", C.c_int64)]
+
+
+class UTrackParams(C.Structure):  # emgpu_utrack_params
+    _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("sample_time", C.c_int32), ("flags", C.c_uint32),
+                ("max_track_attempts", C.c_int32), ("max_attempts", C.c_int32),
+                ("idx_G", C.c_int32), ("idx_A", C.c_int32), ("idx_L", C.c_int32), ("idx_v", C.c_int32), ("idx_dv", C.c_int32),
+                ("idx_dh", C.c_int32), ("idx_dpsi", C.c_int32), ("is_rotorcraft", C.c_int32), ("record_stride", C.c_int32), ("_pad", C.c_int32)]
 
 
 class Block(C.Structure):         # emgpu_block
@@ -105,6 +113,7 @@ SYMBOLS = [
     "emgpu_sample2track_device", "emgpu_sample2track_host",
     "emgpu_model_set_zero_bins", "emgpu_shard_range", "emgpu_device_count", "emgpu_mixed_blocks",
     "emgpu_sample_dbn_blocks_device", "emgpu_sample_dbn_multi_host", "emgpu_sample_dbn_multi_device",
+    "emgpu_track_uncor_host", "emgpu_track_uncor_device", "emgpu_uncor_dynamic_limits",
 ]
 
 _lib = None
@@ -149,6 +158,9 @@ def lib():
                                                  C.POINTER(SampleOut)]
     L.emgpu_sample_dbn_multi_host.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(SampleParams), C.POINTER(SampleOut)]
     L.emgpu_sample_dbn_multi_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(SampleParams), C.POINTER(SampleOut)]
+    for f in (L.emgpu_track_uncor_host, L.emgpu_track_uncor_device):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(UTrackParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emgpu_uncor_dynamic_limits.argtypes = [C.c_void_p, C.POINTER(UTrackParams), C.c_void_p] + [C.c_double] * 4 + [C.c_void_p]
     L.emgpu_ctx_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
     L.emgpu_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.emgpu_ctx_sync.argtypes = [C.c_void_p]

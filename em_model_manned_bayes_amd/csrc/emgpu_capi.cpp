@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -467,6 +468,7 @@ static void fill_run(emgpu_ctx *ctx, const Uploaded &u, const Model &m, const em
     A.event_cap = p->event_cap;
     A.status = ctx->d_status;
     A.ld = p->n;
+    A.indices = p->indices;
 }
 
 // Point the run at the caller's buffers: column col_offset of arrays whose trajectory dimension is ld.
@@ -660,7 +662,14 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_samp
         if (out->ev_count) d.ev_count = (uint32_t *)dalloc(b_ec);
         if (out->events) d.events = (emgpu_event *)dalloc(b_ev);
         if (out->attempts) d.attempts = (int32_t *)dalloc(b_at);
-        rc = emgpu_sample_dbn_device(ctx, h, p, &d);
+        emgpu_sample_params pd = *p;
+        if (p->indices && n) {   // the index list is caller (host) memory here
+            uint64_t *di = (uint64_t *)dalloc(n * sizeof(uint64_t));
+            HIP_OK(hipMemcpyAsync(di, p->indices, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+            HIP_OK(hipStreamSynchronize(ctx->stream));
+            pd.indices = di;
+        }
+        rc = emgpu_sample_dbn_device(ctx, h, &pd, &d);
         if (rc == EMGPU_OK) {
             // rows x (n elements of `elem` bytes) from the shard-sized device array into columns [off, off + n) of the host array
             auto back = [&](void *dst, const void *src, size_t rows, size_t elem) {
@@ -1003,6 +1012,165 @@ int emgpu_sample2track_host(emgpu_ctx *ctx, const emgpu_track_params *p, const d
     }
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_in); (void)hipFree(d_xyz); (void)hipFree(d_vmm); (void)hipFree(d_fl);
+    return rc;
+    EMGPU_CATCH
+}
+
+static emgpu::UncorTrackVars track_vars(const emgpu_utrack_params *p) {
+    emgpu::UncorTrackVars tv;
+    tv.idxG = p->idx_G; tv.idxA = p->idx_A; tv.idxL = p->idx_L; tv.idxV = p->idx_v; tv.idxDV = p->idx_dv; tv.idxDH = p->idx_dh; tv.idxDPsi = p->idx_dpsi;
+    tv.is_rotorcraft = p->is_rotorcraft != 0;
+    return tv;
+}
+
+int emgpu_uncor_dynamic_limits(const emgpu_model *h, const emgpu_utrack_params *vars, const double *initial,
+                               double up_min, double up_max, double v_min, double v_max, double out[3]) {
+    EMGPU_TRY
+    if (!h || !vars || !initial || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    const emgpu::UncorLimits L = emgpu::build_uncor_limits(h->m, track_vars(vars));
+    const double *e = L.table.data();
+    if (L.ordered) {
+        auto disc = [](double x, const double *cut, int n) { return (int)emgpu_discretize_bayes(x, cut, n); };
+        const int dG = (int)initial[vars->idx_G - 1], dA = (int)initial[vars->idx_A - 1];
+        int l0, l1, b0, b1;
+        if (L.discL) l0 = l1 = (int)initial[vars->idx_L - 1];
+        else { l0 = disc(up_min, L.cutL, L.ncL); l1 = disc(up_max, L.cutL, L.ncL); }
+        b0 = disc(v_min * 0.592484, L.cutV, L.ncV); b1 = disc(v_max * 0.592484, L.cutV, L.ncV);
+        if (dG < 1 || dG > L.rG || dA < 1 || dA > L.rA || l0 < 1 || l1 > L.rL || l0 > l1 || b0 > b1) return fail(EMGPU_ERR_ARG, "initial values outside the model's bins");
+        e += ((((((size_t)(dG - 1) * L.rA + (size_t)(dA - 1)) * L.rL + (size_t)(l0 - 1)) * L.rL + (size_t)(l1 - 1)) * L.rV + (size_t)(b0 - 1)) * L.rV + (size_t)(b1 - 1)) * 3;
+    }
+    out[0] = e[0]; out[1] = e[1]; out[2] = e[2];
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+// The rounds of UncorEncounterModel.m:419-471 (see the header).  d_*: device outputs (any may be null).
+static int track_uncor_rounds(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_utrack_params *p, double *d_tracks, double *d_limits, int32_t *d_attempts) {
+    const Model &m = h->m;
+    if (p->n < 0 || p->sample_time < 1 || p->sample_time > 65535) throw Error(EMGPU_ERR_ARG, "n < 0 or sample_time outside 1..65535");
+    if (p->max_track_attempts < 1 || p->max_attempts < 1 || p->record_stride < 1 || (10 * p->sample_time) % p->record_stride)
+        throw Error(EMGPU_ERR_ARG, "max_track_attempts / max_attempts must be >= 1 and record_stride must divide 10 * sample_time");
+    const emgpu::UncorLimits L = emgpu::build_uncor_limits(m, track_vars(p));
+    if (m.n_dyn() < 3) throw Error(EMGPU_ERR_ARG, "dynvar:empty: the model needs dynamic variables for acceleration, vertical rate and turn rate");
+    auto row_of = [&](int idx) {   // row of the temporal map == row of the dense trace
+        for (size_t k = 0; k < m.temporal_map.size(); k++) if (m.temporal_map[k][0] == idx) return (int)k;
+        throw Error(EMGPU_ERR_ARG, "dynvar:empty: \\dot v, \\dot h and \\dot \\psi must be dynamic variables");
+    };
+    const int sDV = row_of(p->idx_dv), sDH = row_of(p->idx_dh), sDPsi = row_of(p->idx_dpsi);
+    const size_t n = (size_t)p->n, ni = (size_t)m.n_initial, nd = (size_t)m.n_dyn(), T = (size_t)p->sample_time, G4 = (T + 3) / 4;
+    if (n == 0) return EMGPU_OK;
+    std::vector<void *> allocs;
+    auto dalloc = [&](size_t bytes) { void *q = nullptr; HIP_OK(hipMalloc(&q, bytes ? bytes : 1)); allocs.push_back(q); return q; };
+    int rc = EMGPU_OK;
+    try {
+        float *d_iv = (float *)dalloc(ni * n * 4), *d_dv = (float *)dalloc(G4 * nd * n * 16);
+        double *d_lim = (double *)dalloc(L.table.size() * 8);
+        uint8_t *d_acc = (uint8_t *)dalloc(n);
+        uint64_t *d_gidx[2] = {(uint64_t *)dalloc(n * 8), (uint64_t *)dalloc(n * 8)};
+        int64_t *d_slot[2] = {(int64_t *)dalloc(n * 8), (int64_t *)dalloc(n * 8)};
+        uint32_t *d_count = (uint32_t *)dalloc(4);
+        HIP_OK(hipMemcpyAsync(d_lim, L.table.data(), L.table.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream)); // L.table is a local
+        Uploaded &u = get_uploaded(ctx, h);
+        EmgpuUTrackRun R;
+        memset(&R, 0, sizeof R);
+        R.T = (int32_t)T; R.stride = p->record_stride; R.nd = (int32_t)nd; R.sDV = sDV; R.sDH = sDH; R.sDPsi = sDPsi;
+        {   // UncorEncounterModel.m:397-414
+            const std::vector<double> &bL = m.boundaries[p->idx_L - 1], &bV = m.boundaries[p->idx_v - 1], &bDH = m.boundaries[p->idx_dh - 1];
+            R.min_alt = bL.empty() ? 0.0 : *std::min_element(bL.begin(), bL.end());
+            R.max_alt = bL.empty() ? INFINITY : *std::max_element(bL.begin(), bL.end());
+            R.dyn[0] = 1.7; R.dyn[1] = *std::max_element(bV.begin(), bV.end()) * 1.68780972222222;
+            R.dyn[2] = *std::min_element(bDH.begin(), bDH.end()) / 60.0; R.dyn[3] = *std::max_element(bDH.begin(), bDH.end()) / 60.0;
+            R.dyn[4] = 3.0 * (3.14159265358979323846 / 180.0); R.dyn[5] = 1000000.0;
+        }
+        R.ordered = L.ordered; R.rG = L.rG; R.rA = L.rA; R.rL = L.rL; R.rV = L.rV; R.ncL = L.ncL; R.ncV = L.ncV; R.discL = L.discL; R.discV = L.discV;
+        memcpy(R.cutL, L.cutL, sizeof R.cutL); memcpy(R.cutV, L.cutV, sizeof R.cutV);
+        R.lim = d_lim; R.tracks = d_tracks; R.S = (int64_t)(10 * T / (size_t)p->record_stride + 1); R.limits = d_limits;
+        R.accepted = d_acc; R.attempts = d_attempts;
+        size_t count = n;
+        for (int j = 0; j < p->max_track_attempts && count > 0; j++) {
+            const int cur = j & 1;
+            emgpu_sample_params sp;
+            memset(&sp, 0, sizeof sp);
+            sp.seed = p->seed + (uint64_t)j;                                  // :428  seed = seed + 1
+            sp.first_index = p->first_index; sp.n = (int64_t)count; sp.sample_time = p->sample_time;
+            sp.flags = p->flags & EMGPU_FLAG_QUANTIZE500; sp.max_attempts = p->max_attempts;
+            sp.idx_L = p->idx_L; sp.idx_v = p->idx_v; sp.idx_dh = p->idx_dh;
+            sp.indices = j ? d_gidx[cur] : nullptr;
+            EmgpuRun A;
+            fill_run(ctx, u, m, &sp, A);
+            A.init_val = d_iv; A.dyn_val = d_dv; A.ld = (int64_t)count;
+            launch_dbn(ctx, u, A);                                            // :424  self.sample(1, sample_time, 'seed', seed)
+            const std::string sampler = ctx->last_kernel;
+            R.n = (int64_t)count; R.ld = (int64_t)count;
+            auto row = [&](int idx) -> const float * { return idx > 0 ? d_iv + (size_t)(idx - 1) * count : nullptr; };
+            R.iG = row(p->idx_G); R.iA = row(p->idx_A); R.iL = row(p->idx_L); R.iV = row(p->idx_v);
+            R.iDV = row(p->idx_dv); R.iDH = row(p->idx_dh); R.iDPsi = row(p->idx_dpsi);
+            R.dyn_val = d_dv; R.slot = j ? d_slot[cur] : nullptr;
+            R.attempt_no = j + 1; R.last_round = (j + 1 == p->max_track_attempts);
+            const char *name = "";
+            hipError_t e = emgpu::launch_uncor_track(R, ctx->stream, &name);
+            if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+            ctx->last_kernel = sampler + " + " + name;
+            HIP_OK(hipMemsetAsync(d_count, 0, 4, ctx->stream));
+            e = emgpu::launch_compact_rejected((int64_t)count, p->first_index, d_acc, j ? d_gidx[cur] : nullptr, j ? d_slot[cur] : nullptr,
+                                               d_gidx[cur ^ 1], d_slot[cur ^ 1], d_count, ctx->stream);
+            if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+            uint32_t hc = 0;
+            HIP_OK(hipMemcpyAsync(&hc, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_OK(hipStreamSynchronize(ctx->stream));
+            count = hc;
+        }
+        rc = emgpu_ctx_sync(ctx);   // the sampler's own rejection cap
+        if (rc == EMGPU_OK && count > 0) rc = fail(EMGPU_ERR_REJECT_CAP, "track: " + std::to_string(count) + " trajectories were still rejected after max_track_attempts");
+    } catch (...) {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void *q : allocs) (void)hipFree(q);
+        throw;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void *q : allocs) (void)hipFree(q);
+    return rc;
+}
+
+int emgpu_track_uncor_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_utrack_params *p, double *tracks, double *limits, int32_t *attempts) {
+    EMGPU_TRY
+    if (!ctx || !h || !p) return fail(EMGPU_ERR_ARG, "null argument");
+    CTX_LOCK(ctx);
+    HIP_OK(hipSetDevice(ctx->device));
+    return track_uncor_rounds(ctx, h, p, tracks, limits, attempts);
+    EMGPU_CATCH
+}
+
+int emgpu_track_uncor_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_utrack_params *p, double *tracks, double *limits, int32_t *attempts) {
+    EMGPU_TRY
+    if (!ctx || !h || !p) return fail(EMGPU_ERR_ARG, "null argument");
+    CTX_LOCK(ctx);
+    HIP_OK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)(p->n > 0 ? p->n : 0);
+    if (p->record_stride < 1 || p->sample_time < 1) return fail(EMGPU_ERR_ARG, "bad record_stride / sample_time");
+    const size_t S = (size_t)(10 * p->sample_time / p->record_stride + 1);
+    double *dt = nullptr, *dl = nullptr; int32_t *da = nullptr;
+    int rc;
+    try {
+        if (tracks) HIP_OK(hipMalloc((void **)&dt, n * S * 8 * sizeof(double) + 8));
+        if (limits) HIP_OK(hipMalloc((void **)&dl, n * 3 * sizeof(double) + 8));
+        HIP_OK(hipMalloc((void **)&da, n * 4 + 4));
+        rc = track_uncor_rounds(ctx, h, p, dt, dl, da);
+        if (rc == EMGPU_OK || rc == EMGPU_ERR_REJECT_CAP) {
+            const std::string msg = g_err;
+            if (tracks && n) HIP_OK(hipMemcpyAsync(tracks, dt, n * S * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            if (limits && n) HIP_OK(hipMemcpyAsync(limits, dl, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            if (attempts && n) HIP_OK(hipMemcpyAsync(attempts, da, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_OK(hipStreamSynchronize(ctx->stream));
+            if (rc != EMGPU_OK) g_err = msg;
+        }
+    } catch (...) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(dt); (void)hipFree(dl); (void)hipFree(da);
+        throw;
+    }
+    (void)hipFree(dt); (void)hipFree(dl); (void)hipFree(da);
     return rc;
     EMGPU_CATCH
 }

@@ -434,6 +434,7 @@ static int fast_shape_of(const EmgpuPlan &P) {
 }
 
 bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
+    if (A.indices != nullptr) return false; // an index list goes through the generic kernel
     if (P.nd != 3 || P.depend || A.per_step) return false;
     if (A.ev_count != nullptr || A.events != nullptr) return false;
     if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;

@@ -272,6 +272,7 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const E
 #undef load4
 
 bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
+    if (A.indices != nullptr) return false; // an index list goes through the generic kernel
     static const bool off = getenv("EMGPU_DEBUG_NO_STEP2") != nullptr;
     if (off) return false;
     if (P.nd < 1 || P.nd > 4) return false;

@@ -1,0 +1,134 @@
+// emgpu_kernels_utrack.hip -- UncorEncounterModel.track (@UncorEncounterModel/UncorEncounterModel.m:419-471, coordSys 'NEU'):
+// the sampled controls integrated into a 10 Hz track and the three rejection tests of :462-470, one lane per trajectory,
+// reading the sampler's device output where it lies (init_val rows + the time-blocked dense trace).
+//
+// The reference integrates with em-core's run_dynamics_fast mex and differentiates the altitude with em-core's
+// computeVerticalRate; em-core is not vendored by the reference ("dynamics unpinned").  The point-mass
+// model used instead is built from the quantities the reference hands to run_dynamics_fast (ic = [v n e h psi theta phi a],
+// :443; dyn = [v_low v_high dh_min dh_max qmax rmax], :414; control rows [t hdot psidot a], :291-297), in f64 without
+// contraction.  dt = 0.1 s, g = 32.2 ft/s^2 (the constant of :440); per step, with the control row active at t:
+//     a      = 0 when it would drive v beyond [v_low, v_high]
+//     hd     = min(max(hdot, dh_min), dh_max)
+//     theta += clamp((asin(clamp(hd / v, -1, 1)) - theta) / dt, -qmax, qmax) * dt     pitch follows the commanded climb
+//     phi   += clamp((atan(v * psidot / g) - phi) / dt, -rmax, rmax) * dt             bank follows the commanded turn
+//     n += v cos(theta) cos(psi) dt;  e += v cos(theta) sin(psi) dt;  h += v sin(theta) dt
+//     psi += g tan(phi) / v * dt;  v = min(max(v + a dt, v_low), v_high)
+// results.time = 0 : 0.1 : T; computeVerticalRate(up(is_sec), time(is_sec)) := forward difference of the 1 Hz altitudes.
+// Limits: @UncorEncounterModel/getDynamicLimits.m:1-130 evaluated on the host for every (G, A, altitude-layer range,
+// speed-bin range) the expression can see, looked up here by the track's own minima and maxima.
+// Bound: f64 transcendental issue (asin, atan, tan, two sincos per 0.1 s step); 64 B per recorded step.
+#include <hip/hip_runtime.h>
+
+#include "emgpu_launch.h"
+#include "emgpu_plan.h"
+
+namespace emgpu {
+
+__device__ __forceinline__ int ut_discretize(double x, const double *cut, int n) { // discretize_bayes.m:14-22
+    if (x >= cut[n - 1]) return n + 1;
+    int d = n + 1;
+    for (int i = n - 1; i >= 0; i--) d = (x < cut[i]) ? i + 1 : d;
+    return d;
+}
+
+__global__ void __launch_bounds__(256) k_uncor_track(const EmgpuUTrackRun A) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const size_t ld = (size_t)A.ld;
+    const int64_t slot = A.slot ? A.slot[i] : i;
+    const double kPi180 = 3.14159265358979323846 / 180.0, dt = 0.1, g = 32.2;
+    // :434-446
+    const double h0 = (double)A.iL[i], v0 = (double)A.iV[i] * 1.68780972222222;
+    const double dv0 = (double)A.iDV[i] * 1.68780972222222, dh0 = (double)A.iDH[i] / 60.0, dpsi0 = (double)A.iDPsi[i] * kPi180;
+    double v = v0, n = 0.0, e = 0.0, h = h0, psi = 0.0, theta = asin(dh0 / v0), phi = atan(v0 * dpsi0 / 32.2);
+    (void)dv0; // ic(8): the model takes its acceleration from the control rows, whose first row repeats it
+    double up_min = h, up_max = h, v_min = v, v_max = v, vr_max = 0.0, h_sec = h;
+    double *out = A.tracks ? A.tracks + (size_t)slot * (size_t)A.S * 8 : nullptr;
+    if (out) { out[0] = 0.0; out[1] = n; out[2] = e; out[3] = h; out[4] = v; out[5] = phi; out[6] = theta; out[7] = psi; }
+    const float4 *dv4 = reinterpret_cast<const float4 *>(A.dyn_val);
+    int64_t step = 0;
+    for (int c4 = 0; c4 * 4 < A.T; c4++) {
+        const float4 qDH = dv4[((size_t)c4 * A.nd + A.sDH) * ld + (size_t)i];
+        const float4 qDP = dv4[((size_t)c4 * A.nd + A.sDPsi) * ld + (size_t)i];
+        const float4 qDV = dv4[((size_t)c4 * A.nd + A.sDV) * ld + (size_t)i];
+        const float fDH[4] = {qDH.x, qDH.y, qDH.z, qDH.w}, fDP[4] = {qDP.x, qDP.y, qDP.z, qDP.w}, fDV[4] = {qDV.x, qDV.y, qDV.z, qDV.w};
+#pragma unroll 1
+        for (int w = 0; w < 4 && 4 * c4 + w < A.T; w++) {
+            // the control row active during this second (events2controls.m:16-27; units :295-297)
+            const double hdot = (double)fDH[w] / 60.0, psidot = (double)fDP[w] * kPi180, acmd = (double)fDV[w] * 1.68780972222222;
+            const double hd = hdot < A.dyn[2] ? A.dyn[2] : (hdot > A.dyn[3] ? A.dyn[3] : hdot);
+#pragma unroll 1
+            for (int s = 0; s < 10; s++) {
+                double a = acmd;
+                if ((v >= A.dyn[1] && a > 0) || (v <= A.dyn[0] && a < 0)) a = 0;
+                double sn = hd / v; sn = sn < -1 ? -1 : (sn > 1 ? 1 : sn);
+                double q = (asin(sn) - theta) / dt; q = q < -A.dyn[4] ? -A.dyn[4] : (q > A.dyn[4] ? A.dyn[4] : q);
+                theta = theta + q * dt;
+                double r = (atan(v * psidot / g) - phi) / dt; r = r < -A.dyn[5] ? -A.dyn[5] : (r > A.dyn[5] ? A.dyn[5] : r);
+                phi = phi + r * dt;
+                const double ct = cos(theta), st = sin(theta);
+                n = n + v * ct * cos(psi) * dt;
+                e = e + v * ct * sin(psi) * dt;
+                h = h + v * st * dt;
+                psi = psi + g * tan(phi) / v * dt;
+                v = v + a * dt; v = v < A.dyn[0] ? A.dyn[0] : (v > A.dyn[1] ? A.dyn[1] : v);
+                step++;
+                if (out && step % A.stride == 0) {
+                    double *o = out + (size_t)(step / A.stride) * 8;
+                    o[0] = (double)step / 10.0; o[1] = n; o[2] = e; o[3] = h; o[4] = v; o[5] = phi; o[6] = theta; o[7] = psi;
+                }
+                up_min = h < up_min ? h : up_min; up_max = h > up_max ? h : up_max;
+                v_min = v < v_min ? v : v_min; v_max = v > v_max ? v : v_max;
+            }
+            const double vr = fabs(h - h_sec);
+            vr_max = vr > vr_max ? vr : vr_max;
+            h_sec = h;
+        }
+    }
+    // getDynamicLimits.m through the host-built table
+    const double *L3 = A.lim;
+    if (A.ordered) {
+        const int dG = (int)A.iG[i], dA = (int)A.iA[i];
+        int l0, l1, b0, b1;
+        if (A.discL) l0 = l1 = (int)A.iL[i];
+        else { l0 = ut_discretize(up_min, A.cutL, A.ncL); l1 = ut_discretize(up_max, A.cutL, A.ncL); }
+        if (A.discV) b0 = b1 = (int)A.iV[i];
+        else { b0 = ut_discretize(v_min * 0.592484, A.cutV, A.ncV); b1 = ut_discretize(v_max * 0.592484, A.cutV, A.ncV); }
+        const size_t idx = (((((size_t)(dG - 1) * A.rA + (size_t)(dA - 1)) * A.rL + (size_t)(l0 - 1)) * A.rL + (size_t)(l1 - 1)) * A.rV + (size_t)(b0 - 1)) * A.rV + (size_t)(b1 - 1);
+        L3 = A.lim + idx * 3;
+    }
+    const double minVel = L3[0], maxVel = L3[1], maxVR = L3[2];
+    if (A.limits) { A.limits[(size_t)slot * 3] = minVel; A.limits[(size_t)slot * 3 + 1] = maxVel; A.limits[(size_t)slot * 3 + 2] = maxVR; }
+    const bool viol = (up_min < A.min_alt || up_max > A.max_alt) || (v_min < minVel || v_max > maxVel) || (vr_max > maxVR);   // :462-470
+    A.accepted[i] = viol ? 0 : 1;
+    if (A.attempts) {
+        if (!viol) A.attempts[slot] = A.attempt_no;
+        else if (A.last_round) A.attempts[slot] = -1;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_compact_rejected(int64_t n, uint64_t first_index, const uint8_t *accepted, const uint64_t *gidx_in, const int64_t *slot_in,
+                                                          uint64_t *gidx_out, int64_t *slot_out, uint32_t *count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || accepted[i]) return;
+    const uint32_t k = atomicAdd(count, 1u);
+    gidx_out[k] = gidx_in ? gidx_in[i] : first_index + (uint64_t)i;   // round 0 covers the contiguous range
+    slot_out[k] = slot_in ? slot_in[i] : i;
+}
+
+hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char **name) {
+    *name = "k_uncor_track";
+    if (A.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_uncor_track, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, s, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_rejected(int64_t n, uint64_t first_index, const uint8_t *accepted, const uint64_t *gidx_in, const int64_t *slot_in,
+                                   uint64_t *gidx_out, int64_t *slot_out, uint32_t *count, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_compact_rejected, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, first_index, accepted, gidx_in, slot_in, gidx_out, slot_out, count);
+    return hipGetLastError();
+}
+
+} // namespace emgpu

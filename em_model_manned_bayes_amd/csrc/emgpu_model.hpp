@@ -67,6 +67,19 @@ struct CompiledPlan {
 // Throws Error(EMGPU_ERR_UNSUPPORTED / EMGPU_ERR_PRESET / ...) when the model cannot be planned.
 CompiledPlan compile_plan(const Model &m);
 
+// @UncorEncounterModel/getDynamicLimits.m as a table (emgpu_limits.cpp)
+struct UncorTrackVars {
+    int idxG = 0, idxA = 0, idxL = 0, idxV = 0, idxDV = 0, idxDH = 0, idxDPsi = 0; // 1-based, 0 = absent (UncorEncounterModel.m:385-391)
+    bool is_rotorcraft = false;                                                     // :181-185
+};
+struct UncorLimits {
+    bool ordered = false, discL = false, discV = false;
+    int rG = 0, rA = 0, rL = 0, rV = 0, ncL = 0, ncV = 0;
+    double cutL[16] = {0}, cutV[16] = {0};
+    std::vector<double> table; // ordered: [rG][rA][rL][rL][rV][rV][3], else [3]: minVel_ft_s maxVel_ft_s maxVertRate_ft_s
+};
+UncorLimits build_uncor_limits(const Model &m, const UncorTrackVars &tv);
+
 // Quantile thresholds of one CPT column (r weights): out[r-1].
 void column_thresholds(const double *w, int r, uint32_t *out);
 uint32_t bernoulli_threshold(double rate);

@@ -110,6 +110,7 @@ struct EmgpuRun {
     uint64_t *events; // emgpu_event rows as packed 64-bit words
     int32_t *attempts;
     uint32_t *status; // device word: bit0 = rejection cap hit, bit1 = event cap hit
+    const uint64_t *indices; // optional: global index of lane i (instead of first_index + i); generic kernel only
 };
 
 struct EmgpuBnRun {
@@ -139,6 +140,29 @@ struct EmgpuTermRun {
     float *out;                      // [6][cap][4n]: t_s x_nm y_nm z_ft heading_deg v_ft_s
     int32_t *rows;                   // [4n] rows written; < 0: failed (cap / resample cap)
     uint32_t *status;
+};
+
+// UncorEncounterModel.track (UncorEncounterModel.m:419-471): point-mass dynamics over the sampler's dense trace and the
+// three rejection tests, one lane per trajectory (k_uncor_track, emgpu_kernels_utrack.hip).
+struct EmgpuUTrackRun {
+    int64_t n;                 // lanes (trajectories of this round)
+    int64_t ld;                // trajectory dimension of the sampler's buffers
+    int32_t T, stride;         // seconds; keep every stride-th 0.1 s step
+    const float *iG, *iA, *iL, *iV, *iDV, *iDH, *iDPsi; // rows of init_val (iG / iA may be null when the limits are global)
+    const float *dyn_val;      // [ceil(T/4)][nd][ld][4]
+    int32_t nd, sDV, sDH, sDPsi; // rows of the dense trace
+    const int64_t *slot;       // [n] output position of lane i (null: i)
+    double dyn[6];             // v_low v_high dh_min dh_max qmax rmax            (:414)
+    double min_alt, max_alt;   //                                                  (:397-405)
+    int32_t ordered, rG, rA, rL, rV, ncL, ncV, discL, discV; // getDynamicLimits.m:17 branch and its dimensions
+    double cutL[16], cutV[16]; // cutpoints_initial{L}, {V}
+    const double *lim;         // ordered: [rG][rA][rL][rL][rV][rV][3]; else [3]: minVel maxVel maxVertRate
+    double *tracks;            // [slots][S][8] time north east up speed phi theta psi (may be null)
+    int64_t S;
+    double *limits;            // [slots][3] (may be null)
+    uint8_t *accepted;         // [n] by lane
+    int32_t *attempts;         // [slots]: written with attempt_no by accepted lanes, with -1 by rejected lanes of the last round
+    int32_t attempt_no, last_round;
 };
 
 // sample2track.m:183-237 for n trajectories (k_sample2track).  Exactly one input form is set.

@@ -6,8 +6,9 @@
   CorTerminalModel       @CorTerminalModel/CorTerminalModel.m, sample.m, getDynamicLimits.m
 
 Same property and method names and argument meaning.  `.sample` runs on the GPU through
-libemgpu (there is no CPU path).  `.track` needs the un-vendored em-core dynamics
-(run_dynamics_fast, placeTrack) and is outside this hot path: it raises NotImplementedError.
+libemgpu (there is no CPU path).  UncorEncounterModel.track runs on the GPU too, on a documented point-mass
+model in place of the un-vendored em-core dynamics ("dynamics unpinned"); its 'geodetic' branch and
+CorTerminalModel.track need em-core / DEM data and raise NotImplementedError.
 """
 import os
 
@@ -370,9 +371,42 @@ class UncorEncounterModel(EncounterModel):
             pos += nn
         return out_inits, out_events, out_samples, out_EME
 
-    def track(self, *a, **k):
-        raise NotImplementedError("UncorEncounterModel.track needs em-core (run_dynamics_fast, placeTrack), which the reference "
-                                  "does not vendor; it is outside the sampling hot path (SURVEY.md section 8 f1)")
+    TRACK_FIELDS = ("time_s", "north_ft", "east_ft", "up_ft", "speed_ft_s", "phi_rad", "theta_rad", "psi_rad")
+
+    def track(self, nSamples, sample_time, initialSeed=None, isQuantize500=False, coordSys="NEU", max_track_attempts=200,
+              record_stride=1, first_index=None, ctx=None, return_info=False):
+        """out_results = track(self, nSamples, sample_time, 'initialSeed', s, 'isQuantize500', b, 'coordSys', 'NEU')
+        (UncorEncounterModel.m:318-471).  Each result is a dict of 1-D arrays with the columns of the reference's timetable
+        (time_s instead of the row times), sampled at 10 Hz (record_stride=1) like results.time.
+
+        Runs on the GPU end to end: per round the still-rejected trajectories are sampled (attempt j with the key
+        initialSeed + j, :424-428), integrated and tested against getDynamicLimits (:459-470) on the device.
+        DYNAMICS UNPINNED: the reference integrates with em-core's run_dynamics_fast, which it does not vendor; this build
+        uses the point-mass model documented in DESIGN.md / emgpu.h.  coordSys 'geodetic' (:480-540) needs a DEM, the FAA
+        obstacle file and em-core's placeTrack and is out of scope."""
+        if str(coordSys).lower() != "neu":
+            raise NotImplementedError("coordSys 'geodetic' needs a DEM, the digital obstacle file and em-core's placeTrack "
+                                      "(UncorEncounterModel.m:480-540): out of scope, use 'NEU'")
+        for lab in ('"\\dot v"', '"\\dot h"', '"\\dot \\psi"'):
+            if lab not in self.labels_initial:
+                e = L.EmgpuError(L.ERR_ARG, "Model does not have a dynamic variable for either acceleration, vertical rate, or turn rate")
+                e.identifier = "dynvar:empty"
+                raise e
+        s, first = _take(initialSeed, nSamples)
+        if first_index is not None:
+            first = int(first_index)
+        res = native.track_uncor_host(ctx or native.default_context(), self.native, int(nSamples), int(sample_time), s, first_index=first,
+                                      is_quantize500=isQuantize500, is_rotorcraft=self.isRotorcraft, max_track_attempts=max_track_attempts,
+                                      record_stride=record_stride)
+        out_results = [{f: res["tracks"][i, :, k].copy() for k, f in enumerate(self.TRACK_FIELDS)} for i in range(int(nSamples))]
+        return (out_results, res) if return_info else out_results
+
+    def getDynamicLimits(self, initial, results, idx_G=None, idx_A=None, idx_L=None, idx_V=None, idx_DH=None, is_discretized=None):
+        """dynamiclimits = getDynamicLimits(self, initial, results, ...)  (@UncorEncounterModel/getDynamicLimits.m).  The index
+        arguments are accepted for signature compatibility; they are looked up from the labels like .track does."""
+        up, sp = np.asarray(results["up_ft"], dtype=np.float64), np.asarray(results.get("speed_ftps", results.get("speed_ft_s")), dtype=np.float64)
+        lim = native.uncor_dynamic_limits(self.native, initial, up.min(), up.max(), sp.min(), sp.max(), self.isRotorcraft)
+        return {"minVel_ft_s": lim[0], "maxVel_ft_s": lim[1], "maxVertRate_ft_s": lim[2]}
 
 
 # @CorTerminalModel/getDynamicLimits.m:15-62

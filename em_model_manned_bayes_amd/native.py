@@ -193,7 +193,9 @@ def all_device_contexts():
 
 
 def make_params(n, sample_time, seed, first_index=0, transition_mode=L.TRANSITION_REFERENCE_AUTO, flags=0,
-                max_attempts=1000, idx_L=0, idx_v=0, idx_dh=0, layers=None, event_cap=0):
+                max_attempts=1000, idx_L=0, idx_v=0, idx_dh=0, layers=None, event_cap=0, indices=None):
+    """emgpu_sample_params.  indices: a numpy uint64 array (host calls) or a raw device pointer (device calls) of n
+    global indices replacing first_index + i."""
     p = L.SampleParams()
     p.seed, p.first_index, p.n, p.sample_time = int(seed) & (2**64 - 1), int(first_index), int(n), int(sample_time)
     p.transition_mode, p.flags, p.max_attempts = int(transition_mode), int(flags), int(max_attempts)
@@ -203,6 +205,14 @@ def make_params(n, sample_time, seed, first_index=0, transition_mode=L.TRANSITIO
         keep = np.ascontiguousarray(np.asarray(layers, dtype=np.float64).reshape(-1, 2))
         p.layers, p.n_layers = _p(keep), keep.shape[0]
     p.event_cap = int(event_cap)
+    if indices is not None:
+        if isinstance(indices, int):
+            p.indices = indices
+        else:
+            idx = np.ascontiguousarray(indices, dtype=np.uint64)
+            assert idx.size == int(n)
+            p.indices = idx.ctypes.data
+            keep = (keep, idx)
     return p, keep
 
 
@@ -361,6 +371,45 @@ def propagate_terminal_host(ctx, models, geo, model_of, seed, first_index=0, tma
     rows = np.zeros(4 * n, dtype=np.int32)
     L.check(L.lib().emgpu_propagate_terminal_host(ctx._h, handles, len(models), C.byref(p), _p(geo), _p(model_of), _p(out), _p(rows)))
     return np.ascontiguousarray(out.transpose(2, 1, 0)), rows
+
+
+def utrack_params(model, n, sample_time, seed, first_index=0, is_quantize500=False, is_rotorcraft=False,
+                  max_track_attempts=200, max_attempts=1000, record_stride=1):
+    """emgpu_utrack_params with the variable ids looked up by label like UncorEncounterModel.m:385-391."""
+    labels = model.get_labels(L.F_LABELS_INITIAL)
+
+    def lab(name):
+        q = '"%s"' % name
+        return labels.index(q) + 1 if q in labels else 0
+    p = L.UTrackParams()
+    p.seed, p.first_index, p.n, p.sample_time = int(seed) & (2**64 - 1), int(first_index), int(n), int(sample_time)
+    p.flags = L.FLAG_QUANTIZE500 if is_quantize500 else 0
+    p.max_track_attempts, p.max_attempts, p.record_stride = int(max_track_attempts), int(max_attempts), int(record_stride)
+    p.idx_G, p.idx_A, p.idx_L, p.idx_v = lab("G"), lab("A"), lab("L"), lab("v")
+    p.idx_dv, p.idx_dh, p.idx_dpsi = lab("\\dot v"), lab("\\dot h"), lab("\\dot \\psi")
+    p.is_rotorcraft = int(bool(is_rotorcraft))
+    return p
+
+
+def track_uncor_host(ctx, model, n, sample_time, seed, want_tracks=True, **kw):
+    """emgpu_track_uncor_host: UncorEncounterModel.track on the GPU (sample -> point-mass dynamics -> rejection rounds).
+    Returns dict: tracks [n, S, 8] (time north east up speed phi theta psi), limits [n, 3], attempts [n], kernel."""
+    p = utrack_params(model, n, sample_time, seed, **kw)
+    S = 10 * int(sample_time) // p.record_stride + 1
+    tracks = np.zeros((n, S, 8)) if want_tracks else None
+    limits = np.zeros((n, 3))
+    attempts = np.zeros(n, dtype=np.int32)
+    L.check(L.lib().emgpu_track_uncor_host(ctx._h, model._h, C.byref(p), _p(tracks), _p(limits), _p(attempts)))
+    return {"tracks": tracks, "limits": limits, "attempts": attempts, "kernel": ctx.last_kernel()}
+
+
+def uncor_dynamic_limits(model, initial, up_min, up_max, speed_min, speed_max, is_rotorcraft=False):
+    """emgpu_uncor_dynamic_limits: getDynamicLimits.m for one trajectory (host only, no GPU needed)."""
+    p = utrack_params(model, 1, 1, 0, is_rotorcraft=is_rotorcraft)
+    iv = np.ascontiguousarray(initial, dtype=np.float64)
+    out = np.zeros(3)
+    L.check(L.lib().emgpu_uncor_dynamic_limits(model._h, C.byref(p), _p(iv), float(up_min), float(up_max), float(speed_min), float(speed_max), _p(out)))
+    return out
 
 
 def track_params(n, T, ur_speed, ur_vertrate, ur_heading, min_speed, max_speed, nd=0, slot_vertrate=0, slot_acc=0, slot_turnrate=0):

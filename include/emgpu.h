@@ -156,6 +156,9 @@ typedef struct {
     const double *layers; /* n_layers x 2 row-major [lo hi] (UncorEncounterModel.m:204,259-260)    */
     int32_t event_cap;    /* rows per trajectory in `events`                                       */
     int32_t _pad;
+    const uint64_t *indices; /* optional: n global indices replacing first_index + i (a device pointer for
+                                *_device calls, a host pointer for *_host): arbitrary subsets of a batch, e.g.
+                                the trajectories .track re-draws; NULL = the contiguous range               */
 } emgpu_sample_params;
 
 /* Event row (8 bytes): what one row [dt var value] of out_events{i} carries. */
@@ -312,6 +315,41 @@ int emgpu_sample2track_device(emgpu_ctx *ctx, const emgpu_track_params *p, const
                               const float *dyn_val, double *xyz, uint8_t *flags, double *speed_minmax);
 int emgpu_sample2track_host(emgpu_ctx *ctx, const emgpu_track_params *p, const double *alt0, const double *speed0,
                             const double *updates, double *xyz, uint8_t *flags, double *speed_minmax);
+
+/* ------------------------------------------------------------------------------------------------
+ * UncorEncounterModel.track (@UncorEncounterModel/UncorEncounterModel.m:318-471) with coordSys 'NEU': per trajectory
+ * sample -> dynamics -> the rejection tests of :462-470 against @UncorEncounterModel/getDynamicLimits.m:1-130, retried
+ * with the next seed (:424-428: attempt j of EVERY trajectory uses the Philox key seed + j; the trajectory is told apart by
+ * its global index).  Rounds: round j samples the trajectories still rejected (round 0: the whole contiguous range on the
+ * fast kernels, later rounds an index list), integrates and tests them on the device; only a counter crosses PCIe per round.
+ * DYNAMICS: the reference calls em-core's run_dynamics_fast / computeVerticalRate, which it does not vendor.  The point-mass
+ * model used instead (dt 0.1 s, first-order pitch / bank response limited by dyn(5:6); "dynamics unpinned") is stated in
+ * DESIGN.md section 10 and at the top of csrc/emgpu_kernels_utrack.hip.  The 'geodetic' branch (:480-540: DEM, obstacles, placeTrack) is out of scope.
+ *   tracks   [n][S][8] f64: time_s north_ft east_ft up_ft speed_ft_s phi_rad theta_rad psi_rad, S = 10*T/record_stride + 1
+ *   limits   [n][3] f64: minVel_ft_s maxVel_ft_s maxVertRate_ft_s of the accepted attempt (getDynamicLimits.m:129-133)
+ *   attempts [n] i32: attempts used (>= 1); -1 => max_track_attempts reached (the call then returns EMGPU_ERR_REJECT_CAP)
+ * Any output may be NULL.  _host: host pointers; _device: device pointers.  Both synchronise the ctx stream.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t seed, first_index;  /* 'initialSeed' (:327)                                               */
+    int64_t n;
+    int32_t sample_time;         /* seconds                                                            */
+    uint32_t flags;              /* EMGPU_FLAG_QUANTIZE500                                             */
+    int32_t max_track_attempts;  /* cap of the outer while (:421; unbounded in the reference)          */
+    int32_t max_attempts;        /* cap of .sample's own loop (:248)                                   */
+    int32_t idx_G, idx_A, idx_L, idx_v, idx_dv, idx_dh, idx_dpsi; /* 1-based variable ids (:385-391), 0 = absent */
+    int32_t is_rotorcraft;       /* self.isRotorcraft (:181-185)                                       */
+    int32_t record_stride;       /* keep every record_stride-th 0.1 s step: 1 = the reference's timetable, 10 = 1 Hz */
+    int32_t _pad;
+} emgpu_utrack_params;
+int emgpu_track_uncor_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_utrack_params *p,
+                           double *tracks, double *limits, int32_t *attempts);
+int emgpu_track_uncor_device(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_utrack_params *p,
+                             double *tracks, double *limits, int32_t *attempts);
+/* getDynamicLimits.m:1-130 for one trajectory on the host (what the table of the track kernel holds): initial = the
+ * n_initial sampled values (bins for categorical variables), the extrema over the 10 Hz result in ft and ft/s. */
+int emgpu_uncor_dynamic_limits(const emgpu_model *m, const emgpu_utrack_params *vars, const double *initial,
+                               double up_min_ft, double up_max_ft, double speed_min_ft_s, double speed_max_ft_s, double out[3]);
 
 /* Introspection for benchmarks/tests: name of the kernel variant the last *_device call used and
  * the algorithmic output bytes per trajectory of that call (5*n_i + 5*T*n_d for dense output). */

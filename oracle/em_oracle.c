@@ -993,3 +993,226 @@ int em_sizeof_model(void) { return (int)sizeof(em_model_t); }
 void em_sincosd_table(const double *deg, int n, double *s, double *c) {
     for (int i = 0; i < n; i++) em_sincosd(deg[i], &s[i], &c[i]);
 }
+
+/* ------------------------------------------------------------------------- */
+/* f1  UncorEncounterModel.track  (@UncorEncounterModel/UncorEncounterModel.m:318-471, coordSys 'NEU')       */
+/*     + @UncorEncounterModel/getDynamicLimits.m:1-130.                                                       */
+/*                                                                                                            */
+/* The reference integrates the sampled controls with em-core's run_dynamics_fast mex and differentiates the */
+/* altitude with em-core's computeVerticalRate.  em-core is NOT vendored by the reference and is absent here: */
+/* "dynamics unpinned".  What replaces them is a point-mass model built from the quantities the reference     */
+/* hands to run_dynamics_fast (ic = [v n e h psi theta phi a], :443; dyn = [v_low v_high dh_min dh_max qmax    */
+/* rmax], :414; controls = [t hdot psidot a], :291-297), stated once here and mirrored line by line by the    */
+/* HIP kernel (csrc/emgpu_kernels_utrack.hip):                                                                */
+/*   dt = 0.1 s, g = 32.2 ft/s^2 (the constant of :440).  Per step, with the control row active at t:         */
+/*     a      = 0 when it would drive v beyond [v_low, v_high]                                               */
+/*     hd     = min(max(hdot, dh_min), dh_max)                                                                */
+/*     theta += clamp((asin(clamp(hd / v, -1, 1)) - theta) / dt, -qmax, qmax) * dt      pitch follows the      */
+/*     phi   += clamp((atan(v * psidot / g) - phi) / dt, -rmax, rmax) * dt              commanded climb / turn */
+/*     n += v cos(theta) cos(psi) dt;  e += v cos(theta) sin(psi) dt;  h += v sin(theta) dt                    */
+/*     psi += g tan(phi) / v * dt;  v = min(max(v + a dt, v_low), v_high)                                     */
+/*   results.time = 0 : 0.1 : T.  computeVerticalRate(up(is_sec), time(is_sec)) := forward difference of the   */
+/*   1 Hz altitudes, the last value repeated.                                                                 */
+/* Everything around the dynamics follows the cited lines.                                                    */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t idxG, idxA, idxL, idxV, idxDV, idxDH, idxDPsi; /* 1-based, 0 = absent (:385-391)      */
+    int32_t is_rotorcraft;                                  /* :181-185                            */
+} em_track_vars_t;
+
+/* getDynamicLimits.m:1-130.  initial: dediscretised values (bins for categorical variables); up_min..speed_max */
+/* in feet and ft/s over the WHOLE result (10 Hz).  out: minVel_ft_s, maxVel_ft_s, maxVertRate_ft_s.            */
+static const double *em_N_init(const em_model_t *m, int var1) { return m->N_initial + m->off_initial[var1 - 1]; }
+static int64_t em_q_init(const em_model_t *m, int var1) {
+    int64_t q = 1;
+    for (int p = 0; p < m->n_initial; p++) if (m->G_initial[(size_t)p * m->n_initial + (var1 - 1)]) q *= m->r_initial[p];
+    return q;
+}
+static int em_cutpoints(const em_model_t *m, int var1, double *cut) { /* em_read.m:130-136: boundaries(2:end-1), or 2:n */
+    int len = m->bnd_len[var1 - 1];
+    if (len == 0) { int n = m->r_initial[var1 - 1]; for (int i = 0; i < n - 1; i++) cut[i] = 2 + i; return n - 1; }
+    for (int i = 1; i < len - 1; i++) cut[i - 1] = m->boundaries[m->bnd_off[var1 - 1] + i];
+    return len - 2;
+}
+void em_uncor_dynamic_limits(const em_model_t *m, const em_track_vars_t *tv, const double *initial,
+                             double up_min, double up_max, double speed_min, double speed_max, double out[3]) {
+    const int idx_G = tv->idxG, idx_A = tv->idxA, idx_L = tv->idxL, idx_V = tv->idxV, idx_DH = tv->idxDH;
+    const int rV = m->r_initial[idx_V - 1], rDH = m->r_initial[idx_DH - 1];
+    double v_initial[EM_MAX_R], dh_initial[EM_MAX_R];
+    for (int i = 0; i < rV; i++) v_initial[i] = 0;
+    for (int i = 0; i < rDH; i++) dh_initial[i] = 0;
+    const double *NV = em_N_init(m, idx_V), *NDH = em_N_init(m, idx_DH);
+    const int64_t qV = em_q_init(m, idx_V), qDH = em_q_init(m, idx_DH);
+    const int is_idx = idx_G > 0 && idx_A > 0 && idx_L > 0 && idx_V > 0 && idx_DH > 0;                   /* :14 */
+    if (is_idx && idx_G == 1 && idx_A == 2 && idx_L == 3 && idx_V == 4 && idx_DH == 6) {                  /* :17 */
+        double cut[EM_MAX_R];
+        const int rG = m->r_initial[0], rA = m->r_initial[1], rL = m->r_initial[2];
+        int nc, dG, dA, dL0, dL1, dV0, dV1;
+        if (m->bnd_len[idx_G - 1] == 0) dG = (int)initial[idx_G - 1];                                     /* :20-24 */
+        else { nc = em_cutpoints(m, idx_G, cut); dG = em_discretize_bayes(initial[idx_G - 1], cut, nc); }
+        if (m->bnd_len[idx_A - 1] == 0) dA = (int)initial[idx_A - 1];                                     /* :27-31 */
+        else { nc = em_cutpoints(m, idx_A, cut); dA = em_discretize_bayes(initial[idx_A - 1], cut, nc); }
+        if (m->bnd_len[idx_L - 1] == 0) dL0 = dL1 = (int)initial[idx_L - 1];                              /* :34-39 */
+        else { nc = em_cutpoints(m, idx_L, cut); dL0 = em_discretize_bayes(up_min, cut, nc); dL1 = em_discretize_bayes(up_max, cut, nc); }
+        if (m->bnd_len[idx_V - 1] == 0) dV0 = dV1 = (int)initial[idx_V - 1];                              /* :45-51 */
+        else {
+            nc = em_cutpoints(m, idx_V, cut);
+            dV0 = em_discretize_bayes(speed_min * 0.592484, cut, nc); dV1 = em_discretize_bayes(speed_max * 0.592484, cut, nc);
+        }
+        /* column j (1-based) of N{V} survives (:, dG:rG:end), then (:, dA:rA:end), then (:, unique(dL)) (:57-66) */
+        const int64_t nGA_V = qV / rG / rA;          /* columns left after the two slices */
+        for (int dl = dL0; dl <= dL1; dl++) {
+            if (dl < 1 || dl > nGA_V) continue;      /* MATLAB would raise an index error here: none of the shipped shapes does */
+            const int64_t col = (dG - 1) + (int64_t)rG * ((dA - 1) + (int64_t)rA * (dl - 1));
+            for (int i = 0; i < rV; i++) v_initial[i] += NV[col * rV + i];
+        }
+        /* N{DH}: G, A sliced, then summed over di = unique(dL) of (:, di:rL:end), then over unique(dV) of (:, di:rV:end) (:69-79) */
+        const int64_t nGA_DH = qDH / rG / rA, nL = nGA_DH / rL, nLV = nL / rV;
+        for (int dl = dL0; dl <= dL1; dl++)
+            for (int dv = dV0; dv <= dV1; dv++)
+                for (int64_t rest = 0; rest < nLV; rest++) {
+                    const int64_t c3 = (dl - 1) + (int64_t)rL * ((dv - 1) + (int64_t)rV * rest); /* column within the G,A slice */
+                    const int64_t col = (dG - 1) + (int64_t)rG * ((dA - 1) + (int64_t)rA * c3);
+                    for (int i = 0; i < rDH; i++) dh_initial[i] += NDH[col * rDH + i];
+                }
+    } else {                                                                                              /* :85-88 */
+        for (int64_t c = 0; c < qV; c++) for (int i = 0; i < rV; i++) v_initial[i] += NV[c * rV + i];
+        for (int64_t c = 0; c < qDH; c++) for (int i = 0; i < rDH; i++) dh_initial[i] += NDH[c * rDH + i];
+    }
+    /* :94-103 */
+    double tot = 0, cs = 0;
+    for (int i = 0; i < rV; i++) tot += v_initial[i];
+    int k_min = 0, k_max = 0;   /* find(cs >= prct, 1, 'first'); 0 = empty */
+    for (int i = 0; i < rV; i++) {
+        cs += 100.0 * v_initial[i] / tot;
+        if (!k_min && cs >= 1.0) k_min = i + 1;
+        if (!k_max && cs >= 99.0) k_max = i + 1;
+    }
+    const double *bV = m->boundaries + m->bnd_off[idx_V - 1], *bDH = m->boundaries + m->bnd_off[idx_DH - 1];
+    double min_speed = bV[k_min] * 1.68780972222222, max_speed = bV[k_max] * 1.68780972222222;          /* boundaries(k + 1), 1-based */
+    if (tv->is_rotorcraft && max_speed > 304) max_speed = 304;                                            /* :107-112 */
+    if (!tv->is_rotorcraft && min_speed < 30) min_speed = 30;
+    /* :118-127 */
+    tot = 0; cs = 0;
+    for (int i = 0; i < rDH; i++) tot += dh_initial[i];
+    k_min = 0; k_max = 0;
+    for (int i = 0; i < rDH; i++) {
+        cs += 100.0 * dh_initial[i] / tot;
+        if (!k_min && cs >= 1.0) k_min = i + 1;
+        if (!k_max && cs >= 99.0) k_max = i + 1;
+    }
+    double a = fabs(bDH[k_min] / 60.0), b = fabs(bDH[k_max] / 60.0);
+    double max_vr = a > b ? a : b;
+    if (isnan(max_vr) || !(tot > 0)) max_vr = 0;          /* :124-127 (all-zero slice: NaN in MATLAB) */
+    out[0] = min_speed; out[1] = max_speed; out[2] = max_vr;
+}
+
+/* The point-mass dynamics stated in the header comment.  ic: v n e h psi theta phi a; ctrl: per whole second c,  */
+/* [hdot_ft_s psidot_rad_s a_ft_ss] (the control row active during [c, c+1), events2controls.m:16-27); dyn[6].    */
+/* out: (10 T + 1) rows [time north east up speed phi theta psi]; mm: up_min up_max speed_min speed_max max|vr|. */
+void em_point_mass_dynamics(const double ic[8], const double *ctrl, int T, const double dyn[6], double *out, double mm[5]) {
+    const double dt = 0.1, g = 32.2;
+    double v = ic[0], n = ic[1], e = ic[2], h = ic[3], psi = ic[4], theta = ic[5], phi = ic[6];
+    double up_min = h, up_max = h, v_min = v, v_max = v, vr_max = 0, h_sec = h;
+    size_t row = 0;
+    if (out) { double *o = out; o[0] = 0; o[1] = n; o[2] = e; o[3] = h; o[4] = v; o[5] = phi; o[6] = theta; o[7] = psi; }
+    for (int c = 0; c < T; c++) {
+        const double hdot = ctrl[3 * c], psidot = ctrl[3 * c + 1], acmd = ctrl[3 * c + 2];
+        for (int s = 0; s < 10; s++) {
+            double a = acmd;
+            if ((v >= dyn[1] && a > 0) || (v <= dyn[0] && a < 0)) a = 0;
+            double hd = hdot < dyn[2] ? dyn[2] : (hdot > dyn[3] ? dyn[3] : hdot);
+            double sn = hd / v; sn = sn < -1 ? -1 : (sn > 1 ? 1 : sn);
+            double q = (asin(sn) - theta) / dt; q = q < -dyn[4] ? -dyn[4] : (q > dyn[4] ? dyn[4] : q);
+            theta = theta + q * dt;
+            double r = (atan(v * psidot / g) - phi) / dt; r = r < -dyn[5] ? -dyn[5] : (r > dyn[5] ? dyn[5] : r);
+            phi = phi + r * dt;
+            const double ct = cos(theta), st = sin(theta);
+            n = n + v * ct * cos(psi) * dt;
+            e = e + v * ct * sin(psi) * dt;
+            h = h + v * st * dt;
+            psi = psi + g * tan(phi) / v * dt;
+            v = v + a * dt; v = v < dyn[0] ? dyn[0] : (v > dyn[1] ? dyn[1] : v);
+            row++;
+            if (out) { double *o = out + row * 8; o[0] = (double)(10 * c + s + 1) / 10.0; o[1] = n; o[2] = e; o[3] = h; o[4] = v; o[5] = phi; o[6] = theta; o[7] = psi; }
+            up_min = h < up_min ? h : up_min; up_max = h > up_max ? h : up_max;
+            v_min = v < v_min ? v : v_min; v_max = v > v_max ? v : v_max;
+        }
+        const double vr = fabs(h - h_sec);   /* computeVerticalRate on the 1 Hz samples: (up(c+1) - up(c)) / 1 s */
+        vr_max = vr > vr_max ? vr : vr_max;
+        h_sec = h;
+    }
+    mm[0] = up_min; mm[1] = up_max; mm[2] = v_min; mm[3] = v_max; mm[4] = vr_max;
+}
+
+/* One trajectory of UncorEncounterModel.track (:419-471).  Philox mode: attempt j uses the key seed + j and the   */
+/* trajectory's global index (the reference restarts a fresh stream per attempt with seed + 1, :424-428).         */
+/* MT19937 mode: *seed_io is the running seed, advanced once per attempt like the reference's `seed = seed + 1`.  */
+/* f32_inputs: round the sampled values to f32 first (what the GPU path's boundary hands its dynamics kernel).    */
+int em_uncor_track_one(const em_model_t *m, int mode, uint64_t *seed_io, uint64_t gidx, int T, const em_uncor_opts_t *o,
+                       const em_track_vars_t *tv, int max_track_attempts, int f32_inputs,
+                       double *out /* (10T+1) x 8 or NULL */, double limits[3], int32_t *attempts_out, int32_t *sample_attempts_out) {
+    int ni = m->n_initial;
+    int cap = (ni + m->n_dyn + 1) * T + 8; if (cap < 64) cap = 64;
+    em_event_t *ev = (em_event_t *)malloc(sizeof(em_event_t) * (size_t)cap);
+    double *dv = (double *)malloc(sizeof(double) * (size_t)ni * (size_t)(T + 1));
+    int32_t *db = (int32_t *)malloc(sizeof(int32_t) * (size_t)ni * (size_t)(T + 1));
+    double *ctrl = (double *)malloc(sizeof(double) * 3 * (size_t)T);
+    int32_t ib[128]; double iv[128];
+    int rc = -3;
+    const int nbL = m->bnd_len[tv->idxL - 1], nbV = m->bnd_len[tv->idxV - 1], nbDH = m->bnd_len[tv->idxDH - 1];
+    const double *bL = m->boundaries + m->bnd_off[tv->idxL - 1], *bV = m->boundaries + m->bnd_off[tv->idxV - 1], *bDH = m->boundaries + m->bnd_off[tv->idxDH - 1];
+    double min_alt = 0, max_alt = INFINITY;                                                               /* :397-405 */
+    if (nbL > 0) { min_alt = max_alt = bL[0]; for (int i = 1; i < nbL; i++) { min_alt = bL[i] < min_alt ? bL[i] : min_alt; max_alt = bL[i] > max_alt ? bL[i] : max_alt; } }
+    double lo = bDH[0], hi = bDH[0], vmaxb = bV[0];
+    for (int i = 1; i < nbDH; i++) { lo = bDH[i] < lo ? bDH[i] : lo; hi = bDH[i] > hi ? bDH[i] : hi; }
+    for (int i = 1; i < nbV; i++) vmaxb = bV[i] > vmaxb ? bV[i] : vmaxb;
+    const double dyn[6] = {1.7, vmaxb * 1.68780972222222, lo / 60.0, hi / 60.0, 3.0 * (3.14159265358979323846 / 180.0), 1000000.0}; /* :414 */
+    for (int j = 0; j < max_track_attempts; j++) {
+        em_rng_t g;
+        em_rng_init(&g, mode, *seed_io);
+        g.gidx = gidx;
+        *seed_io += 1;                                                                                   /* :428 */
+        int32_t att = 0;
+        int k = em_uncor_sample_one(m, &g, T, o, ib, iv, ev, cap, &att);                                 /* :424 */
+        if (k < 0) { rc = k; break; }
+        if (sample_attempts_out) *sample_attempts_out = att;
+        if (em_events2samples(ni, iv, ib, ev, k, dv, db, T) != T) { rc = -4; break; }
+        if (f32_inputs) {
+            for (int i = 0; i < ni; i++) iv[i] = (double)(float)iv[i];
+            for (size_t q = 0; q < (size_t)ni * (size_t)T; q++) dv[q] = (double)(float)dv[q];
+        }
+        for (int c = 0; c < T; c++) {                                                                    /* :291-297 */
+            ctrl[3 * c] = dv[(size_t)c * ni + tv->idxDH - 1] / 60.0;
+            ctrl[3 * c + 1] = dv[(size_t)c * ni + tv->idxDPsi - 1] * (3.14159265358979323846 / 180.0);
+            ctrl[3 * c + 2] = dv[(size_t)c * ni + tv->idxDV - 1] * 1.68780972222222;
+        }
+        const double h_ft = iv[tv->idxL - 1], v_ft_s = iv[tv->idxV - 1] * 1.68780972222222;              /* :434-438 */
+        const double dv_ft_ss = iv[tv->idxDV - 1] * 1.68780972222222, dh_ft_s = iv[tv->idxDH - 1] / 60.0;
+        const double dpsi = iv[tv->idxDPsi - 1] * (3.14159265358979323846 / 180.0);
+        const double ic[8] = {v_ft_s, 0, 0, h_ft, 0, asin(dh_ft_s / v_ft_s), atan(v_ft_s * dpsi / 32.2), dv_ft_ss}; /* :441-446 */
+        double mm[5];
+        em_point_mass_dynamics(ic, ctrl, T, dyn, out, mm);
+        em_uncor_dynamic_limits(m, tv, iv, mm[0], mm[1], mm[2], mm[3], limits);                           /* :459 */
+        const int viol_L = mm[0] < min_alt || mm[1] > max_alt;                                            /* :462-464 */
+        const int viol_V = mm[2] < limits[0] || mm[3] > limits[1];
+        const int viol_DH = mm[4] > limits[2];
+        if (!(viol_L || viol_V || viol_DH)) { rc = 0; *attempts_out = j + 1; break; }
+    }
+    free(ev); free(dv); free(db); free(ctrl);
+    return rc;
+}
+
+int64_t em_uncor_track_batch(const em_model_t *m, int mode, uint64_t seed, uint64_t first_index, int64_t n, int T,
+                             const em_uncor_opts_t *o, const em_track_vars_t *tv, int max_track_attempts, int f32_inputs,
+                             double *out /* n x (10T+1) x 8 or NULL */, double *limits /* n x 3 */, int32_t *attempts) {
+    uint64_t running = seed;   /* MT19937: one seed counter across samples AND attempts, like the reference's loop */
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t s = mode == EM_RNG_MT19937 ? running : seed;
+        int rc = em_uncor_track_one(m, mode, &s, first_index + (uint64_t)i, T, o, tv, max_track_attempts, f32_inputs,
+                                    out ? out + (size_t)i * (size_t)(10 * T + 1) * 8 : NULL, limits + 3 * i, attempts + i, NULL);
+        if (rc != 0) { if (rc == -3) { attempts[i] = -1; continue; } return rc; }
+        if (mode == EM_RNG_MT19937) running = s;
+    }
+    return 0;
+}

@@ -532,3 +532,61 @@ def stay_prior_alpha(parms, prior=1.0):
         L.em_transition_prior_node(C.c_int(int(r[jj])), C.c_int64(q), C.c_double(prior), _ptr(a))
         out[ii] = a.reshape(q, int(r[jj])).T.copy()
     return out
+
+
+class _TrackVars(C.Structure):
+    _fields_ = [("idxG", C.c_int32), ("idxA", C.c_int32), ("idxL", C.c_int32), ("idxV", C.c_int32), ("idxDV", C.c_int32),
+                ("idxDH", C.c_int32), ("idxDPsi", C.c_int32), ("is_rotorcraft", C.c_int32)]
+
+
+def _track_vars(om, is_rotorcraft=False):
+    tv = _TrackVars()
+    tv.idxG, tv.idxA, tv.idxL, tv.idxV = (om.label_index(s) for s in ("G", "A", "L", "v"))
+    tv.idxDV, tv.idxDH, tv.idxDPsi = (om.label_index(s) for s in ("\\dot v", "\\dot h", "\\dot \\psi"))
+    tv.is_rotorcraft = int(bool(is_rotorcraft))
+    return tv
+
+
+def uncor_dynamic_limits(om, initial, up_min, up_max, speed_min, speed_max, is_rotorcraft=False):
+    """@UncorEncounterModel/getDynamicLimits.m restated: (minVel_ft_s, maxVel_ft_s, maxVertRate_ft_s)."""
+    L = lib()
+    L.em_uncor_dynamic_limits.restype = None
+    tv = _track_vars(om, is_rotorcraft)
+    iv = np.ascontiguousarray(initial, dtype=np.float64)
+    out = np.zeros(3)
+    L.em_uncor_dynamic_limits(C.byref(om.c), C.byref(tv), _ptr(iv), C.c_double(up_min), C.c_double(up_max),
+                              C.c_double(speed_min), C.c_double(speed_max), _ptr(out))
+    return out
+
+
+def point_mass_dynamics(ic, ctrl, dyn):
+    """The point-mass model that stands in for em-core's run_dynamics_fast (header of the f1 section of em_oracle.c).
+    ctrl [T, 3] per whole second; returns (rows [10T+1, 8] = time north east up speed phi theta psi, minmax[5])."""
+    L = lib()
+    L.em_point_mass_dynamics.restype = None
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.float64).reshape(-1, 3)
+    T = ctrl.shape[0]
+    out = np.zeros((10 * T + 1, 8)); mm = np.zeros(5)
+    icv = np.ascontiguousarray(ic, dtype=np.float64); dy = np.ascontiguousarray(dyn, dtype=np.float64)
+    L.em_point_mass_dynamics(_ptr(icv), _ptr(ctrl), C.c_int(T), _ptr(dy), _ptr(out), _ptr(mm))
+    return out, mm
+
+
+def uncor_track(om, n, T, seed, mode=RNG_PHILOX, first_index=0, is_quantize500=False, is_rotorcraft=False,
+                max_track_attempts=200, max_attempts=1000, f32_inputs=True, want_tracks=True):
+    """UncorEncounterModel.track restated (UncorEncounterModel.m:318-471, coordSys 'NEU') on the documented point-mass
+    dynamics.  Returns dict: tracks [n, 10T+1, 8], limits [n, 3], attempts [n] (-1: cap hit)."""
+    L = lib()
+    L.em_uncor_track_batch.restype = C.c_int64
+    o = _UncorOpts()
+    o.idxL, o.idxV, o.idxDH = om.label_index("L"), om.label_index("v"), om.label_index("\\dot h")
+    o.is_quantize500, o.max_attempts, o.per_step = int(bool(is_quantize500)), int(max_attempts), 0
+    tv = _track_vars(om, is_rotorcraft)
+    tracks = np.zeros((n, 10 * T + 1, 8)) if want_tracks else None
+    limits = np.zeros((n, 3)); attempts = np.zeros(n, dtype=np.int32)
+    rc = L.em_uncor_track_batch(C.byref(om.c), C.c_int(mode), C.c_uint64(seed), C.c_uint64(first_index), C.c_int64(n), C.c_int(T),
+                                C.byref(o), C.byref(tv), C.c_int(max_track_attempts), C.c_int(int(f32_inputs)),
+                                _ptr(tracks) if want_tracks else None, _ptr(limits), _ptr(attempts))
+    if rc != 0:
+        raise RuntimeError("em_uncor_track_batch failed rc=%d" % rc)
+    return {"tracks": tracks, "limits": limits, "attempts": attempts}

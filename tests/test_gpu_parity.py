@@ -874,3 +874,55 @@ def test_sample2track_kernel_reproduces_the_committed_golden(gpu_ctx):
     assert np.array_equal(flags, g["flags"])
     np.testing.assert_allclose(xyz, g["xyz"], rtol=1e-12, atol=1e-7)
     np.testing.assert_allclose(vmm, g["speed_minmax"], rtol=1e-14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,rot,T", [("uncor_1200code_v2p1", False, 60), ("uncor_1200only_rotorcraft_v1p2", True, 45), ("glider_v1", False, 37)])
+def test_uncor_track_matches_oracle(name, rot, T, gpu_ctx, model_dir):
+    """UncorEncounterModel.track on the GPU (UncorEncounterModel.m:419-471): rounds of sample -> point-mass dynamics ->
+    getDynamicLimits rejection, against the oracle's per-trajectory loop on the same Philox keys (attempt j: seed + j).
+    Accepted attempt and limits must be identical; the f64 track agrees to 1e-9 relative (device vs host libm differ in
+    the last bits of asin / atan / tan / sin / cos, and 600 steps accumulate them)."""
+    nm, pp, _ = load_pair(name, model_dir)
+    om = O.OracleModel(pp)
+    n, seed = 3000, 0xF1
+    got = native.track_uncor_host(gpu_ctx, nm, n, T, seed, first_index=77, is_rotorcraft=rot)
+    ref = O.uncor_track(om, n, T, seed, first_index=77, is_rotorcraft=rot)
+    assert "k_uncor_track" in got["kernel"]
+    assert (ref["attempts"] > 1).sum() > 10, "the case must exercise the retry rounds"
+    same = got["attempts"] == ref["attempts"]
+    assert same.mean() > 0.999, "accept/reject decisions differ beyond libm noise: %d of %d" % ((~same).sum(), n)
+    assert np.array_equal(got["limits"][same], ref["limits"][same])
+    np.testing.assert_allclose(got["tracks"][same], ref["tracks"][same], rtol=1e-9, atol=1e-6)
+    # the sampled part is bit-exact: time 0 row = the initial state of the accepted attempt
+    assert np.array_equal(got["tracks"][same][:, 0, :5], ref["tracks"][same][:, 0, :5])
+    # 1 Hz recording = every 10th row of the 10 Hz result; results do not depend on how the batch is cut
+    one_hz = native.track_uncor_host(gpu_ctx, nm, 500, T, seed, first_index=77, is_rotorcraft=rot, record_stride=10)
+    assert np.array_equal(one_hz["tracks"], got["tracks"][:500, ::10])
+    part = native.track_uncor_host(gpu_ctx, nm, 300, T, seed, first_index=77 + 200, is_rotorcraft=rot)
+    assert np.array_equal(part["tracks"], got["tracks"][200:500]) and np.array_equal(part["attempts"], got["attempts"][200:500])
+
+
+@pytest.mark.gpu
+def test_uncor_class_track_and_index_lists(gpu_ctx, model_dir):
+    """The class method (timetable columns, initialSeed semantics, the cap) and emgpu_sample_params.indices on its own:
+    an arbitrary subset of a batch re-drawn through the index list equals those rows of the batch."""
+    nm, pp, path = load_pair("uncor_1200code_v2p1", model_dir)
+    mdl = E.UncorEncounterModel(path)
+    res, info = mdl.track(50, 30, initialSeed=5, ctx=gpu_ctx, return_info=True)
+    assert len(res) == 50 and set(res[0]) == set(E.UncorEncounterModel.TRACK_FIELDS) and res[0]["time_s"].shape == (301,)
+    assert res[0]["time_s"][10] == 1.0 and res[0]["north_ft"][0] == 0.0 and np.all(info["attempts"] >= 1)
+    ref = O.uncor_track(O.OracleModel(pp), 50, 30, 5)
+    assert np.array_equal(info["attempts"], ref["attempts"])
+    with pytest.raises(L.EmgpuError) as e:                          # an impossible cap: some trajectory needs a second attempt
+        native.track_uncor_host(gpu_ctx, nm, 3000, 60, 0xF1, first_index=77, max_track_attempts=1)
+    assert e.value.code == L.ERR_REJECT_CAP
+    idx = uncor_indices(pp)
+    full = native.sample_dbn_host(gpu_ctx, nm, 400, 33, 9, first_index=1000, want_dense=True, want_events=True, **idx)
+    pick = np.array([1399, 1000, 1007, 1250, 1251, 1003], dtype=np.uint64)
+    sub = native.sample_dbn_host(gpu_ctx, nm, len(pick), 33, 9, want_dense=True, want_events=True, indices=pick, **idx)
+    assert sub["kernel"].startswith("k_dbn_generic")
+    rows = (pick - 1000).astype(int)
+    for k in ("init_bin", "init_val", "dyn_bin", "dyn_val", "attempts"):
+        assert np.array_equal(sub[k], full[k][rows]), k
+    assert all(np.array_equal(sub["events"][q], full["events"][r]) for q, r in enumerate(rows))

@@ -286,7 +286,9 @@ def test_class_surface(model_dir):
     t = E.CorTerminalModel(parameters_directory=None)
     assert t.n_initial == 15 and t.getDynamicLimits(2)["maxVel_ft_s"] == 506 and t.bounds_sample.shape == (15, 2)
     with pytest.raises(NotImplementedError):
-        mdl.track(1, 10)
+        mdl.track(1, 10, coordSys="geodetic")      # DEM / obstacle file / placeTrack: out of scope
+    with pytest.raises(NotImplementedError):
+        t.track(1)
 
 
 def test_init_start_terminal_grid():
@@ -379,3 +381,48 @@ def test_mex_gateway_compiles():
                         "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "em_model_manned_bayes_amd", "matlab", "emgpu_mex.c")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_uncor_dynamic_limits_match_the_oracle_and_known_answers(model_dir):
+    """@UncorEncounterModel/getDynamicLimits.m: the product's host restatement (emgpu_limits.cpp, the table the track
+    kernel indexes) against the oracle's separately written one over random arguments, on an 'ordered' model
+    (G A L v . \\dot h at 1 2 3 4 6: the sliced branch, :17-83), a rotorcraft file (:107-109) and a model whose
+    variables are elsewhere (glider_v1: the global branch, :85-88)."""
+    rs = np.random.RandomState(7)
+    for name, rot in (("uncor_1200code_v2p1", False), ("uncor_1200only_rotorcraft_v1p2", True), ("glider_v1", False)):
+        path = em_io.materialize_model(name, model_dir)
+        om, nm = O.OracleModel(O.parse_model_txt(path)), native.NativeModel.load_txt(path)
+        for _ in range(120):
+            init = np.array([rs.randint(1, r + 1) for r in om.parms["r_initial"]], dtype=float)
+            up, sp = np.sort(rs.uniform(300, 13000, 2)), np.sort(rs.uniform(10, 520, 2))
+            a = O.uncor_dynamic_limits(om, init, up[0], up[1], sp[0], sp[1], rot)
+            b = native.uncor_dynamic_limits(nm, init, up[0], up[1], sp[0], sp[1], rot)
+            assert np.array_equal(a, b), (name, init, up, sp)
+            assert b[2] >= 0      # (b[0] <= b[1] only holds for (G, A, L) combinations the model has counts for)
+            if rot:
+                assert b[1] <= 304                       # :107-109
+            else:
+                assert b[0] >= 30                        # :110-112
+    # hand-checkable: a 2-variable toy has no G/A/L => global branch; v counts [1 97 1 1] -> 1st pct in bin 1, 99th in bin 3
+    mdl = E.UncorEncounterModel(em_io.materialize_model("uncor_1200code_v2p1", model_dir))
+    lim = mdl.getDynamicLimits(np.array([1, 4, 700.0, 100.0, 0.0, 0.0, 0.0]), {"up_ft": np.array([650.0, 700.0]), "speed_ftps": np.array([160.0, 170.0])})
+    assert set(lim) == {"minVel_ft_s", "maxVel_ft_s", "maxVertRate_ft_s"} and lim["minVel_ft_s"] >= 30
+
+
+def test_point_mass_dynamics_known_answers():
+    """The documented stand-in for em-core's run_dynamics_fast (oracle/em_oracle.c, section f1): straight and level flight
+    stays straight and level; a commanded climb converges to hdot; a coordinated turn of psidot closes a circle."""
+    dyn = [1.7, 500.0, -50.0, 50.0, np.deg2rad(3.0), 1e6]
+    rows, mm = O.point_mass_dynamics([200.0, 0, 0, 1000.0, 0, 0, 0, 0], np.zeros((30, 3)), dyn)
+    assert rows.shape == (301, 8) and np.allclose(rows[:, 0], np.arange(301) / 10.0)
+    assert np.allclose(rows[-1, 1:5], [6000.0, 0.0, 1000.0, 200.0]) and mm[4] == 0
+    ctrl = np.zeros((60, 3)); ctrl[:, 0] = 10.0                                   # 600 ft/min climb
+    rows, mm = O.point_mass_dynamics([200.0, 0, 0, 1000.0, 0, 0, 0, 0], ctrl, dyn)
+    assert abs((rows[-1, 3] - rows[-11, 3]) - 10.0) < 1e-9 and abs(rows[-1, 6] - np.arcsin(10.0 / 200.0)) < 1e-12
+    assert np.all(np.abs(np.diff(rows[:, 6])) <= np.deg2rad(3.0) * 0.1 + 1e-15)  # pitch rate limited by dyn(5)
+    ctrl = np.zeros((120, 3)); ctrl[:, 1] = np.deg2rad(3.0)                       # standard-rate turn: 360 deg in 120 s
+    rows, mm = O.point_mass_dynamics([200.0, 0, 0, 1000.0, 0, 0, np.arctan(200.0 * np.deg2rad(3.0) / 32.2), 0], ctrl, dyn)
+    assert abs(rows[-1, 7] - 2 * np.pi) < 1e-9 and np.hypot(rows[-1, 1], rows[-1, 2]) < 25.0
+    ctrl = np.zeros((40, 3)); ctrl[:, 2] = 20.0                                   # acceleration stops at v_high
+    rows, mm = O.point_mass_dynamics([400.0, 0, 0, 1000.0, 0, 0, 0, 20.0], ctrl, dyn)
+    assert rows[:, 4].max() == 500.0 and mm[3] == 500.0
