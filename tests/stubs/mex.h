@@ -22,6 +22,21 @@ int mxIsLogicalScalarTrue(const mxArray *a);
 mxArray *mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID c, mxComplexity f);
 mxArray *mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity f);
 mxArray *mxCreateNumericArray(mwSize nd, const mwSize *dims, mxClassID c, mxComplexity f);
+mxArray *mxCreateDoubleScalar(double v);
+mxArray *mxCreateLogicalMatrix(mwSize m, mwSize n);
+mxArray *mxCreateCellMatrix(mwSize m, mwSize n);
+mxArray *mxCreateStructMatrix(mwSize m, mwSize n, int nfields, const char **fieldnames);
+mxArray *mxCreateString(const char *s);
+mxArray *mxGetCell(const mxArray *a, mwSize i);
+void mxSetCell(mxArray *a, mwSize i, mxArray *v);
+mxArray *mxGetField(const mxArray *a, mwSize i, const char *name);
+void mxSetField(mxArray *a, mwSize i, const char *name, mxArray *v);
+unsigned char *mxGetLogicals(const mxArray *a);
+int mxIsLogical(const mxArray *a);
+int mxIsDouble(const mxArray *a);
+int mxIsCell(const mxArray *a);
+int mxIsStruct(const mxArray *a);
+int mexAtExit(void (*fn)(void));
 void *mxMalloc(size_t n);
 void mxFree(void *p);
 void mexErrMsgIdAndTxt(const char *id, const char *fmt, ...);
