@@ -381,6 +381,21 @@ def test_mex_gateway_compiles():
                         "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "em_model_manned_bayes_amd", "matlab", "emgpu_mex.c")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    # every command a .m file sends exists in the gateway, and the gateway covers every caller SURVEY.md 8(b) lists
+    src = open(os.path.join(ROOT, "em_model_manned_bayes_amd", "matlab", "emgpu_mex.c")).read()
+    have = set(re.findall(r'!strcmp\(cmd, "([a-z_0-9]+)"\)', src))
+    assert {"load_txt", "em_read", "from_struct", "set_prior", "set_alpha", "set_start", "bn_sample", "sample_uncor", "geom_sample",
+            "propagate_terminal", "track_uncor", "sample2track", "device_count", "use_devices", "free"} <= have
+    used = set()
+    mdir = os.path.join(ROOT, "em_model_manned_bayes_amd", "matlab")
+    for base, _, files in os.walk(mdir):
+        for f in files:
+            if f.endswith(".m"):
+                used |= set(re.findall(r"emgpu_mex\('([a-z_0-9]+)'", open(os.path.join(base, f)).read()))
+    assert used and used <= have, used - have
+    for f in ("shadow/bn_sample.m", "shadow/dbn_sample.m", "shadow/dbn_hierarchical_sample.m", "shadow/em_read.m",
+              "@UncorEncounterModelGPU/UncorEncounterModelGPU.m", "@CorTerminalModelGPU/CorTerminalModelGPU.m"):
+        assert os.path.exists(os.path.join(mdir, f)), f
 
 
 def test_uncor_dynamic_limits_match_the_oracle_and_known_answers(model_dir):
