@@ -113,7 +113,7 @@ SYMBOLS = [
     "emgpu_sample2track_device", "emgpu_sample2track_host",
     "emgpu_model_set_zero_bins", "emgpu_shard_range", "emgpu_device_count", "emgpu_mixed_blocks",
     "emgpu_sample_dbn_blocks_device", "emgpu_sample_dbn_multi_host", "emgpu_sample_dbn_multi_device",
-    "emgpu_track_uncor_host", "emgpu_track_uncor_device", "emgpu_uncor_dynamic_limits",
+    "emgpu_track_uncor_host", "emgpu_track_uncor_device", "emgpu_uncor_dynamic_limits", "emgpu_model_start_log_weight",
 ]
 
 _lib = None
@@ -149,6 +149,7 @@ def lib():
     L.emgpu_model_set_prior.argtypes = [C.c_void_p, C.c_int32, C.c_double]
     L.emgpu_model_set_transition_stay_prior.argtypes = [C.c_void_p, C.c_double]
     L.emgpu_model_set_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.emgpu_model_start_log_weight.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.emgpu_model_set_zero_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.emgpu_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.emgpu_device_count.argtypes = [C.POINTER(C.c_int32)]

@@ -319,6 +319,14 @@ int emgpu_model_set_start(emgpu_model *h, const int32_t *start, int32_t n) {
     return EMGPU_OK;
 }
 
+int emgpu_model_start_log_weight(const emgpu_model *h, double *out) {
+    EMGPU_TRY
+    if (!h || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    *out = h->m.start_log_weight();
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
 int emgpu_model_set_zero_bins(emgpu_model *h, const int32_t *zero_bins, int32_t n) {
     if (!h || !zero_bins || n != h->m.n_initial) return fail(EMGPU_ERR_ARG, "zero_bins needs n_initial entries");
     for (int i = 0; i < n; i++)

@@ -134,6 +134,34 @@ void Model::set_prior(int kind, double value) {
     version++;
 }
 
+// Importance weight of EncounterModel.start (UncorEncounterModel.m:204 `start`, RUN_uncor.m:43-48; InitStartTerminal.m grids):
+// a preset node is legal only when all its parents are preset (bn_sample.m:45-47), so the probability of the forced values
+// under the model is the same for every sample of a call: sum over preset nodes of log P(x_i = start_i | preset parents),
+// P from N + alpha like select_random (an all-zero column selects bin 1 with probability 1, select_random.m:17-20).
+double Model::start_log_weight() const {
+    double lw = 0.0;
+    for (int v = 0; v < n_initial; v++) {
+        if (start.empty() || start[(size_t)v] == 0) continue;
+        int64_t col = 0, stride = 1;
+        for (int p = 0; p < n_initial; p++) {                  // asub2ind.m:13-14 over the parents in ascending index
+            if (!G_initial[(size_t)p * n_initial + v]) continue;
+            if (start[(size_t)p] == 0) throw Error(EMGPU_ERR_PRESET, "Attempt to preset a dependent variable"); // bn_sample.m:45-47
+            col += stride * (start[(size_t)p] - 1);
+            stride *= r_initial[(size_t)p];
+        }
+        const int r = r_initial[(size_t)v];
+        double tot = 0.0, w = 0.0;
+        for (int k = 0; k < r; k++) {
+            const double x = N_initial[(size_t)v][(size_t)(col * r + k)] + A_initial[(size_t)v][(size_t)(col * r + k)];
+            tot += x;
+            if (k == start[(size_t)v] - 1) w = x;
+        }
+        if (tot > 0) lw += std::log(w / tot);
+        else lw += (start[(size_t)v] == 1) ? 0.0 : -INFINITY;
+    }
+    return lw;
+}
+
 void Model::set_transition_stay_prior(double prior) {
     // setTransitionPriors.m:12-33
     for (auto &tm : temporal_map) {

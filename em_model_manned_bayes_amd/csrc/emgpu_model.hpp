@@ -44,6 +44,7 @@ struct Model {
     void finalize();                         // orders, q's, default alphas, start
     void set_prior(int kind, double value);  // bn_dirichlet_prior.m:18-37
     void set_transition_stay_prior(double p); // setTransitionPriors.m:12-33
+    double start_log_weight() const;          // log P(preset values) under the model: the importance weight of `start`
 };
 
 Model *load_txt(const char *path, const int32_t *idx_zero, int n_idx, bool overwrite);

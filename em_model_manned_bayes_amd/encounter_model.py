@@ -225,6 +225,12 @@ class EncounterModel:
         if self._native is not None:
             self._native.set_start(v)
 
+    @property
+    def start_log_weight(self):
+        """Importance-sampling hook: log of the model probability of the values `start` forces -- the
+        log-weight of every sample drawn with this start distribution (0.0 without presets)."""
+        return self.native.start_log_weight()
+
     def _push_prior(self):
         if self._native is not None:
             self._native.set_prior(self._prior)

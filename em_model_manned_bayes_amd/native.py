@@ -133,6 +133,12 @@ class NativeModel:
     def set_transition_stay_prior(self, prior):
         L.check(L.lib().emgpu_model_set_transition_stay_prior(self._h, float(prior)))
 
+    def start_log_weight(self):
+        """log P(preset values of `start`) under the model: the importance weight of every sample drawn with it."""
+        out = C.c_double(0.0)
+        L.check(L.lib().emgpu_model_start_log_weight(self._h, C.byref(out)))
+        return float(out.value)
+
     def set_zero_bins(self, zero_bins):
         zb = np.array([0 if (z is None or (hasattr(z, "__len__") and len(z) == 0)) else int(np.asarray(z).reshape(-1)[0]) for z in zero_bins],
                       dtype=np.int32)

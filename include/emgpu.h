@@ -115,6 +115,11 @@ int emgpu_model_set_prior(emgpu_model *m, int32_t kind, double value);
 int emgpu_model_set_transition_stay_prior(emgpu_model *m, double prior);
 /* EncounterModel.start (EncounterModel.m:52,205-207): n_initial entries, 0 = unset ([] or NaN). */
 int emgpu_model_set_start(emgpu_model *m, const int32_t *start, int32_t n);
+/* Importance-sampling hook next to `start` and `layers` (UncorEncounterModel.m:204,259-272; InitStartTerminal.m:1-92):
+ * log of the model probability of the preset values, sum over preset nodes of log P(x_i = start_i | parents) with
+ * P = (N + alpha) column-normalised.  Preset nodes have only preset parents (bn_sample.m:45-47), so this is ONE number per
+ * call -- the log-weight of every sample drawn with this `start` (0 when nothing is preset, -inf for an impossible preset). */
+int emgpu_model_start_log_weight(const emgpu_model *m, double *out);
 /* EncounterModel.zero_bins (EncounterModel.m:40; derived once by em_read.m:110-114,143-156 and, like in
  * the reference, NOT re-derived when boundaries are replaced): n_initial entries, 0 = none. */
 int emgpu_model_set_zero_bins(emgpu_model *m, const int32_t *zero_bins, int32_t n);

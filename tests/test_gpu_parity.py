@@ -926,3 +926,18 @@ def test_uncor_class_track_and_index_lists(gpu_ctx, model_dir):
     for k in ("init_bin", "init_val", "dyn_bin", "dyn_val", "attempts"):
         assert np.array_equal(sub[k], full[k][rows]), k
     assert all(np.array_equal(sub["events"][q], full["events"][r]) for q, r in enumerate(rows))
+
+
+@pytest.mark.gpu
+def test_start_log_weight_is_the_frequency_of_the_preset_values(gpu_ctx, model_dir):
+    """f4: exp(start_log_weight) == how often unconstrained sampling lands on the preset values (G=1, A=4, L=2)."""
+    nm, pp, path = load_pair("uncor_1200code_v2p1", model_dir)
+    mdl = E.UncorEncounterModel(path)
+    st = [None] * 7
+    st[0], st[1], st[2] = 1, 4, 2
+    mdl.start = st
+    p = np.exp(mdl.start_log_weight)
+    n = 400_000
+    ob, _, _ = native.sample_bn_host(gpu_ctx, nm, n, 123)             # plain bn_sample on the unconstrained model
+    hit = np.mean((ob[:, 0] == 1) & (ob[:, 1] == 4) & (ob[:, 2] == 2))
+    assert abs(hit - p) < 5 * np.sqrt(p * (1 - p) / n), (hit, p)

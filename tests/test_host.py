@@ -441,3 +441,27 @@ def test_point_mass_dynamics_known_answers():
     ctrl = np.zeros((40, 3)); ctrl[:, 2] = 20.0                                   # acceleration stops at v_high
     rows, mm = O.point_mass_dynamics([400.0, 0, 0, 1000.0, 0, 0, 0, 20.0], ctrl, dyn)
     assert rows[:, 4].max() == 500.0 and mm[3] == 500.0
+
+
+def test_start_log_weight(model_dir):
+    """the importance weight of a start distribution = the model probability of the preset values
+    (UncorEncounterModel.m:204, RUN_uncor.m:43-48), from N + alpha like select_random; dependent presets are refused."""
+    path = em_io.materialize_model("uncor_1200code_v2p1", model_dir)
+    mdl = E.UncorEncounterModel(path)
+    assert mdl.start_log_weight == 0.0
+    st = [None] * 7
+    st[0], st[1], st[2] = 1, 4, 2                                     # RUN_uncor.m:43-45
+    mdl.start = st
+    N = mdl.N_initial
+    col_L = (1 - 1) + 4 * (4 - 1)                                      # asub2ind([4 4], [1 4]) - 1
+    want = np.log(N[0][0, 0] / N[0][:, 0].sum()) + np.log(N[1][3, 0] / N[1][:, 0].sum()) + np.log(N[2][1, col_L] / N[2][:, col_L].sum())
+    assert abs(mdl.start_log_weight - want) < 1e-12
+    mdl.prior = 0.5                                                    # alpha enters like in select_random
+    want = sum(np.log((N[v][b, c] + 0.5) / (N[v][:, c] + 0.5).sum()) for v, b, c in ((0, 0, 0), (1, 3, 0), (2, 1, col_L)))
+    assert abs(mdl.start_log_weight - want) < 1e-12
+    st = [None] * 7
+    st[2] = 2                                                          # L preset without its parents G, A
+    mdl.start = st
+    with pytest.raises(E.EmgpuError) as ei:
+        mdl.start_log_weight
+    assert ei.value.code == L.ERR_PRESET
