@@ -184,7 +184,9 @@ class TorchRocm:
 # workloads
 # ------------------------------------------------------------------------------------------------
 def _materialize(name, tmp):
-    from em_model_manned_bayes_amd import em_io
+    from em_model_manned_bayes_amd import em_io, synthetic
+    if name == "cor_v2p1_like":   # generator-made stand-in for the absent cor_v2p1.txt (seed 0x5EED0003)
+        return synthetic.write_correlated_v2p1_like(tmp)
     return name if os.path.isfile(name) else em_io.materialize_model(name, tmp)
 
 

@@ -84,3 +84,68 @@ def write_terminal_directory(out_dir, src="terminalradar", seed=0x5EED0005):
             n_intent = 2 if stem.startswith("ownship") else 3
             em_io.em_write(terminal_trajectory_model(seed + k, n_intent, stem.endswith("reverse")), path)
     return out_dir
+
+
+def correlated_v2p1_like(seed=0x5EED0003):
+    """A deterministic stand-in for model/cor_v2p1.txt (absent from the reference mount: .MISSING_LARGE_BLOBS:1) for
+    BASELINE.json configs[2]: the correlated two-aircraft network of cor_v1 -- same 16 initial
+    variables, same initial graph and bins, the 4 dynamic variables \\dot h_1, \\dot h_2, \\dot\\psi_1, \\dot\\psi_2 -- with the
+    transition tables ALSO conditioned on the airspace class A (cor_v1: L only), i.e. 4x more columns, and counts redrawn from
+    `seed`: a "stay" mass plus neighbours plus sparse far jumps, 3 % unobserved (all-zero) columns.  Dependent branch like cor_v1
+    (\\dot\\psi_k(t+1) has \\dot h_k(t+1) as a parent).  Synthetic counts: it exercises the path, it is not a trained model."""
+    import os
+    from . import em_io
+    base = em_io.load_npz(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models", "cor_v1.npz"))
+    rs = np.random.RandomState(seed & 0x7FFFFFFF)
+    ni, nt = base["n_initial"], base["n_transition"]
+    r_i = np.asarray(base["r_initial"], dtype=np.int32)
+    r_t = np.asarray(base["r_transition"], dtype=np.int32)
+    G_i = np.asarray(base["G_initial"], dtype=bool)
+    G_t = np.asarray(base["G_transition"], dtype=bool).copy()
+    G_t[0, ni:nt] = True                                   # + airspace class A (variable 1) as a parent of every (t+1) node
+
+    def initial_counts(v):
+        q = int(np.prod(r_i[G_i[:, v]])) if G_i[:, v].any() else 1
+        N = rs.gamma(0.6, 400.0, (int(r_i[v]), q)).round()
+        N *= rs.rand(int(r_i[v]), q) < 0.8
+        N[rs.randint(int(r_i[v])), :] += 50                # no empty initial column: every configuration can be drawn
+        return N
+    N_i = [initial_counts(v) for v in range(ni)]
+
+    tmap = {ni + k: 10 + k for k in range(nt - ni)}       # (t+1) node -> its (t) node, 0-based: cor_v1.txt temporal map [11 17; 12 18; 13 19; 14 20]
+
+    def transition_counts(v):
+        par = np.flatnonzero(G_t[:, v])
+        q = int(np.prod(r_t[par]))
+        rv = int(r_t[v])
+        own = tmap[v]                                      # the variable's own value at t
+        stride = int(np.prod(r_t[par[par < own]]))         # asub2ind: earlier parents vary faster
+        cur = (np.arange(q) // stride) % int(r_t[own])
+        N = np.zeros((rv, q))
+        cols = np.arange(q)
+        N[cur, cols] = rs.randint(2000, 60000, q)
+        for d in (-1, 1):
+            nb = np.clip(cur + d, 0, rv - 1)
+            N[nb, cols] += rs.randint(0, 900, q) * (rs.rand(q) < 0.8)
+        for d in (-2, 2):
+            nb = np.clip(cur + d, 0, rv - 1)
+            N[nb, cols] += rs.randint(0, 60, q) * (rs.rand(q) < 0.3)
+        N[rs.randint(0, rv, q), cols] += rs.randint(0, 5, q) * (rs.rand(q) < 0.1)
+        N[:, rs.rand(q) < 0.03] = 0
+        return N
+    N_t = [np.zeros((0, 0))] * ni + [transition_counts(v) for v in range(ni, nt)]
+    return Parms(labels_initial=list(base["labels_initial"]), n_initial=ni, G_initial=G_i, r_initial=r_i, N_initial=N_i,
+                 labels_transition=list(base["labels_transition"]), n_transition=nt, G_transition=G_t, r_transition=r_t, N_transition=N_t,
+                 boundaries=[np.asarray(b, dtype=np.float64) for b in base["boundaries"]],
+                 resample_rates=np.asarray(base["resample_rates"], dtype=np.float64))
+
+
+def write_correlated_v2p1_like(out_dir, seed=0x5EED0003):
+    """Materialise correlated_v2p1_like as <out_dir>/cor_v2p1_like.txt in the reference's file format; returns the path."""
+    import os
+    from . import em_io
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "cor_v2p1_like.txt")
+    if not os.path.exists(path):
+        em_io.em_write(correlated_v2p1_like(seed), path)
+    return path

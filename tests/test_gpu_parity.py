@@ -90,7 +90,7 @@ def test_hip_path_reproduces_committed_golden_vectors(path, gpu_ctx, model_dir):
         assert_uncor_parity(got, ref, T)
 
 
-@pytest.mark.parametrize("name", ["cor_v1", "littoral_cor_v1"])
+@pytest.mark.parametrize("name", ["cor_v1", "littoral_cor_v1", "cor_v2p1_like"])
 def test_correlated_model_matches_oracle(name, gpu_ctx, model_dir):
     """16 initial / 4 dynamic variables; cor_v1 takes the dependent branch, littoral_cor_v1 the fast
     branch (which errors in the reference, dbn_sample.m:61,156; here it just works)."""
@@ -837,12 +837,14 @@ def test_random_models_match_oracle(seed, gpu_ctx, tmp_path):
     assert kernels <= {"k_uncor_fast", "k_dbn_step2", "k_dbn_step", "k_dbn_generic"}
 
 
-@pytest.mark.parametrize("name,n,kernel", [("cor_v1", 3_000_000, "k_dbn_step2<16,4,w4,reg>"), ("glider_v1", 4_000_000, "k_dbn_step2<7,3"),
-                                           ("uncor_1200only_rotorcraft_v1p2", 6_000_000, "k_uncor_fast<7,4,6,6>")])
+@pytest.mark.parametrize("name,n,kernel", [("cor_v1", 10_000_000, "k_dbn_step2<16,4,w4,reg>"), ("cor_v2p1_like", 10_000_000, "k_dbn_step2<16,4,w8,reg>"),
+                                           ("glider_v1", 4_000_000, "k_dbn_step2<7,3"),
+                                           ("uncor_1200only_rotorcraft_v1p2", 6_250_000, "k_uncor_fast<7,4,6,6>")])
 def test_large_batches_of_the_other_kernels_spot_checked(name, n, kernel, model_dir):
-    """BASELINE configs 3 and 4 at sizes the oracle cannot finish: millions of trajectories x 240 s on the device,
-    slices from the start, the middle and the ragged end of the batch against the oracle (slots are keyed by the
-    global index, so the oracle can produce any slice on its own)."""
+    """BASELINE configs 3 and 4 at sizes the oracle cannot finish -- config 3 at its full 10 M encounters x 240 s on cor_v1 AND on the
+    generator-made "v2p1-like" correlated model (seed 0x5EED0003), config 4 at one rank's 6.25 M -- slices from the
+    start, the middle and the ragged end of the batch against the oracle (slots are keyed by the global index, so the oracle can
+    produce any slice on its own)."""
     import torch
     nm, pp, _ = load_pair(name, model_dir)
     idx = uncor_indices(pp)

@@ -12,7 +12,11 @@ def load_pair(name, model_dir, **read_kw):
     the native one by the C++ loader, the oracle one by oracle.parse_model_txt."""
     key = (name, tuple(sorted(read_kw.items())))
     if key not in _cache:
-        path = em_io.materialize_model(name, model_dir)
+        if name == "cor_v2p1_like":           # the generator-made stand-in for the absent cor_v2p1.txt
+            from em_model_manned_bayes_amd import synthetic
+            path = synthetic.write_correlated_v2p1_like(model_dir)
+        else:
+            path = em_io.materialize_model(name, model_dir)
         nm = native.NativeModel.load_txt(path, read_kw.get("idx_zero_boundaries", (1, 2, 3)), read_kw.get("is_overwrite_zero_boundaries", False))
         pp = O.parse_model_txt(path, read_kw.get("idx_zero_boundaries", (1, 2, 3)), read_kw.get("is_overwrite_zero_boundaries", False))
         _cache[key] = (nm, pp, path)
