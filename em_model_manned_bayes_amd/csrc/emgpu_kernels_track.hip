@@ -13,14 +13,14 @@
 
 namespace emgpu {
 
-__device__ __forceinline__ void k_sincosd(double deg, double &s, double &c) { // cosd / sind: exact at multiples of 90
-    const double r = fmod(deg, 360.0);
-    if (r == 0) { s = 0; c = 1; return; }
-    if (r == 90 || r == -270) { s = 1; c = 0; return; }
-    if (r == 180 || r == -180) { s = 0; c = -1; return; }
-    if (r == 270 || r == -90) { s = -1; c = 0; return; }
-    const double rad = r * (3.14159265358979323846 / 180.0);
-    s = sin(rad); c = cos(rad);
+// cosd / sind with MATLAB's reduction in degrees: n = round(x/90), x - 90 n in [-45, 45], quadrant m = mod(n, 4)
+__device__ __forceinline__ void k_sincosd(double deg, double &s, double &c) {
+    const double n = round(deg / 90.0);
+    const double x = (3.14159265358979323846 / 180.0) * (deg - n * 90.0);
+    const int m = (int)((long long)n & 3ll);
+    const double sx = sin(x), cx = cos(x);
+    s = (m == 0) ? sx : ((m == 1) ? cx : ((m == 2) ? -sx : -cx));
+    c = (m == 0) ? cx : ((m == 1) ? -sx : ((m == 2) ? -cx : sx));
 }
 
 template <bool DENSE>

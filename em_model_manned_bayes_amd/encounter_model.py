@@ -548,11 +548,14 @@ class CorTerminalModel(EncounterModel):
     # ---- createEncounter.m:1-91 without em-core's local_smooth (:88-89)
     @staticmethod
     def _sincosd(deg):
-        r = np.fmod(np.asarray(deg, dtype=np.float64), 360.0)
-        s, c = np.sin(np.deg2rad(r)), np.cos(np.deg2rad(r))
-        for ang, sv, cv in ((0, 0, 1), (90, 1, 0), (-270, 1, 0), (180, 0, -1), (-180, 0, -1), (270, -1, 0), (-90, -1, 0)):
-            m = r == ang
-            s = np.where(m, sv, s); c = np.where(m, cv, c)
+        # sind / cosd with MATLAB's reduction in degrees: n = round(x/90), x - 90 n in [-45, 45], quadrant m = mod(n, 4)
+        deg = np.asarray(deg, dtype=np.float64)
+        n = np.sign(deg) * np.floor(np.abs(deg) / 90.0 + 0.5)          # round half away from zero
+        x = (np.pi / 180.0) * (deg - n * 90.0)
+        m = np.mod(n, 4.0)
+        sx, cx = np.sin(x), np.cos(x)
+        s = np.select([m == 0, m == 1, m == 2], [sx, cx, -sx], -cx)
+        c = np.select([m == 0, m == 1, m == 2], [cx, -sx, -cx], sx)
         return s, c
 
     def _geo_rows(self, samples):

@@ -802,14 +802,17 @@ static double em_wrapTo360(double lon) {   /* Mapping Toolbox wrapTo360 */
 }
 static double em_atan2d(double y, double x) { return atan2(y, x) * (180.0 / 3.14159265358979323846); }
 static void em_sincosd(double deg, double *s, double *c) {
-    /* cosd / sind: exact at multiples of 90 degrees like MATLAB, otherwise radians */
-    double r = fmod(deg, 360.0);
-    if (r == 0) { *s = 0; *c = 1; return; }
-    if (r == 90 || r == -270) { *s = 1; *c = 0; return; }
-    if (r == 180 || r == -180) { *s = 0; *c = -1; return; }
-    if (r == 270 || r == -90) { *s = -1; *c = 0; return; }
-    const double rad = r * (3.14159265358979323846 / 180.0);
-    *s = sin(rad); *c = cos(rad);
+    /* sind / cosd the way MATLAB's own sind.m / cosd.m reduce the argument: IN DEGREES, to [-45, 45] around the nearest
+     * multiple of 90 (n = round(x/90); x = x - n*90; m = mod(n, 4)), then sin / cos of pi/180*x with the quadrant's sign
+     * and swap.  Exact at every multiple of 90; the reduced argument is what the radian functions see. */
+    const double n = round(deg / 90.0);
+    const double x = (3.14159265358979323846 / 180.0) * (deg - n * 90.0);
+    double m = fmod(n, 4.0); if (m < 0) m += 4.0;
+    const double sx = sin(x), cx = cos(x);
+    if (m == 0) { *s = sx; *c = cx; }
+    else if (m == 1) { *s = cx; *c = -sx; }
+    else if (m == 2) { *s = -sx; *c = -cx; }
+    else { *s = -cx; *c = sx; }
 }
 static double em_round2(double x) { return round(x * 100.0) / 100.0; } /* round(x, 2) */
 static double em_sign(double x) { return (x > 0) - (x < 0); }
