@@ -555,6 +555,64 @@ def test_terminal_propagation_matches_oracle(actypes, terminal_dir, gpu_ctx):
             assert abs(pair[a]["v_ft_s"][k0] - samples[e_][("own", "int")[a] + "_speed"]) < 1e-3
 
 
+def test_terminal_ten_million_encounters_properties(terminal_dir):
+    """BASELINE.json configs[4] at one GPU's scale: 10 M terminal encounters (40 M tracks) propagated in five chunks of 2 M,
+    checked through properties that hold for every track (createEncounter.m:160-264, :296-329) and against the oracle on slices:
+    row counts within [1, tmax+2], time = +-(row index), speeds inside the dynamic limits, altitude steps inside maxVertRate,
+    headings in (0, 360], every track ending for one of the reasons CheckTrajectoryConditions knows."""
+    import ctypes as C
+    import torch
+    t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=terminal_dir)
+    dev = torch.device("cuda", 0)
+    ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    seed, m, n, cap = 0x5EED0005, 8192, 2_000_000, 123
+    _, samples = t.sample(m, seed=seed, ctx=ctx)
+    g, mo = t._geo_rows(samples)
+    reps = (n + m - 1) // m
+    geo = torch.tensor(np.tile(g, (reps, 1))[:n], device=dev)
+    mof = torch.tensor(np.tile(mo, (reps, 1))[:n].reshape(-1), dtype=torch.int32, device=dev)
+    out = torch.empty((6, cap, 4 * n), dtype=torch.float32, device=dev)
+    rows = torch.empty(4 * n, dtype=torch.int32, device=dev)
+    dl = t._dyn_rows()
+    handles = (C.c_void_p * 10)(*[x.native._h for x in t._traj])
+    oms = []
+    for f in [mm.parameters_filename for mm in t._traj]:
+        pp = O.parse_model_txt(f)
+        oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
+    total_seconds = 0
+    for chunk in range(5):
+        p = L.TermParams()
+        p.seed, p.first_index, p.n, p.tmax_s, p.max_resample, p.cap = seed, chunk * n, n, 120.0, 100000, cap
+        for i, v in enumerate(dl.reshape(-1)):
+            p.dyn_limits[i] = float(v)
+        L.check(L.lib().emgpu_propagate_terminal_device(ctx._h, handles, 10, C.byref(p), C.c_void_p(geo.data_ptr()), C.c_void_p(mof.data_ptr()),
+                                                        C.c_void_p(out.data_ptr()), C.c_void_p(rows.data_ptr())))
+        ctx.sync()
+        assert int(rows.min()) >= 1 and int(rows.max()) <= 122
+        total_seconds += int(rows.sum())
+        valid = torch.arange(cap, device=dev)[:, None] < rows[None, :]                       # [cap, 4n]
+        sign = torch.where((torch.arange(4 * n, device=dev) & 1) == 1, -1.0, 1.0)
+        assert bool(((out[0] == torch.arange(cap, device=dev, dtype=torch.float32)[:, None] * sign[None, :]) | ~valid).all())   # t_s
+        lim = torch.tensor(dl, dtype=torch.float32, device=dev)[(torch.arange(4 * n, device=dev) >> 1) & 1]   # [4n, 5] by aircraft
+        v = out[5]
+        assert bool((((v >= lim[:, 0][None, :] - 1e-2) & (v <= lim[:, 1][None, :] + 1e-2)) | ~valid).all())
+        hdg = out[4]
+        assert bool((((hdg > 0) & (hdg <= 360)) | ~valid).all())
+        dz = (out[3][1:] - out[3][:-1]).abs()
+        assert bool(((dz <= lim[:, 4][None, :] * 1.0001 + 1e-2) | ~valid[1:]).all())
+        if chunk in (0, 3):                                                                   # slices against the oracle
+            for lo_e in (0, n - 300):
+                sl = slice(lo_e, lo_e + 300)
+                ref, ref_rows = O.propagate(oms, mof[4 * lo_e: 4 * lo_e + 1200].cpu().numpy(), geo[sl].cpu().numpy(), seed, dl,
+                                            first_index=chunk * n + lo_e, tmax_s=120.0)
+                got_rows = rows[4 * lo_e: 4 * lo_e + 1200].cpu().numpy()
+                assert np.array_equal(got_rows, ref_rows)
+                got = out[:, :, 4 * lo_e: 4 * lo_e + 1200].cpu().numpy().transpose(2, 1, 0)
+                for q in range(0, 1200, 7):
+                    np.testing.assert_allclose(got[q, : got_rows[q]], ref[q, : got_rows[q]], rtol=1e-6, atol=1e-6)
+    assert 300 < total_seconds / (5 * n) < 488        # mean track-seconds per encounter (4 tracks x <= 122)
+
+
 def test_edge_cases_and_error_paths(gpu_ctx, model_dir):
     nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
     idx = uncor_indices(pp)
