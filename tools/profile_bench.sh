@@ -4,7 +4,7 @@
 # cannot share a pass on gfx950: MI355X_MICROARCH.md "rocprofv3 PMC slots"), then SQ counters.
 # Raw output lands in gpurun_out/prof_$TAG; tools/summarize_profiles.py condenses it into profiles/.
 set -u
-TAG=${1:-r01}   # bench.py defaults: --warmup 5 --steps 10
+TAG=${1:-r02}   # bench.py defaults: --warmup 5 --steps 10
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
