@@ -78,6 +78,14 @@ class UTrackParams(C.Structure):  # emgpu_utrack_params
                 ("idx_dh", C.c_int32), ("idx_dpsi", C.c_int32), ("is_rotorcraft", C.c_int32), ("record_stride", C.c_int32), ("_pad", C.c_int32)]
 
 
+class TTrackParams(C.Structure):  # emgpu_ttrack_params
+    _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("tmax_s", C.c_double),
+                ("max_resample", C.c_int32), ("max_track_attempts", C.c_int32), ("max_attempts", C.c_int32), ("_pad", C.c_int32),
+                ("dyn_limits", C.c_double * 10), ("max_cum_turn_deg", C.c_double * 2), ("pitch_deg", C.c_double * 2),
+                ("min_enc_time_s", C.c_double), ("thres_dist_ft", C.c_double), ("thres_alt_low_ft", C.c_double), ("thres_vertrate_ft_s", C.c_double),
+                ("bounds_sample", C.c_void_p), ("idx", C.c_int32 * 12)]
+
+
 class Block(C.Structure):         # emgpu_block
     _fields_ = [("model", C.c_int32), ("_pad", C.c_int32), ("first_index", C.c_uint64), ("n", C.c_int64)]
 
@@ -114,6 +122,7 @@ SYMBOLS = [
     "emgpu_model_set_zero_bins", "emgpu_shard_range", "emgpu_device_count", "emgpu_mixed_blocks",
     "emgpu_sample_dbn_blocks_device", "emgpu_sample_dbn_multi_host", "emgpu_sample_dbn_multi_device",
     "emgpu_track_uncor_host", "emgpu_track_uncor_device", "emgpu_uncor_dynamic_limits", "emgpu_model_start_log_weight",
+    "emgpu_track_terminal_host",
 ]
 
 _lib = None
@@ -161,6 +170,8 @@ def lib():
     L.emgpu_sample_dbn_multi_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(SampleParams), C.POINTER(SampleOut)]
     for f in (L.emgpu_track_uncor_host, L.emgpu_track_uncor_device):
         f.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(UTrackParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emgpu_track_terminal_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TTrackParams), C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
     L.emgpu_uncor_dynamic_limits.argtypes = [C.c_void_p, C.POINTER(UTrackParams), C.c_void_p] + [C.c_double] * 4 + [C.c_void_p]
     L.emgpu_ctx_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
     L.emgpu_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]

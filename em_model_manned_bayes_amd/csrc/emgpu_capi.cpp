@@ -834,29 +834,26 @@ int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int3
     EMGPU_CATCH
 }
 
-int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
-                                    const emgpu_term_params *p, const double *geo, const int32_t *model_of,
-                                    float *out, int32_t *rows) {
-    EMGPU_TRY
-    if (!ctx || !models || n_models < 1 || !p || !geo || !model_of || !out || !rows) return fail(EMGPU_ERR_ARG, "null argument");
-    if (p->n < 0 || p->cap < 2 || p->max_resample < 1) return fail(EMGPU_ERR_ARG, "bad n / cap / max_resample");
-    CTX_LOCK(ctx);
-    HIP_OK(hipSetDevice(ctx->device));
+// Upload / validate the trajectory models of a terminal call and publish their table pointers in ctx->d_thr_base.
+// Returns the first model's uploaded plan (the shapes every model shares).
+static const Uploaded *terminal_tables(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models) {
     std::vector<const uint32_t *> bases;
     const Uploaded *first = nullptr;
     std::set<uint64_t> pinned; // the table pointers collected below must survive the cache's LRU sweep
     for (int i = 0; i < n_models; i++) {
-        if (!models[i]) return fail(EMGPU_ERR_ARG, "null model");
+        if (!models[i]) throw Error(EMGPU_ERR_ARG, "null model");
         pinned.insert(models[i]->m.uid);
     }
     for (int i = 0; i < n_models; i++) {
         Uploaded &u = get_uploaded(ctx, models[i], &pinned);
         const EmgpuPlan &P = u.cp.plan;
-        if (P.ni != 6 || P.nd != 3 || P.depend) return fail(EMGPU_ERR_UNSUPPORTED, "trajectory model must have 6 initial and 3 independent dynamic variables");
+        if (P.ni != 6 || P.nd != 3 || P.depend) throw Error(EMGPU_ERR_UNSUPPORTED, "trajectory model must have 6 initial and 3 independent dynamic variables");
         for (int q = 0; q < 6; q++)
-            if (P.i_var[q] != q) return fail(EMGPU_ERR_UNSUPPORTED, "trajectory model initial network must be in index order");
+            if (P.i_var[q] != q) throw Error(EMGPU_ERR_UNSUPPORTED, "trajectory model initial network must be in index order");
         if (P.d_ivar[0] > 5 || P.i_nb[1] < 3 || P.i_nb[2] < 3 || P.i_nb[3] < 3 || P.i_nb[4] < 3 || P.i_nb[5] < 3)
-            return fail(EMGPU_ERR_UNSUPPORTED, "distance, bearing, heading, altitude and speed need boundaries");
+            throw Error(EMGPU_ERR_UNSUPPORTED, "distance, bearing, heading, altitude and speed need boundaries");
+        if (P.i_nb[1] > 66 || P.i_nb[2] > 66 || P.i_nb[3] > 66 || P.i_nb[4] > 66 || P.i_nb[5] > 66)
+            throw Error(EMGPU_ERR_UNSUPPORTED, "more than 64 cut points in a trajectory-model variable");
         if (!first) first = &u;
         else {
             const EmgpuPlan &Q = first->cp.plan;
@@ -866,7 +863,7 @@ int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *mo
                         memcmp(P.d_stride_static, Q.d_stride_static, sizeof P.d_stride_static) == 0 &&
                         memcmp(P.d_stride_cur, Q.d_stride_cur, sizeof P.d_stride_cur) == 0 && u.cp.bnd == first->cp.bnd && memcmp(P.i_boff, Q.i_boff, sizeof P.i_boff) == 0 &&
                         memcmp(P.d_ivar, Q.d_ivar, sizeof P.d_ivar) == 0 && memcmp(P.d_tvar, Q.d_tvar, sizeof P.d_tvar) == 0;
-            if (!same) return fail(EMGPU_ERR_UNSUPPORTED, "trajectory models differ in shape or boundaries");
+            if (!same) throw Error(EMGPU_ERR_UNSUPPORTED, "trajectory models differ in shape or boundaries");
         }
         bases.push_back(u.d_thr + P.d_off[0]); // tables of the dynamic variables, relative to the first one
     }
@@ -879,6 +876,18 @@ int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *mo
     }
     HIP_OK(hipMemcpyAsync(ctx->d_thr_base, bases.data(), bases.size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     HIP_OK(hipStreamSynchronize(ctx->stream));
+    return first;
+}
+
+int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
+                                    const emgpu_term_params *p, const double *geo, const int32_t *model_of,
+                                    float *out, int32_t *rows) {
+    EMGPU_TRY
+    if (!ctx || !models || n_models < 1 || !p || !geo || !model_of || !out || !rows) return fail(EMGPU_ERR_ARG, "null argument");
+    if (p->n < 0 || p->cap < 2 || p->max_resample < 1) return fail(EMGPU_ERR_ARG, "bad n / cap / max_resample");
+    CTX_LOCK(ctx);
+    HIP_OK(hipSetDevice(ctx->device));
+    const Uploaded *first = terminal_tables(ctx, models, n_models);
     EmgpuTermRun A;
     memset(&A, 0, sizeof A);
     A.seed = p->seed; A.first_index = p->first_index; A.n = p->n; A.geo = geo; A.model_of = model_of; A.thr_base = ctx->d_thr_base;
@@ -926,6 +935,116 @@ int emgpu_propagate_terminal_host(emgpu_ctx *ctx, const emgpu_model *const *mode
     }
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dg); (void)hipFree(dm); (void)hipFree(dr); (void)hipFree(dout);
+    return rc;
+    EMGPU_CATCH
+}
+
+int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *gm, const emgpu_model *const *traj_models,
+                              const emgpu_ttrack_params *p, double *sample, double *traj, int32_t cap2, int32_t *len,
+                              double *meta, int32_t *attempts) {
+    EMGPU_TRY
+    if (!ctx || !gm || !traj_models || !p) return fail(EMGPU_ERR_ARG, "null argument");
+    if (p->n < 0 || p->max_resample < 1 || p->max_track_attempts < 1 || p->max_attempts < 1 || !(p->tmax_s >= 1) || (traj && cap2 < 2))
+        return fail(EMGPU_ERR_ARG, "bad n / caps / tmax_s");
+    const Model &g = gm->m;
+    for (int k = 0; k < 12; k++) if (p->idx[k] < 1 || p->idx[k] > g.n_initial) return fail(EMGPU_ERR_ARG, "geometry variable index out of range");
+    CTX_LOCK(ctx);
+    HIP_OK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)p->n, ni = (size_t)g.n_initial;
+    if (n == 0) return EMGPU_OK;
+    const int cap = (int)p->tmax_s + 3;
+    std::vector<void *> allocs;
+    auto dalloc = [&](size_t bytes) { void *q = nullptr; HIP_OK(hipMalloc(&q, bytes ? bytes : 1)); allocs.push_back(q); return q; };
+    int rc = EMGPU_OK;
+    try {
+        float *d_val = (float *)dalloc(ni * n * 4);
+        double *d_geo = (double *)dalloc(n * 12 * 8);
+        int32_t *d_mo = (int32_t *)dalloc(4 * n * 4), *d_rows = (int32_t *)dalloc(4 * n * 4);
+        float *d_out = (float *)dalloc((size_t)6 * cap * 4 * n * 4);
+        uint8_t *d_acc = (uint8_t *)dalloc(n);
+        uint64_t *d_gidx[2] = {(uint64_t *)dalloc(n * 8), (uint64_t *)dalloc(n * 8)};
+        int64_t *d_slot[2] = {(int64_t *)dalloc(n * 8), (int64_t *)dalloc(n * 8)};
+        uint32_t *d_count = (uint32_t *)dalloc(4);
+        double *d_sample = sample ? (double *)dalloc(n * ni * 8) : nullptr;
+        double *d_traj = traj ? (double *)dalloc(n * 2 * (size_t)cap2 * 6 * 8) : nullptr;
+        int32_t *d_len = len ? (int32_t *)dalloc(n * 2 * 4) : nullptr;
+        double *d_meta = meta ? (double *)dalloc(n * 4 * 8) : nullptr;
+        int32_t *d_att = (int32_t *)dalloc(n * 4);
+        const Uploaded *first = terminal_tables(ctx, traj_models, 10);
+        Uploaded &ug = get_uploaded(ctx, gm);
+        emgpu_bn_params bp;
+        memset(&bp, 0, sizeof bp);
+        bp.max_attempts = p->max_attempts; bp.bounds_sample = p->bounds_sample;
+        bp.idx_own_speed = p->idx[3]; bp.idx_int_speed = p->idx[9];
+        bp.min_vel1 = p->dyn_limits[0][0]; bp.max_vel1 = p->dyn_limits[0][1]; bp.min_vel2 = p->dyn_limits[1][0]; bp.max_vel2 = p->dyn_limits[1][1];
+        size_t count = n;
+        std::string kernels;
+        for (int j = 0; j < p->max_track_attempts && count > 0; j++) {
+            const int cur = j & 1;
+            const uint64_t seed = p->seed + (uint64_t)j;
+            const uint64_t *ind = j ? d_gidx[cur] : nullptr;
+            // geometry draw (sample.m:29-77)
+            bp.seed = seed; bp.first_index = p->first_index; bp.n = (int64_t)count;
+            EmgpuBnRun B;
+            fill_bn(ctx, ug, g, &bp, B);
+            B.out_val = d_val; B.ld = (int64_t)count; B.indices = ind;
+            const char *name = "";
+            hipError_t e = emgpu::launch_bn(ug.cp.plan, B, ctx->stream, &name);
+            if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+            kernels = name;
+            // createEncounter.m:21-49
+            EmgpuTGeoRun G;
+            memset(&G, 0, sizeof G);
+            G.n = (int64_t)count; G.val = d_val; G.geo = d_geo; G.model_of = d_mo;
+            for (int k = 0; k < 12; k++) G.idx[k] = p->idx[k] - 1;
+            e = emgpu::launch_terminal_geo(G, ctx->stream);
+            if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+            // PropagateTrajectory x 4 (createEncounter.m:52-72)
+            EmgpuTermRun A;
+            memset(&A, 0, sizeof A);
+            A.seed = seed; A.first_index = p->first_index; A.n = (int64_t)count; A.geo = d_geo; A.model_of = d_mo; A.thr_base = ctx->d_thr_base;
+            A.tmax_s = p->tmax_s; A.max_resample = p->max_resample; A.cap = cap;
+            memcpy(A.dl, p->dyn_limits, sizeof A.dl);
+            A.out = d_out; A.rows = d_rows; A.status = ctx->d_status; A.indices = ind; A.quiet = 1;
+            e = emgpu::launch_terminal_propagate(first->cp.plan, A, ctx->stream, &name);
+            if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+            kernels += std::string(" + ") + name;
+            // the filters (track.m:62-145)
+            EmgpuTFilterRun F;
+            memset(&F, 0, sizeof F);
+            F.n = (int64_t)count; F.out = d_out; F.rows = d_rows; F.cap = cap; F.geo = d_geo; F.val = d_val; F.n_i = (int32_t)ni;
+            memcpy(F.dl, p->dyn_limits, sizeof F.dl);
+            for (int a = 0; a < 2; a++) { F.max_cum_turn[a] = p->max_cum_turn_deg[a]; F.pitch[a] = p->pitch_deg[a]; }
+            F.min_enc_time_s = p->min_enc_time_s; F.thres_dist_ft = p->thres_dist_ft; F.thres_alt_low_ft = p->thres_alt_low_ft; F.thres_vertrate_ft_s = p->thres_vertrate_ft_s;
+            F.slot = j ? d_slot[cur] : nullptr; F.accepted = d_acc;
+            F.sample = d_sample; F.traj = d_traj; F.cap2 = cap2; F.len = d_len; F.meta = d_meta; F.attempts = d_att;
+            F.attempt_no = j + 1; F.last_round = (j + 1 == p->max_track_attempts);
+            e = emgpu::launch_terminal_filter(F, ctx->stream, &name);
+            if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+            ctx->last_kernel = kernels + " + " + name;
+            HIP_OK(hipMemsetAsync(d_count, 0, 4, ctx->stream));
+            e = emgpu::launch_compact_rejected((int64_t)count, p->first_index, d_acc, ind, j ? d_slot[cur] : nullptr, d_gidx[cur ^ 1], d_slot[cur ^ 1], d_count, ctx->stream);
+            if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+            uint32_t hc = 0;
+            HIP_OK(hipMemcpyAsync(&hc, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_OK(hipStreamSynchronize(ctx->stream));
+            count = hc;
+        }
+        rc = emgpu_ctx_sync(ctx);   // the geometry draw's own rejection cap
+        std::string msg = g_err;
+        auto back = [&](void *dst, const void *src, size_t bytes) { if (dst && bytes) HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream)); };
+        back(sample, d_sample, n * ni * 8); back(traj, d_traj, n * 2 * (size_t)cap2 * 6 * 8); back(len, d_len, n * 2 * 4);
+        back(meta, d_meta, n * 4 * 8); back(attempts, d_att, n * 4);
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        if (rc != EMGPU_OK) g_err = msg;
+        else if (count > 0) rc = fail(EMGPU_ERR_REJECT_CAP, "terminal track: " + std::to_string(count) + " encounters were still rejected after max_track_attempts");
+    } catch (...) {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void *q : allocs) (void)hipFree(q);
+        throw;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void *q : allocs) (void)hipFree(q);
     return rc;
     EMGPU_CATCH
 }

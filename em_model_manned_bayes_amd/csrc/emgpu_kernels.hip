@@ -212,7 +212,7 @@ template <int NI>
 __global__ void __launch_bounds__(256) k_bn(const EmgpuPlan P, const EmgpuBnRun A) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= A.n) return;
-    const uint64_t gidx = A.first_index + (uint64_t)i;
+    const uint64_t gidx = A.indices ? A.indices[i] : A.first_index + (uint64_t)i;
     Rng rng{(uint32_t)gidx, (uint32_t)(gidx >> 32), 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
     const bool no_dedisc = (A.flags & EMGPU_FLAG_NO_DEDISC) != 0;
     int bin[NI];

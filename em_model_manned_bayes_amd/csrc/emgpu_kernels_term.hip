@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     const int role = (int)(L & 3), ac = role >> 1;
     const double dt_s = (role & 1) ? -1.0 : 1.0;
     const bool is_ownship = ac == 0;
-    const uint64_t gidx = A.first_index + (uint64_t)e;
+    const uint64_t gidx = A.indices ? A.indices[e] : A.first_index + (uint64_t)e;
     Rng rng{(uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)role, (uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
     const double *g = A.geo + e * 12 + ac * 6;
     const int intent = (int)g[5];
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
         const bool stop = (fabs(t_s) > A.tmax_s) || (d_nm > bounds_dist_hi) || ((intent == 1 || intent == 2) && d_nm <= 0.25) || (is_ownship && xy1 > 0.25);
         go = !stop;
     }
-    if (failed) atomicOr(A.status, 1u);
+    if (failed && !A.quiet) atomicOr(A.status, 1u);
     A.rows[L] = failed ? -rows - 1 : rows;
 }
 

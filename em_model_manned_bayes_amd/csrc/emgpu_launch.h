@@ -16,6 +16,8 @@ hipError_t launch_dbn_step(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s,
 bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A);
 hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
 hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, hipStream_t s, const char **name);
+hipError_t launch_terminal_geo(const EmgpuTGeoRun &A, hipStream_t s);
+hipError_t launch_terminal_filter(const EmgpuTFilterRun &A, hipStream_t s, const char **name);
 hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char **name);
 // rejected lanes of a round -> the next round's index lists (order is not defined; results are keyed by index)
 hipError_t launch_compact_rejected(int64_t n, uint64_t first_index, const uint8_t *accepted, const uint64_t *gidx_in, const int64_t *slot_in,

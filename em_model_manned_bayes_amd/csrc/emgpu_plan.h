@@ -126,6 +126,7 @@ struct EmgpuBnRun {
     float *out_val;
     int32_t *attempts;
     uint32_t *status;
+    const uint64_t *indices; // optional: global index of lane i (instead of first_index + i)
 };
 
 struct EmgpuTermRun {
@@ -140,6 +141,39 @@ struct EmgpuTermRun {
     float *out;                      // [6][cap][4n]: t_s x_nm y_nm z_ft heading_deg v_ft_s
     int32_t *rows;                   // [4n] rows written; < 0: failed (cap / resample cap)
     uint32_t *status;
+    const uint64_t *indices;         // optional: global index of encounter e (instead of first_index + e)
+    int32_t quiet;                   // a failed track only marks rows < 0 (CorTerminalModel.track re-draws it) instead of raising the status bit
+};
+
+// CorTerminalModel.track (track.m:45-150): geometry sample -> createEncounter inputs, and the filters on the propagated tracks.
+struct EmgpuTGeoRun {
+    int64_t n;
+    const float *val;                // [n_i][n] geometry sample (k_bn)
+    int32_t idx[12];                 // 0-based rows: own {distance bearing alt speed heading intent}, then int
+    double *geo;                     // [n][12]
+    int32_t *model_of;               // [4n]
+};
+struct EmgpuTFilterRun {
+    int64_t n;                       // encounters of this round
+    const float *out;                // [6][cap][4n] from k_terminal_propagate
+    const int32_t *rows;             // [4n]
+    int32_t cap;
+    const double *geo;               // [n][12] (intents)
+    const float *val;                // [n_i][n] geometry sample of this round
+    int32_t n_i;
+    double dl[2][5];                 // minVel maxVel maxTurnRate maxAltitude maxVertRate per aircraft
+    double max_cum_turn[2], pitch[2];
+    double min_enc_time_s, thres_dist_ft, thres_alt_low_ft, thres_vertrate_ft_s;
+    const int64_t *slot;             // [n] output position (null: i)
+    uint8_t *accepted;               // [n]
+    // outputs by slot (any may be null)
+    double *sample;                  // [slots][n_i]
+    double *traj;                    // [slots][2][cap2][6]
+    int32_t cap2;
+    int32_t *len;                    // [slots][2]
+    double *meta;                    // [slots][4]: tcpa_s hmd_ft vmd_ft enc_time_s
+    int32_t *attempts;               // [slots]
+    int32_t attempt_no, last_round;
 };
 
 // UncorEncounterModel.track (UncorEncounterModel.m:419-471): point-mass dynamics over the sampler's dense trace and the

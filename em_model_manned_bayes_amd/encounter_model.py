@@ -606,6 +606,50 @@ class CorTerminalModel(EncounterModel):
             res.append(pair)
         return res[0] if single else res
 
-    def track(self, *a, **k):
-        raise NotImplementedError("CorTerminalModel.track needs the terminal trajectory-model files (absent from the reference "
-                                  "mount) and em-core; outside the sampling hot path (SURVEY.md section 8 f2)")
+    def track(self, nSamples, initialSeed=None, firstID=1, minEncTime_s=30, thresDist_ft=2.5 * 6076, thresAltLow_ft=750,
+              thresVertRate_ft_s=300 / 60, max_track_attempts=500, first_index=None, ctx=None, return_info=False):
+        """[out_results, gen_time_s] = track(self, nSamples, 'initialSeed', s, 'firstID', 1, 'minEncTime_s', 30, ...)
+        (@CorTerminalModel/track.m).  out_results[i] = {"sample": dict of the geometry sample + id, tcpa, hmd_ft, vmd_ft, nmac, ...,
+        "traj": [ownship, intruder]} with each trajectory cut to the common time span and re-based like reformatTrajFiles
+        (CorTerminalModel.m:318-345: t from 0, x / y in feet, h, v).
+
+        Runs on the GPU in rounds (geometry draw -> createEncounter inputs -> propagation -> filters, attempt j under the key
+        initialSeed + j).  Unpinned pieces: em-core's computeVerticalRate / computeHeadingRate are forward differences here,
+        `isClimb` (track.m:122,134, undefined in the reference) is read as is_climb, local_smooth is not applied; the
+        trajectory-model files must be in parameters_directory (synthetic.write_terminal_directory builds stand-ins)."""
+        if self._traj is None:
+            raise NotImplementedError("the terminal trajectory-model files are not in parameters_directory (they are absent from the "
+                                      "reference mount); synthetic.write_terminal_directory builds stand-ins")
+        import time
+        t0 = time.perf_counter()
+        s, first = _take(initialSeed, nSamples)
+        if first_index is not None:
+            first = int(first_index)
+        d = (self.dynLimits1, self.dynLimits2)
+        bs = None if np.all(np.isinf(self.bounds_sample)) else self.bounds_sample
+        res = native.track_terminal_host(ctx or native.default_context(), self.native, [m.native for m in self._traj], int(nSamples), s,
+                                         self._dyn_rows(), [x["maxCumTurn_deg"] for x in d], [x["pitch_deg"] for x in d], first_index=first,
+                                         min_enc_time_s=minEncTime_s, thres_dist_ft=thresDist_ft, thres_alt_low_ft=thresAltLow_ft,
+                                         thres_vertrate_ft_s=thresVertRate_ft_s, bounds_sample=bs, max_track_attempts=max_track_attempts)
+        names = [lab.replace('"', "") for lab in self.labels_initial]
+        out = []
+        for i in range(int(nSamples)):
+            sample = dict(zip(names, res["sample"][i]))
+            tr = [res["traj"][i, a, : res["len"][i, a]] for a in range(2)]
+            tcpa, hmd, vmd, _ = res["meta"][i]
+            lo, hi = max(tr[0][0, 0], tr[1][0, 0]), min(tr[0][-1, 0], tr[1][-1, 0])      # reformatTrajFiles: intersect(t_s)
+            fm = []
+            for a in range(2):
+                q = tr[a][(tr[a][:, 0] >= lo) & (tr[a][:, 0] <= hi)]
+                fm.append({"t": q[:, 0] - q[0, 0], "y": q[:, 2] * 6076.1154855643, "x": q[:, 1] * 6076.1154855643, "h": q[:, 3], "v": q[:, 5]})
+            tcpa_adj = int(tcpa - lo) or 1                                                 # track.m:160-163
+            sample.update(id=i + int(firstID), tcpa=tcpa_adj, hmd_ft=hmd, vmd_ft=vmd, nmac=bool(abs(hmd) < 500 and abs(vmd) < 100))
+            for a, pre in enumerate(("own", "int")):                                       # :171-180
+                vr = np.abs(np.diff(fm[a]["h"])) * 60
+                if vr.size:
+                    sample[pre + "_vertRate_ftpm"] = vr[min(tcpa_adj, vr.size) - 1]
+                    sample[pre + "_initVertRate_ftpm"] = vr[0]
+                sample[pre + "_initSpeed_ftps"], sample[pre + "_initAlt_ft"] = fm[a]["v"][0], fm[a]["h"][0]
+            out.append({"sample": sample, "traj": fm})
+        gen_time_s = np.full(int(nSamples), (time.perf_counter() - t0) / max(1, int(nSamples)))
+        return (out, gen_time_s, res) if return_info else (out, gen_time_s)

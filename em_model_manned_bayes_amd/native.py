@@ -418,6 +418,40 @@ def uncor_dynamic_limits(model, initial, up_min, up_max, speed_min, speed_max, i
     return out
 
 
+TERMINAL_GEO_FIELDS = ("distance", "bearing", "alt", "speed", "heading", "intent")
+
+
+def track_terminal_host(ctx, geom_model, traj_models, n, seed, dyn_limits, max_cum_turn_deg, pitch_deg, first_index=0, tmax_s=120.0,
+                        min_enc_time_s=30.0, thres_dist_ft=2.5 * 6076, thres_alt_low_ft=750.0, thres_vertrate_ft_s=300.0 / 60.0,
+                        bounds_sample=None, max_track_attempts=500, max_attempts=100000, max_resample=100000, allow_cap=False):
+    """emgpu_track_terminal_host: CorTerminalModel.track (track.m:45-150) on the GPU.  Returns dict: sample [n, n_i], traj [n, 2, cap2, 6]
+    (t_s x_nm y_nm z_ft heading_deg v_ft_s, time-ordered), len [n, 2], meta [n, 4] (tcpa_s hmd_ft vmd_ft enc_time_s), attempts [n]."""
+    labels = [s.strip('"') for s in geom_model.get_labels(L.F_LABELS_INITIAL)]
+    p = L.TTrackParams()
+    p.seed, p.first_index, p.n, p.tmax_s = int(seed) & (2**64 - 1), int(first_index), int(n), float(tmax_s)
+    p.max_resample, p.max_track_attempts, p.max_attempts = int(max_resample), int(max_track_attempts), int(max_attempts)
+    for i, v in enumerate(np.asarray(dyn_limits, dtype=np.float64).reshape(10)):
+        p.dyn_limits[i] = float(v)
+    for a in range(2):
+        p.max_cum_turn_deg[a], p.pitch_deg[a] = float(max_cum_turn_deg[a]), float(pitch_deg[a])
+    p.min_enc_time_s, p.thres_dist_ft, p.thres_alt_low_ft, p.thres_vertrate_ft_s = float(min_enc_time_s), float(thres_dist_ft), float(thres_alt_low_ft), float(thres_vertrate_ft_s)
+    bs = None
+    if bounds_sample is not None:
+        bs = np.ascontiguousarray(np.asarray(bounds_sample, dtype=np.float64).reshape(geom_model.n_initial, 2))
+        p.bounds_sample = _p(bs)
+    for a, pre in enumerate(("own", "int")):
+        for k, f in enumerate(TERMINAL_GEO_FIELDS):
+            p.idx[6 * a + k] = labels.index(pre + "_" + f) + 1
+    ni, cap2 = geom_model.n_initial, 2 * (int(tmax_s) + 3)
+    sample = np.zeros((n, ni)); traj = np.zeros((n, 2, cap2, 6)); ln = np.zeros((n, 2), dtype=np.int32)
+    meta = np.zeros((n, 4)); att = np.zeros(n, dtype=np.int32)
+    handles = (C.c_void_p * len(traj_models))(*[m._h for m in traj_models])
+    rc = L.lib().emgpu_track_terminal_host(ctx._h, geom_model._h, handles, C.byref(p), _p(sample), _p(traj), cap2, _p(ln), _p(meta), _p(att))
+    if not (allow_cap and rc == L.ERR_REJECT_CAP):   # the outputs of the encounters that were accepted are delivered either way (attempts -1 marks the rest)
+        L.check(rc)
+    return {"sample": sample, "traj": traj, "len": ln, "meta": meta, "attempts": att, "kernel": ctx.last_kernel()}
+
+
 def track_params(n, T, ur_speed, ur_vertrate, ur_heading, min_speed, max_speed, nd=0, slot_vertrate=0, slot_acc=0, slot_turnrate=0):
     p = L.TrackParams()
     p.n, p.T, p.nd = int(n), int(T), int(nd)

@@ -24,7 +24,9 @@ _BND = {
 }
 
 
-def terminal_trajectory_model(seed, n_intent=3, reverse=False):
+def terminal_trajectory_model(seed, n_intent=3, reverse=False, alt_drift=0):
+    """alt_drift: -1 / +1 adds mass to the next lower / higher altitude bin per step (a landing descends in forward time and climbs
+    in backward time, a take-off the other way), so that the vertical-intent filters of CorTerminalModel.track see plausible tracks."""
     rs = np.random.RandomState(seed)
     labels_i = ['"intent"', '"distance"', '"bearing"', '"heading"', '"altitude"', '"speed"']
     tag = "(t-1)" if reverse else "(t+1)"
@@ -39,7 +41,7 @@ def terminal_trajectory_model(seed, n_intent=3, reverse=False):
     G_t[[1, 2, 3, 5], 8] = True       # speed(t+1)
     N_i = [np.ones((int(r), 1)) for r in r_i]
 
-    def table(r_own, q_other, wrap):
+    def table(r_own, q_other, wrap, drift=0):
         # columns: own variable is the slowest-varying parent (setTransitionPriors.m:20-27 relies on it)
         q = q_other * r_own
         own = np.repeat(np.arange(r_own), q_other)
@@ -50,12 +52,15 @@ def terminal_trajectory_model(seed, n_intent=3, reverse=False):
             nb = own + d
             nb = np.mod(nb, r_own) if wrap else np.clip(nb, 0, r_own - 1)
             N[nb, cols] += rs.randint(0, 30, q) * (rs.rand(q) < 0.7)
+        if drift:
+            nb = np.clip(own + drift, 0, r_own - 1)
+            N[nb, cols] += rs.randint(40, 160, q)
         far = rs.randint(0, r_own, q)
         N[far, cols] += rs.randint(0, 6, q) * (rs.rand(q) < 0.15)
         empty = rs.rand(q) < 0.02          # unobserved parent configurations: all-zero columns (bin 1 without the prior)
         N[:, empty] = 0
         return N
-    N_t = [np.zeros((0, 0))] * 6 + [table(36, 7 * 36, True), table(7, 7 * 36 * 36, False), table(5, 7 * 36 * 36, False)]
+    N_t = [np.zeros((0, 0))] * 6 + [table(36, 7 * 36, True), table(7, 7 * 36 * 36, False, alt_drift), table(5, 7 * 36 * 36, False)]
     p = Parms(labels_initial=labels_i, n_initial=6, G_initial=G_i, r_initial=r_i, N_initial=N_i,
               labels_transition=labels_t, n_transition=9, G_transition=G_t, r_transition=r_t, N_transition=N_t,
               boundaries=[np.zeros(0), _BND["distance"], _BND["bearing"], _BND["heading"], _BND["altitude"], _BND["speed"]],
@@ -82,7 +87,9 @@ def write_terminal_directory(out_dir, src="terminalradar", seed=0x5EED0005):
         path = os.path.join(out_dir, prefix + stem + ".txt")
         if not os.path.exists(path):
             n_intent = 2 if stem.startswith("ownship") else 3
-            em_io.em_write(terminal_trajectory_model(seed + k, n_intent, stem.endswith("reverse")), path)
+            rev = stem.endswith("reverse")
+            drift = (-1 if "landing" in stem else (1 if "takeoff" in stem else 0)) * (-1 if rev else 1)
+            em_io.em_write(terminal_trajectory_model(seed + k, n_intent, rev, drift), path)
     return out_dir
 
 

@@ -356,6 +356,38 @@ int emgpu_track_uncor_device(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_u
 int emgpu_uncor_dynamic_limits(const emgpu_model *m, const emgpu_utrack_params *vars, const double *initial,
                                double up_min_ft, double up_max_ft, double speed_min_ft_s, double speed_max_ft_s, double out[3]);
 
+/* ------------------------------------------------------------------------------------------------
+ * CorTerminalModel.track (@CorTerminalModel/track.m:45-150): per encounter, loop { geometry sample (sample.m) ->
+ * createEncounter -> the filters of :62-145 (CPA within +-10 s, overlap >= minEncTime_s, runway proximity, vertical intent,
+ * CheckDynamicLimits with CheckCumTurn: CorTerminalModel.m:117-316) } until one passes.  Rounds on the device like
+ * emgpu_track_uncor_*: attempt j of every encounter uses the Philox key seed + j (the reference continues one MT19937 stream,
+ * track.m:36-58) and the encounter's global index; a track that hits the re-draw cap voids its attempt.
+ * em-core's computeVerticalRate / computeHeadingRate (not vendored) are forward differences of the 1 s samples; `isClimb`
+ * (track.m:122,134, undefined in the reference) is read as is_climb; local_smooth (createEncounter.m:88-89) is not applied.
+ *   geom_model   the 15-variable geometry network; traj_models[10] in CorTerminalModel.m:84-100 order with the stay prior set
+ *   sample   [n][n_initial(geom)] f64   the accepted geometry sample (out_results(ii).sample, track.m:158)
+ *   traj     [n][2][cap2][6] f64        ownship / intruder, time-ordered: t_s x_nm y_nm z_ft heading_deg v_ft_s (createEncounter.m:74-84)
+ *   len      [n][2] i32 rows of each;  meta [n][4] f64: tcpa_s hmd_ft vmd_ft enc_time_s (:79, :90);  attempts [n] i32 (-1: cap)
+ * Host pointers; any output may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t seed, first_index;      /* 'initialSeed' (track.m:11)                                         */
+    int64_t n;
+    double tmax_s;                   /* 120 (track.m:33)                                                   */
+    int32_t max_resample;            /* re-draw cap inside PropagateTrajectory                             */
+    int32_t max_track_attempts;      /* cap of the while of track.m:55 (unbounded in the reference)        */
+    int32_t max_attempts;            /* cap of the geometry rejection loop (sample.m:32)                   */
+    int32_t _pad;
+    double dyn_limits[2][5];         /* per aircraft: minVel maxVel maxTurnRate_deg_s maxAltitude maxVertRate (getDynamicLimits.m:15-62) */
+    double max_cum_turn_deg[2], pitch_deg[2];
+    double min_enc_time_s, thres_dist_ft, thres_alt_low_ft, thres_vertrate_ft_s;  /* track.m:14-17 */
+    const double *bounds_sample;     /* n_initial x 2 row-major or NULL (sample.m:45-53)                   */
+    int32_t idx[12];                 /* 1-based geometry variable ids: own {distance bearing alt speed heading intent}, then int */
+} emgpu_ttrack_params;
+int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *geom_model, const emgpu_model *const *traj_models,
+                              const emgpu_ttrack_params *p, double *sample, double *traj, int32_t cap2, int32_t *len,
+                              double *meta, int32_t *attempts);
+
 /* Introspection for benchmarks/tests: name of the kernel variant the last *_device call used and
  * the algorithmic output bytes per trajectory of that call (5*n_i + 5*T*n_d for dense output). */
 const char *emgpu_last_kernel_name(const emgpu_ctx *ctx);

@@ -1219,3 +1219,209 @@ int64_t em_uncor_track_batch(const em_model_t *m, int mode, uint64_t seed, uint6
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------- */
+/* f2  CorTerminalModel.track  (@CorTerminalModel/track.m:45-150) and the static checks it calls                */
+/*     (CorTerminalModel.m:117-333: getGeneratedMissDistance, CheckCumTurn, CheckRunwayProximity,               */
+/*     CheckIntentVertical, CheckDynamicLimits).  em-core's computeVerticalRate / computeHeadingRate are not     */
+/*     vendored ("dynamics unpinned"): taken as forward differences over the 1 s samples, the last value         */
+/*     repeated, the heading difference wrapped to (-pi, pi].  computeAcceleration only feeds a counter (:67-76) */
+/*     and has no effect on acceptance.  Reference defects kept or decided: `isClimb` (:122,134) is undefined in  */
+/*     the reference (take-off intents error out there): read as is_climb; the turn-rate test compares rad/s with  */
+/*     a deg/s limit (CorTerminalModel.m:296) and the runway distance uses 1.68781 as nm->ft (:215): both kept.   */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t idx[12];            /* 1-based variable ids: own {distance bearing alt speed heading intent}, then int */
+    double min_enc_time_s, thres_dist_ft, thres_alt_low_ft, thres_vertrate_ft_s;   /* track.m:14-17 */
+    double max_cum_turn_deg[2], pitch_deg[2];                                       /* getDynamicLimits.m */
+} em_ttrack_opts_t;
+
+typedef struct { int n; double t[260], x[260], y[260], z[260], hdg[260], v[260]; } em_traj_t;
+
+static double em_wrapTo180(double x) { return (x < -180 || 180 < x) ? em_wrapTo360(x + 180) - 180 : x; }
+static double em_wrapToPi(double x) {
+    const double pi = 3.14159265358979323846;
+    if (x < -pi || pi < x) { const int pos = (x + pi) > 0; double y = (x + pi) - floor((x + pi) / (2 * pi)) * (2 * pi); if (y == 0 && pos) y = 2 * pi; return y - pi; }
+    return x;
+}
+static double em_round1(double x) { return round(x * 10.0) / 10.0; }
+
+/* CorTerminalModel.m:135-185.  heading: degrees, n values.  Returns is_reject. */
+int em_check_cum_turn(const double *heading_in, int n, double limit) {
+    if (n < 2) return 0;
+    double hd[260];
+    const int m = n - 1;
+    for (int i = 0; i < m; i++) hd[i] = em_round1(em_wrapTo180(heading_in[i + 1]) - em_wrapTo180(heading_in[i]));
+    int ts[260], te[260], nts = 0, nte = 0;
+    for (int i = 0; i + 1 < m; i++) {
+        if (hd[i] == 0 && hd[i + 1] != 0) ts[nts++] = i + 2;   /* find(...) + 1, 1-based */
+        if (hd[i] != 0 && hd[i + 1] == 0) te[nte++] = i + 1;
+    }
+    if (nts == 0) { ts[0] = 1; nts = 1; }
+    if (nte == 0) { te[0] = m; nte = 1; }
+    if (nts > nte) te[nte++] = m;
+    for (int i = 0; i < nts; i++) {
+        double h[260];
+        int k = 0;
+        for (int q = ts[i]; q <= te[i]; q++) h[k++] = em_wrapTo180(hd[q - 1]);
+        /* segments of constant sign: startIdx = find([0; diff(sign(h))] ~= 0), with 1 and k+1 added when non-empty */
+        int seg0 = 0;
+        double cum = 0;
+        int any_break = 0;
+        for (int q = 1; q < k; q++) if (em_sign(h[q]) != em_sign(h[q - 1])) any_break = 1;
+        for (int q = 0; q < k; q++) {
+            if (any_break && q > seg0 && em_sign(h[q]) != em_sign(h[q - 1])) { seg0 = q; cum = 0; }
+            cum += h[q];
+            if (fabs(cum) > limit) return 1;
+        }
+    }
+    return 0;
+}
+
+/* forward difference per 1 s sample, last repeated (stand-in for em-core's computeVerticalRate) */
+static void em_forward_rate(const double *z, int n, double *out) {
+    if (n == 1) { out[0] = 0; return; }
+    for (int i = 0; i + 1 < n; i++) out[i] = z[i + 1] - z[i];
+    out[n - 1] = out[n - 2];
+}
+
+/* CorTerminalModel.m:268-316 */
+int em_check_dynamic_limits(const em_traj_t *tr, const em_dynlims_t *dl, double max_cum_turn_deg, double pitch_deg) {
+    const int n = tr->n;
+    if (n <= 1) return 0;
+    double dh[260];
+    em_forward_rate(tr->z, n, dh);
+    for (int i = 0; i < n; i++) {
+        const int is_alt = tr->z[i] > 0 && tr->z[i] <= dl->maxAltitude_ft;
+        const int is_spd = tr->v[i] >= dl->minVel_ft_s && tr->v[i] <= dl->maxVel_ft_s;
+        const int is_vr = fabs(dh[i]) <= dl->maxVertRate_ft_s;
+        double rate;
+        {   /* computeHeadingRate(deg2rad(heading), 1:n) */
+            const int k = i + 1 < n ? i : n - 2;
+            rate = em_wrapToPi(tr->hdg[k + 1] * (3.14159265358979323846 / 180.0) - tr->hdg[k] * (3.14159265358979323846 / 180.0));
+        }
+        const int is_turn = fabs(rate) <= dl->maxTurnRate_deg_s;
+        int is_pitch = 1;
+        if (i > 0) {
+            const double ratio = fabs(tr->z[i] - tr->z[i - 1]) / tr->v[i];
+            /* abs(asind(r)): for r > 1 MATLAB returns a complex number whose magnitude exceeds 90 */
+            is_pitch = ratio <= 1 ? fabs(asin(ratio) * (180.0 / 3.14159265358979323846)) <= pitch_deg : (pitch_deg == INFINITY);
+        }
+        if (!(is_alt && is_spd && is_vr && is_turn && is_pitch)) return 0;
+    }
+    return !em_check_cum_turn(tr->hdg, n, max_cum_turn_deg);
+}
+
+/* One encounter through the filters of track.m:62-145.  tr[0] ownship, tr[1] intruder, time-sorted 1 s samples.  */
+/* meta: tcpa_s hmd_ft vmd_ft enc_time_s.  Returns is_good.                                                       */
+int em_terminal_filters(const em_traj_t *tr, int own_intent, int int_intent, const em_dynlims_t *dl, const em_ttrack_opts_t *o, double meta[4]) {
+    /* getGeneratedMissDistance (CorTerminalModel.m:117-133): the times are consecutive integers */
+    const double t0 = fmax(tr[0].t[0], tr[1].t[0]), t1 = fmin(tr[0].t[tr[0].n - 1], tr[1].t[tr[1].n - 1]);
+    const int nc = (int)(t1 - t0) + 1;
+    meta[0] = meta[1] = meta[2] = 0; meta[3] = nc > 0 ? nc : 0;
+    if (nc <= 0) return 0;    /* no common time: min() of an empty set; the reference would error, here: rejected */
+    const int ia = (int)(t0 - tr[0].t[0]), ib = (int)(t0 - tr[1].t[0]);
+    double hmd = INFINITY; int best = 0;
+    for (int k = 0; k < nc; k++) {
+        const double dx = tr[0].x[ia + k] - tr[1].x[ib + k], dy = tr[0].y[ia + k] - tr[1].y[ib + k];
+        const double d = sqrt(dx * dx + dy * dy) * 6076.1154855643;
+        if (d < hmd) { hmd = d; best = k; }
+    }
+    meta[0] = tr[0].t[ia + best]; meta[1] = hmd; meta[2] = tr[1].z[ib + best] - tr[0].z[ia + best];
+    if (!(fabs(meta[0]) <= 10)) return 0;                                                    /* :84-87 */
+    const int is_long = nc >= o->min_enc_time_s;                                             /* :90-91 */
+    int close[2], low[2], climb[2], descend[2];
+    for (int a = 0; a < 2; a++) {                                                            /* CorTerminalModel.m:203-226 */
+        close[a] = low[a] = 0;
+        for (int i = 0; i < tr[a].n; i++) {
+            const double d_ft = hypot(tr[a].x[i], tr[a].y[i]) * 1.68781;
+            if (d_ft <= o->thres_dist_ft) { close[a] = 1; if (tr[a].z[i] <= o->thres_alt_low_ft) low[a] = 1; }
+        }
+        double dh[260], zmax = tr[a].z[0], zmin = tr[a].z[0];                                /* CheckIntentVertical :228-266 */
+        em_forward_rate(tr[a].z, tr[a].n, dh);
+        for (int i = 1; i < tr[a].n; i++) { zmax = fmax(zmax, tr[a].z[i]); zmin = fmin(zmin, tr[a].z[i]); }
+        const double thr_time = (zmax - zmin) / o->thres_vertrate_ft_s, pth = fmin(0.2, thr_time / (double)tr[a].n);
+        int nclimb = 0, ndesc = 0;
+        for (int i = 0; i < tr[a].n; i++) { nclimb += dh[i] >= o->thres_vertrate_ft_s; ndesc += dh[i] <= -o->thres_vertrate_ft_s; }
+        climb[a] = (double)nclimb / tr[a].n >= pth; descend[a] = (double)ndesc / tr[a].n >= pth;
+    }
+    const int prox1 = (close[0] && low[0]) || !close[0];                                     /* :98-112 */
+    const int prox2 = int_intent == 3 ? !(close[1] && low[1]) : ((close[1] && low[1]) || !close[1]);
+    const int int_ok = int_intent == 1 ? descend[1] : (int_intent == 2 ? climb[1] : 1);      /* :119-127 */
+    int own_ok = 0;                                                                          /* :130-137 (other intents: the variable stays unset in the reference) */
+    if (own_intent == 1 || own_intent == 2) {
+        const double c = own_intent == 1 ? 90.0 : 270.0;
+        int ok = 0;
+        for (int i = 0; i < tr[0].n; i++) ok += tr[0].hdg[i] >= c - 30 && tr[0].hdg[i] <= c + 30;
+        own_ok = (own_intent == 1 ? descend[0] : climb[0]) && ((double)ok / tr[0].n >= .95);
+    }
+    const int dyn1 = em_check_dynamic_limits(&tr[0], &dl[0], o->max_cum_turn_deg[0], o->pitch_deg[0]);   /* :140-141 */
+    const int dyn2 = em_check_dynamic_limits(&tr[1], &dl[1], o->max_cum_turn_deg[1], o->pitch_deg[1]);
+    return is_long && prox1 && prox2 && own_ok && int_ok && dyn1 && dyn2;                    /* :144 */
+}
+
+/* forward + backward tracks of one aircraft, as the device stores them (f32), merged and ordered in time (createEncounter.m:74-84) */
+static void em_merge_tracks(const double *fwd, int rf, const double *bck, int rb, int f32, em_traj_t *out) {
+    int n = 0;
+    for (int r = rb - 1; r >= 1; r--, n++) {
+        const double *q = bck + (size_t)r * 6;
+        out->t[n] = q[0]; out->x[n] = q[1]; out->y[n] = q[2]; out->z[n] = q[3]; out->hdg[n] = q[4]; out->v[n] = q[5];
+    }
+    for (int r = 0; r < rf; r++, n++) {
+        const double *q = fwd + (size_t)r * 6;
+        out->t[n] = q[0]; out->x[n] = q[1]; out->y[n] = q[2]; out->z[n] = q[3]; out->hdg[n] = q[4]; out->v[n] = q[5];
+    }
+    out->n = n;
+    if (f32) for (int i = 0; i < n; i++) {
+        out->t[i] = (float)out->t[i]; out->x[i] = (float)out->x[i]; out->y[i] = (float)out->y[i];
+        out->z[i] = (float)out->z[i]; out->hdg[i] = (float)out->hdg[i]; out->v[i] = (float)out->v[i];
+    }
+}
+
+/* CorTerminalModel.track for n encounters (Philox mode): attempt j of encounter i draws the geometry and propagates with */
+/* the key seed + j and the global index first_index + i (the reference continues one MT19937 stream, track.m:36-58).    */
+/* models[0] = geometry model, models[1..10] = the trajectory models in CorTerminalModel.m:84-100 order.                  */
+/* sample [n][n_i], traj [n][2][cap2][6] (cap2 >= 2*(tmax+2)), len [n][2], meta [n][4], attempts [n] (-1: cap).           */
+int64_t em_terminal_track_batch(const em_model_t *const *models, uint64_t seed, uint64_t first_index, int64_t n, const em_geom_opts_t *go,
+                                const em_dynlims_t *dl, const em_ttrack_opts_t *o, double tmax_s, int max_resample, int max_track_attempts,
+                                int f32, double *sample, double *traj, int32_t *len, double *meta, int32_t *attempts, int cap2) {
+    const em_model_t *gm = models[0];
+    const int ni = gm->n_initial, cap = (int)tmax_s + 3;
+    double *out4 = (double *)malloc(sizeof(double) * 4 * (size_t)cap * 6);
+    for (int64_t i = 0; i < n; i++) {
+        attempts[i] = -1;
+        for (int j = 0; j < max_track_attempts; j++) {
+            double v[128]; int32_t S[128], att;
+            if (em_geom_sample_batch(gm, EM_RNG_PHILOX, seed + (uint64_t)j, first_index + (uint64_t)i, 1, go, S, v, &att) != 0) { free(out4); return -3; }
+            if (f32) for (int k = 0; k < ni; k++) v[k] = (float)v[k];
+            double geo[12]; int32_t mo[4]; int32_t rows[4];
+            for (int a = 0; a < 2; a++) {                                                   /* createEncounter.m:21-49 */
+                const int32_t *ix = o->idx + 6 * a;
+                double s, c;
+                em_sincosd(v[ix[1] - 1], &s, &c);
+                geo[6 * a] = v[ix[0] - 1] * c; geo[6 * a + 1] = v[ix[0] - 1] * s; geo[6 * a + 2] = v[ix[2] - 1];
+                geo[6 * a + 3] = v[ix[3] - 1]; geo[6 * a + 4] = v[ix[4] - 1]; geo[6 * a + 5] = v[ix[5] - 1];
+            }
+            const int oi = (int)geo[5], ii_ = (int)geo[11];
+            mo[0] = 2 * (oi - 1); mo[1] = mo[0] + 1; mo[2] = 4 + 2 * (ii_ - 1); mo[3] = mo[2] + 1;
+            if (em_propagate_batch(models + 1, mo, EM_RNG_PHILOX, seed + (uint64_t)j, first_index + (uint64_t)i, 1, geo, dl, tmax_s, max_resample, out4, rows, cap) != 0) continue;
+            em_traj_t tr[2];
+            for (int a = 0; a < 2; a++) em_merge_tracks(out4 + (size_t)(2 * a) * cap * 6, rows[2 * a], out4 + (size_t)(2 * a + 1) * cap * 6, rows[2 * a + 1], f32, &tr[a]);
+            double mt[4];
+            if (!em_terminal_filters(tr, oi, ii_, dl, o, mt)) continue;
+            attempts[i] = j + 1;
+            for (int k = 0; k < ni; k++) sample[i * ni + k] = v[k];
+            for (int a = 0; a < 2; a++) {
+                len[2 * i + a] = tr[a].n;
+                for (int r = 0; r < tr[a].n && r < cap2; r++) {
+                    double *q = traj + (((size_t)i * 2 + a) * cap2 + r) * 6;
+                    q[0] = tr[a].t[r]; q[1] = tr[a].x[r]; q[2] = tr[a].y[r]; q[3] = tr[a].z[r]; q[4] = tr[a].hdg[r]; q[5] = tr[a].v[r];
+                }
+            }
+            for (int k = 0; k < 4; k++) meta[4 * i + k] = mt[k];
+            break;
+        }
+    }
+    free(out4);
+    return 0;
+}

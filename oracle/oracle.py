@@ -590,3 +590,53 @@ def uncor_track(om, n, T, seed, mode=RNG_PHILOX, first_index=0, is_quantize500=F
     if rc != 0:
         raise RuntimeError("em_uncor_track_batch failed rc=%d" % rc)
     return {"tracks": tracks, "limits": limits, "attempts": attempts}
+
+
+class _TTrackOpts(C.Structure):
+    _fields_ = [("idx", C.c_int32 * 12), ("min_enc_time_s", C.c_double), ("thres_dist_ft", C.c_double), ("thres_alt_low_ft", C.c_double),
+                ("thres_vertrate_ft_s", C.c_double), ("max_cum_turn_deg", C.c_double * 2), ("pitch_deg", C.c_double * 2)]
+
+
+def check_cum_turn(heading_deg, limit):
+    """CorTerminalModel.CheckCumTurn restated (CorTerminalModel.m:135-185): True = reject."""
+    h = np.ascontiguousarray(heading_deg, dtype=np.float64)
+    return bool(lib().em_check_cum_turn(_ptr(h), C.c_int(h.size), C.c_double(limit)))
+
+
+def terminal_track(gom, oms, n, seed, dyn_limits, max_cum_turn_deg, pitch_deg, first_index=0, tmax_s=120.0, min_enc_time_s=30.0,
+                   thres_dist_ft=2.5 * 6076, thres_alt_low_ft=750.0, thres_vertrate_ft_s=5.0, bounds_sample=None, max_track_attempts=500,
+                   max_attempts=100000, max_resample=100000, f32=True):
+    """CorTerminalModel.track restated (track.m:45-150), Philox mode.  gom: geometry OracleModel; oms: the 10 trajectory OracleModels with the
+    stay prior.  Returns dict like native.track_terminal_host."""
+    L = lib()
+    L.em_terminal_track_batch.restype = C.c_int64
+    labels = [s.strip('"') for s in gom.parms["labels_initial"]]
+    o = _TTrackOpts()
+    for a, pre in enumerate(("own", "int")):
+        for k, f in enumerate(("distance", "bearing", "alt", "speed", "heading", "intent")):
+            o.idx[6 * a + k] = labels.index(pre + "_" + f) + 1
+    o.min_enc_time_s, o.thres_dist_ft, o.thres_alt_low_ft, o.thres_vertrate_ft_s = min_enc_time_s, thres_dist_ft, thres_alt_low_ft, thres_vertrate_ft_s
+    for a in range(2):
+        o.max_cum_turn_deg[a], o.pitch_deg[a] = float(max_cum_turn_deg[a]), float(pitch_deg[a])
+    go = _GeomOpts()
+    bs = None
+    if bounds_sample is not None:
+        bs = np.ascontiguousarray(np.asarray(bounds_sample, dtype=np.float64).reshape(gom.n_initial, 2))
+        go.bounds_sample = _ptr(bs)
+    d = np.asarray(dyn_limits, dtype=np.float64).reshape(2, 5)
+    go.idx_own_speed, go.idx_int_speed = o.idx[3], o.idx[9]
+    go.min1, go.max1, go.min2, go.max2 = d[0, 0], d[0, 1], d[1, 0], d[1, 1]
+    go.max_attempts = int(max_attempts)
+    dl = (_DynLims * 2)()
+    for a in range(2):
+        dl[a].minVel_ft_s, dl[a].maxVel_ft_s, dl[a].maxTurnRate_deg_s, dl[a].maxAltitude_ft, dl[a].maxVertRate_ft_s = [float(x) for x in d[a]]
+    ptrs = (C.c_void_p * 11)(C.addressof(gom.c), *[C.addressof(om.c) for om in oms])
+    ni, cap2 = gom.n_initial, 2 * (int(tmax_s) + 3)
+    sample = np.zeros((n, ni)); traj = np.zeros((n, 2, cap2, 6)); ln = np.zeros((n, 2), dtype=np.int32)
+    meta = np.zeros((n, 4)); att = np.zeros(n, dtype=np.int32)
+    rc = L.em_terminal_track_batch(ptrs, C.c_uint64(seed), C.c_uint64(first_index), C.c_int64(n), C.byref(go), dl, C.byref(o), C.c_double(tmax_s),
+                                   C.c_int(max_resample), C.c_int(max_track_attempts), C.c_int(int(f32)), _ptr(sample), _ptr(traj), _ptr(ln), _ptr(meta),
+                                   _ptr(att), C.c_int(cap2))
+    if rc != 0:
+        raise RuntimeError("em_terminal_track_batch failed rc=%d" % rc)
+    return {"sample": sample, "traj": traj, "len": ln, "meta": meta, "attempts": att}

@@ -613,6 +613,62 @@ def test_terminal_ten_million_encounters_properties(terminal_dir):
     assert 300 < total_seconds / (5 * n) < 488        # mean track-seconds per encounter (4 tracks x <= 122)
 
 
+@pytest.mark.parametrize("actypes", [("GENERIC", "GENERIC"), ("GENERIC", "RTCA228_A1"), ("RTCA228_A3", "RTCA228_A2")])
+def test_terminal_track_matches_oracle(actypes, terminal_dir, gpu_ctx):
+    """CorTerminalModel.track (track.m:45-150) on the GPU -- rounds of geometry draw -> createEncounter inputs -> propagation ->
+    the filters of CorTerminalModel.m:117-316 -- against the oracle's per-encounter loop on the same Philox keys (attempt j:
+    seed + j).  The accepted attempt, the geometry sample and the CPA metadata must be identical; the tracks are the f32 values
+    the propagation kernel stores (1e-6: device and host libm differ in the last bits before that rounding)."""
+    t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=terminal_dir)
+    t.acType1, t.acType2 = actypes
+    gom = O.OracleModel(O.parse_model_txt(t.parameters_filename))
+    oms = []
+    for m in t._traj:
+        pp = O.parse_model_txt(m.parameters_filename)
+        oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
+    d = (t.dynLimits1, t.dynLimits2)
+    cum, pitch = [x["maxCumTurn_deg"] for x in d], [x["pitch_deg"] for x in d]
+    n, seed, cap = 120, 0xF2, 600
+    ref = O.terminal_track(gom, oms, n, seed, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap)
+    got = native.track_terminal_host(gpu_ctx, t.native, [m.native for m in t._traj], n, seed, t._dyn_rows(), cum, pitch, first_index=5,
+                                     max_track_attempts=cap, allow_cap=True)   # encounters still rejected after `cap` attempts: -1 on both sides
+    if (ref["attempts"] < 0).any():
+        with pytest.raises(L.EmgpuError) as ei:
+            native.track_terminal_host(gpu_ctx, t.native, [m.native for m in t._traj], n, seed, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap)
+        assert ei.value.code == L.ERR_REJECT_CAP
+    assert "k_terminal_filter" in got["kernel"] and "k_terminal_propagate" in got["kernel"]
+    same = got["attempts"] == ref["attempts"]
+    assert same.mean() >= 0.98, (got["attempts"], ref["attempts"])
+    ok = same & (ref["attempts"] > 0)
+    if actypes == ("GENERIC", "GENERIC"):   # (the RTCA limits -- pitch 15 deg, cumulative turn 180 deg, narrow speed bands -- reject most synthetic tracks:
+        assert ok.sum() >= n // 4 and (ref["attempts"][ok] > 1).any()   #  there the test is that both sides reject the same attempts)
+    assert np.array_equal(got["sample"][ok], ref["sample"][ok]) and np.array_equal(got["len"][ok], ref["len"][ok])
+    np.testing.assert_allclose(got["meta"][ok], ref["meta"][ok], rtol=1e-5, atol=1e-3)
+    for i in np.flatnonzero(ok):
+        for a in range(2):
+            k = ref["len"][i, a]
+            np.testing.assert_allclose(got["traj"][i, a, :k], ref["traj"][i, a, :k], rtol=1e-6, atol=1e-5)
+            assert np.all(np.diff(got["traj"][i, a, :k, 0]) == 1)           # time-ordered 1 s samples through t = 0
+    assert np.all(np.abs(got["meta"][ok, 0]) <= 10) and np.all(got["meta"][ok, 3] >= 30)     # track.m:86, :91
+
+
+def test_terminal_class_track_and_cum_turn(terminal_dir, gpu_ctx):
+    """The class method (out_results(ii).sample / .traj, reformatTrajFiles) and CheckCumTurn known answers."""
+    t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=terminal_dir)
+    out, gen_time, info = t.track(12, initialSeed=3, max_track_attempts=3000, ctx=gpu_ctx, return_info=True)
+    assert len(out) == 12 and gen_time.shape == (12,) and np.all(info["attempts"] >= 1)
+    for r in out:
+        s, tr = r["sample"], r["traj"]
+        assert {"own_intent", "int_intent", "id", "tcpa", "hmd_ft", "vmd_ft", "nmac", "own_initSpeed_ftps"} <= set(s)
+        assert len(tr) == 2 and tr[0]["t"][0] == 0 and np.array_equal(tr[0]["t"], tr[1]["t"]) and len(tr[0]["t"]) >= 30
+        assert s["own_intent"] in (1, 2) and s["nmac"] == (abs(s["hmd_ft"]) < 500 and abs(s["vmd_ft"]) < 100)
+    # CheckCumTurn (CorTerminalModel.m:135-185) on hand-made headings: a steady 3 deg/s turn through 210 deg is rejected at 180,
+    # the same amount split into a left and a right turn is not
+    steady = np.concatenate([np.zeros(5), np.arange(0, 211, 3.0), np.full(5, 210.0)])
+    zigzag = np.concatenate([np.zeros(5), np.arange(0, 106, 3.0), np.arange(105, -1, -3.0), np.zeros(5)])
+    assert O.check_cum_turn(steady, 180.0) and not O.check_cum_turn(zigzag, 180.0) and not O.check_cum_turn(steady, np.inf)
+
+
 def test_edge_cases_and_error_paths(gpu_ctx, model_dir):
     nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
     idx = uncor_indices(pp)

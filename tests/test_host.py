@@ -288,7 +288,7 @@ def test_class_surface(model_dir):
     with pytest.raises(NotImplementedError):
         mdl.track(1, 10, coordSys="geodetic")      # DEM / obstacle file / placeTrack: out of scope
     with pytest.raises(NotImplementedError):
-        t.track(1)
+        t.track(1)                                 # the trajectory-model files are not in this (default) directory
 
 
 def test_init_start_terminal_grid():
