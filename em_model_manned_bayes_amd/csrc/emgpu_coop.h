@@ -12,7 +12,7 @@
 
 namespace emgpu {
 
-constexpr int kQueueCap = 128; // request descriptors per wave and compaction round
+constexpr int kQueueCap = 128; // request descriptors per wave and compaction round (default; CoopLds<.., QCAP> may hold more)
 
 // -DEMGPU_DEBUG_COUNTERS: wave-level event counts of the data-dependent paths (diagnostic builds only, read
 // through emgpu_debug_counters): 0 exact redos, 1 compaction rounds, 2 compaction steps, 3 worker passes, 4 requests, 5 blocks
@@ -25,13 +25,15 @@ __device__ unsigned long long g_dbg[8];
 
 // LB: the lanes also publish the packed bins of the block (2 words per variable, after the 8*ND result
 // slots) so that a worker looks the bin of a request up itself instead of the owner encoding it.
-template <int ND, bool LB = false>
+// QCAP: request descriptors per wave and compaction round (a round is one worker pass: at most 64 are used).
+template <int ND, bool LB = false, int QCAP = kQueueCap>
 struct CoopLds {
     static constexpr int kBins = 8 * ND;                          // word offset of the published bins
     static constexpr int kSpare = 8 * ND + (LB ? 2 * ND : 0);     // word offset of the lane's spare words (>= 3 of them)
     static constexpr int kStride = ((kSpare + 3 + 3) / 8) * 8 + 4; // words per lane; = 4 (mod 8) keeps the b128 reads conflict-free
     static_assert(kStride % 8 == 4, "lane stride");
-    uint32_t queue[kQueueCap];
+    static constexpr int kCap = QCAP;
+    uint32_t queue[QCAP];
     float res[64 * kStride];
     uint32_t attempt[64];
 };
@@ -52,8 +54,8 @@ __device__ __forceinline__ uint32_t pick_word(const uint32_t (&a)[ND], uint32_t 
 // needmask / kindmask: bit (8k + j) for dynamic variable k, second j of the block; with MSBFIRST
 // the byte of a variable is an MSB-first stream instead: bit (8k + 7 - j).
 // pbA / pbB: packed 1-based bins of seconds 0-3 / 4-7.  s_bnd[k][]: boundaries of variable k.
-template <int ND, bool MSBFIRST = false, bool LB = false>
-__device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64_t gidx, const Rng &rng, int g8,
+template <int ND, bool MSBFIRST = false, bool LB = false, int QCAP = kQueueCap>
+__device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB, QCAP> &W, int lane, uint64_t gidx, const Rng &rng, int g8,
                                             uint32_t needmask, uint32_t kindmask, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND],
                                             const uint32_t (&ivar)[ND], const double (*s_bnd)[16]) {
     uint32_t ivpack = 0u; // wave-uniform byte table of the variables' RNG ids
@@ -64,7 +66,9 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64
     while (bal != 0ull) {
         uint32_t base = 0u; // wave-uniform number of queued requests in this round
         EMGPU_COUNT(1, lane, 1);
-        while (bal != 0ull && base + 64u <= (uint32_t)kQueueCap) {
+        // a compaction step joins the round only while the round still fits ONE worker pass of 64 requests (the first step
+        // always does): rounds of 70 requests cost two passes, the second nearly empty -- 2.9 passes per block on cor_v1 where 2 do
+        while (bal != 0ull && base + (uint32_t)__popcll(bal) <= 64u) {
             EMGPU_COUNT(2, lane, 1);
             if (m != 0u) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
@@ -90,7 +94,7 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64
             if (q < base) {
                 const uint32_t d = W.queue[q];
                 const uint32_t owner = d & 63u, s = (d >> 6) & 31u, kind = (d >> 11) & 1u;
-                const uint32_t b1 = LB ? reinterpret_cast<const uint8_t *>(&W.res[owner * CoopLds<ND, LB>::kStride + CoopLds<ND, LB>::kBins])[s]
+                const uint32_t b1 = LB ? reinterpret_cast<const uint8_t *>(&W.res[owner * CoopLds<ND, LB, QCAP>::kStride + CoopLds<ND, LB, QCAP>::kBins])[s]
                                        : ((d >> 12) & 63u);
                 const uint32_t k = s >> 3, j = s & 7u;
                 const uint64_t go = gidx - (uint64_t)lane + (uint64_t)owner;
@@ -108,7 +112,7 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64
                     const double mm = dd * uniform32(x);
                     v = a + mm;
                 }
-                W.res[owner * CoopLds<ND, LB>::kStride + s] = (float)v;
+                W.res[owner * CoopLds<ND, LB, QCAP>::kStride + s] = (float)v;
             }
         }
         wave_sync();
@@ -150,27 +154,27 @@ __device__ __forceinline__ void coop_fill_store(const CoopLds<ND> &W, int lane, 
 // change into the zero bin (coop_zero_results cleared the slots before the workers wrote).
 // One v_add_co (shift the stream, carry = the flag) + one v_cndmask per second; two wait states
 // between the VCC write and its read (see emgpu_kernels_fast.hip).
-template <int ND, bool LB>
-__device__ __forceinline__ void coop_zero_results(CoopLds<ND, LB> &W, int lane) {
-    float4 *rp = reinterpret_cast<float4 *>(&W.res[lane * CoopLds<ND, LB>::kStride]);
+template <int ND, bool LB, int QCAP = kQueueCap>
+__device__ __forceinline__ void coop_zero_results(CoopLds<ND, LB, QCAP> &W, int lane) {
+    float4 *rp = reinterpret_cast<float4 *>(&W.res[lane * CoopLds<ND, LB, QCAP>::kStride]);
 #pragma unroll
     for (int q = 0; q < 2 * ND; q++) rp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // publish the packed bins of this lane's block for the workers (CoopLds<ND, true>)
-template <int ND>
-__device__ __forceinline__ void coop_publish_bins(CoopLds<ND, true> &W, int lane, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND]) {
-    uint2 *bp = reinterpret_cast<uint2 *>(&W.res[lane * CoopLds<ND, true>::kStride + CoopLds<ND, true>::kBins]);
+template <int ND, int QCAP = kQueueCap>
+__device__ __forceinline__ void coop_publish_bins(CoopLds<ND, true, QCAP> &W, int lane, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND]) {
+    uint2 *bp = reinterpret_cast<uint2 *>(&W.res[lane * CoopLds<ND, true, QCAP>::kStride + CoopLds<ND, true, QCAP>::kBins]);
 #pragma unroll
     for (int k = 0; k < ND; k++) bp[k] = make_uint2(pbA[k], pbB[k]);
 }
 
-template <int ND, bool LB>
-__device__ __forceinline__ void coop_fill_store_msb(const CoopLds<ND, LB> &W, int lane, int k, int g8, int T, int G4, bool valid,
+template <int ND, bool LB, int QCAP = kQueueCap>
+__device__ __forceinline__ void coop_fill_store_msb(const CoopLds<ND, LB, QCAP> &W, int lane, int k, int g8, int T, int G4, bool valid,
                                                     uint32_t fill8, float &cval, uint32_t pbA, uint32_t pbB,
                                                     uint32_t nd, uint32_t slot, int64_t i_wg, uint32_t tid, int64_t n,
                                                     uint32_t *dyn_bin, float *dyn_val) {
-    const float4 *rp = reinterpret_cast<const float4 *>(&W.res[lane * CoopLds<ND, LB>::kStride]);
+    const float4 *rp = reinterpret_cast<const float4 *>(&W.res[lane * CoopLds<ND, LB, QCAP>::kStride]);
     const float4 ra = rp[2 * k], rb = rp[2 * k + 1];
     const float r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
     float pv[8];

@@ -20,6 +20,10 @@
 
 namespace emgpu {
 
+#ifndef EMGPU_STEP2_QCAP
+#define EMGPU_STEP2_QCAP kQueueCap
+#endif
+
 struct Step2Args {
     uint32_t Rk[EMGPU_MAX_ND];   // resample hit threshold of dynamic variable k (0 = rate 0)
     uint32_t slot[EMGPU_MAX_ND]; // output row of dynamic variable k
@@ -107,10 +111,10 @@ __device__ __attribute__((noinline)) uint32_t exact_hit(uint32_t c0, uint32_t c1
 // instances drop the wave-uniform tests and the code behind them (cor_v1: 25.2 -> 20.8 ms).
 template <int NI, int ND, int WMODE, bool REG>
 __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
-    __shared__ CoopLds<ND, true> s_wave[4];
+    __shared__ CoopLds<ND, true, EMGPU_STEP2_QCAP> s_wave[4];
     __shared__ double s_bnd[ND][16];
     const int tid = threadIdx.x, lane = tid & 63;
-    CoopLds<ND, true> &W = s_wave[tid >> 6];
+    CoopLds<ND, true, EMGPU_STEP2_QCAP> &W = s_wave[tid >> 6];
     const int64_t i = (int64_t)blockIdx.x * 256 + tid;
     const bool valid = i < A.n; // lanes past the end stay alive: they serve as workers for their wave
     const uint64_t gidx = A.first_index + (uint64_t)i;
@@ -257,6 +261,7 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const E
             kind |= (chg8[k] & 0xFFu) << (8 * k);
         }
         if (!valid) need = 0u;
+        EMGPU_COUNT(5, lane, 1);
         coop_zero_results<ND, true>(W, lane);
         coop_publish_bins<ND>(W, lane, pbA, pbB);
         coop_dedisc<ND, true, true>(W, lane, gidx, rng, g8, need, kind, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
@@ -326,5 +331,13 @@ hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s
     if (shape == 1) return launch_t<9, 3>(P, A, F, s, wmode, reg);
     return launch_t<16, 4>(P, A, F, s, wmode, reg);
 }
+
+#ifdef EMGPU_DEBUG_COUNTERS
+extern "C" int emgpu_debug_counters_step2(unsigned long long *out, int reset) {   // this translation unit's copy of g_dbg
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof z); }
+    return 0;
+}
+#endif
 
 } // namespace emgpu

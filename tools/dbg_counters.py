@@ -14,13 +14,14 @@ for name in sys.argv[1:] or ["uncor_1200code_v2p1", "uncor_1200only_fwse_v1p2"]:
     m = native.NativeModel.load_txt(em_io.materialize_model(name, tmp))
     labs = m.get_labels(L.F_LABELS_INITIAL)
     idx = {k: (labs.index('"%s"' % v) + 1 if '"%s"' % v in labs else 0) for k, v in (("idx_L", "L"), ("idx_v", "v"), ("idx_dh", "\\dot h"))}
-    db = torch.empty((T // 4, 3, n), dtype=torch.int32, device=dev); dv = torch.empty((T // 4, 3, n, 4), dtype=torch.float32, device=dev)
+    nd = m.n_dyn
+    db = torch.empty((T // 4, nd, n), dtype=torch.int32, device=dev); dv = torch.empty((T // 4, nd, n, 4), dtype=torch.float32, device=dev)
     p, _ = native.make_params(n, T, 5, **idx)
     out = (C.c_ulonglong * 8)()
-    lib.emgpu_debug_counters(out, 1)
+    lib.emgpu_debug_counters(out, 1); lib.emgpu_debug_counters_step2(out, 1)
     native.sample_dbn_device(ctx, m, p, dyn_bin=db.data_ptr(), dyn_val=dv.data_ptr())
     ctx.sync()
-    lib.emgpu_debug_counters(out, 1)
+    (lib.emgpu_debug_counters_step2 if "step2" in ctx.last_kernel() else lib.emgpu_debug_counters)(out, 1)
     blocks = out[5] or 1
     print("%s %s: per wave-block: exact redos %.3f, compaction rounds %.3f, compaction steps %.2f, worker passes %.3f, requests %.1f"
           % (name, ctx.last_kernel(), out[0] / blocks, out[1] / blocks, out[2] / blocks, out[3] / blocks, out[4] / blocks))
