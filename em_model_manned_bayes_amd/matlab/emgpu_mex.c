@@ -30,6 +30,10 @@
  *         out 4n x cap x 6 double (lane, second, [t_s x_nm y_nm z_ft heading_deg v_ft_s]); rows 4n x 1     createEncounter.m:93-265
  *     [tracks, limits, attempts] = emgpu_mex('track_uncor', h, n, T, seed, first_index, isQuantize500, isRotorcraft, idx7, stride, max_track_attempts)
  *         tracks 8 x S x n [time north east up speed phi theta psi]                                UncorEncounterModel.m:318-471
+ *     [sample, traj, len, meta, attempts] = emgpu_mex('track_terminal', hGeom, handles, n, seed, first_index, dyn_limits, cumturn_pitch, thresholds, idx12, bounds_sample, max_track_attempts)
+ *         CorTerminalModel.track (track.m:45-150) in device rounds: dyn_limits 5 x 2, cumturn_pitch = [maxCumTurn1 maxCumTurn2 pitch1 pitch2],
+ *         thresholds = [minEncTime_s thresDist_ft thresAltLow_ft thresVertRate_ft_s], idx12 = variable ids of own / int {distance bearing alt
+ *         speed heading intent}; sample n_i x n, traj 6 x cap2 x 2 x n, len 2 x n, meta 4 x n [tcpa_s hmd_ft vmd_ft enc_time_s]
  *     [xyz, flags, vminmax] = emgpu_mex('sample2track', alt0, speed0, updates, ur, min_speed, max_speed)   sample2track.m:182-243
  *
  * Errors keep the reference's identifiers where it has them: prior:notdbe / prior:unknown (bn_dirichlet_prior.m:28,37);
@@ -488,6 +492,45 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         if (nlhs > 1) plhs[1] = lim;
         if (nlhs > 2) { plhs[2] = mxCreateDoubleMatrix((mwSize)n, 1, mxREAL); for (size_t i = 0; i < n; i++) mxGetPr(plhs[2])[i] = att[i]; }
         mxFree(att);
+    } else if (!strcmp(cmd, "track_terminal")) {
+        need(nrhs, 10, "[sample, traj, len, meta, attempts] = emgpu_mex('track_terminal', hGeom, handles, n, seed, first_index, dyn_limits, cumturn_pitch, thresholds, idx12, bounds_sample, max_track_attempts)");
+        emgpu_model *gm = handle_of(prhs[1]);
+        if (mxGetNumberOfElements(prhs[2]) != 10) mexErrMsgIdAndTxt("emgpu:usage", "handles: the 10 trajectory models in CorTerminalModel.m:84-100 order");
+        const emgpu_model *models[10];
+        for (int i = 0; i < 10; i++) models[i] = (const emgpu_model *)(uintptr_t)((uint64_t *)mxGetData(prhs[2]))[i];
+        emgpu_ttrack_params p;
+        memset(&p, 0, sizeof p);
+        p.n = (int64_t)mxGetScalar(prhs[3]); p.seed = (uint64_t)mxGetScalar(prhs[4]); p.first_index = (uint64_t)mxGetScalar(prhs[5]);
+        p.tmax_s = 120.0; p.max_resample = 100000; p.max_attempts = 100000;                       /* track.m:33 */
+        p.max_track_attempts = nrhs > 11 ? (int32_t)mxGetScalar(prhs[11]) : 2000;
+        if (mxGetNumberOfElements(prhs[6]) != 10 || mxGetNumberOfElements(prhs[7]) != 4 || mxGetNumberOfElements(prhs[8]) != 4 || mxGetNumberOfElements(prhs[9]) != 12)
+            mexErrMsgIdAndTxt("emgpu:usage", "dyn_limits 5 x 2, cumturn_pitch 1 x 4, thresholds 1 x 4, idx12 1 x 12");
+        for (int a = 0; a < 2; a++) for (int k = 0; k < 5; k++) p.dyn_limits[a][k] = mxGetPr(prhs[6])[5 * a + k];
+        p.max_cum_turn_deg[0] = mxGetPr(prhs[7])[0]; p.max_cum_turn_deg[1] = mxGetPr(prhs[7])[1]; p.pitch_deg[0] = mxGetPr(prhs[7])[2]; p.pitch_deg[1] = mxGetPr(prhs[7])[3];
+        p.min_enc_time_s = mxGetPr(prhs[8])[0]; p.thres_dist_ft = mxGetPr(prhs[8])[1]; p.thres_alt_low_ft = mxGetPr(prhs[8])[2]; p.thres_vertrate_ft_s = mxGetPr(prhs[8])[3];
+        for (int k = 0; k < 12; k++) p.idx[k] = (int32_t)mxGetPr(prhs[9])[k];
+        const size_t ni = (size_t)n_initial_of(gm), n = (size_t)(p.n > 0 ? p.n : 0);
+        double *bs = NULL;
+        if (nrhs > 10 && !mxIsEmpty(prhs[10])) {
+            if (mxGetM(prhs[10]) != ni || mxGetN(prhs[10]) != 2) mexErrMsgIdAndTxt("emgpu:usage", "bounds_sample must be n_initial x 2");
+            bs = (double *)mxMalloc(sizeof(double) * 2 * ni);
+            for (size_t v = 0; v < ni; v++) { bs[2 * v] = mxGetPr(prhs[10])[v]; bs[2 * v + 1] = mxGetPr(prhs[10])[ni + v]; }
+            p.bounds_sample = bs;
+        }
+        const int32_t cap2 = 2 * ((int32_t)p.tmax_s + 3);
+        mwSize d4[4];
+        d4[0] = 6; d4[1] = (mwSize)cap2; d4[2] = 2; d4[3] = (mwSize)n;                           /* 6 x cap2 x 2 x n == [n][2][cap2][6] */
+        plhs[0] = mxCreateDoubleMatrix((mwSize)ni, (mwSize)n, mxREAL);
+        mxArray *tr = mxCreateNumericArray(4, d4, mxDOUBLE_CLASS, mxREAL), *mt = mxCreateDoubleMatrix(4, (mwSize)n, mxREAL);
+        int32_t *ln = (int32_t *)mxMalloc(sizeof(int32_t) * (2 * n + 1)), *att = (int32_t *)mxMalloc(sizeof(int32_t) * (n + 1));
+        const int rc = emgpu_track_terminal_host(ctx0(), gm, models, &p, mxGetPr(plhs[0]), mxGetPr(tr), cap2, ln, mxGetPr(mt), att);
+        if (bs) mxFree(bs);
+        if (rc != EMGPU_ERR_REJECT_CAP) check(rc);           /* at the cap the accepted encounters are still returned: attempts = -1 marks the rest */
+        if (nlhs > 1) plhs[1] = tr;
+        if (nlhs > 2) { plhs[2] = mxCreateDoubleMatrix(2, (mwSize)n, mxREAL); for (size_t i = 0; i < 2 * n; i++) mxGetPr(plhs[2])[i] = ln[i]; }
+        if (nlhs > 3) plhs[3] = mt;
+        if (nlhs > 4) { plhs[4] = mxCreateDoubleMatrix((mwSize)n, 1, mxREAL); for (size_t i = 0; i < n; i++) mxGetPr(plhs[4])[i] = att[i]; }
+        mxFree(ln); mxFree(att);
     } else if (!strcmp(cmd, "sample2track")) {
         need(nrhs, 7, "sample2track needs alt0, speed0, updates, ur, min_speed, max_speed");
         emgpu_track_params tp;
