@@ -78,7 +78,17 @@ classdef CorTerminalModelGPU < CorTerminalModel
         function [hGeom, handles] = nativeModels(self)
             s = self.struct;
             hGeom = emgpu_mex('from_struct', s); emgpu_mex('set_alpha', hGeom, s.dirichlet_initial, {});
-            [hGeom, handles] = self.nativeModels(); emgpu_mex('free', hGeom);
+            mdls = {self.mdlFwd1_1, self.mdlBck1_1, self.mdlFwd1_2, self.mdlBck1_2, self.mdlFwd2_1, self.mdlBck2_1, ...
+                    self.mdlFwd2_2, self.mdlBck2_2, self.mdlFwd2_3, self.mdlBck2_3};       % CorTerminalModel.m:84-100
+            handles = zeros(1, 10, 'uint64');
+            for k = 1:10
+                s = mdls{k}.struct;
+                s.r_transition = cellfun(@(N) size(N, 1), s.N_transition);                  % from the tables, not EncounterModel.m:313-323
+                s.r_transition(1:s.n_initial) = s.r_initial;
+                handles(k) = emgpu_mex('from_struct', s);
+                a = setTransitionPriors(s.G_transition, s.r_transition, s.temporal_map, 1);  % createEncounter.m:128-129
+                emgpu_mex('set_alpha', handles(k), s.dirichlet_initial, a);
+            end
         end
 
         function traj = createEncounterGPU(self, sample_geo, tmax_s, varargin)
