@@ -821,6 +821,15 @@ int emgpu_debug_dynamic_column(const emgpu_model *m, int32_t k, int64_t col, int
     EMGPU_CATCH
 }
 
+int emgpu_debug_parent_masks(const emgpu_model *m, uint32_t *cur_mask, uint32_t *new_mask) {
+    EMGPU_TRY
+    if (!m || !cur_mask || !new_mask) return fail(EMGPU_ERR_ARG, "null argument");
+    const emgpu::CompiledPlan cp = emgpu::compile_plan(m->m);
+    emgpu::step_parent_masks(cp.plan, cur_mask, new_mask);
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
 int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int32_t *width, uint32_t *words) {
     EMGPU_TRY
     if (!m || !width || !words) return fail(EMGPU_ERR_ARG, "null argument");

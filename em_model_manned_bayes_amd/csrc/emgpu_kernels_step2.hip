@@ -12,6 +12,7 @@
 // Bound: VALU issue (Philox + ~25 instructions per draw) and the dependent LDS round trips.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "emgpu_coop.h"
@@ -25,9 +26,21 @@ namespace emgpu {
 #endif
 
 struct Step2Args {
-    uint32_t Rk[EMGPU_MAX_ND];   // resample hit threshold of dynamic variable k (0 = rate 0)
+    uint32_t Rk[EMGPU_MAX_ND];   // resample hit threshold of dynamic variable k (0 = rate 0), < 0xFFFF0000
     uint32_t slot[EMGPU_MAX_ND]; // output row of dynamic variable k
+    uint32_t RR1[EMGPU_MAX_ND];  // (Rk >> 16) + 1 in both halfwords: the packed resample compare of a whole block
 };
+
+// Dependency level of (t+1) node k among the dynamic variables: 0 when none of its parents is another (t+1) node, else one more than
+// the deepest such parent (NEW: bit 4k+q <=> the (t+1) node of q is a parent of k, q < k).  The columns of one level are fetched
+// together: their round trips through L1/L2 overlap instead of following each other.
+template <uint32_t NEW>
+constexpr int s2_level(int k) {
+    int l = 0;
+    for (int q = 0; q < k; q++)
+        if ((NEW >> (4 * k + q)) & 1u) { const int lq = s2_level<NEW>(q) + 1; l = lq > l ? lq : l; }
+    return l;
+}
 
 constexpr uint32_t kSelBase2 = 0x0c0c0c00u; // v_perm_b32 selector: bytes 1-3 zero, byte 0 <- table[borrows]
 
@@ -109,8 +122,10 @@ __device__ __attribute__((noinline)) uint32_t exact_hit(uint32_t c0, uint32_t c1
 // WMODE: 4 / 8 = every variable's columns are 4 / 8 words wide, 0 = decided per variable at run time.
 // REG ("regular"): exactly ND dynamic variables, all with a resample rate > 0.  The specialised
 // instances drop the wave-uniform tests and the code behind them (cor_v1: 25.2 -> 20.8 ms).
-template <int NI, int ND, int WMODE, bool REG>
-__global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
+// CUR / NEW: which dynamic variables are parents of which (t+1) node (bit 4k+q; step_parent_masks): an instance built for a
+// model's masks multiplies only the strides that exist (cor_v1: 6 of 22) and fetches the columns of a dependency level together.
+template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW>
+__global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
     __shared__ CoopLds<ND, true, EMGPU_STEP2_QCAP> s_wave[4];
     __shared__ double s_bnd[ND][16];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -173,66 +188,102 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const E
     uint32_t selbase; // kSelBase2 held in a VGPR (the first v_addc of every compare chain reads it)
     asm volatile("v_mov_b32 %0, %1" : "=v"(selbase) : "s"(kSelBase2));
 
+    // dependency levels as compile-time constants (a constexpr call with the loop variable is only folded after unrolling, too late
+    // for the register allocator: the level loop would index its arrays dynamically)
+    constexpr int kLev[4] = {s2_level<NEW>(0), s2_level<NEW>(1), s2_level<NEW>(2), s2_level<NEW>(3)};
+    constexpr int kMaxLev = kLev[0] > kLev[1] ? (kLev[0] > kLev[2] ? (kLev[0] > kLev[3] ? kLev[0] : kLev[3]) : (kLev[2] > kLev[3] ? kLev[2] : kLev[3]))
+                                             : (kLev[1] > kLev[2] ? (kLev[1] > kLev[3] ? kLev[1] : kLev[3]) : (kLev[2] > kLev[3] ? kLev[2] : kLev[3]));
     const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
     for (int g8 = 0; g8 < G8; g8++) {
-        uint4 th[ND], rh[ND];
+        uint4 th[ND];
+        uint32_t pbA[ND], pbB[ND], hit8[ND], chg8[ND], zer8[ND]; // flag streams MSB-first: bit 7-j <-> second j
+        // seconds of this block that are draws at all (1 <= c < T), as an MSB-first mask
+        uint32_t live8 = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) live8 |= (8 * g8 + j >= 1 && 8 * g8 + j < T) ? (0x80u >> j) : 0u;
 #pragma unroll
         for (int k = 0; k < ND; k++) {
-            th[k] = rh[k] = make_uint4(0, 0, 0, 0);
-            if (k < P.nd) {
-                th[k] = rng.block(EMGPU_SEC_TRANS, P.d_tvar[k], (uint32_t)g8);
-                if (F.Rk[k] != 0u) rh[k] = rng.block(EMGPU_SEC_RES, P.d_ivar[k], (uint32_t)g8);
+            th[k] = make_uint4(0, 0, 0, 0);
+            pbA[k] = pbB[k] = hit8[k] = chg8[k] = zer8[k] = 0u;
+            if (!REG && k >= P.nd) continue;
+            th[k] = rng.block(EMGPU_SEC_TRANS, P.d_tvar[k], (uint32_t)g8);
+            if (REG || F.Rk[k] != 0u) {
+                // resample_events.m:24 for the whole block: the Bernoulli does not depend on the state, so its eight seconds are
+                // decided two per instruction from the high halfwords (0 no hit, 1 tie, 2 hit; k_uncor_fast does the same)
+                const uint4 rh = rng.block(EMGPU_SEC_RES, P.d_ivar[k], (uint32_t)g8);
+                uint32_t hitA = 0u;
+#pragma unroll
+                for (int p2 = 0; p2 < 4; p2++) {
+                    uint32_t u;
+                    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(u) : "s"(F.RR1[k]), "v"(word_of(rh, p2)));
+                    asm("v_pk_min_u16 %0, %0, 2 op_sel_hi:[1,0]" : "+v"(u));
+                    hitA = p2 ? ((hitA << 2) | u) : u;
+                }
+                hit8[k] = (hitA & 0xAAu) | ((hitA >> 17) & 0x55u);
+                if (__ballot((hitA & 0x00550055u) != 0u) != 0ull) {   // some lane ties with R's high half: this variable's block with 32 bits
+                    uint32_t h = 0u;
+#pragma unroll 1
+                    for (int j = 0; j < 8; j++)
+                        h = (h << 1) | exact_hit(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, word_of(rh, j >> 1), P.d_ivar[k], (uint32_t)g8, (uint32_t)j, F.Rk[k]);
+                    hit8[k] = h;
+                }
+                hit8[k] &= live8;
             }
         }
-        uint32_t pbA[ND], pbB[ND], hit8[ND], chg8[ND], zer8[ND]; // flag streams MSB-first: bit 7-j <-> second j
-#pragma unroll
-        for (int k = 0; k < ND; k++) pbA[k] = pbB[k] = hit8[k] = chg8[k] = zer8[k] = 0u;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int c = 8 * g8 + j; // absolute event time == column produced
             if (c >= 1 && c < T) {    // wave-uniform
                 uint32_t nb1[ND];
 #pragma unroll
-                for (int k = 0; k < ND; k++) {
-                    nb1[k] = 1u;
-                    if (!REG && k >= P.nd) continue;
-                    // ---- resample_events.m:24
-                    if (REG || F.Rk[k] != 0u) {
-                        const uint32_t wr = word_of(rh[k], j >> 1);
-                        const uint32_t dr = (j & 1) ? res_hit<true>(wr, F.Rk[k], hit8[k]) : res_hit<false>(wr, F.Rk[k], hit8[k]);
-                        if (__ballot(dr == 0u) != 0ull) { // the low halfword decides in some lane: redo with 32 bits
-                            hit8[k] = (hit8[k] & ~1u) | exact_hit(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, wr, P.d_ivar[k], (uint32_t)g8, (uint32_t)j, F.Rk[k]);
-                        }
-                    } else {
-                        hit8[k] += hit8[k];
-                    }
-                    // ---- the column of this second: asub2ind.m:13-14 over the current and the new bins
-                    uint32_t col = basecol[k];
-                    // (a stride of 0 = not a parent; testing for it would keep 2 SGPRs per pair alive and spill)
+                for (int k = 0; k < ND; k++) nb1[k] = 1u;
 #pragma unroll
-                    for (int q = 0; q < ND; q++) col = __umul24(P.d_stride_cur[k][q], cur1[q]) + col;
+                for (int lev = 0; lev <= kMaxLev; lev++) {
+                    uint4 ca[ND], cb[ND];   // live only across this level's gathers and draws
 #pragma unroll
-                    for (int q = 0; q < k; q++) col = __umul24(P.d_stride_new[k][q], nb1[q]) + col;
-                    const uint32_t wt = word_of(th[k], j >> 1);
-                    uint32_t sel, dmin, bml, bmh = 0u;
-                    if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) { // wave-uniform
-                        const uint4 a = load4(P.d_poff[k] + col * 4u);
-                        sel = (j & 1) ? chain3<true>(wt, a.x, a.y, a.z, selbase, dmin) : chain3<false>(wt, a.x, a.y, a.z, selbase, dmin);
-                        bml = a.w;
-                        if (__ballot(dmin == 0u) != 0ull) {
-                            sel = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, wt, P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
-                                                            a.x, a.y, a.z, 0u, 0u, 0u);
-                        }
-                    } else {
-                        const uint4 a = load4(P.d_poff[k] + col * 8u), b = load4(P.d_poff[k] + col * 8u + 4u);
-                        sel = (j & 1) ? chain6<true>(wt, a, b.x, b.y, selbase, dmin) : chain6<false>(wt, a, b.x, b.y, selbase, dmin);
-                        bml = b.z; bmh = b.w;
-                        if (__ballot(dmin == 0u) != 0ull) {
-                            sel = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, wt, P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
-                                                            a.x, a.y, a.z, a.w, b.x, b.y);
+                    for (int k = 0; k < ND; k++) ca[k] = cb[k] = make_uint4(0, 0, 0, 0);
+                    // ---- the columns of this level: asub2ind.m:13-14 over the current and the new bins, one or two 16-byte gathers each
+#pragma unroll
+                    for (int k = 0; k < ND; k++) {
+                        if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
+                        uint32_t col = basecol[k];
+#pragma unroll
+                        for (int q = 0; q < ND; q++)
+                            if ((CUR >> (4 * k + q)) & 1u) col = __umul24(P.d_stride_cur[k][q], cur1[q]) + col;
+#pragma unroll
+                        for (int q = 0; q < k; q++)
+                            if ((NEW >> (4 * k + q)) & 1u) col = __umul24(P.d_stride_new[k][q], nb1[q]) + col;
+                        if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) { // wave-uniform
+                            ca[k] = load4(P.d_poff[k] + col * 4u);
+                        } else {
+                            ca[k] = load4(P.d_poff[k] + col * 8u); cb[k] = load4(P.d_poff[k] + col * 8u + 4u);
                         }
                     }
-                    nb1[k] = __builtin_amdgcn_perm(bmh, bml, sel);                                  // dbn_sample.m:77
+                    // ---- the draws of this level (dbn_sample.m:77)
+#pragma unroll
+                    for (int k = 0; k < ND; k++) {
+                        if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
+                        const uint32_t wt = word_of(th[k], j >> 1);
+                        uint32_t sel, dmin, bml, bmh = 0u;
+                        if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) {
+                            const uint4 a = ca[k];
+                            sel = (j & 1) ? chain3<true>(wt, a.x, a.y, a.z, selbase, dmin) : chain3<false>(wt, a.x, a.y, a.z, selbase, dmin);
+                            bml = a.w;
+                            if (__ballot(dmin == 0u) != 0ull) {
+                                sel = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, wt, P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
+                                                                a.x, a.y, a.z, 0u, 0u, 0u);
+                            }
+                        } else {
+                            const uint4 a = ca[k], b = cb[k];
+                            sel = (j & 1) ? chain6<true>(wt, a, b.x, b.y, selbase, dmin) : chain6<false>(wt, a, b.x, b.y, selbase, dmin);
+                            bml = b.z; bmh = b.w;
+                            if (__ballot(dmin == 0u) != 0ull) {
+                                sel = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, wt, P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
+                                                                a.x, a.y, a.z, a.w, b.x, b.y);
+                            }
+                        }
+                        nb1[k] = __builtin_amdgcn_perm(bmh, bml, sel);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < ND; k++) {
@@ -244,7 +295,7 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const E
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < ND; k++) { hit8[k] += hit8[k]; chg8[k] += chg8[k]; zer8[k] += zer8[k]; }
+                for (int k = 0; k < ND; k++) { chg8[k] += chg8[k]; zer8[k] += zer8[k]; }
             }
 #pragma unroll
             for (int k = 0; k < ND; k++) {
@@ -276,6 +327,16 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step2(const EmgpuPlan P, const E
 
 #undef load4
 
+void step_parent_masks(const EmgpuPlan &P, uint32_t *cur_mask, uint32_t *new_mask) {
+    uint32_t c = 0u, n = 0u;
+    for (int k = 0; k < P.nd; k++)
+        for (int q = 0; q < P.nd; q++) {
+            if (P.d_stride_cur[k][q] != 0u) c |= 1u << (4 * k + q);
+            if (P.d_stride_new[k][q] != 0u) n |= 1u << (4 * k + q);
+        }
+    *cur_mask = c; *new_mask = n;
+}
+
 bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     if (A.indices != nullptr) return false; // an index list goes through the generic kernel
     static const bool off = getenv("EMGPU_DEBUG_NO_STEP2") != nullptr;
@@ -289,19 +350,43 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
         for (int q = 0; q < P.nd; q++)
             if (P.d_stride_cur[k][q] >= (1u << 24) || P.d_stride_new[k][q] >= (1u << 24)) return false; // 24-bit multiplies
         for (int a = 0; a < P.nact; a++)
-            if (P.a_dyn[a] == k && P.a_R[a] == 0xFFFFFFFFu) return false;
+            if (P.a_dyn[a] == k && P.a_R[a] >= 0xFFFF0000u) return false; // rate ~ 1 (R_h + 1 must fit 16 bits): older kernels
     }
     return true;
 }
 
+// every parent / the full chain of dependencies: the instance any model can run on
+constexpr uint32_t kCurAll3 = 0x0777u, kNewAll3 = 0x0310u, kCurAll4 = 0xFFFFu, kNewAll4 = 0x7310u;
+
 template <int NI, int ND>
 static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args &F, hipStream_t s, int wmode, bool reg) {
     const dim3 g((unsigned)((A.n + 255) / 256)), b(256);
-    if (reg && wmode == 4) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 4, true>), g, b, 0, s, P, A, F);
-    else if (reg && wmode == 8) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 8, true>), g, b, 0, s, P, A, F);
-    else if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true>), g, b, 0, s, P, A, F);
-    else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false>), g, b, 0, s, P, A, F);
+    constexpr uint32_t C = ND == 4 ? kCurAll4 : kCurAll3, N = ND == 4 ? kNewAll4 : kNewAll3;
+    if (reg && wmode == 4) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 4, true, C, N>), g, b, 0, s, P, A, F);
+    else if (reg && wmode == 8) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 8, true, C, N>), g, b, 0, s, P, A, F);
+    else if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N>), g, b, 0, s, P, A, F);
+    else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false, C, N>), g, b, 0, s, P, A, F);
     return hipGetLastError();
+}
+
+// Instances built for the parent masks of the shipped model families (regular models only).  Returns false when none fits.
+static bool launch_masked(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args &F, hipStream_t s, int wmode, uint32_t cur, uint32_t nw, const char **tag) {
+    const dim3 g((unsigned)((A.n + 255) / 256)), b(256);
+#define EMGPU_S2_CASE(NI_, ND_, W_, C_, N_, TAG_)                                                                  \
+    if (P.ni <= NI_ && P.nd == ND_ && (W_ == 0 || wmode == W_) && cur == C_ && nw == N_) {                         \
+        hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, true, C_, N_>), g, b, 0, s, P, A, F);                        \
+        *tag = TAG_;                                                                                               \
+        return true;                                                                                               \
+    }
+    EMGPU_S2_CASE(16, 4, 4, 0x8421u, 0x2100u, "[cor]")         // cor_v1: two independent aircraft, turn rate after vertical rate
+    EMGPU_S2_CASE(16, 4, 8, 0x8421u, 0x2100u, "[cor]")
+    EMGPU_S2_CASE(7, 3, 0, 0x0421u, 0x0310u, "[chain]")        // glider_v1, paraglider_v1
+    EMGPU_S2_CASE(7, 3, 0, 0x0421u, 0x0210u, "[2<-1]")         // littoral_uncor_v1, paramotor_v1, skydiving_v1
+    EMGPU_S2_CASE(7, 3, 0, 0x0421u, 0x0110u, "[1<-0,2<-0]")    // fai1_v1, fai5_v1
+    EMGPU_S2_CASE(7, 3, 0, 0x0421u, 0x0300u, "[2<-0,1]")       // uncor_1200code_v1
+    EMGPU_S2_CASE(7, 3, 0, 0x0577u, 0x0000u, "[per-step]")     // EMGPU_TRANSITION_PER_STEP on the conventional uncorrelated models
+#undef EMGPU_S2_CASE
+    return false;
 }
 
 hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
@@ -313,19 +398,31 @@ hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s
         F.slot[k] = P.d_row[k];
         for (int a = 0; a < P.nact; a++)
             if (P.a_dyn[a] == k) F.Rk[k] = P.a_R[a];
+        F.RR1[k] = ((F.Rk[k] >> 16) + 1u) * 0x00010001u;
         all_res = all_res && F.Rk[k] != 0u;
         if (P.d_pw[k] != wmode) wmode = 0;
     }
     // (Staging the tables in LDS was measured and dropped: random 16-byte gathers from LDS pay bank
-    // conflicts and the extra LDS costs a workgroup of occupancy -- cor_v1 36.9 ms staged, 28.9 ms through
-    // L1/L2.  Fetching the columns of one dependency level together: 53 ms, the registers cost more
-    // occupancy than the overlapped round trips give back.)
+    // conflicts and the extra LDS costs a workgroup of occupancy -- cor_v1 36.9 ms staged, 28.9 ms through L1/L2.)
     static const char *names[3][4] = {
         {"k_dbn_step2<7,3,w4,reg>", "k_dbn_step2<7,3,w8,reg>", "k_dbn_step2<7,3,reg>", "k_dbn_step2<7,3>"},
         {"k_dbn_step2<9,3,w4,reg>", "k_dbn_step2<9,3,w8,reg>", "k_dbn_step2<9,3,reg>", "k_dbn_step2<9,3>"},
         {"k_dbn_step2<16,4,w4,reg>", "k_dbn_step2<16,4,w8,reg>", "k_dbn_step2<16,4,reg>", "k_dbn_step2<16,4>"}};
     const int shape = (P.ni <= 7 && P.nd <= 3) ? 0 : ((P.ni <= 9 && P.nd <= 3) ? 1 : 2);
     const bool reg = all_res && P.nd == (shape == 2 ? 4 : 3);
+    static const bool no_masks = getenv("EMGPU_DEBUG_NO_STEP2_MASKS") != nullptr;
+    if (reg && !no_masks) {
+        uint32_t cur, nw;
+        step_parent_masks(P, &cur, &nw);
+        static thread_local char buf[64];
+        const char *tag = "";
+        const int w = shape == 2 ? wmode : 0;   // the 3-variable families run the per-variable width instance
+        if ((shape == 2 ? (wmode == 4 || wmode == 8) : true) && launch_masked(P, A, F, s, w, cur, nw, &tag)) {
+            snprintf(buf, sizeof buf, "%s%s", names[shape][w == 4 ? 0 : (w == 8 ? 1 : 2)], tag);
+            *name = buf;
+            return hipGetLastError();
+        }
+    }
     *name = names[shape][reg ? (wmode == 4 ? 0 : (wmode == 8 ? 1 : 2)) : 3];
     if (shape == 0) return launch_t<7, 3>(P, A, F, s, wmode, reg);
     if (shape == 1) return launch_t<9, 3>(P, A, F, s, wmode, reg);

@@ -14,6 +14,9 @@ hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t 
 bool step_eligible(const EmgpuPlan &P, const EmgpuRun &A);
 hipError_t launch_dbn_step(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
 bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A);
+// which dynamic variables are parents of which in the transition network, as the per-timestep kernel's instances see it:
+// bit 4k+q of cur_mask: the time-t node of dynamic variable q is a parent of (t+1) node k; of new_mask: its (t+1) node is (q < k)
+void step_parent_masks(const EmgpuPlan &P, uint32_t *cur_mask, uint32_t *new_mask);
 hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
 hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, hipStream_t s, const char **name);
 hipError_t launch_terminal_geo(const EmgpuTGeoRun &A, hipStream_t s);

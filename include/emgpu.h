@@ -410,6 +410,11 @@ int emgpu_debug_dynamic_column(const emgpu_model *m, int32_t k, int64_t col, int
  * the map is a byte table: entry b = 1-based bin when b of the 3 (6) thresholds did NOT fire. */
 int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int32_t *width, uint32_t *words);
 
+/* Which dynamic variables are parents of which (t+1) node, in plan order k = 0..n_dyn-1: bit 4k+q of cur_mask = the time-t
+ * node of dynamic variable q is a parent of k's (t+1) node; of new_mask = its (t+1) node is (dbn_sample.m:65-93: the
+ * dependent branch; q < k by the topological order).  The per-timestep kernel picks its instance by these masks. */
+int emgpu_debug_parent_masks(const emgpu_model *m, uint32_t *cur_mask, uint32_t *new_mask);
+
 /* Host helpers that mirror small reference functions (used by the class layer and tests). */
 int32_t emgpu_discretize_bayes(double x, const double *thresholds, int32_t n); /* discretize_bayes.m:14-22 */
 int64_t emgpu_asub2ind(const int32_t *siz, const int32_t *x, int32_t n);       /* asub2ind.m:13-14        */
