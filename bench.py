@@ -453,9 +453,9 @@ def recorded_traffic(kernel_name, algorithmic_bytes, lib_version):
         except Exception:
             continue
         line = s.get("bench_line", {})
-        same = (kernel_name.replace(" ", "") in s.get("kernel", "").replace(" ", "")
-                and line.get("roofline", {}).get("algorithmic_bytes_per_launch") == algorithmic_bytes
-                and line.get("config", {}).get("lib") == lib_version)
+        same = (line.get("config", {}).get("kernel") == kernel_name      # the summary's own bench line ran this kernel variant ...
+                and line.get("roofline", {}).get("algorithmic_bytes_per_launch") == algorithmic_bytes   # ... on this launch size ...
+                and line.get("config", {}).get("lib") == lib_version)                                     # ... from these sources
         if same and "hbm_traffic_bytes_per_launch" in s:
             best = (s["hbm_traffic_bytes_per_launch"], os.path.basename(f))
     if best is None:

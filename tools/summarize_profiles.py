@@ -40,7 +40,7 @@ for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv")):
 # per-dispatch resource usage from the kernel trace
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
-        if "k_uncor_fast" in r["Kernel_Name"] or "k_dbn_generic" in r["Kernel_Name"]:
+        if r["Kernel_Name"] == summary.get("kernel"):
             summary["dispatch"] = {k: r[k] for k in ("Workgroup_Size", "Grid_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in r}
             break
 # PMC passes
@@ -48,7 +48,7 @@ pmc = collections.defaultdict(list)
 for d in ("pmc_write", "pmc_fetch", "pmc_sq1", "pmc_sq2"):
     for f in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if "k_uncor_fast" in r["Kernel_Name"] or "k_dbn_generic" in r["Kernel_Name"]:
+            if r["Kernel_Name"] == summary.get("kernel"):
                 pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary["pmc_per_launch"] = {k: sum(v) / len(v) for k, v in pmc.items()}
 if "WRITE_SIZE" in pmc:
