@@ -181,7 +181,14 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
     __syncthreads();
     // one 16-byte group of a padded column, gathered through L1/L2 (the tables are small)
     const uint32_t *__restrict__ gtab = P.pthr;
-#define load4(word_off) (*reinterpret_cast<const uint4 *>(gtab + (word_off)))
+    // a buffer resource over the table: the gather's address is a 32-bit byte offset (one vector instruction, buffer_load ... offen)
+    // instead of a 64-bit pointer per lane
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(gtab), 0, -1, 0x00020000);
+    auto load4 = [&](uint32_t word_off) {
+        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(word_off << 2), 0, 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
     uint32_t ivs[ND];
 #pragma unroll
     for (int k = 0; k < ND; k++) ivs[k] = P.d_ivar[k];
@@ -325,7 +332,6 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
     }
 }
 
-#undef load4
 
 void step_parent_masks(const EmgpuPlan &P, uint32_t *cur_mask, uint32_t *new_mask) {
     uint32_t c = 0u, n = 0u;
