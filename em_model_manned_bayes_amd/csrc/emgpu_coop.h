@@ -4,15 +4,15 @@
 // A dediscretize draw (dediscretize.m:39) is due only at an event (~0.3 per lane and 8-second
 // block), but a per-lane `if (event) philox()` makes the whole wave pay for a Philox call whenever
 // ANY of its 64 lanes has an event.  Instead the flagged positions s = 8k + j of all lanes are
-// compacted into a per-wave LDS queue (ballot + mbcnt ranks, no atomics), lanes 0..R-1 each serve
-// one request (one Philox call per wave serves up to 64 events), and the f32 results go back
-// through LDS to the owners.  Everything is wave-local: no __syncthreads, only a wave fence.
+// compacted into a per-wave LDS queue (positions from one prefix sum over the lanes' request counts,
+// no atomics), lanes 0..R-1 each serve one request (one Philox call per wave serves up to 64 events),
+// and the f32 results go back through LDS to the owners.  Everything is wave-local: no __syncthreads, only a wave fence.
 #pragma once
+#include <type_traits>
+
 #include "emgpu_device.h"
 
 namespace emgpu {
-
-constexpr int kQueueCap = 128; // request descriptors per wave and compaction round (default; CoopLds<.., QCAP> may hold more)
 
 // -DEMGPU_DEBUG_COUNTERS: wave-level event counts of the data-dependent paths (diagnostic builds only, read
 // through emgpu_debug_counters): 0 exact redos, 1 compaction rounds, 2 compaction steps, 3 worker passes, 4 requests, 5 blocks
@@ -24,16 +24,19 @@ __device__ unsigned long long g_dbg[8];
 #endif
 
 // LB: the lanes also publish the packed bins of the block (2 words per variable, after the 8*ND result
-// slots) so that a worker looks the bin of a request up itself instead of the owner encoding it.
-// QCAP: request descriptors per wave and compaction round (a round is one worker pass: at most 64 are used).
-template <int ND, bool LB = false, int QCAP = kQueueCap>
+// slots) and their kind mask so that a worker looks the bin and kind of a request up itself: a request is
+// then 11 bits (owner lane | bit of the owner's need mask << 6) and the queue holds 256 of them in the
+// 512 bytes that hold 128 of the self-contained 32-bit requests of the other form.
+template <int ND, bool LB = false>
 struct CoopLds {
     static constexpr int kBins = 8 * ND;                          // word offset of the published bins
-    static constexpr int kSpare = 8 * ND + (LB ? 2 * ND : 0);     // word offset of the lane's spare words (>= 3 of them)
+    static constexpr int kSpare = 8 * ND + (LB ? 2 * ND : 0);     // word offset of the lane's spare words (>= 4 of them)
+    static constexpr int kKind = kSpare + 3;                      // the lane's kind mask of the block, read by the workers (LB)
     static constexpr int kStride = ((kSpare + 3 + 3) / 8) * 8 + 4; // words per lane; = 4 (mod 8) keeps the b128 reads conflict-free
-    static_assert(kStride % 8 == 4, "lane stride");
-    static constexpr int kCap = QCAP;
-    uint32_t queue[QCAP];
+    static_assert(kStride % 8 == 4 && kStride >= kSpare + 4, "lane stride");
+    static constexpr int kCap = LB ? 256 : 128;                   // requests per compaction round
+    using Request = typename std::conditional<LB, uint16_t, uint32_t>::type;
+    Request queue[kCap];
     float res[64 * kStride];
     uint32_t attempt[64];
 };
@@ -51,72 +54,147 @@ __device__ __forceinline__ uint32_t pick_word(const uint32_t (&a)[ND], uint32_t 
     return r;
 }
 
+// inclusive prefix sum over the 64 lanes of a (fully active) wave: four row-local DPP steps, two row broadcasts
+__device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2, 3
+    return x;
+}
+
+// One worker pass: lanes 0..cnt-1 each serve the request queue[q0 + lane].  A request is owner | sb << 6 (sb = the
+// bit of the owner's need mask); with LB the worker reads the owner's bin and kind word from the owner's LDS row,
+// without it the owner encoded them (kind << 11, bin << 12).
+template <int ND, bool MSBFIRST, bool LB>
+__device__ __forceinline__ void coop_worker_pass(CoopLds<ND, LB> &W, int lane, uint32_t q0, uint32_t cnt, uint64_t gidx, const Rng &rng, int g8,
+                                                 uint32_t ivpack, const double (*s_bnd)[16]) {
+    using L = CoopLds<ND, LB>;
+    const uint32_t q = q0 + (uint32_t)lane;
+    if (q < cnt) {
+        const uint32_t d = W.queue[q];
+        const uint32_t owner = d & 63u, sb = (d >> 6) & 31u;
+        const uint32_t s = MSBFIRST ? (sb ^ 7u) : sb;
+        const uint32_t kind = LB ? ((reinterpret_cast<const uint32_t *>(&W.res[owner * L::kStride + L::kKind])[0] >> sb) & 1u) : ((d >> 11) & 1u);
+        const uint32_t b1 = LB ? reinterpret_cast<const uint8_t *>(&W.res[owner * L::kStride + L::kBins])[s] : ((d >> 12) & 63u);
+        const uint32_t k = s >> 3, j = s & 7u;
+        const uint64_t go = gidx - (uint64_t)lane + (uint64_t)owner;
+        const uint32_t iv = (ivpack >> (8u * k)) & 0xFFu;
+        const uint32_t sec = kind ? EMGPU_SEC_DEDISC_TRANS : EMGPU_SEC_DEDISC_RES;
+        const uint4 r4 = philox4x32_10((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner],
+                                       (sec << 28) | (iv << 20) | (uint32_t)(2 * g8 + (int)(j >> 2)), rng.k0, rng.k1);
+        const uint32_t w = j & 3u;
+        const uint32_t x = w == 0 ? r4.x : (w == 1 ? r4.y : (w == 2 ? r4.z : r4.w));
+        double v;
+        {
+#pragma clang fp contract(off)
+            const double a = s_bnd[k][b1 - 1u], b = s_bnd[k][b1];
+            const double dd = b - a;
+            const double mm = dd * uniform32(x);
+            v = a + mm;
+        }
+        W.res[owner * L::kStride + s] = (float)v;
+    }
+}
+
 // needmask / kindmask: bit (8k + j) for dynamic variable k, second j of the block; with MSBFIRST
 // the byte of a variable is an MSB-first stream instead: bit (8k + 7 - j).
 // pbA / pbB: packed 1-based bins of seconds 0-3 / 4-7.  s_bnd[k][]: boundaries of variable k.
-template <int ND, bool MSBFIRST = false, bool LB = false, int QCAP = kQueueCap>
-__device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB, QCAP> &W, int lane, uint64_t gidx, const Rng &rng, int g8,
+//
+// LB: the requests of the wave get their queue positions from ONE prefix sum over the lanes' request counts; a
+// lane then writes its own requests to consecutive slots (find-first-set, one LDS store, clear the bit: no ballot
+// or rank per request), kCap positions per round, and the workers serve exactly ceil(requests / 64) passes.
+// Without LB (k_dbn_step, the fallback kernel) the round-1 scheme stays: one ballot + rank per compaction step.
+template <int ND, bool MSBFIRST = false, bool LB = false>
+__device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64_t gidx, const Rng &rng, int g8,
                                             uint32_t needmask, uint32_t kindmask, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND],
                                             const uint32_t (&ivar)[ND], const double (*s_bnd)[16]) {
+    using L = CoopLds<ND, LB>;
     uint32_t ivpack = 0u; // wave-uniform byte table of the variables' RNG ids
 #pragma unroll
     for (int q = 0; q < ND; q++) ivpack |= ivar[q] << (8 * q);
     uint32_t m = needmask;
-    unsigned long long bal = __ballot(m != 0u);
-    while (bal != 0ull) {
-        uint32_t base = 0u; // wave-uniform number of queued requests in this round
-        EMGPU_COUNT(1, lane, 1);
-        // a compaction step joins the round only while the round still fits ONE worker pass of 64 requests (the first step
-        // always does): rounds of 70 requests cost two passes, the second nearly empty -- 2.9 passes per block on cor_v1 where 2 do
-        while (bal != 0ull && base + (uint32_t)__popcll(bal) <= 64u) {
-            EMGPU_COUNT(2, lane, 1);
-            if (m != 0u) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                const uint32_t sb = (uint32_t)__ffs((int)m) - 1u;
-                const uint32_t s = MSBFIRST ? (sb ^ 7u) : sb;
-                uint32_t b1 = 0u;
-                if (!LB) {
+    if constexpr (LB) {
+        if (__ballot(m != 0u) == 0ull) return;
+        const uint32_t c = (uint32_t)__popc(m);
+        const uint32_t inc = wave_inclusive_add(c);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        // byte positions of this lane's requests in the (virtual, unbounded) queue: [a, aend)
+        constexpr uint32_t kReq = (uint32_t)sizeof(typename L::Request);
+        uint32_t a = (inc - c) * kReq;
+        const uint32_t aend = inc * kReq;
+        reinterpret_cast<uint32_t *>(&W.res[lane * L::kStride + L::kKind])[0] = kindmask;
+        EMGPU_COUNT(4, lane, total);
+        if (total <= (uint32_t)L::kCap) {
+            // the usual case, one round: find-first-set, one LDS store, clear the bit
+            EMGPU_COUNT(1, lane, 1);
+            typename L::Request *qp = reinterpret_cast<typename L::Request *>(reinterpret_cast<char *>(W.queue) + a);
+            while (__ballot(m != 0u) != 0ull) {
+                EMGPU_COUNT(2, lane, 1);
+                if (m != 0u) {
+                    *qp++ = (typename L::Request)((uint32_t)lane | (((uint32_t)__ffs((int)m) - 1u) << 6));
+                    m &= m - 1u;
+                }
+            }
+            wave_sync();
+            for (uint32_t q0 = 0u; q0 < total; q0 += 64u) {
+                EMGPU_COUNT(3, lane, 1);
+                coop_worker_pass<ND, MSBFIRST, LB>(W, lane, q0, total, gidx, rng, g8, ivpack, s_bnd);
+            }
+            wave_sync();
+        } else {
+            // more than kCap requests in the wave-block: rounds of kCap positions
+            for (uint32_t rb = 0u; rb < total; rb += (uint32_t)L::kCap) {
+                EMGPU_COUNT(1, lane, 1);
+                const uint32_t lim = min(aend, (rb + (uint32_t)L::kCap) * kReq); // a lane is active while a < lim
+                char *const qb = reinterpret_cast<char *>(W.queue) - rb * kReq;
+                while (__ballot(a < lim) != 0ull) {
+                    EMGPU_COUNT(2, lane, 1);
+                    if (a < lim) {
+                        *reinterpret_cast<typename L::Request *>(qb + a) = (typename L::Request)((uint32_t)lane | (((uint32_t)__ffs((int)m) - 1u) << 6));
+                        a += kReq;
+                        m &= m - 1u;
+                    }
+                }
+                wave_sync();
+                const uint32_t cnt = min(total - rb, (uint32_t)L::kCap);
+                for (uint32_t q0 = 0u; q0 < cnt; q0 += 64u) {
+                    EMGPU_COUNT(3, lane, 1);
+                    coop_worker_pass<ND, MSBFIRST, LB>(W, lane, q0, cnt, gidx, rng, g8, ivpack, s_bnd);
+                }
+                wave_sync();
+            }
+        }
+    } else {
+        unsigned long long bal = __ballot(m != 0u);
+        while (bal != 0ull) {
+            uint32_t base = 0u; // wave-uniform number of queued requests in this round
+            EMGPU_COUNT(1, lane, 1);
+            // a compaction step joins the round only while the round still fits ONE worker pass of 64 requests (the first step always does)
+            while (bal != 0ull && base + (uint32_t)__popcll(bal) <= 64u) {
+                EMGPU_COUNT(2, lane, 1);
+                if (m != 0u) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    const uint32_t sb = (uint32_t)__ffs((int)m) - 1u;
+                    const uint32_t s = MSBFIRST ? (sb ^ 7u) : sb;
                     const uint32_t k = s >> 3, j = s & 7u;
                     const uint32_t wA = pick_word<ND>(pbA, k), wB = pick_word<ND>(pbB, k);
-                    b1 = (((j & 4u) ? wB : wA) >> (8u * (j & 3u))) & 0xFFu;
+                    const uint32_t b1 = (((j & 4u) ? wB : wA) >> (8u * (j & 3u))) & 0xFFu;
+                    W.queue[base + rank] = (uint32_t)lane | (sb << 6) | (((kindmask >> sb) & 1u) << 11) | (b1 << 12);
+                    m &= m - 1u;
                 }
-                W.queue[base + rank] = (uint32_t)lane | (s << 6) | (((kindmask >> sb) & 1u) << 11) | (b1 << 12);
-                m &= m - 1u;
+                base += (uint32_t)__popcll(bal);
+                bal = __ballot(m != 0u);
             }
-            base += (uint32_t)__popcll(bal);
+            wave_sync();
+            EMGPU_COUNT(4, lane, base);
+            EMGPU_COUNT(3, lane, 1);
+            coop_worker_pass<ND, MSBFIRST, LB>(W, lane, 0u, base, gidx, rng, g8, ivpack, s_bnd);
+            wave_sync();
             bal = __ballot(m != 0u);
         }
-        wave_sync();
-        EMGPU_COUNT(4, lane, base);
-        for (uint32_t q0 = 0u; q0 < base; q0 += 64u) {
-            EMGPU_COUNT(3, lane, 1);
-            const uint32_t q = q0 + (uint32_t)lane;
-            if (q < base) {
-                const uint32_t d = W.queue[q];
-                const uint32_t owner = d & 63u, s = (d >> 6) & 31u, kind = (d >> 11) & 1u;
-                const uint32_t b1 = LB ? reinterpret_cast<const uint8_t *>(&W.res[owner * CoopLds<ND, LB, QCAP>::kStride + CoopLds<ND, LB, QCAP>::kBins])[s]
-                                       : ((d >> 12) & 63u);
-                const uint32_t k = s >> 3, j = s & 7u;
-                const uint64_t go = gidx - (uint64_t)lane + (uint64_t)owner;
-                const uint32_t iv = (ivpack >> (8u * k)) & 0xFFu;
-                const uint32_t sec = kind ? EMGPU_SEC_DEDISC_TRANS : EMGPU_SEC_DEDISC_RES;
-                const uint4 r4 = philox4x32_10((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner],
-                                               (sec << 28) | (iv << 20) | (uint32_t)(2 * g8 + (int)(j >> 2)), rng.k0, rng.k1);
-                const uint32_t w = j & 3u;
-                const uint32_t x = w == 0 ? r4.x : (w == 1 ? r4.y : (w == 2 ? r4.z : r4.w));
-                double v;
-                {
-#pragma clang fp contract(off)
-                    const double a = s_bnd[k][b1 - 1u], b = s_bnd[k][b1];
-                    const double dd = b - a;
-                    const double mm = dd * uniform32(x);
-                    v = a + mm;
-                }
-                W.res[owner * CoopLds<ND, LB, QCAP>::kStride + s] = (float)v;
-            }
-        }
-        wave_sync();
-        bal = __ballot(m != 0u);
     }
 }
 
@@ -154,27 +232,27 @@ __device__ __forceinline__ void coop_fill_store(const CoopLds<ND> &W, int lane, 
 // change into the zero bin (coop_zero_results cleared the slots before the workers wrote).
 // One v_add_co (shift the stream, carry = the flag) + one v_cndmask per second; two wait states
 // between the VCC write and its read (see emgpu_kernels_fast.hip).
-template <int ND, bool LB, int QCAP = kQueueCap>
-__device__ __forceinline__ void coop_zero_results(CoopLds<ND, LB, QCAP> &W, int lane) {
-    float4 *rp = reinterpret_cast<float4 *>(&W.res[lane * CoopLds<ND, LB, QCAP>::kStride]);
+template <int ND, bool LB>
+__device__ __forceinline__ void coop_zero_results(CoopLds<ND, LB> &W, int lane) {
+    float4 *rp = reinterpret_cast<float4 *>(&W.res[lane * CoopLds<ND, LB>::kStride]);
 #pragma unroll
     for (int q = 0; q < 2 * ND; q++) rp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // publish the packed bins of this lane's block for the workers (CoopLds<ND, true>)
-template <int ND, int QCAP = kQueueCap>
-__device__ __forceinline__ void coop_publish_bins(CoopLds<ND, true, QCAP> &W, int lane, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND]) {
-    uint2 *bp = reinterpret_cast<uint2 *>(&W.res[lane * CoopLds<ND, true, QCAP>::kStride + CoopLds<ND, true, QCAP>::kBins]);
+template <int ND>
+__device__ __forceinline__ void coop_publish_bins(CoopLds<ND, true> &W, int lane, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND]) {
+    uint2 *bp = reinterpret_cast<uint2 *>(&W.res[lane * CoopLds<ND, true>::kStride + CoopLds<ND, true>::kBins]);
 #pragma unroll
     for (int k = 0; k < ND; k++) bp[k] = make_uint2(pbA[k], pbB[k]);
 }
 
-template <int ND, bool LB, int QCAP = kQueueCap>
-__device__ __forceinline__ void coop_fill_store_msb(const CoopLds<ND, LB, QCAP> &W, int lane, int k, int g8, int T, int G4, bool valid,
+template <int ND, bool LB>
+__device__ __forceinline__ void coop_fill_store_msb(const CoopLds<ND, LB> &W, int lane, int k, int g8, int T, int G4, bool valid,
                                                     uint32_t fill8, float &cval, uint32_t pbA, uint32_t pbB,
                                                     uint32_t nd, uint32_t slot, int64_t i_wg, uint32_t tid, int64_t n,
                                                     uint32_t *dyn_bin, float *dyn_val) {
-    const float4 *rp = reinterpret_cast<const float4 *>(&W.res[lane * CoopLds<ND, LB, QCAP>::kStride]);
+    const float4 *rp = reinterpret_cast<const float4 *>(&W.res[lane * CoopLds<ND, LB>::kStride]);
     const float4 ra = rp[2 * k], rb = rp[2 * k + 1];
     const float r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
     float pv[8];

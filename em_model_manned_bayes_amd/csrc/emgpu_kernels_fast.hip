@@ -78,11 +78,23 @@ __device__ __forceinline__ void load_cthr(uint32_t (&tp)[(M + 1) / 2], uint32_t 
     bml = lo; bmh = hi;
 }
 
-// bit 7 of the 8 packed bytes (seconds 0-3 in a, 4-7 in b) as an MSB-first stream: bit 7-j <-> second j
-__device__ __forceinline__ uint32_t zero_stream(uint32_t a, uint32_t b) {
-    const uint32_t na = (((a >> 7) & 0x01010101u) * 0x80402010u) >> 28, nb = (((b >> 7) & 0x01010101u) * 0x80402010u) >> 28;
+// Bit B (4..7) of the 8 packed bytes (seconds 0-3 in a, 4-7 in b) as an MSB-first stream: bit 7-j <-> second j.  One mask and
+// one v_mul_hi_u32 per word: the multiplier moves bit 8i + B of the masked word to bit 35 - i of the 64-bit product (the 16
+// partial products land on 16 different bits: no carries), so the low nibble of the high word is the stream of that word.
+template <int B>
+__device__ __forceinline__ uint32_t byte_bit_stream(uint32_t a, uint32_t b) {
+    static_assert(B >= 4 && B <= 7, "the shifts 35 - B - 9i must fit a 32-bit multiplier");
+    constexpr uint32_t K = (1u << (35 - B)) | (1u << (26 - B)) | (1u << (17 - B)) | (1u << (8 - B));
+#ifdef EMGPU_OLD_STREAM
+    const uint32_t na = (((a >> B) & 0x01010101u) * 0x80402010u) >> 28, nb = (((b >> B) & 0x01010101u) * 0x80402010u) >> 28;
     return (na << 4) | nb;
+#endif
+    const uint32_t ha = __umulhi(a & (0x01010101u << B), K), hb = __umulhi(b & (0x01010101u << B), K);
+    uint32_t t;
+    asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(t) : "v"(ha), "v"(hb)); // (the compiler splits the mask over both operands: one more instruction)
+    return t & 0xFFu; // other partial products sit at bits >= 9 of the high words
 }
+__device__ __forceinline__ uint32_t zero_stream(uint32_t a, uint32_t b) { return byte_bit_stream<7>(a, b); }
 
 // ---- the packed (two seconds per instruction) form of the same column ------------------------------------
 // For the high-halfword compare every threshold X_t is represented by the 16-bit value T'_t such that
@@ -125,18 +137,11 @@ __device__ __forceinline__ void load_cthr_pk(uint32_t (&tp)[(M + 1) / 2], uint32
     bnl = lo; bnh = hi;
 }
 
-// bit `B` of the 8 packed bytes as an MSB-first stream (see zero_stream)
-template <int B>
-__device__ __forceinline__ uint32_t byte_bit_stream(uint32_t a, uint32_t b) {
-    const uint32_t na = (((a >> B) & 0x01010101u) * 0x80402010u) >> 28, nb = (((b >> B) & 0x01010101u) * 0x80402010u) >> 28;
-    return (na << 4) | nb;
-}
-
 // Eight seconds of one dynamic variable, interior block (every second is a draw), decided from the high halfwords:
-// same outputs as eight_seconds_pass<M, false, false>.  Returns true when some compare of this lane needs the low
-// halfword (the caller then redoes the block exactly).  No carries, no VCC: nothing here needs wait states.
+// same outputs as eight_seconds_pass<M, false, false>.  Returns bit 0 when a transition compare of this lane needs the low
+// halfword, bit 1 when a resample compare does (the caller then redoes the block exactly).  No carries, no VCC: nothing here needs wait states.
 template <int M>
-__device__ __forceinline__ bool eight_seconds_pk(const uint4 &th, const uint4 &rh, const uint32_t (&tp)[(M + 1) / 2], uint32_t bnl, uint32_t bnh,
+__device__ __forceinline__ uint32_t eight_seconds_pk(const uint4 &th, const uint4 &rh, const uint32_t (&tp)[(M + 1) / 2], uint32_t bnl, uint32_t bnh,
                                                  uint32_t RR1, uint32_t cur_in, uint32_t &cur_out, uint32_t &pbA, uint32_t &pbB, uint32_t &hit8, uint32_t &chg8) {
     uint32_t nb2[4], par = 0u, hitA = 0u;
 #pragma unroll
@@ -171,10 +176,11 @@ __device__ __forceinline__ bool eight_seconds_pk(const uint4 &th, const uint4 &r
     hit8 = (hitA & 0xAAu) | ((hitA >> 17) & 0x55u);                                          // bit 1 of every 2-bit field, MSB-first
     // changed <=> the bin differs from the second before (dbn_sample.m:151-161); the low nibble alone tells
     const uint32_t prevA = (pbA << 8) | cur_in, prevB = __builtin_amdgcn_alignbit(pbB, pbA, 24);
-    const uint32_t yA = ((pbA ^ prevA) & 0x0F0F0F0Fu) + 0x0F0F0F0Fu, yB = ((pbB ^ prevB) & 0x0F0F0F0Fu) + 0x0F0F0F0Fu;
+    // bins are < 16 and only bit 7 (the zero flag) may be set above them: bit 4 of byte + 0x0F is the carry out of the low nibble
+    const uint32_t yA = (pbA ^ prevA) + 0x0F0F0F0Fu, yB = (pbB ^ prevB) + 0x0F0F0F0Fu;
     chg8 = byte_bit_stream<4>(yA, yB);
     cur_out = pbB >> 24;
-    return (((par & 0x00010001u) | (hitA & 0x00550055u)) | zt) != 0u;
+    return ((((par & 0x00010001u) | zt) != 0u) ? 1u : 0u) | (((hitA & 0x00550055u) != 0u) ? 2u : 0u);
 }
 
 // Eight seconds of one dynamic variable.  Outputs: bins packed 1-based 4 per word (pbA: seconds
@@ -261,11 +267,14 @@ template <int M>
 __device__ __attribute__((noinline)) void eight_seconds_exact(uint32_t c0, uint32_t c1r, uint32_t attempt, uint32_t k0, uint32_t k1,
                                                               uint4 th, uint4 rh, uint32_t tvar, uint32_t ivar, int g8, int T,
                                                               const uint32_t *thr_col /* this lane's column in EmgpuPlan::cthr */, int meff,
-                                                              uint32_t zbin1, uint32_t Rres, uint32_t cur_in,
+                                                              uint32_t zbin1, uint32_t Rres, uint32_t cur_in, uint32_t which /* wave-uniform: 1 transition, 2 resample low halfwords needed */,
                                                               uint32_t *out /* cur, pbA, pbB, hit8, chg8 */) {
     const Rng rng{c0, c1r, attempt, k0, k1};
-    const uint4 tl = rng.block(EMGPU_SEC_TRANS_LO, tvar, (uint32_t)g8);
-    const uint4 rl = rng.block(EMGPU_SEC_RES_LO, ivar, (uint32_t)g8);
+    // a low-halfword block that no lane of the wave needs is not generated: with zeros in its place every compare
+    // that the high halfword decides (all of them, then) comes out the same
+    uint4 tl = make_uint4(0u, 0u, 0u, 0u), rl = make_uint4(0u, 0u, 0u, 0u);
+    if (which & 1u) tl = rng.block(EMGPU_SEC_TRANS_LO, tvar, (uint32_t)g8);
+    if (which & 2u) rl = rng.block(EMGPU_SEC_RES_LO, ivar, (uint32_t)g8);
     uint32_t thr[M], bml, bmh;
     {   // the column again, in full and with the by-borrows byte table (rare path: nothing of this stays in registers)
         uint32_t tph[(M + 1) / 2];
@@ -290,10 +299,10 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
     // take the out-of-line exact pass (full 32-bit draws, guarded): lanes without a tie get the
     // same answers again, so control flow stays wave-uniform.
     const bool edge = 8 * g8 + 7 >= T; // the block runs past the end of the trajectory
-    bool redo = edge;
+    uint32_t redo = edge ? 3u : 0u;
     if (!edge) {
-        const bool amb = eight_seconds_pk<M>(th, rh, thr, bnl, bnh, RR1, cur1, cur_out, pbA, pbB, hit8, chg8);
-        redo = __ballot(amb) != 0ull;
+        const uint32_t amb = eight_seconds_pk<M>(th, rh, thr, bnl, bnh, RR1, cur1, cur_out, pbA, pbB, hit8, chg8);
+        redo = (__ballot(amb & 1u) != 0ull ? 1u : 0u) | (__ballot(amb & 2u) != 0ull ? 2u : 0u);
         if (g8 == 0) {
             // Second 0 of a trajectory is the initial state, not a draw (slot 0 is never used,
             // dbn_sample.m:133,138).  The unguarded pass treated it as one: put the initial bin back,
@@ -308,7 +317,7 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
         EMGPU_COUNT(0, (int)(threadIdx.x & 63), 1);
         uint32_t out[5];
         const uint32_t *thr_col = ctab + (size_t)(*col_slot) * (uint32_t)(meff + 1);
-        eight_seconds_exact<M>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, thr_col, meff, zbin1, Rres, cur1, out);
+        eight_seconds_exact<M>(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, th, rh, tvar, ivar, g8, T, thr_col, meff, zbin1, Rres, cur1, redo, out);
         cur_out = out[0]; pbA = out[1]; pbB = out[2]; hit8 = out[3]; chg8 = out[4];
     }
     cur1 = cur_out;                      // still carries the zero-bin flag

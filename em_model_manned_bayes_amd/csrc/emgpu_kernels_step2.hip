@@ -21,9 +21,6 @@
 
 namespace emgpu {
 
-#ifndef EMGPU_STEP2_QCAP
-#define EMGPU_STEP2_QCAP kQueueCap
-#endif
 
 struct Step2Args {
     uint32_t Rk[EMGPU_MAX_ND];   // resample hit threshold of dynamic variable k (0 = rate 0), < 0xFFFF0000
@@ -126,10 +123,10 @@ __device__ __attribute__((noinline)) uint32_t exact_hit(uint32_t c0, uint32_t c1
 // model's masks multiplies only the strides that exist (cor_v1: 6 of 22) and fetches the columns of a dependency level together.
 template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW>
 __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
-    __shared__ CoopLds<ND, true, EMGPU_STEP2_QCAP> s_wave[4];
+    __shared__ CoopLds<ND, true> s_wave[4];
     __shared__ double s_bnd[ND][16];
     const int tid = threadIdx.x, lane = tid & 63;
-    CoopLds<ND, true, EMGPU_STEP2_QCAP> &W = s_wave[tid >> 6];
+    CoopLds<ND, true> &W = s_wave[tid >> 6];
     const int64_t i = (int64_t)blockIdx.x * 256 + tid;
     const bool valid = i < A.n; // lanes past the end stay alive: they serve as workers for their wave
     const uint64_t gidx = A.first_index + (uint64_t)i;

@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t a0, uint32_t b0
 #define NOPONLY(n) asm volatile("s_nop 1");
 #define XORNOP(n) asm volatile("v_xor_b32 %0, %0, %1\n\ts_nop 1" : "+v"(x##n) : "v"(c));
 #define MULLO(n) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x##n) : "v"(c));
+#define MULHI(n) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x##n) : "v"(c));
 #define MULU24(n) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x##n) : "v"(c));
 #define MADU24(n) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x##n) : "v"(c), "v"(d));
 #define PKSUBC(n) asm volatile("v_pk_sub_u16 %0, %0, %1 op_sel_hi:[1,1] clamp" : "+v"(x##n) : "v"(c));
@@ -84,6 +85,7 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t a0, uint32_t b0
             if (KIND == 49) { REP8(CNDM) }
             if (KIND == 21) { REP8(MULLO) }
             if (KIND == 22) { REP8(MULU24) }
+            if (KIND == 24) { REP8(MULHI) }
             if (KIND == 23) { REP8(MADU24) }
             if (KIND == 17) { REP8(PAIRNONOP) }
             if (KIND == 19) { REP8(NOPONLY) }
@@ -149,6 +151,7 @@ int main() {
     run<14>("v_cmp_ne + s_nop 1 + v_addc", 2);
     run<11>("v_perm_b32", 1);
     run<21>("v_mul_lo_u32", 1);
+    run<24>("v_mul_hi_u32", 1);
     run<22>("v_mul_u32_u24 (VOP2)", 1);
     run<23>("v_mad_u32_u24", 1);
     run<15>("v_min3_u32", 1);
