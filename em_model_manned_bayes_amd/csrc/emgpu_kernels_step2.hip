@@ -39,6 +39,15 @@ constexpr int s2_level(int k) {
     return l;
 }
 
+// bin * stride + acc with the 24-bit multiplier.  Written out: the compiler masks an operand of __umul24 it cannot prove to fit
+// 24 bits (one more instruction per parent).  The stride is a scalar register that a VALU may just have written (v_readlane of a
+// spilled one), and gfx950 wants two wait states before a VALU reads it; the assembler does not look into asm blocks.
+__device__ __forceinline__ uint32_t mad24(uint32_t bin, uint32_t stride, uint32_t acc) {
+    uint32_t r;
+    asm("s_nop 1\n\tv_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(bin), "s"(stride), "v"(acc));
+    return r;
+}
+
 constexpr uint32_t kSelBase2 = 0x0c0c0c00u; // v_perm_b32 selector: bytes 1-3 zero, byte 0 <- table[borrows]
 
 // borrows of x_h - X_h over the thresholds of one padded column (SDWA reads the draw's halfword and the
@@ -182,10 +191,18 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
     // instead of a 64-bit pointer per lane
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(gtab), 0, -1, 0x00020000);
-    auto load4 = [&](uint32_t word_off) {
-        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(word_off << 2), 0, 0);
+    auto load4 = [&](uint32_t byte_off) {
+        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
         return make_uint4(v.x, v.y, v.z, v.w);
     };
+    // columns are addressed in BYTES: the strides (scalar registers) and the lane's base are scaled by the column width once, so a
+    // gather's address is the multiply-adds over the parents and nothing else
+    uint32_t wbytes[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+        wbytes[k] = (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) ? 16u : 32u; // wave-uniform
+        basecol[k] = P.d_poff[k] * 4u + basecol[k] * wbytes[k];
+    }
     uint32_t ivs[ND];
 #pragma unroll
     for (int k = 0; k < ND; k++) ivs[k] = P.d_ivar[k];
@@ -234,59 +251,69 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                 hit8[k] &= live8;
             }
         }
+        // the address of (t+1) node k's column: asub2ind.m:13-14 over the current and the new bins of its parents
+        auto column_of = [&](int k, const uint32_t (&nb1)[ND]) {
+            uint32_t col = basecol[k];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int c = 8 * g8 + j; // absolute event time == column produced
-            if (c >= 1 && c < T) {    // wave-uniform
+            for (int q = 0; q < ND; q++)
+                if ((CUR >> (4 * k + q)) & 1u) col = mad24(cur1[q], P.d_stride_cur[k][q] * wbytes[k], col);
+#pragma unroll
+            for (int q = 0; q < k; q++)
+                if ((NEW >> (4 * k + q)) & 1u) col = mad24(nb1[q], P.d_stride_new[k][q] * wbytes[k], col);
+            return col;
+        };
+        if (g8 >= 1 && 8 * g8 + 7 < T) {
+            // ---- interior block: every second is a draw, nothing is guarded
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
                 uint32_t nb1[ND];
 #pragma unroll
                 for (int k = 0; k < ND; k++) nb1[k] = 1u;
 #pragma unroll
                 for (int lev = 0; lev <= kMaxLev; lev++) {
                     uint4 ca[ND], cb[ND];   // live only across this level's gathers and draws
+                    uint32_t sel[ND], dmin[ND];
 #pragma unroll
-                    for (int k = 0; k < ND; k++) ca[k] = cb[k] = make_uint4(0, 0, 0, 0);
-                    // ---- the columns of this level: asub2ind.m:13-14 over the current and the new bins, one or two 16-byte gathers each
+                    for (int k = 0; k < ND; k++) { ca[k] = cb[k] = make_uint4(0, 0, 0, 0); sel[k] = 0u; dmin[k] = 0xFFFFFFFFu; }
+                    // ---- the columns of this level, one or two 16-byte gathers each
 #pragma unroll
                     for (int k = 0; k < ND; k++) {
                         if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
-                        uint32_t col = basecol[k];
-#pragma unroll
-                        for (int q = 0; q < ND; q++)
-                            if ((CUR >> (4 * k + q)) & 1u) col = __umul24(P.d_stride_cur[k][q], cur1[q]) + col;
-#pragma unroll
-                        for (int q = 0; q < k; q++)
-                            if ((NEW >> (4 * k + q)) & 1u) col = __umul24(P.d_stride_new[k][q], nb1[q]) + col;
-                        if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) { // wave-uniform
-                            ca[k] = load4(P.d_poff[k] + col * 4u);
-                        } else {
-                            ca[k] = load4(P.d_poff[k] + col * 8u); cb[k] = load4(P.d_poff[k] + col * 8u + 4u);
-                        }
+                        const uint32_t col = column_of(k, nb1);
+                        ca[k] = load4(col);
+                        if (!(WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4))) cb[k] = load4(col + 16u); // wave-uniform
                     }
-                    // ---- the draws of this level (dbn_sample.m:77)
+                    // ---- the draws of this level from the high halfwords (dbn_sample.m:77)
+                    uint32_t dlev = 0xFFFFFFFFu;
 #pragma unroll
                     for (int k = 0; k < ND; k++) {
                         if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
                         const uint32_t wt = word_of(th[k], j >> 1);
-                        uint32_t sel, dmin, bml, bmh = 0u;
                         if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) {
                             const uint4 a = ca[k];
-                            sel = (j & 1) ? chain3<true>(wt, a.x, a.y, a.z, selbase, dmin) : chain3<false>(wt, a.x, a.y, a.z, selbase, dmin);
-                            bml = a.w;
-                            if (__ballot(dmin == 0u) != 0ull) {
-                                sel = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, wt, P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
-                                                                a.x, a.y, a.z, 0u, 0u, 0u);
-                            }
+                            sel[k] = (j & 1) ? chain3<true>(wt, a.x, a.y, a.z, selbase, dmin[k]) : chain3<false>(wt, a.x, a.y, a.z, selbase, dmin[k]);
                         } else {
                             const uint4 a = ca[k], b = cb[k];
-                            sel = (j & 1) ? chain6<true>(wt, a, b.x, b.y, selbase, dmin) : chain6<false>(wt, a, b.x, b.y, selbase, dmin);
-                            bml = b.z; bmh = b.w;
-                            if (__ballot(dmin == 0u) != 0ull) {
-                                sel = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, wt, P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
-                                                                a.x, a.y, a.z, a.w, b.x, b.y);
-                            }
+                            sel[k] = (j & 1) ? chain6<true>(wt, a, b.x, b.y, selbase, dmin[k]) : chain6<false>(wt, a, b.x, b.y, selbase, dmin[k]);
                         }
-                        nb1[k] = __builtin_amdgcn_perm(bmh, bml, sel);
+                        dlev = min(dlev, dmin[k]);
+                    }
+                    // one tie test per level; the draws that tied (in some lane) are repeated on the full 32-bit draw, out of line
+                    if (__ballot(dlev == 0u) != 0ull) {
+#pragma unroll
+                        for (int k = 0; k < ND; k++) {
+                            if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
+                            if (__ballot(dmin[k] == 0u) == 0ull) continue;
+                            const bool w4 = WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4);
+                            sel[k] = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, word_of(th[k], j >> 1), P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
+                                                               ca[k].x, ca[k].y, ca[k].z, w4 ? 0u : ca[k].w, w4 ? 0u : cb[k].x, w4 ? 0u : cb[k].y);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < ND; k++) {
+                        if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
+                        const bool w4 = WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4);
+                        nb1[k] = __builtin_amdgcn_perm(w4 ? 0u : cb[k].w, w4 ? ca[k].w : cb[k].z, sel[k]);
                     }
                 }
 #pragma unroll
@@ -296,15 +323,58 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                         "v_cmp_eq_u32 vcc, %4, %2\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
                         : "+v"(chg8[k]), "+v"(zer8[k]) : "v"(nb1[k]), "v"(cur1[k]), "s"((uint32_t)P.d_zero[k]) : "vcc");
                     cur1[k] = nb1[k];                                                               // map back, dbn_sample.m:82
+                    const uint32_t b = cur1[k] << (8 * (j & 3));
+                    if (j < 4) pbA[k] |= b; else pbB[k] |= b;
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < ND; k++) { chg8[k] += chg8[k]; zer8[k] += zer8[k]; }
             }
+        } else {
+            // ---- the first block of a trajectory (second 0 is the initial state, not a draw) and a partial last block: one rolled
+            // loop over the seconds, every draw decided from its full 32 bits (no tie logic); same answers, 1 block in 30
+            uint4 tl[ND];
 #pragma unroll
             for (int k = 0; k < ND; k++) {
-                const uint32_t b = (c < T) ? (cur1[k] << (8 * (j & 3))) : 0u;
-                if (j < 4) pbA[k] |= b; else pbB[k] |= b;
+                tl[k] = make_uint4(0, 0, 0, 0);
+                if (REG || k < P.nd) tl[k] = rng.block(EMGPU_SEC_TRANS_LO, P.d_tvar[k], (uint32_t)g8);
+            }
+#pragma unroll 1
+            for (int j = 0; j < 8; j++) {
+                const int c = 8 * g8 + j; // absolute event time == column produced
+                if (c >= 1 && c < T) {    // wave-uniform
+                    uint32_t nb1[ND];
+#pragma unroll
+                    for (int k = 0; k < ND; k++) nb1[k] = 1u;
+#pragma unroll
+                    for (int lev = 0; lev <= kMaxLev; lev++) {
+#pragma unroll
+                        for (int k = 0; k < ND; k++) {
+                            if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
+                            const bool w4 = WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4);
+                            const uint32_t col = column_of(k, nb1);
+                            const uint4 a = load4(col);
+                            uint4 b = make_uint4(0, 0, 0, 0);
+                            if (!w4) b = load4(col + 16u);
+                            const uint32_t wt = word_of(th[k], j >> 1), wl = word_of(tl[k], j >> 1);
+                            const uint32_t x = clamp32((j & 1) ? ((wt & 0xFFFF0000u) | (wl >> 16)) : ((wt << 16) | (wl & 0xFFFFu)));
+                            uint32_t borrows = (x < a.x ? 1u : 0u) + (x < a.y ? 1u : 0u) + (x < a.z ? 1u : 0u);   // select_random.m:19-20
+                            if (!w4) borrows += (x < a.w ? 1u : 0u) + (x < b.x ? 1u : 0u) + (x < b.y ? 1u : 0u);
+                            nb1[k] = __builtin_amdgcn_perm(w4 ? 0u : b.w, w4 ? a.w : b.z, kSelBase2 + borrows);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < ND; k++) {
+                        chg8[k] = (chg8[k] << 1) | (nb1[k] != cur1[k] ? 1u : 0u);
+                        zer8[k] = (zer8[k] << 1) | (nb1[k] == (uint32_t)P.d_zero[k] ? 1u : 0u);
+                        if (REG || k < P.nd) cur1[k] = nb1[k];                                      // map back, dbn_sample.m:82
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < ND; k++) { chg8[k] += chg8[k]; zer8[k] += zer8[k]; }
+                }
+#pragma unroll
+                for (int k = 0; k < ND; k++) {
+                    const uint32_t b = (c < T) ? (cur1[k] << (8 * (j & 3))) : 0u;
+                    if (j < 4) pbA[k] |= b; else pbB[k] |= b;
+                }
             }
         }
         uint32_t need = 0u, kind = 0u, fill8[ND];
@@ -351,7 +421,8 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     for (int k = 0; k < P.nd; k++) {
         if (P.d_nb[k] == 0 || P.d_nb[k] > 16 || P.d_pw[k] == 0) return false;
         for (int q = 0; q < P.nd; q++)
-            if (P.d_stride_cur[k][q] >= (1u << 24) || P.d_stride_new[k][q] >= (1u << 24)) return false; // 24-bit multiplies
+            if ((uint64_t)P.d_stride_cur[k][q] * P.d_pw[k] * 4u >= (1u << 24) || (uint64_t)P.d_stride_new[k][q] * P.d_pw[k] * 4u >= (1u << 24))
+                return false; // 24-bit multiplies of the strides in bytes
         for (int a = 0; a < P.nact; a++)
             if (P.a_dyn[a] == k && P.a_R[a] >= 0xFFFF0000u) return false; // rate ~ 1 (R_h + 1 must fit 16 bits): older kernels
     }
