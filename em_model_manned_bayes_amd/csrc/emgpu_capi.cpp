@@ -425,8 +425,11 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h, const std::s
     if (u.d_bnd) { HIP_OK(hipFree(u.d_bnd)); u.d_bnd = nullptr; }
     if (u.d_cthr) { HIP_OK(hipFree(u.d_cthr)); u.d_cthr = nullptr; }
     if (u.d_pthr) { HIP_OK(hipFree(u.d_pthr)); u.d_pthr = nullptr; }
-    const size_t nthr = cp.thr.size() ? cp.thr.size() : 1;
+    // 64 words of slack: k_terminal_propagate reads a row's thresholds in fixed groups (8, or every 6th up to index 41) and masks
+    // the ones past the row's end instead of clamping every index
+    const size_t nthr = cp.thr.size() + 64;
     HIP_OK(hipMalloc((void **)&u.d_thr, nthr * sizeof(uint32_t)));
+    HIP_OK(hipMemset(u.d_thr + cp.thr.size(), 0xFF, 64 * sizeof(uint32_t)));
     HIP_OK(hipMalloc((void **)&u.d_bnd, cp.bnd.size() * sizeof(double)));
     if (!cp.thr.empty()) HIP_OK(hipMemcpy(u.d_thr, cp.thr.data(), cp.thr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(u.d_bnd, cp.bnd.data(), cp.bnd.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -859,6 +862,12 @@ static const Uploaded *terminal_tables(emgpu_ctx *ctx, const emgpu_model *const 
         if (P.ni != 6 || P.nd != 3 || P.depend) throw Error(EMGPU_ERR_UNSUPPORTED, "trajectory model must have 6 initial and 3 independent dynamic variables");
         for (int q = 0; q < 6; q++)
             if (P.i_var[q] != q) throw Error(EMGPU_ERR_UNSUPPORTED, "trajectory model initial network must be in index order");
+        {   // createEncounter.m:93-265 propagates heading, altitude and speed (variables 4, 5, 6): the kernel handles them by name
+            bool seen[3] = {false, false, false};
+            for (int k = 0; k < 3; k++)
+                if (P.d_ivar[k] >= 3 && P.d_ivar[k] <= 5) seen[P.d_ivar[k] - 3] = true;
+            if (!(seen[0] && seen[1] && seen[2])) throw Error(EMGPU_ERR_UNSUPPORTED, "trajectory model: the dynamic variables must be heading, altitude and speed (variables 4, 5, 6)");
+        }
         if (P.d_ivar[0] > 5 || P.i_nb[1] < 3 || P.i_nb[2] < 3 || P.i_nb[3] < 3 || P.i_nb[4] < 3 || P.i_nb[5] < 3)
             throw Error(EMGPU_ERR_UNSUPPORTED, "distance, bearing, heading, altitude and speed need boundaries");
         if (P.i_nb[1] > 66 || P.i_nb[2] > 66 || P.i_nb[3] > 66 || P.i_nb[4] > 66 || P.i_nb[5] > 66)

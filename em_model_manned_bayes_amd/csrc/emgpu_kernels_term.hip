@@ -15,29 +15,68 @@
 
 namespace emgpu {
 
-__device__ __forceinline__ double t_wrapTo360(double lon) {
-    const bool positive = lon > 0;
-    lon = lon - floor(lon / 360.0) * 360.0;
-    return (lon == 0 && positive) ? 360.0 : lon;
-}
 __device__ __forceinline__ double t_atan2d(double y, double x) { return atan2(y, x) * (180.0 / 3.14159265358979323846); }
+// wrapTo360(atan2d(y, x)): the angle is in [-180, 180], where lon - floor(lon / 360) * 360 is lon + 360 below zero and lon from
+// zero up (the same roundings: floor is -1 or 0), and the "== 0 && positive" rule never fires
+__device__ __forceinline__ double t_wrap_atan2d(double y, double x) {
+    const double a = t_atan2d(y, x);
+    return a < 0.0 ? a + 360.0 : a + 0.0;
+}
+// sin and cos of |x| <= pi/4 (what MATLAB's cosd / sind hand to the library after their reduction in degrees): Taylor sums to
+// x^19 / x^18 in Horner form on explicit fma -- truncation below 1e-19, about an ulp of rounding; the library routines behind
+// sin() / cos() spend three times the instructions on range reduction this argument never needs.  (Continuous output only:
+// the tests compare tracks with the CPU checker at 1e-6.)
+__device__ __forceinline__ void t_sincos_small(double x, double &s, double &c) {
+    const double z = x * x;
+    double ps = -1.0 / 121645100408832000.0;          // -1/19!
+    ps = fma(ps, z, 1.0 / 355687428096000.0);         //  1/17!
+    ps = fma(ps, z, -1.0 / 1307674368000.0);          // -1/15!
+    ps = fma(ps, z, 1.0 / 6227020800.0);              //  1/13!
+    ps = fma(ps, z, -1.0 / 39916800.0);               // -1/11!
+    ps = fma(ps, z, 1.0 / 362880.0);                  //  1/9!
+    ps = fma(ps, z, -1.0 / 5040.0);                   // -1/7!
+    ps = fma(ps, z, 1.0 / 120.0);                     //  1/5!
+    ps = fma(ps, z, -1.0 / 6.0);                      // -1/3!
+    s = fma(x * z, ps, x);
+    double pc = -1.0 / 6402373705728000.0;            // -1/18!
+    pc = fma(pc, z, 1.0 / 20922789888000.0);          //  1/16!
+    pc = fma(pc, z, -1.0 / 87178291200.0);            // -1/14!
+    pc = fma(pc, z, 1.0 / 479001600.0);               //  1/12!
+    pc = fma(pc, z, -1.0 / 3628800.0);                // -1/10!
+    pc = fma(pc, z, 1.0 / 40320.0);                   //  1/8!
+    pc = fma(pc, z, -1.0 / 720.0);                    // -1/6!
+    pc = fma(pc, z, 1.0 / 24.0);                      //  1/4!
+    const double hz = 0.5 * z;
+    c = (1.0 - hz) + (z * z) * pc;
+}
 // cosd / sind with MATLAB's reduction in degrees: n = round(x/90), x - 90 n in [-45, 45], quadrant m = mod(n, 4)
 __device__ __forceinline__ void t_sincosd(double deg, double &s, double &c) {
-    const double n = round(deg / 90.0);
+    const double n = round(deg * (1.0 / 90.0));
     const double x = (3.14159265358979323846 / 180.0) * (deg - n * 90.0);
     const int m = (int)((long long)n & 3ll);
-    const double sx = sin(x), cx = cos(x);
+    double sx, cx;
+    t_sincos_small(x, sx, cx);
     s = (m == 0) ? sx : ((m == 1) ? cx : ((m == 2) ? -sx : -cx));
     c = (m == 0) ? cx : ((m == 1) ? -sx : ((m == 2) ? -cx : sx));
 }
+// dediscretize.m:33-39 on the two boundaries of 1-based bin d (LDS), f64 without contraction
+__device__ __forceinline__ double t_dedisc(const double *__restrict__ bnd, int d, uint32_t x) {
+#pragma clang fp contract(off)
+    const double a = bnd[d - 1], b = bnd[d];
+    const double dd = b - a;
+    const double mm = dd * uniform32(x);
+    return a + mm;
+}
 __device__ __forceinline__ double t_sign(double x) { return (double)((x > 0) - (x < 0)); }
 
-// discretize_bayes.m:14-22 on cut points held in LDS: 1-based bin = 1 + #{q : x >= cut[q]} for sorted cuts.  The answer is
-// guessed from the grid's first point and mean spacing (exact for the 10-degree bearing / heading grids) and then walked to
-// the true bin: any sorted grid gives the reference's answer, a uniform one in one or two LDS reads instead of a scan.
+// discretize_bayes.m:14-22 on boundaries held in LDS: 1-based bin = 1 + #{q : x >= cut[q]} for the sorted cut points
+// cut = boundaries(2:end-1).  The answer is guessed from the grid's first point and mean spacing (exact for the 10-degree bearing /
+// heading grids) and then walked to the true bin: any sorted grid gives the reference's answer, a uniform one in one or two LDS
+// reads instead of a scan.
+constexpr int kBndStride = 68; // boundaries per variable in LDS (the host checks i_nb <= 66)
 struct CutGrid { int off, n; double lo, inv_step; };
-__device__ __forceinline__ int t_discretize(double x, const double *__restrict__ s_cut, const CutGrid &gd) {
-    const double *cut = s_cut + gd.off;
+__device__ __forceinline__ int t_discretize(double x, const double *__restrict__ s_bnd, const CutGrid &gd) {
+    const double *cut = s_bnd + gd.off + 1;
     double kd = (x - gd.lo) * gd.inv_step;               // candidate number of cut points <= x, minus one
     kd = kd < -1.0 ? -1.0 : (kd > (double)gd.n ? (double)gd.n : kd);
     int k = (int)kd + 1;
@@ -47,58 +86,79 @@ __device__ __forceinline__ int t_discretize(double x, const double *__restrict__
     return k + 1;
 }
 
-// 1-based bin = 1 + #{t < rm1 : x' >= thr[t]} on a sorted threshold row.  Up to 8 thresholds: loaded together and counted
-// (one memory round trip).  More (bearing / heading: 35): every 6th first, then the 6 of the group it falls in (two round
-// trips instead of the six of a binary search; the kernel is bound by dependent gathers, not by compares).
-// Kept out of line: inlined three times (one per variable) it takes the kernel from 231 to 304 registers and from 48 to 86 ms per
-// million encounters.
-__device__ __attribute__((noinline)) int t_draw(const uint32_t *__restrict__ thr, int rm1, uint32_t x) {
-    const uint32_t xp = clamp32(x);
-    if (rm1 <= 8) {
-        uint32_t t[8];
+// The transition draws of the three dynamic variables of one attempt (select_random.m:17-20 on precompiled thresholds):
+// 1-based bin = 1 + #{t < rm1 : x' >= thr[t]} on a sorted threshold row.  Up to 8 thresholds are loaded together and counted;
+// more (bearing / heading: 35) take every 6th first, then the 6 of the group the draw falls in.  The first groups of all three
+// variables are requested before any is used: one memory round trip for the lot, a second one only for the long rows.
+// Indices past a row's end are read (the table carries 64 words of slack) and masked, not clamped.
+typedef const uint32_t __attribute__((address_space(1))) *gptr_t;   // a global-memory pointer (the compiler cannot tell from a loaded one)
+typedef uint32_t uint4u_t __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t uint2u_t __attribute__((ext_vector_type(2), aligned(4)));
+struct Draw3 { int bin[3]; };
+__device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const int (&rm1)[3], const uint32_t (&x)[3]) {
+    uint32_t first[3][8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) t[q] = thr[q < rm1 ? q : rm1 - 1];
-        int b = 0;
+    for (int k = 0; k < 3; k++) {
+        if (rm1[k] <= 8) {                                    // wave-uniform
+            // eight consecutive words from a 4-byte aligned address: two 16-byte loads
+            const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)row[k], b = *(const uint4u_t __attribute__((address_space(1))) *)(row[k] + 4);
+            first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
+            first[k][4] = b.x; first[k][5] = b.y; first[k][6] = b.z; first[k][7] = b.w;
+        } else {
 #pragma unroll
-        for (int q = 0; q < 8; q++) b += (q < rm1 && xp >= t[q]) ? 1 : 0;
-        return b + 1;
+            for (int q = 0; q < 7; q++) first[k][q] = row[k][6 * q + 5];
+            first[k][7] = 0u;
+        }
     }
-    const int ngrp = (rm1 + 5) / 6;                         // groups of 6 thresholds; pivot = last threshold of a group
-    uint32_t pv[7];
+    Draw3 out;
 #pragma unroll
-    for (int q = 0; q < 7; q++) { const int idx = 6 * q + 5; pv[q] = thr[idx < rm1 ? idx : rm1 - 1]; }
-    int g = 0;
+    for (int k = 0; k < 3; k++) {
+        const uint32_t xp = clamp32(x[k]);
+        if (rm1[k] <= 8) {
+            int b = 0;
 #pragma unroll
-    for (int q = 0; q < 7; q++) g += (q < ngrp - 1 && xp >= pv[q]) ? 1 : 0;   // full groups entirely at or below x
-    if (ngrp > 8) {                                          // beyond 48 thresholds (none of the shipped shapes): plain search
-        int lo = 0, hi = rm1;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (xp >= thr[mid]) lo = mid + 1; else hi = mid; }
-        return lo + 1;
+            for (int q = 0; q < 8; q++) b += (q < rm1[k] && xp >= first[k][q]) ? 1 : 0;
+            out.bin[k] = b + 1;
+        } else if (rm1[k] <= 48) {
+            const int ngrp = (rm1[k] + 5) / 6;                // groups of 6 thresholds; pivot = last threshold of a group
+            int g = 0;
+#pragma unroll
+            for (int q = 0; q < 7; q++) g += (q < ngrp - 1 && xp >= first[k][q]) ? 1 : 0;   // full groups entirely at or below x
+            uint32_t t[6];
+            {
+                const gptr_t gp = row[k] + 6 * g;
+                const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)gp;
+                const uint2u_t b = *(const uint2u_t __attribute__((address_space(1))) *)(gp + 4);
+                t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w; t[4] = b.x; t[5] = b.y;
+            }
+            int b = 6 * g;
+#pragma unroll
+            for (int q = 0; q < 6; q++) b += (6 * g + q < rm1[k] && xp >= t[q]) ? 1 : 0;
+            out.bin[k] = b + 1;
+        } else {                                              // beyond 48 thresholds (none of the shipped shapes): plain search
+            int lo = 0, hi = rm1[k];
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (xp >= row[k][mid]) lo = mid + 1; else hi = mid; }
+            out.bin[k] = lo + 1;
+        }
     }
-    uint32_t t[6];
-#pragma unroll
-    for (int q = 0; q < 6; q++) { const int idx = 6 * g + q; t[q] = thr[idx < rm1 ? idx : rm1 - 1]; }
-    int b = 6 * g;
-#pragma unroll
-    for (int q = 0; q < 6; q++) b += (6 * g + q < rm1 && xp >= t[q]) ? 1 : 0;
-    return b + 1;
+    return out;
 }
 
 #ifndef EMGPU_TERM_WAVES
-#define EMGPU_TERM_WAVES 1
+#define EMGPU_TERM_WAVES 2
 #endif
 __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(const EmgpuPlan P, const EmgpuTermRun A) {
 #pragma clang fp contract(off)
-    // cut points of variables 2..6 (distance, bearing, heading, altitude, speed): boundaries(2:end-1), identical for every
-    // trajectory model (checked on the host)
-    __shared__ double s_cut[5 * 64];
+    // boundaries of variables 2..6 (distance, bearing, heading, altitude, speed), identical for every trajectory model (checked
+    // on the host): the cut points of discretize_bayes are boundaries(2:end-1), dediscretize reads a bin's two edges
+    __shared__ double s_bnd[5 * kBndStride];
     __shared__ CutGrid s_grid[5];
     for (int v = 2; v <= 6; v++) {
         const int nbv = P.i_nb[v - 1], n = nbv - 2;
-        for (int q = threadIdx.x; q < n; q += 256) s_cut[(v - 2) * 64 + q] = P.bnd[P.i_boff[v - 1] + 1 + q];
+        for (int q = threadIdx.x; q < nbv; q += 256) s_bnd[(v - 2) * kBndStride + q] = P.bnd[P.i_boff[v - 1] + q];
         if (threadIdx.x == 0) {
             const double lo = P.bnd[P.i_boff[v - 1] + 1], hi = P.bnd[P.i_boff[v - 1] + nbv - 2];
-            s_grid[v - 2] = CutGrid{(v - 2) * 64, n, lo, (n > 1 && hi > lo) ? (double)(n - 1) / (hi - lo) : 0.0};
+            s_grid[v - 2] = CutGrid{(v - 2) * kBndStride, n, lo, (n > 1 && hi > lo) ? (double)(n - 1) / (hi - lo) : 0.0};
         }
     }
     __syncthreads();
@@ -112,16 +172,24 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     Rng rng{(uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)role, (uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
     const double *g = A.geo + e * 12 + ac * 6;
     const int intent = (int)g[5];
-    const uint32_t *__restrict__ thr = A.thr_base[A.model_of[L]];
+    const gptr_t thr = (gptr_t)A.thr_base[A.model_of[L]];
     const double minVel = A.dl[ac][0], maxVel = A.dl[ac][1], maxTurn = A.dl[ac][2], maxAlt = A.dl[ac][3], maxVert = A.dl[ac][4];
     const CutGrid gDist = s_grid[0], gBear = s_grid[1], gHead = s_grid[2], gAlt = s_grid[3], gSpd = s_grid[4];
     int alt_last = 0, spd_first = 0, spd_last = 0;     // discreteValidAlt / discreteValidV as bin ranges (createEncounter.m:118-126)
     {
-        const double *bA = P.bnd + P.i_boff[4], *bS = P.bnd + P.i_boff[5];
+        const double *bA = s_bnd + 3 * kBndStride, *bS = s_bnd + 4 * kBndStride;
         for (int q = 0; q < (int)P.i_nb[4]; q++) if (bA[q] <= maxAlt) alt_last = q + 1;
         for (int q = 0; q < (int)P.i_nb[5]; q++) { if (!(bS[q] >= minVel)) spd_first = q + 1; if (bS[q] <= maxVel) spd_last = q + 1; }
     }
-    const double bounds_dist_hi = P.bnd[P.i_boff[1] + P.i_nb[1] - 1];
+    const double bounds_dist_hi = s_bnd[P.i_nb[1] - 1];
+    const int rm1[3] = {(int)P.d_r[0] - 1, (int)P.d_r[1] - 1, (int)P.d_r[2] - 1};
+    // which dynamic variable is heading / altitude / speed (the host checks that all three are there)
+    const int kh = P.d_ivar[0] == 3 ? 0 : (P.d_ivar[1] == 3 ? 1 : 2), ka = P.d_ivar[0] == 4 ? 0 : (P.d_ivar[1] == 4 ? 1 : 2),
+              ks = P.d_ivar[0] == 5 ? 0 : (P.d_ivar[1] == 5 ? 1 : 2);
+    // the part of a column index that never changes along a track: the intent (variable 1)
+    uint32_t col_static[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) col_static[k] = P.d_stride_static[k][0] * (uint32_t)(intent - 1);
 
     double xy0 = g[0], xy1 = g[1], z_ft = g[2], heading_deg = g[4], t_s = 0, prev_z_rec = 0;
     double sh, chh;
@@ -130,95 +198,95 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     int ii = 1, rows = 0;
     const size_t nl = (size_t)4 * (size_t)A.n;
     bool go = true, failed = false;
-    // the TERM_TRANS / TERM_DEDISC blocks of the first attempt serve four consecutive steps (word ii & 3): kept across steps
-    uint4 wt[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-    int wt_blk = -1;
+    // ONE loop whose body is one attempt of the lane's current step: a lane whose draw produced an invalid event (createEncounter.m:
+    // 218-262 re-draws the step) comes round again with att + 1 while its neighbours start their next step, instead of the whole
+    // wave idling through an inner re-draw loop of the few.
+    int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
+    gptr_t row[3] = {thr, thr, thr};
+    double curr_hdg = 0, d_nm = 0;
+    float rec[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     while (go) {
-        if (rows >= A.cap) { failed = true; break; }
-        const double speed = sqrt(v0 * v0 + v1 * v1);
-        const double rec_x = xy0, rec_y = xy1;
-        xy0 += v0 * dt_s / 6076.1154855643;
-        xy1 += v1 * dt_s / 6076.1154855643;
-        const double curr_hdg = t_wrapTo360(t_atan2d(v1, v0));
-        double rec_z = z_ft;
-        if (ii > 1) {
-            const double alt_diff = z_ft - prev_z_rec;
-            rec_z = prev_z_rec + t_sign(alt_diff) * fmin(maxVert, fabs(alt_diff));
-        }
-        prev_z_rec = rec_z;
-        {
-            float *o = A.out + (size_t)rows * nl + (size_t)L;
-            const size_t fs = (size_t)A.cap * nl;
-            o[0] = (float)t_s; o[fs] = (float)rec_x; o[2 * fs] = (float)rec_y; o[3 * fs] = (float)rec_z;
-            o[4 * fs] = (float)curr_hdg; o[5 * fs] = (float)speed;
-        }
-        rows++;
-        // CreateStartDistribution (0-based bins), createEncounter.m:268-294
-        const double d_nm = sqrt(xy0 * xy0 + xy1 * xy1);
-        int st[6];
-        st[0] = intent - 1;
-        st[1] = t_discretize(d_nm, s_cut, gDist) - 1;
-        st[2] = t_discretize(t_wrapTo360(t_atan2d(xy1, xy0)), s_cut, gBear) - 1;
-        st[3] = t_discretize(heading_deg, s_cut, gHead) - 1;
-        st[4] = t_discretize(z_ft, s_cut, gAlt) - 1;
-        st[5] = t_discretize(speed, s_cut, gSpd) - 1;          // norm(v_ft_s): the velocity has not changed since `speed`
-        // CPT column of each dynamic variable (asub2ind.m:13-14 as strides); topological position == variable id
-        uint32_t col[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            uint32_t c = 0;
-#pragma unroll
-            for (int p = 0; p < 6; p++) c += P.d_stride_static[k][p] * (uint32_t)st[p];
-#pragma unroll
-            for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)st[P.d_ivar[q]];
-            col[k] = c;
-        }
-        if ((ii >> 2) != wt_blk) {
-            rng.attempt = (uint32_t)role;
-#pragma unroll
-            for (int k = 0; k < 3; k++) wt[k] = rng.block(11u /* TERM_TRANS */, P.d_tvar[k], (uint32_t)ii >> 2);
-            wt_blk = ii >> 2;
-        }
-        bool resample = true;
-        int att = 0;
-        while (resample) {
-            if (att >= A.max_resample) { failed = true; go = false; break; }
-            rng.attempt = (uint32_t)role + 4u * (uint32_t)att;
-            int newbin[3]; // 1-based
+        const bool first_attempt = att == 0;
+        if (first_attempt) {
+            // ---- the step begins: the state to record, move, discretize (createEncounter.m:156-200)
+            if (rows >= A.cap) { failed = true; break; }
+            const double speed = sqrt(v0 * v0 + v1 * v1);
+            rec[0] = (float)t_s; rec[1] = (float)xy0; rec[2] = (float)xy1; rec[5] = (float)speed;
+            xy0 += (v0 * dt_s) * (1.0 / 6076.1154855643);
+            xy1 += (v1 * dt_s) * (1.0 / 6076.1154855643);
+            curr_hdg = t_wrap_atan2d(v1, v0);
+            double rec_z = z_ft;
+            if (ii > 1) {
+                const double alt_diff = z_ft - prev_z_rec;
+                rec_z = prev_z_rec + t_sign(alt_diff) * fmin(maxVert, fabs(alt_diff));
+            }
+            prev_z_rec = rec_z;
+            rec[3] = (float)rec_z; rec[4] = (float)curr_hdg;
+            // CreateStartDistribution (0-based bins), createEncounter.m:268-294
+            d_nm = sqrt(xy0 * xy0 + xy1 * xy1);
+            st[0] = intent - 1;
+            st[1] = t_discretize(d_nm, s_bnd, gDist) - 1;
+            st[2] = t_discretize(t_wrap_atan2d(xy1, xy0), s_bnd, gBear) - 1;
+            st[3] = t_discretize(heading_deg, s_bnd, gHead) - 1;
+            st[4] = t_discretize(z_ft, s_bnd, gAlt) - 1;
+            st[5] = t_discretize(speed, s_bnd, gSpd) - 1;          // norm(v_ft_s): the velocity has not changed since `speed`
+            // CPT column of each dynamic variable (asub2ind.m:13-14 as strides); topological position == variable id
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const int rm1 = (int)P.d_r[k] - 1;
-                const uint4 w4 = att == 0 ? wt[k] : rng.block(11u /* TERM_TRANS */, P.d_tvar[k], (uint32_t)ii >> 2);
-                newbin[k] = t_draw(thr + (P.d_off[k] - P.d_off[0]) + (size_t)col[k] * (uint32_t)rm1, rm1, word_of(w4, ii & 3));
-            }
-            att++;
-            resample = false;
+                uint32_t c = col_static[k];
 #pragma unroll
-            for (int e3 = 0; e3 < 3; e3++) { // events in ascending variable id
-                if (resample) break;
-                const int k = P.d_emit[e3];
-                const int var = (int)P.d_ivar[k] + 1;
-                const int d = k == 0 ? newbin[0] : (k == 1 ? newbin[1] : newbin[2]);
-                if (d == st[var - 1] + 1) continue;
-                // MATLAB: 1:[] and []:1:e are empty, so with no boundary at or below the limit no event of that variable is valid
-                const bool ok = var == 4 || (var == 5 && alt_last >= 1 && d >= 1 && d <= alt_last) ||
-                                (var == 6 && spd_first >= 1 && d >= spd_first && d <= spd_last);
-                if (!ok) { resample = true; break; }
-                const uint4 w4 = rng.block(12u /* TERM_DEDISC */, (uint32_t)(var - 1), (uint32_t)ii >> 2);
-                const double val = dedisc_f64(P.bnd, P.i_boff[var - 1], d - 1, word_of(w4, ii & 3));
-                if (var == 4) heading_deg = val;
-                else if (var == 5) z_ft = val;
-                else {
-                    double s1 = val;
+                for (int p = 1; p < 6; p++) c += P.d_stride_static[k][p] * (uint32_t)st[p];
+#pragma unroll
+                for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)st[P.d_ivar[q]];
+                row[k] = thr + (P.d_off[k] - P.d_off[0]) + (size_t)c * (uint32_t)rm1[k];
+            }
+        }
+        // ---- one attempt at the step's transition draw (attempt number in the Philox key)
+        if (att >= A.max_resample) { failed = true; if (first_attempt) rows++; break; }   // (max_resample = 0: the row counts, as in the step-wise order)
+        rng.attempt = (uint32_t)role + 4u * (uint32_t)att;
+        uint32_t xw[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) xw[k] = word_of(rng.block(11u /* TERM_TRANS */, P.d_tvar[k], (uint32_t)ii >> 2), ii & 3);
+        const Draw3 nb = t_draw3(row, rm1, xw);
+        if (first_attempt) {
+            // the record of this step, written once the draws' gathers are back: the stores then drain under the rest of the step
+            // instead of sitting in front of the gathers' wait
+            float *o = A.out + (size_t)rows * nl + (size_t)L;
+            const size_t fs = (size_t)A.cap * nl;
+            o[0] = rec[0]; o[fs] = rec[1]; o[2 * fs] = rec[2]; o[3 * fs] = rec[3]; o[4 * fs] = rec[4]; o[5 * fs] = rec[5];
+            rows++;
+        }
+        // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude or
+        // speed bin makes the step be drawn again -- the events applied before it stay applied, as in the reference's loop
+        bool resample = false;
+        {
+            const int d = kh == 0 ? nb.bin[0] : (kh == 1 ? nb.bin[1] : nb.bin[2]);
+            if (d != st[3] + 1) heading_deg = t_dedisc(s_bnd + 2 * kBndStride, d, word_of(rng.block(12u /* TERM_DEDISC */, 3u, (uint32_t)ii >> 2), ii & 3));
+        }
+        {
+            const int d = ka == 0 ? nb.bin[0] : (ka == 1 ? nb.bin[1] : nb.bin[2]);
+            if (d != st[4] + 1) {
+                // MATLAB: 1:[] is empty, so with no boundary at or below the limit no altitude event is valid
+                if (alt_last >= 1 && d >= 1 && d <= alt_last) z_ft = t_dedisc(s_bnd + 3 * kBndStride, d, word_of(rng.block(12u, 4u, (uint32_t)ii >> 2), ii & 3));
+                else resample = true;
+            }
+        }
+        if (!resample) {
+            const int d = ks == 0 ? nb.bin[0] : (ks == 1 ? nb.bin[1] : nb.bin[2]);
+            if (d != st[5] + 1) {
+                if (spd_first >= 1 && d >= spd_first && d <= spd_last) {
+                    double s1 = t_dedisc(s_bnd + 4 * kBndStride, d, word_of(rng.block(12u, 5u, (uint32_t)ii >> 2), ii & 3));
                     if (s1 < minVel) s1 = minVel;
                     if (s1 > maxVel) s1 = maxVel;
                     t_sincosd(heading_deg, sh, chh);
                     v0 = chh * s1; v1 = sh * s1;
-                }
+                } else resample = true;
             }
         }
-        if (failed) break;
-        const double turn1 = round((heading_deg - curr_hdg) * 100.0) / 100.0;
+        if (resample) { att++; continue; }
+        att = 0;
+        // ---- the step ends: turn towards the new heading, advance the clock, stop conditions
+        const double turn1 = round((heading_deg - curr_hdg) * 100.0) * 0.01;
         const double delta = fmin(fabs(turn1), maxTurn) * t_sign(turn1);
         if (delta != 0.0) {                                  // rotationmatrix(0) is the identity
             t_sincosd(delta, sh, chh);
