@@ -15,6 +15,8 @@
 
 namespace emgpu {
 
+// the carried direction angle brought into [0, 360): what wrapTo360(atan2d(v)) gives for the same direction
+__device__ __forceinline__ double t_mod360(double lon) { return lon - floor(lon * (1.0 / 360.0)) * 360.0; }
 __device__ __forceinline__ double t_atan2d(double y, double x) { return atan2(y, x) * (180.0 / 3.14159265358979323846); }
 // wrapTo360(atan2d(y, x)): the angle is in [-180, 180], where lon - floor(lon / 360) * 360 is lon + 360 below zero and lon from
 // zero up (the same roundings: floor is -1 or 0), and the "== 0 && positive" rule never fires
@@ -73,6 +75,7 @@ __device__ __forceinline__ double t_sign(double x) { return (double)((x > 0) - (
 // cut = boundaries(2:end-1).  The answer is guessed from the grid's first point and mean spacing (exact for the 10-degree bearing /
 // heading grids) and then walked to the true bin: any sorted grid gives the reference's answer, a uniform one in one or two LDS
 // reads instead of a scan.
+constexpr int kRing = 8;       // rows a lane may run ahead of the slowest lane of its wave
 constexpr int kBndStride = 68; // boundaries per variable in LDS (the host checks i_nb <= 66)
 struct CutGrid { int off, n; double lo, inv_step; };
 __device__ __forceinline__ int t_discretize(double x, const double *__restrict__ s_bnd, const CutGrid &gd) {
@@ -84,6 +87,15 @@ __device__ __forceinline__ int t_discretize(double x, const double *__restrict__
     while (k > 0 && x < cut[k - 1]) k--;
     while (k < gd.n && x >= cut[k]) k++;
     return k + 1;
+}
+
+// The same count on a grid of at most 8 cut points, held in LDS padded with +inf to 8: eight broadcast reads issued together and
+// eight compares, no walk (distance, altitude and speed have 4 to 6 cut points)
+__device__ __forceinline__ int t_discretize8(double x, const double *__restrict__ cut8) {
+    int b = 1;
+#pragma unroll
+    for (int q = 0; q < 8; q++) b += (x >= cut8[q]) ? 1 : 0;
+    return b;
 }
 
 // The transition draws of the three dynamic variables of one attempt (select_random.m:17-20 on precompiled thresholds):
@@ -147,15 +159,22 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const int (&rm1
 #ifndef EMGPU_TERM_WAVES
 #define EMGPU_TERM_WAVES 2
 #endif
+// RM1_k: thresholds per row of dynamic variable k as a compile-time constant (0: read from the plan).  The instance built for the
+// terminal model's shape (36 headings, 7 altitude and 5 speed bins) folds every "is this index inside the row" test; left to run
+// time those wave-uniform masks are hoisted out of the loop, spill, and come back through v_readlane every iteration.
+template <int RM1_0, int RM1_1, int RM1_2>
 __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(const EmgpuPlan P, const EmgpuTermRun A) {
 #pragma clang fp contract(off)
     // boundaries of variables 2..6 (distance, bearing, heading, altitude, speed), identical for every trajectory model (checked
     // on the host): the cut points of discretize_bayes are boundaries(2:end-1), dediscretize reads a bin's two edges
     __shared__ double s_bnd[5 * kBndStride];
     __shared__ CutGrid s_grid[5];
+    __shared__ double s_cut8[5][8];   // the cut points of a grid with at most 8 of them, padded with +inf
+    __shared__ float s_ring[4][kRing][6][64];   // per wave: the last kRing recorded rows of every lane, field-major (conflict-free)
     for (int v = 2; v <= 6; v++) {
         const int nbv = P.i_nb[v - 1], n = nbv - 2;
         for (int q = threadIdx.x; q < nbv; q += 256) s_bnd[(v - 2) * kBndStride + q] = P.bnd[P.i_boff[v - 1] + q];
+        if (threadIdx.x < 8) s_cut8[v - 2][threadIdx.x] = ((int)threadIdx.x < n) ? P.bnd[P.i_boff[v - 1] + 1 + threadIdx.x] : __builtin_inf();
         if (threadIdx.x == 0) {
             const double lo = P.bnd[P.i_boff[v - 1] + 1], hi = P.bnd[P.i_boff[v - 1] + nbv - 2];
             s_grid[v - 2] = CutGrid{(v - 2) * kBndStride, n, lo, (n > 1 && hi > lo) ? (double)(n - 1) / (hi - lo) : 0.0};
@@ -165,7 +184,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     const int64_t L = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (L >= 4 * A.n) return;
     const int64_t e = L >> 2;
-    const int role = (int)(L & 3), ac = role >> 1;
+    const int role = (int)(L & 3), ac = role >> 1, lane = (int)(threadIdx.x & 63);
     const double dt_s = (role & 1) ? -1.0 : 1.0;
     const bool is_ownship = ac == 0;
     const uint64_t gidx = A.indices ? A.indices[e] : A.first_index + (uint64_t)e;
@@ -182,7 +201,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
         for (int q = 0; q < (int)P.i_nb[5]; q++) { if (!(bS[q] >= minVel)) spd_first = q + 1; if (bS[q] <= maxVel) spd_last = q + 1; }
     }
     const double bounds_dist_hi = s_bnd[P.i_nb[1] - 1];
-    const int rm1[3] = {(int)P.d_r[0] - 1, (int)P.d_r[1] - 1, (int)P.d_r[2] - 1};
+    const int rm1[3] = {RM1_0 ? RM1_0 : (int)P.d_r[0] - 1, RM1_1 ? RM1_1 : (int)P.d_r[1] - 1, RM1_2 ? RM1_2 : (int)P.d_r[2] - 1};
     // which dynamic variable is heading / altitude / speed (the host checks that all three are there)
     const int kh = P.d_ivar[0] == 3 ? 0 : (P.d_ivar[1] == 3 ? 1 : 2), ka = P.d_ivar[0] == 4 ? 0 : (P.d_ivar[1] == 4 ? 1 : 2),
               ks = P.d_ivar[0] == 5 ? 0 : (P.d_ivar[1] == 5 ? 1 : 2);
@@ -195,107 +214,123 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     double sh, chh;
     t_sincosd(heading_deg, sh, chh);
     double v0 = chh * g[3], v1 = sh * g[3];
+    // The direction of the velocity, carried as an angle: the velocity is only ever set to speed * (cosd, sind)(heading) and rotated
+    // by the step's turn, so atan2d(v) is this angle up to rounding (1e-14 degrees) -- the reference's per-step atan2d
+    // (createEncounter.m:163) costs a hundred instructions here.  (v = 0 would give atan2d = 0: speeds are clamped to minVel > 0.)
+    double vang = heading_deg;
     int ii = 1, rows = 0;
     const size_t nl = (size_t)4 * (size_t)A.n;
-    bool go = true, failed = false;
+    bool done = false, failed = false;
     // ONE loop whose body is one attempt of the lane's current step: a lane whose draw produced an invalid event (createEncounter.m:
     // 218-262 re-draws the step) comes round again with att + 1 while its neighbours start their next step, instead of the whole
-    // wave idling through an inner re-draw loop of the few.
+    // wave idling through an inner re-draw loop of the few.  The lanes of a wave therefore drift apart in their row numbers, and a
+    // row written straight to the [6][cap][4n] output would be 64 scattered 4-byte stores; each lane keeps its last kRing rows in
+    // LDS instead, and row r leaves for memory -- one 256-byte store per field for the wave -- once every running lane is past it.
+    // A lane more than kRing rows ahead of the slowest waits (the slowest lane sets the wave's run time either way).
     int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
     gptr_t row[3] = {thr, thr, thr};
     double curr_hdg = 0, d_nm = 0;
-    float rec[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    while (go) {
-        const bool first_attempt = att == 0;
-        if (first_attempt) {
-            // ---- the step begins: the state to record, move, discretize (createEncounter.m:156-200)
-            if (rows >= A.cap) { failed = true; break; }
-            const double speed = sqrt(v0 * v0 + v1 * v1);
-            rec[0] = (float)t_s; rec[1] = (float)xy0; rec[2] = (float)xy1; rec[5] = (float)speed;
-            xy0 += (v0 * dt_s) * (1.0 / 6076.1154855643);
-            xy1 += (v1 * dt_s) * (1.0 / 6076.1154855643);
-            curr_hdg = t_wrap_atan2d(v1, v0);
-            double rec_z = z_ft;
-            if (ii > 1) {
-                const double alt_diff = z_ft - prev_z_rec;
-                rec_z = prev_z_rec + t_sign(alt_diff) * fmin(maxVert, fabs(alt_diff));
-            }
-            prev_z_rec = rec_z;
-            rec[3] = (float)rec_z; rec[4] = (float)curr_hdg;
-            // CreateStartDistribution (0-based bins), createEncounter.m:268-294
-            d_nm = sqrt(xy0 * xy0 + xy1 * xy1);
-            st[0] = intent - 1;
-            st[1] = t_discretize(d_nm, s_bnd, gDist) - 1;
-            st[2] = t_discretize(t_wrap_atan2d(xy1, xy0), s_bnd, gBear) - 1;
-            st[3] = t_discretize(heading_deg, s_bnd, gHead) - 1;
-            st[4] = t_discretize(z_ft, s_bnd, gAlt) - 1;
-            st[5] = t_discretize(speed, s_bnd, gSpd) - 1;          // norm(v_ft_s): the velocity has not changed since `speed`
-            // CPT column of each dynamic variable (asub2ind.m:13-14 as strides); topological position == variable id
+    int flushed = 0; // wave-uniform: rows [0, flushed) of every lane are in memory
+    while (__ballot(!done) != 0ull) {
+        if (!done && (att != 0 || rows - flushed < kRing)) do {
+            if (att == 0) {
+                // ---- the step begins: record the state, move, discretize (createEncounter.m:156-200)
+                if (rows >= A.cap) { failed = true; done = true; break; }
+                const double speed = sqrt(v0 * v0 + v1 * v1);
+                float *rec = &s_ring[threadIdx.x >> 6][rows % kRing][0][lane];
+                rec[0 * 64] = (float)t_s; rec[1 * 64] = (float)xy0; rec[2 * 64] = (float)xy1; rec[5 * 64] = (float)speed;
+                xy0 += (v0 * dt_s) * (1.0 / 6076.1154855643);
+                xy1 += (v1 * dt_s) * (1.0 / 6076.1154855643);
+                curr_hdg = (speed > 0.0) ? t_mod360(vang) : 0.0;
+                double rec_z = z_ft;
+                if (ii > 1) {
+                    const double alt_diff = z_ft - prev_z_rec;
+                    rec_z = prev_z_rec + t_sign(alt_diff) * fmin(maxVert, fabs(alt_diff));
+                }
+                prev_z_rec = rec_z;
+                rec[3 * 64] = (float)rec_z; rec[4 * 64] = (float)curr_hdg;
+                rows++;
+                // CreateStartDistribution (0-based bins), createEncounter.m:268-294
+                d_nm = sqrt(xy0 * xy0 + xy1 * xy1);
+                st[0] = intent - 1;
+                st[1] = (gDist.n <= 8 ? t_discretize8(d_nm, s_cut8[0]) : t_discretize(d_nm, s_bnd, gDist)) - 1;     // wave-uniform choices
+                st[2] = t_discretize(t_wrap_atan2d(xy1, xy0), s_bnd, gBear) - 1;
+                st[3] = t_discretize(heading_deg, s_bnd, gHead) - 1;
+                st[4] = (gAlt.n <= 8 ? t_discretize8(z_ft, s_cut8[3]) : t_discretize(z_ft, s_bnd, gAlt)) - 1;
+                st[5] = (gSpd.n <= 8 ? t_discretize8(speed, s_cut8[4]) : t_discretize(speed, s_bnd, gSpd)) - 1;      // norm(v_ft_s): the velocity has not changed since `speed`
+                // CPT column of each dynamic variable (asub2ind.m:13-14 as strides); topological position == variable id
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                uint32_t c = col_static[k];
+                for (int k = 0; k < 3; k++) {
+                    uint32_t c = col_static[k];
 #pragma unroll
-                for (int p = 1; p < 6; p++) c += P.d_stride_static[k][p] * (uint32_t)st[p];
+                    for (int p = 1; p < 6; p++) c += P.d_stride_static[k][p] * (uint32_t)st[p];
 #pragma unroll
-                for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)st[P.d_ivar[q]];
-                row[k] = thr + (P.d_off[k] - P.d_off[0]) + (size_t)c * (uint32_t)rm1[k];
+                    for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)st[P.d_ivar[q]];
+                    row[k] = thr + (P.d_off[k] - P.d_off[0]) + (size_t)c * (uint32_t)rm1[k];
+                }
             }
-        }
-        // ---- one attempt at the step's transition draw (attempt number in the Philox key)
-        if (att >= A.max_resample) { failed = true; if (first_attempt) rows++; break; }   // (max_resample = 0: the row counts, as in the step-wise order)
-        rng.attempt = (uint32_t)role + 4u * (uint32_t)att;
-        uint32_t xw[3];
+            // ---- one attempt at the step's transition draw (attempt number in the Philox key)
+            if (att >= A.max_resample) { failed = true; done = true; break; }
+            rng.attempt = (uint32_t)role + 4u * (uint32_t)att;
+            uint32_t xw[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) xw[k] = word_of(rng.block(11u /* TERM_TRANS */, P.d_tvar[k], (uint32_t)ii >> 2), ii & 3);
-        const Draw3 nb = t_draw3(row, rm1, xw);
-        if (first_attempt) {
-            // the record of this step, written once the draws' gathers are back: the stores then drain under the rest of the step
-            // instead of sitting in front of the gathers' wait
-            float *o = A.out + (size_t)rows * nl + (size_t)L;
-            const size_t fs = (size_t)A.cap * nl;
-            o[0] = rec[0]; o[fs] = rec[1]; o[2 * fs] = rec[2]; o[3 * fs] = rec[3]; o[4 * fs] = rec[4]; o[5 * fs] = rec[5];
-            rows++;
-        }
-        // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude or
-        // speed bin makes the step be drawn again -- the events applied before it stay applied, as in the reference's loop
-        bool resample = false;
-        {
-            const int d = kh == 0 ? nb.bin[0] : (kh == 1 ? nb.bin[1] : nb.bin[2]);
-            if (d != st[3] + 1) heading_deg = t_dedisc(s_bnd + 2 * kBndStride, d, word_of(rng.block(12u /* TERM_DEDISC */, 3u, (uint32_t)ii >> 2), ii & 3));
-        }
-        {
-            const int d = ka == 0 ? nb.bin[0] : (ka == 1 ? nb.bin[1] : nb.bin[2]);
-            if (d != st[4] + 1) {
-                // MATLAB: 1:[] is empty, so with no boundary at or below the limit no altitude event is valid
-                if (alt_last >= 1 && d >= 1 && d <= alt_last) z_ft = t_dedisc(s_bnd + 3 * kBndStride, d, word_of(rng.block(12u, 4u, (uint32_t)ii >> 2), ii & 3));
-                else resample = true;
+            for (int k = 0; k < 3; k++) xw[k] = word_of(rng.block(11u /* TERM_TRANS */, P.d_tvar[k], (uint32_t)ii >> 2), ii & 3);
+            const Draw3 nb = t_draw3(row, rm1, xw);
+            // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude
+            // or speed bin makes the step be drawn again -- the events applied before it stay applied, as in the reference's loop
+            bool resample = false;
+            {
+                const int d = kh == 0 ? nb.bin[0] : (kh == 1 ? nb.bin[1] : nb.bin[2]);
+                if (d != st[3] + 1) heading_deg = t_dedisc(s_bnd + 2 * kBndStride, d, word_of(rng.block(12u /* TERM_DEDISC */, 3u, (uint32_t)ii >> 2), ii & 3));
             }
-        }
-        if (!resample) {
-            const int d = ks == 0 ? nb.bin[0] : (ks == 1 ? nb.bin[1] : nb.bin[2]);
-            if (d != st[5] + 1) {
-                if (spd_first >= 1 && d >= spd_first && d <= spd_last) {
-                    double s1 = t_dedisc(s_bnd + 4 * kBndStride, d, word_of(rng.block(12u, 5u, (uint32_t)ii >> 2), ii & 3));
-                    if (s1 < minVel) s1 = minVel;
-                    if (s1 > maxVel) s1 = maxVel;
-                    t_sincosd(heading_deg, sh, chh);
-                    v0 = chh * s1; v1 = sh * s1;
-                } else resample = true;
+            {
+                const int d = ka == 0 ? nb.bin[0] : (ka == 1 ? nb.bin[1] : nb.bin[2]);
+                if (d != st[4] + 1) {
+                    // MATLAB: 1:[] is empty, so with no boundary at or below the limit no altitude event is valid
+                    if (alt_last >= 1 && d >= 1 && d <= alt_last) z_ft = t_dedisc(s_bnd + 3 * kBndStride, d, word_of(rng.block(12u, 4u, (uint32_t)ii >> 2), ii & 3));
+                    else resample = true;
+                }
             }
+            if (!resample) {
+                const int d = ks == 0 ? nb.bin[0] : (ks == 1 ? nb.bin[1] : nb.bin[2]);
+                if (d != st[5] + 1) {
+                    if (spd_first >= 1 && d >= spd_first && d <= spd_last) {
+                        double s1 = t_dedisc(s_bnd + 4 * kBndStride, d, word_of(rng.block(12u, 5u, (uint32_t)ii >> 2), ii & 3));
+                        if (s1 < minVel) s1 = minVel;
+                        if (s1 > maxVel) s1 = maxVel;
+                        t_sincosd(heading_deg, sh, chh);
+                        v0 = chh * s1; v1 = sh * s1;
+                        vang = heading_deg;
+                    } else resample = true;
+                }
+            }
+            if (resample) { att++; break; }
+            att = 0;
+            // ---- the step ends: turn towards the new heading, advance the clock, stop conditions
+            const double turn1 = round((heading_deg - curr_hdg) * 100.0) * 0.01;
+            const double delta = fmin(fabs(turn1), maxTurn) * t_sign(turn1);
+            if (delta != 0.0) {                                  // rotationmatrix(0) is the identity
+                t_sincosd(delta, sh, chh);
+                const double vx = chh * v0 - sh * v1, vy = sh * v0 + chh * v1;
+                v0 = vx; v1 = vy;
+                vang += delta;
+            }
+            t_s += dt_s; ii++;
+            done = (fabs(t_s) > A.tmax_s) || (d_nm > bounds_dist_hi) || ((intent == 1 || intent == 2) && d_nm <= 0.25) || (is_ownship && xy1 > 0.25);
+        } while (false);
+        // ---- rows that every running lane has produced leave for memory
+        for (;;) {
+            if (__ballot(!done && rows <= flushed) != 0ull) break;   // a running lane has not produced this row yet
+            if (__ballot(rows > flushed) == 0ull) break;             // nobody holds it
+            if (rows > flushed) {
+                const float *rec = &s_ring[threadIdx.x >> 6][flushed % kRing][0][lane];
+                float *o = A.out + (size_t)flushed * nl + (size_t)L;
+                const size_t fs = (size_t)A.cap * nl;
+#pragma unroll
+                for (int f = 0; f < 6; f++) o[f * fs] = rec[f * 64];
+            }
+            flushed++;
         }
-        if (resample) { att++; continue; }
-        att = 0;
-        // ---- the step ends: turn towards the new heading, advance the clock, stop conditions
-        const double turn1 = round((heading_deg - curr_hdg) * 100.0) * 0.01;
-        const double delta = fmin(fabs(turn1), maxTurn) * t_sign(turn1);
-        if (delta != 0.0) {                                  // rotationmatrix(0) is the identity
-            t_sincosd(delta, sh, chh);
-            const double vx = chh * v0 - sh * v1, vy = sh * v0 + chh * v1;
-            v0 = vx; v1 = vy;
-        }
-        t_s += dt_s; ii++;
-        const bool stop = (fabs(t_s) > A.tmax_s) || (d_nm > bounds_dist_hi) || ((intent == 1 || intent == 2) && d_nm <= 0.25) || (is_ownship && xy1 > 0.25);
-        go = !stop;
     }
     if (failed && !A.quiet) atomicOr(A.status, 1u);
     A.rows[L] = failed ? -rows - 1 : rows;
@@ -305,7 +340,12 @@ hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, 
     *name = "k_terminal_propagate";
     if (A.n <= 0) return hipSuccess;
     const int64_t blocks = (4 * A.n + 255) / 256;
-    hipLaunchKernelGGL(k_terminal_propagate, dim3((unsigned)blocks), dim3(256), 0, s, P, A);
+    if (P.d_r[0] == 36 && P.d_r[1] == 7 && P.d_r[2] == 5) {
+        *name = "k_terminal_propagate<35,6,4>";
+        hipLaunchKernelGGL((k_terminal_propagate<35, 6, 4>), dim3((unsigned)blocks), dim3(256), 0, s, P, A);
+    } else {
+        hipLaunchKernelGGL((k_terminal_propagate<0, 0, 0>), dim3((unsigned)blocks), dim3(256), 0, s, P, A);
+    }
     return hipGetLastError();
 }
 
