@@ -5,9 +5,11 @@
 // continuous state (discretize_bayes.m:14-22), one transition step of the trajectory DBN with the
 // "stay" prior (dbn_sample.m with t_max = 2 and every initial variable preset; a column's thresholds gathered
 // from the per-model table in one or two independent groups, r up to 36), validity re-draws, dediscretize.
-// Cut points live in LDS (a guessed bin walked to the exact one), the Philox blocks of the first attempt serve four steps.
+// Structure: ONE loop over attempts (a re-drawing lane does not hold its wave back), boundaries in LDS,
+// the recorded rows in a per-lane LDS ring that is flushed row by row with coalesced stores, the velocity's direction carried
+// as an angle, sin/cos of the reduced angle as Horner sums, an instance for the terminal model's row shapes.
 // em-core's local_smooth (createEncounter.m:88-89) is not applied: un-vendored dependency.
-// Bound: dependent L2 gathers + f64 transcendental math (sincos, atan2); output 24 B per second.
+// Bound: vector instruction issue at two waves per SIMD (256 registers of f64 state) + dependent gathers; output 24 B per second.
 #include <hip/hip_runtime.h>
 
 #include "emgpu_device.h"
