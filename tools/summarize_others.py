@@ -1,6 +1,17 @@
 """tools/summarize_others.py TAG -- profiles/TAG_other_kernels.csv from gpurun_out/others_TAG (tools/profile_others.sh):
 one row per workload with the dominant emgpu kernel's rocprofv3 --stats line."""
-import csv, glob, os, sys
+import csv, os, sys
+import glob as _glob
+class glob:  # gpurun merges a call's files into what earlier calls left behind: only the newest file of a kind in a directory counts
+    @staticmethod
+    def glob(pattern):
+        best = {}
+        for f in _glob.glob(pattern):
+            key = (os.path.dirname(f), os.path.basename(f).split("_", 1)[-1])   # <pid>_kernel_stats.csv -> kernel_stats.csv
+            if key not in best or os.path.getmtime(f) > os.path.getmtime(best[key]):
+                best[key] = f
+        return sorted(best.values())
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", "others_" + tag)

@@ -3,10 +3,20 @@ profiles/TAG_*: the kernel-stats table, per-launch PMC values of the dominant ke
 summary that bench.py reads for roofline.traffic."""
 import collections
 import csv
-import glob
+import glob as _glob
 import json
 import os
 import sys
+
+class glob:  # gpurun merges a call's files into what earlier calls left behind: only the newest file of a kind in a directory counts
+    @staticmethod
+    def glob(pattern):
+        best = {}
+        for f in _glob.glob(pattern):
+            key = (os.path.dirname(f), os.path.basename(f).split("_", 1)[-1])   # <pid>_kernel_stats.csv -> kernel_stats.csv
+            if key not in best or os.path.getmtime(f) > os.path.getmtime(best[key]):
+                best[key] = f
+        return sorted(best.values())
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
