@@ -16,13 +16,47 @@
 // results.time = 0 : 0.1 : T; computeVerticalRate(up(is_sec), time(is_sec)) := forward difference of the 1 Hz altitudes.
 // Limits: @UncorEncounterModel/getDynamicLimits.m:1-130 evaluated on the host for every (G, A, altitude-layer range,
 // speed-bin range) the expression can see, looked up here by the track's own minima and maxima.
-// Bound: f64 transcendental issue (asin, atan, tan, two sincos per 0.1 s step); 64 B per recorded step.
+// Bound: f64 issue (asin, atan and three sin/cos pairs on Horner sums per 0.1 s step); 64 B per recorded step.
 #include <hip/hip_runtime.h>
 
 #include "emgpu_launch.h"
 #include "emgpu_plan.h"
 
 namespace emgpu {
+
+// sin and cos of an angle of moderate size (|x| < 1e5; pitch, bank, heading in radians): k = rint(x * 2/pi), the remainder
+// x - k * pi/2 taken in two pieces of pi/2 (the first has 33 significant bits: k * hi is exact), Taylor sums to x^19 / x^18 in
+// Horner form on the remainder (|r| <= pi/4: truncation below 1e-19), the quadrant from k.  About 45 instructions for both
+// where the library's sin() + cos() take 180; results within 2 ulp of them (the tracks are compared at 1e-9).
+__device__ __forceinline__ void ut_sincos(double x, double &s, double &c) {
+    if (!(fabs(x) < 1.0e5)) { s = sin(x); c = cos(x); return; }
+    const double k = rint(x * 0.63661977236758134308);                 // 2/pi
+    double r = fma(-k, 1.57079632673412561417, x);                     // pi/2, first 33 bits
+    r = fma(-k, 6.07710050650619224932e-11, r);                        // pi/2 - the above
+    const double z = r * r;
+    double ps = -1.0 / 121645100408832000.0;          // -1/19!
+    ps = fma(ps, z, 1.0 / 355687428096000.0);         //  1/17!
+    ps = fma(ps, z, -1.0 / 1307674368000.0);          // -1/15!
+    ps = fma(ps, z, 1.0 / 6227020800.0);              //  1/13!
+    ps = fma(ps, z, -1.0 / 39916800.0);               // -1/11!
+    ps = fma(ps, z, 1.0 / 362880.0);                  //  1/9!
+    ps = fma(ps, z, -1.0 / 5040.0);                   // -1/7!
+    ps = fma(ps, z, 1.0 / 120.0);                     //  1/5!
+    ps = fma(ps, z, -1.0 / 6.0);                      // -1/3!
+    const double sr = fma(r * z, ps, r);
+    double pc = -1.0 / 6402373705728000.0;            // -1/18!
+    pc = fma(pc, z, 1.0 / 20922789888000.0);          //  1/16!
+    pc = fma(pc, z, -1.0 / 87178291200.0);            // -1/14!
+    pc = fma(pc, z, 1.0 / 479001600.0);               //  1/12!
+    pc = fma(pc, z, -1.0 / 3628800.0);                // -1/10!
+    pc = fma(pc, z, 1.0 / 40320.0);                   //  1/8!
+    pc = fma(pc, z, -1.0 / 720.0);                    // -1/6!
+    pc = fma(pc, z, 1.0 / 24.0);                      //  1/4!
+    const double cr = (1.0 - 0.5 * z) + (z * z) * pc;
+    const int q = (int)((long long)k & 3ll);
+    s = (q == 0) ? sr : ((q == 1) ? cr : ((q == 2) ? -sr : -cr));
+    c = (q == 0) ? cr : ((q == 1) ? -sr : ((q == 2) ? -cr : sr));
+}
 
 __device__ __forceinline__ int ut_discretize(double x, const double *cut, int n) { // discretize_bayes.m:14-22
     if (x >= cut[n - 1]) return n + 1;
@@ -47,7 +81,7 @@ __global__ void __launch_bounds__(256) k_uncor_track(const EmgpuUTrackRun A) {
     double *out = A.tracks ? A.tracks + (size_t)slot * (size_t)A.S * 8 : nullptr;
     if (out) { out[0] = 0.0; out[1] = n; out[2] = e; out[3] = h; out[4] = v; out[5] = phi; out[6] = theta; out[7] = psi; }
     const float4 *dv4 = reinterpret_cast<const float4 *>(A.dyn_val);
-    int64_t step = 0;
+    int step = 0, since_rec = 0, rec = 0;
     for (int c4 = 0; c4 * 4 < A.T; c4++) {
         const float4 qDH = dv4[((size_t)c4 * A.nd + A.sDH) * ld + (size_t)i];
         const float4 qDP = dv4[((size_t)c4 * A.nd + A.sDPsi) * ld + (size_t)i];
@@ -67,16 +101,22 @@ __global__ void __launch_bounds__(256) k_uncor_track(const EmgpuUTrackRun A) {
                 theta = theta + q * dt;
                 double r = (atan(v * psidot / g) - phi) / dt; r = r < -A.dyn[5] ? -A.dyn[5] : (r > A.dyn[5] ? A.dyn[5] : r);
                 phi = phi + r * dt;
-                const double ct = cos(theta), st = sin(theta);
-                n = n + v * ct * cos(psi) * dt;
-                e = e + v * ct * sin(psi) * dt;
+                double ct, st, cp, sp, cb, sb;
+                ut_sincos(theta, st, ct);
+                ut_sincos(psi, sp, cp);
+                ut_sincos(phi, sb, cb);
+                n = n + v * ct * cp * dt;
+                e = e + v * ct * sp * dt;
                 h = h + v * st * dt;
-                psi = psi + g * tan(phi) / v * dt;
+                psi = psi + g * (sb / cb) / v * dt;
                 v = v + a * dt; v = v < A.dyn[0] ? A.dyn[0] : (v > A.dyn[1] ? A.dyn[1] : v);
                 step++;
-                if (out && step % A.stride == 0) {
-                    double *o = out + (size_t)(step / A.stride) * 8;
-                    o[0] = (double)step / 10.0; o[1] = n; o[2] = e; o[3] = h; o[4] = v; o[5] = phi; o[6] = theta; o[7] = psi;
+                if (++since_rec == A.stride) {   // every stride-th step is kept
+                    since_rec = 0; rec++;
+                    if (out) {
+                        double *o = out + (size_t)rec * 8;
+                        o[0] = (double)step / 10.0; o[1] = n; o[2] = e; o[3] = h; o[4] = v; o[5] = phi; o[6] = theta; o[7] = psi;
+                    }
                 }
                 up_min = h < up_min ? h : up_min; up_max = h > up_max ? h : up_max;
                 v_min = v < v_min ? v : v_min; v_max = v > v_max ? v : v_max;
