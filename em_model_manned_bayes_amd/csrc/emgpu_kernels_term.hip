@@ -26,43 +26,8 @@ __device__ __forceinline__ double t_wrap_atan2d(double y, double x) {
     const double a = t_atan2d(y, x);
     return a < 0.0 ? a + 360.0 : a + 0.0;
 }
-// sin and cos of |x| <= pi/4 (what MATLAB's cosd / sind hand to the library after their reduction in degrees): Taylor sums to
-// x^19 / x^18 in Horner form on explicit fma -- truncation below 1e-19, about an ulp of rounding; the library routines behind
-// sin() / cos() spend three times the instructions on range reduction this argument never needs.  (Continuous output only:
-// the tests compare tracks with the CPU checker at 1e-6.)
-__device__ __forceinline__ void t_sincos_small(double x, double &s, double &c) {
-    const double z = x * x;
-    double ps = -1.0 / 121645100408832000.0;          // -1/19!
-    ps = fma(ps, z, 1.0 / 355687428096000.0);         //  1/17!
-    ps = fma(ps, z, -1.0 / 1307674368000.0);          // -1/15!
-    ps = fma(ps, z, 1.0 / 6227020800.0);              //  1/13!
-    ps = fma(ps, z, -1.0 / 39916800.0);               // -1/11!
-    ps = fma(ps, z, 1.0 / 362880.0);                  //  1/9!
-    ps = fma(ps, z, -1.0 / 5040.0);                   // -1/7!
-    ps = fma(ps, z, 1.0 / 120.0);                     //  1/5!
-    ps = fma(ps, z, -1.0 / 6.0);                      // -1/3!
-    s = fma(x * z, ps, x);
-    double pc = -1.0 / 6402373705728000.0;            // -1/18!
-    pc = fma(pc, z, 1.0 / 20922789888000.0);          //  1/16!
-    pc = fma(pc, z, -1.0 / 87178291200.0);            // -1/14!
-    pc = fma(pc, z, 1.0 / 479001600.0);               //  1/12!
-    pc = fma(pc, z, -1.0 / 3628800.0);                // -1/10!
-    pc = fma(pc, z, 1.0 / 40320.0);                   //  1/8!
-    pc = fma(pc, z, -1.0 / 720.0);                    // -1/6!
-    pc = fma(pc, z, 1.0 / 24.0);                      //  1/4!
-    const double hz = 0.5 * z;
-    c = (1.0 - hz) + (z * z) * pc;
-}
-// cosd / sind with MATLAB's reduction in degrees: n = round(x/90), x - 90 n in [-45, 45], quadrant m = mod(n, 4)
-__device__ __forceinline__ void t_sincosd(double deg, double &s, double &c) {
-    const double n = round(deg * (1.0 / 90.0));
-    const double x = (3.14159265358979323846 / 180.0) * (deg - n * 90.0);
-    const int m = (int)((long long)n & 3ll);
-    double sx, cx;
-    t_sincos_small(x, sx, cx);
-    s = (m == 0) ? sx : ((m == 1) ? cx : ((m == 2) ? -sx : -cx));
-    c = (m == 0) ? cx : ((m == 1) ? -sx : ((m == 2) ? -cx : sx));
-}
+// cosd / sind: MATLAB's reduction in degrees + Horner sums on the reduced angle (sincosd_small, emgpu_device.h)
+__device__ __forceinline__ void t_sincosd(double deg, double &s, double &c) { sincosd_small(deg, s, c); }
 // dediscretize.m:33-39 on the two boundaries of 1-based bin d (LDS), f64 without contraction
 __device__ __forceinline__ double t_dedisc(const double *__restrict__ bnd, int d, uint32_t x) {
 #pragma clang fp contract(off)

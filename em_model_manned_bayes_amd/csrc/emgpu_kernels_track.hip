@@ -4,24 +4,18 @@
 //   DENSE  -- the sampler's device output as it lies in HBM (init_val rows + the time-blocked
 //             dyn_val float4 blocks): the device consumer of the hot path;
 //   PLANAR -- f64 columns parsed from initial.txt / transition.txt, laid out [T][3][n].
-// Per trajectory and second: one f64 sincos (quadrant-exact like cosd/sind), 5 adds, 5 multiplies;
-// reads 12 B (DENSE) and writes 24 B of f64 track.  Bound: f64 transcendental issue, then HBM.
+// Per trajectory and second: one f64 sin/cos pair (quadrant-exact like cosd/sind, Horner sums), 5 adds, 5 multiplies;
+// reads 12 B (DENSE) and writes 24 B of f64 track.  Bound: HBM.
 #include <hip/hip_runtime.h>
 
+#include "emgpu_device.h"
 #include "emgpu_launch.h"
 #include "emgpu_plan.h"
 
 namespace emgpu {
 
-// cosd / sind with MATLAB's reduction in degrees: n = round(x/90), x - 90 n in [-45, 45], quadrant m = mod(n, 4)
-__device__ __forceinline__ void k_sincosd(double deg, double &s, double &c) {
-    const double n = round(deg / 90.0);
-    const double x = (3.14159265358979323846 / 180.0) * (deg - n * 90.0);
-    const int m = (int)((long long)n & 3ll);
-    const double sx = sin(x), cx = cos(x);
-    s = (m == 0) ? sx : ((m == 1) ? cx : ((m == 2) ? -sx : -cx));
-    c = (m == 0) ? cx : ((m == 1) ? -sx : ((m == 2) ? -cx : sx));
-}
+// cosd / sind: MATLAB's reduction in degrees + Horner sums on the reduced angle (emgpu_device.h; within 2 ulp of the library)
+__device__ __forceinline__ void k_sincosd(double deg, double &s, double &c) { sincosd_small(deg, s, c); }
 
 template <bool DENSE>
 __global__ void __launch_bounds__(256) k_sample2track(const EmgpuTrackRun A) {

@@ -19,40 +19,23 @@
 // Bound: f64 issue (asin, atan and three sin/cos pairs on Horner sums per 0.1 s step); 64 B per recorded step.
 #include <hip/hip_runtime.h>
 
+#include "emgpu_device.h"
 #include "emgpu_launch.h"
 #include "emgpu_plan.h"
 
 namespace emgpu {
 
 // sin and cos of an angle of moderate size (|x| < 1e5; pitch, bank, heading in radians): k = rint(x * 2/pi), the remainder
-// x - k * pi/2 taken in two pieces of pi/2 (the first has 33 significant bits: k * hi is exact), Taylor sums to x^19 / x^18 in
-// Horner form on the remainder (|r| <= pi/4: truncation below 1e-19), the quadrant from k.  About 45 instructions for both
+// x - k * pi/2 taken in two pieces of pi/2 (the first has 33 significant bits: k * hi is exact), Horner sums on the remainder
+// (sincos_small, emgpu_device.h), the quadrant from k.  About 45 instructions for both
 // where the library's sin() + cos() take 180; results within 2 ulp of them (the tracks are compared at 1e-9).
 __device__ __forceinline__ void ut_sincos(double x, double &s, double &c) {
     if (!(fabs(x) < 1.0e5)) { s = sin(x); c = cos(x); return; }
     const double k = rint(x * 0.63661977236758134308);                 // 2/pi
     double r = fma(-k, 1.57079632673412561417, x);                     // pi/2, first 33 bits
     r = fma(-k, 6.07710050650619224932e-11, r);                        // pi/2 - the above
-    const double z = r * r;
-    double ps = -1.0 / 121645100408832000.0;          // -1/19!
-    ps = fma(ps, z, 1.0 / 355687428096000.0);         //  1/17!
-    ps = fma(ps, z, -1.0 / 1307674368000.0);          // -1/15!
-    ps = fma(ps, z, 1.0 / 6227020800.0);              //  1/13!
-    ps = fma(ps, z, -1.0 / 39916800.0);               // -1/11!
-    ps = fma(ps, z, 1.0 / 362880.0);                  //  1/9!
-    ps = fma(ps, z, -1.0 / 5040.0);                   // -1/7!
-    ps = fma(ps, z, 1.0 / 120.0);                     //  1/5!
-    ps = fma(ps, z, -1.0 / 6.0);                      // -1/3!
-    const double sr = fma(r * z, ps, r);
-    double pc = -1.0 / 6402373705728000.0;            // -1/18!
-    pc = fma(pc, z, 1.0 / 20922789888000.0);          //  1/16!
-    pc = fma(pc, z, -1.0 / 87178291200.0);            // -1/14!
-    pc = fma(pc, z, 1.0 / 479001600.0);               //  1/12!
-    pc = fma(pc, z, -1.0 / 3628800.0);                // -1/10!
-    pc = fma(pc, z, 1.0 / 40320.0);                   //  1/8!
-    pc = fma(pc, z, -1.0 / 720.0);                    // -1/6!
-    pc = fma(pc, z, 1.0 / 24.0);                      //  1/4!
-    const double cr = (1.0 - 0.5 * z) + (z * z) * pc;
+    double sr, cr;
+    sincos_small(r, sr, cr);
     const int q = (int)((long long)k & 3ll);
     s = (q == 0) ? sr : ((q == 1) ? cr : ((q == 2) ? -sr : -cr));
     c = (q == 0) ? cr : ((q == 1) ? -sr : ((q == 2) ? -cr : sr));
