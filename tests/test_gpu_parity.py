@@ -951,6 +951,25 @@ def test_random_models_match_oracle(seed, gpu_ctx, tmp_path):
     assert kernels <= {"k_uncor_fast", "k_dbn_step2", "k_dbn_step", "k_dbn_generic"}
 
 
+@pytest.mark.parametrize("name,kernel", [("uncor_1200code_v2p1", "k_uncor_fast"), ("cor_v1", "k_dbn_step2"), ("glider_v1", "k_dbn_step2")])
+def test_hundreds_of_dediscretize_requests_per_wave_block(name, kernel, gpu_ctx, model_dir):
+    """Resample rates of 0.75 on every variable: ~6 dediscretize requests per lane and variable-block, i.e. 1 100-1 500 per
+    wave-block -- several rounds of the 256-entry request queue and a dozen worker passes per block (the shipped rates give
+    20-200 requests, one round)."""
+    nm0, pp, path = load_pair(name, model_dir)
+    nm = native.NativeModel.load_txt(path)
+    rates = np.full(len(pp["resample_rates"]), 0.75)
+    nm.set_f64(L.F_RESAMPLE_RATES, 0, rates)
+    pp2 = dict(pp); pp2["resample_rates"] = rates
+    om = O.OracleModel(pp2)
+    idx = uncor_indices(pp)
+    n, T, seed = 1500, 50, 77
+    ref = O.uncor_sample(om, n, T, seed, want_events=False)
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, want_dense=True, want_events=False, **idx)
+    assert got["kernel"].startswith(kernel), got["kernel"]
+    assert_uncor_parity(got, ref, T, check_events=False)
+
+
 @pytest.mark.parametrize("name,n,kernel", [("cor_v1", 10_000_000, "k_dbn_step2<16,4,w4,reg>"), ("cor_v2p1_like", 10_000_000, "k_dbn_step2<16,4,w8,reg>"),
                                            ("glider_v1", 4_000_000, "k_dbn_step2<7,3"),
                                            ("uncor_1200only_rotorcraft_v1p2", 6_250_000, "k_uncor_fast<7,4,6,6>")])
