@@ -69,6 +69,11 @@ struct emgpu_ctx {
     size_t d_layers_cap = 0;
     const uint32_t **d_thr_base = nullptr; // terminal propagation: per-model table pointers
     size_t d_thr_base_cap = 0;
+    // Side streams for the blocks of a mixed batch (created on first use): independent launches that share the ctx stream's
+    // ordering at both ends, so that one block's tail runs under the next block's head instead of in front of it.
+    static constexpr int kSide = 3;
+    hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr, nullptr};
 };
 
 #define CTX_LOCK(ctx) std::lock_guard<std::recursive_mutex> _ctx_lock((ctx)->mu)
@@ -389,6 +394,11 @@ void emgpu_ctx_free(emgpu_ctx *ctx) {
     (void)hipFree(ctx->d_thr_base);
     (void)hipHostFree(ctx->h_status);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    for (int q = 0; q < emgpu_ctx::kSide; q++) {
+        if (ctx->side[q]) (void)hipStreamDestroy(ctx->side[q]);
+        if (ctx->ev_join[q]) (void)hipEventDestroy(ctx->ev_join[q]);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     delete ctx;
 }
 
@@ -500,13 +510,14 @@ static void bind_outputs(EmgpuRun &A, const Model &m, const emgpu_sample_params 
     (void)m;
 }
 
-static void launch_dbn(emgpu_ctx *ctx, const Uploaded &u, const EmgpuRun &A) {
+static void launch_dbn(emgpu_ctx *ctx, const Uploaded &u, const EmgpuRun &A, hipStream_t stream = nullptr) {
     const char *name = "";
     hipError_t e;
-    if (emgpu::fast_uncor_eligible(u.cp.plan, A)) e = emgpu::launch_uncor_fast(u.cp.plan, A, ctx->stream, &name);
-    else if (emgpu::step2_eligible(u.cp.plan, A)) e = emgpu::launch_dbn_step2(u.cp.plan, A, ctx->stream, &name);
-    else if (emgpu::step_eligible(u.cp.plan, A)) e = emgpu::launch_dbn_step(u.cp.plan, A, ctx->stream, &name);
-    else e = emgpu::launch_dbn_generic(u.cp.plan, A, ctx->stream, &name);
+    if (!stream) stream = ctx->stream;
+    if (emgpu::fast_uncor_eligible(u.cp.plan, A)) e = emgpu::launch_uncor_fast(u.cp.plan, A, stream, &name);
+    else if (emgpu::step2_eligible(u.cp.plan, A)) e = emgpu::launch_dbn_step2(u.cp.plan, A, stream, &name);
+    else if (emgpu::step_eligible(u.cp.plan, A)) e = emgpu::launch_dbn_step(u.cp.plan, A, stream, &name);
+    else e = emgpu::launch_dbn_generic(u.cp.plan, A, stream, &name);
     ctx->last_kernel = name;
     if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
 }
@@ -590,6 +601,28 @@ int emgpu_sample_dbn_blocks_device(emgpu_ctx *ctx, const emgpu_model *const *mod
     }
     emgpu_sample_out o = *out;
     if (!o.ld) o.ld = p->n;
+    // Blocks write disjoint columns: they go round-robin over the ctx stream and three side streams, forked from and joined
+    // back into the ctx stream with events (a caller sees one in-order operation).  Uploads happen before the fork:
+    // get_uploaded may synchronise the ctx stream.
+    int n_live = 0;
+    for (int b = 0; b < n_blocks; b++) {
+        if (blocks[b].model < 0 || blocks[b].model >= n_models) return fail(EMGPU_ERR_ARG, "block names a model outside the list");
+        if (blocks[b].n > 0) { (void)get_uploaded(ctx, models[blocks[b].model], &pinned); n_live++; }
+    }
+    static const bool no_side = getenv("EMGPU_DEBUG_NO_SIDE_STREAMS") != nullptr;
+    const bool fork = n_live >= 2 && !no_side;
+    int used = 0; // side streams in use
+    if (fork) {
+        if (!ctx->ev_fork) {
+            HIP_OK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            for (int q = 0; q < emgpu_ctx::kSide; q++) {
+                HIP_OK(hipStreamCreateWithFlags(&ctx->side[q], hipStreamNonBlocking));
+                HIP_OK(hipEventCreateWithFlags(&ctx->ev_join[q], hipEventDisableTiming));
+            }
+        }
+        HIP_OK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    }
+    int live = 0;
     for (int b = 0; b < n_blocks; b++) {
         const emgpu_block &B = blocks[b];
         if (B.model < 0 || B.model >= n_models) return fail(EMGPU_ERR_ARG, "block names a model outside the list");
@@ -603,7 +636,20 @@ int emgpu_sample_dbn_blocks_device(emgpu_ctx *ctx, const emgpu_model *const *mod
         EmgpuRun A;
         fill_run(ctx, u, h->m, &q, A);
         bind_outputs(A, h->m, &q, &o, (int64_t)(B.first_index - p->first_index));
-        launch_dbn(ctx, u, A);
+        hipStream_t st = ctx->stream;
+        if (fork) {
+            const int lane = live % (emgpu_ctx::kSide + 1);
+            if (lane > 0) {
+                st = ctx->side[lane - 1];
+                if (lane > used) { HIP_OK(hipStreamWaitEvent(st, ctx->ev_fork, 0)); used = lane; }
+            }
+        }
+        live++;
+        launch_dbn(ctx, u, A, st);
+    }
+    for (int q = 0; q < used; q++) {
+        HIP_OK(hipEventRecord(ctx->ev_join[q], ctx->side[q]));
+        HIP_OK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[q], 0));
     }
     return EMGPU_OK;
     EMGPU_CATCH
