@@ -429,6 +429,8 @@ def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
         }
         if getattr(pl, "shared", False):
             line["oversubscribed"] = True
+        if w.launches_per_step > 1:   # a mixed batch: its blocks run on the ctx stream and three side streams
+            line["roofline"]["launches_overlap"] = "avg_launch_ms is avg_step_ms / launches_per_step; single launches in a kernel trace overlap"
         line["roofline"].update(recorded_traffic(kernel, alg // w.launches_per_step, line["config"]["lib"]))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = w.cpu_baseline(args.cpu_sample)
