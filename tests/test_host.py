@@ -398,6 +398,71 @@ def test_mex_gateway_compiles():
         assert os.path.exists(os.path.join(mdir, f)), f
 
 
+def _matlab_code_lines(text):
+    """Code of a .m file with comments, strings and line continuations removed (enough for a structural lint)."""
+    out, cont = [], ""
+    for raw in text.split("\n"):
+        line, i, code = raw, 0, []
+        in_s = in_d = False
+        prev = ""
+        while i < len(line):
+            c = line[i]
+            if in_s:
+                if c == "'":
+                    if i + 1 < len(line) and line[i + 1] == "'": i += 1
+                    else: in_s = False
+            elif in_d:
+                if c == '"':
+                    if i + 1 < len(line) and line[i + 1] == '"': i += 1
+                    else: in_d = False
+            elif c == "%":
+                break
+            elif c == "'" and not (prev.isalnum() or prev in "_)]}.'"):   # a quote after an operand is a transpose
+                in_s = True; code.append(" S ")
+            elif c == '"':
+                in_d = True; code.append(" S ")
+            else:
+                code.append(c)
+            prev = c      # (a quote right after a blank starts a string, as inside [a 'b'])
+            i += 1
+        assert not in_s and not in_d, "unterminated string: " + raw
+        t = "".join(code).rstrip()
+        if t.endswith("..."):
+            cont += t[:-3] + " "
+            continue
+        out.append(cont + t); cont = ""
+    return out
+
+
+def test_matlab_files_are_structurally_sound():
+    """No MATLAB here: a lint of every shipped .m file -- strings terminated, brackets balanced per statement, every block
+    opener (function / if / for / while / switch / try / classdef / methods / properties / parfor) closed by an `end`."""
+    import glob
+    files = glob.glob(os.path.join(ROOT, "em_model_manned_bayes_amd", "matlab", "**", "*.m"), recursive=True) + glob.glob(os.path.join(ROOT, "tools", "matlab", "*.m"))
+    assert len(files) >= 9
+    openers = {"function", "if", "for", "while", "switch", "try", "classdef", "methods", "properties", "parfor"}
+    for f in files:
+        depth, n_fun, has_classdef = 0, 0, False
+        for line in _matlab_code_lines(open(f).read()):
+            assert line.count("(") == line.count(")") and line.count("[") == line.count("]") and line.count("{") == line.count("}"), (f, line)
+            # `end` inside an index expression is arithmetic, not a block end: drop bracketed text first
+            flat = line
+            for _ in range(8):
+                flat = re.sub(r"\([^()]*\)|\[[^\[\]]*\]|\{[^{}]*\}", " ", flat)
+            for stmt in re.split(r"[;,]", flat):
+                words = re.findall(r"[A-Za-z_][A-Za-z_0-9]*", stmt)
+                if not words: continue
+                if words[0] in openers:
+                    depth += 1
+                    n_fun += words[0] == "function"; has_classdef |= words[0] == "classdef"
+                depth -= sum(1 for w in words if w == "end")
+                assert depth >= 0, (f, line)
+        if has_classdef or n_fun == 0:
+            assert depth == 0, (f, depth)
+        else:
+            assert depth in (0, n_fun), (f, depth, n_fun)      # script-style function files may leave their functions open
+
+
 def test_uncor_dynamic_limits_match_the_oracle_and_known_answers(model_dir):
     """@UncorEncounterModel/getDynamicLimits.m: the product's host restatement (emgpu_limits.cpp, the table the track
     kernel indexes) against the oracle's separately written one over random arguments, on an 'ordered' model
