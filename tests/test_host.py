@@ -463,6 +463,39 @@ def test_matlab_files_are_structurally_sound():
             assert depth in (0, n_fun), (f, depth, n_fun)      # script-style function files may leave their functions open
 
 
+_MATLAB_BUILTINS = set("""abs addParameter addRequired all any arrayfun assert cell cell2struct cellfun char cosd double eps erase error
+fclose fgetl fileparts find fopen fprintf fullfile getenv ischar isempty isequal isfolder isinf isnan logical mat2str max mfilename min nan
+num2cell numel onCleanup parse randi readmatrix repmat rethrow rng seconds sind size sortrows sprintf squeeze str2double strcmp strcmpi
+strsplit timetable toc tic zeros inputParser struct isnumeric isfield""".split())
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/code/matlab"), reason="needs the reference mount (build container only)")
+def test_matlab_files_call_only_functions_that_exist():
+    """Every name the shipped .m files call like a function is a variable of that file, one of our own functions, a function or
+    method of the reference (read from the mount), the mex gateway, or on a hand-kept list of MATLAB builtins: a misspelt helper
+    would otherwise only surface on a machine with MATLAB."""
+    import glob
+    files = glob.glob(os.path.join(ROOT, "em_model_manned_bayes_amd", "matlab", "**", "*.m"), recursive=True) + glob.glob(os.path.join(ROOT, "tools", "matlab", "*.m"))
+    fun_re = r"function\s+(?:\[?([^=\n]*?)\]?\s*=\s*)?([A-Za-z_]\w*)\s*(?:\(([^)]*)\))?"
+    known = {"emgpu_mex"} | {os.path.basename(f)[:-2] for f in files}
+    for f in glob.glob("/root/reference/code/matlab/**/*.m", recursive=True):
+        known.add(os.path.basename(f)[:-2])
+        known |= {m.group(2) for m in re.finditer(fun_re, open(f, errors="ignore").read())}
+    for f in files:
+        text = "\n".join(_matlab_code_lines(open(f).read()))
+        names = set(re.findall(r"([A-Za-z_]\w*)\s*(?:\([^=\n]*\)|\{[^=\n]*\})?\s*=(?!=)", text))          # assigned
+        for grp in re.findall(r"\[([^\]=\n]*)\]\s*=", text) + re.findall(r"@\(([^)]*)\)", text):          # [a, b] = ..., @(x) ...
+            names |= set(re.findall(r"[A-Za-z_]\w*", grp))
+        names |= set(re.findall(r"for\s+([A-Za-z_]\w*)\s*=", text)) | set(re.findall(r"catch\s+([A-Za-z_]\w*)", text))
+        for m in re.finditer(fun_re, text):
+            known.add(m.group(2))
+            for g in (m.group(1), m.group(3)):
+                if g: names |= set(re.findall(r"[A-Za-z_]\w*", g))
+        calls = {m.group(1) for m in re.finditer(r"(?<![\w.])([A-Za-z_]\w*)\s*\(", text)}
+        unknown = sorted(c for c in calls if c not in names and c not in known and c not in _MATLAB_BUILTINS)
+        assert not unknown, (os.path.basename(f), unknown)
+
+
 def test_uncor_dynamic_limits_match_the_oracle_and_known_answers(model_dir):
     """@UncorEncounterModel/getDynamicLimits.m: the product's host restatement (emgpu_limits.cpp, the table the track
     kernel indexes) against the oracle's separately written one over random arguments, on an 'ordered' model
