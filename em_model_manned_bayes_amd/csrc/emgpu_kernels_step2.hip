@@ -70,20 +70,25 @@ __device__ __forceinline__ uint32_t chain3(uint32_t w, uint32_t t0, uint32_t t1,
     dmin = min(min(d0, d1), d2);
     return sel;
 }
+// six thresholds whose high halves sit two per word (the 16-byte column form): the borrow count starts at 0 (it indexes nibbles)
+#define EMGPU_S2_PK(SELX, SELT, D, TW, FIRST)                                                                       \
+    asm("v_sub_co_u32_sdwa %0, vcc, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:" SELT "\n\t"   \
+        "s_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"                                                              \
+        : "=&v"(D), "+v"(sel) : "v"(w), "v"(TW) : "vcc")
 template <bool ODD>
-__device__ __forceinline__ uint32_t chain6(uint32_t w, const uint4 &a, uint32_t t4, uint32_t t5, uint32_t selbase, uint32_t &dmin) {
-    uint32_t d0, d1, d2, d3, d4, d5, sel;
-    const uint32_t t0 = a.x;
+__device__ __forceinline__ uint32_t chain6p(uint32_t w, uint32_t t01, uint32_t t23, uint32_t t45, uint32_t &dmin) {
+    uint32_t d0, d1, d2, d3, d4, d5, sel = 0u;
     if (ODD) {
-        EMGPU_S2_FIRST("WORD_1"); EMGPU_S2_NEXT("WORD_1", d1, a.y); EMGPU_S2_NEXT("WORD_1", d2, a.z);
-        EMGPU_S2_NEXT("WORD_1", d3, a.w); EMGPU_S2_NEXT("WORD_1", d4, t4); EMGPU_S2_NEXT("WORD_1", d5, t5);
+        EMGPU_S2_PK("WORD_1", "WORD_0", d0, t01, 1); EMGPU_S2_PK("WORD_1", "WORD_1", d1, t01, 0); EMGPU_S2_PK("WORD_1", "WORD_0", d2, t23, 0);
+        EMGPU_S2_PK("WORD_1", "WORD_1", d3, t23, 0); EMGPU_S2_PK("WORD_1", "WORD_0", d4, t45, 0); EMGPU_S2_PK("WORD_1", "WORD_1", d5, t45, 0);
     } else {
-        EMGPU_S2_FIRST("WORD_0"); EMGPU_S2_NEXT("WORD_0", d1, a.y); EMGPU_S2_NEXT("WORD_0", d2, a.z);
-        EMGPU_S2_NEXT("WORD_0", d3, a.w); EMGPU_S2_NEXT("WORD_0", d4, t4); EMGPU_S2_NEXT("WORD_0", d5, t5);
+        EMGPU_S2_PK("WORD_0", "WORD_0", d0, t01, 1); EMGPU_S2_PK("WORD_0", "WORD_1", d1, t01, 0); EMGPU_S2_PK("WORD_0", "WORD_0", d2, t23, 0);
+        EMGPU_S2_PK("WORD_0", "WORD_1", d3, t23, 0); EMGPU_S2_PK("WORD_0", "WORD_0", d4, t45, 0); EMGPU_S2_PK("WORD_0", "WORD_1", d5, t45, 0);
     }
     dmin = min(min(min(d0, d1), d2), min(min(d3, d4), d5));
     return sel;
 }
+#undef EMGPU_S2_PK
 #undef EMGPU_S2_FIRST
 #undef EMGPU_S2_NEXT
 
@@ -196,12 +201,12 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
         return make_uint4(v.x, v.y, v.z, v.w);
     };
     // columns are addressed in BYTES: the strides (scalar registers) and the lane's base are scaled by the column width once, so a
-    // gather's address is the multiply-adds over the parents and nothing else
+    // gather's address is the multiply-adds over the parents and nothing else.  full_of: the same column in the 8-word table.
     uint32_t wbytes[ND];
 #pragma unroll
     for (int k = 0; k < ND; k++) {
-        wbytes[k] = (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) ? 16u : 32u; // wave-uniform
-        basecol[k] = P.d_poff[k] * 4u + basecol[k] * wbytes[k];
+        wbytes[k] = 16u; // a 4-word column, or the 16-byte form of an 8-word one (EmgpuPlan::d_poff16)
+        basecol[k] = ((WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) ? P.d_poff[k] : P.d_poff16[k]) * 4u + basecol[k] * 16u; // wave-uniform choice
     }
     uint32_t ivs[ND];
 #pragma unroll
@@ -262,6 +267,7 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                 if ((NEW >> (4 * k + q)) & 1u) col = mad24(nb1[q], P.d_stride_new[k][q] * wbytes[k], col);
             return col;
         };
+        auto full_of = [&](int k, uint32_t col16) { return (col16 - P.d_poff16[k] * 4u) * 2u + P.d_poff[k] * 4u; };
         if (g8 >= 1 && 8 * g8 + 7 < T) {
             // ---- interior block: every second is a draw, nothing is guarded
 #pragma unroll
@@ -271,17 +277,16 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                 for (int k = 0; k < ND; k++) nb1[k] = 1u;
 #pragma unroll
                 for (int lev = 0; lev <= kMaxLev; lev++) {
-                    uint4 ca[ND], cb[ND];   // live only across this level's gathers and draws
-                    uint32_t sel[ND], dmin[ND];
+                    uint4 ca[ND];   // live only across this level's gathers and draws
+                    uint32_t sel[ND], dmin[ND], colv[ND];
 #pragma unroll
-                    for (int k = 0; k < ND; k++) { ca[k] = cb[k] = make_uint4(0, 0, 0, 0); sel[k] = 0u; dmin[k] = 0xFFFFFFFFu; }
-                    // ---- the columns of this level, one or two 16-byte gathers each
+                    for (int k = 0; k < ND; k++) { ca[k] = make_uint4(0, 0, 0, 0); sel[k] = 0u; dmin[k] = 0xFFFFFFFFu; colv[k] = 0u; }
+                    // ---- the columns of this level, one 16-byte gather each
 #pragma unroll
                     for (int k = 0; k < ND; k++) {
                         if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
-                        const uint32_t col = column_of(k, nb1);
-                        ca[k] = load4(col);
-                        if (!(WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4))) cb[k] = load4(col + 16u); // wave-uniform
+                        colv[k] = column_of(k, nb1);
+                        ca[k] = load4(colv[k]);
                     }
                     // ---- the draws of this level from the high halfwords (dbn_sample.m:77)
                     uint32_t dlev = 0xFFFFFFFFu;
@@ -293,8 +298,8 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                             const uint4 a = ca[k];
                             sel[k] = (j & 1) ? chain3<true>(wt, a.x, a.y, a.z, selbase, dmin[k]) : chain3<false>(wt, a.x, a.y, a.z, selbase, dmin[k]);
                         } else {
-                            const uint4 a = ca[k], b = cb[k];
-                            sel[k] = (j & 1) ? chain6<true>(wt, a, b.x, b.y, selbase, dmin[k]) : chain6<false>(wt, a, b.x, b.y, selbase, dmin[k]);
+                            const uint4 a = ca[k];
+                            sel[k] = (j & 1) ? chain6p<true>(wt, a.x, a.y, a.z, dmin[k]) : chain6p<false>(wt, a.x, a.y, a.z, dmin[k]);
                         }
                         dlev = min(dlev, dmin[k]);
                     }
@@ -304,16 +309,22 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                         for (int k = 0; k < ND; k++) {
                             if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
                             if (__ballot(dmin[k] == 0u) == 0ull) continue;
-                            const bool w4 = WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4);
-                            sel[k] = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, word_of(th[k], j >> 1), P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
-                                                               ca[k].x, ca[k].y, ca[k].z, w4 ? 0u : ca[k].w, w4 ? 0u : cb[k].x, w4 ? 0u : cb[k].y);
+                            if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) {
+                                sel[k] = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, word_of(th[k], j >> 1), P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
+                                                                   ca[k].x, ca[k].y, ca[k].z, 0u, 0u, 0u);
+                            } else {   // the full thresholds of the column, from the 8-word table
+                                const uint32_t cf = full_of(k, colv[k]);
+                                const uint4 fa = load4(cf), fb = load4(cf + 16u);
+                                sel[k] = exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, word_of(th[k], j >> 1), P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
+                                                       fa.x, fa.y, fa.z, fa.w, fb.x, fb.y);
+                            }
                         }
                     }
 #pragma unroll
                     for (int k = 0; k < ND; k++) {
                         if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
-                        const bool w4 = WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4);
-                        nb1[k] = __builtin_amdgcn_perm(w4 ? 0u : cb[k].w, w4 ? ca[k].w : cb[k].z, sel[k]);
+                        if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) nb1[k] = __builtin_amdgcn_perm(0u, ca[k].w, sel[k]);
+                        else nb1[k] = __builtin_amdgcn_ubfe(ca[k].w, 4u * sel[k], 4u);   // nibble table indexed by the borrows
                     }
                 }
 #pragma unroll
@@ -349,7 +360,7 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                         for (int k = 0; k < ND; k++) {
                             if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
                             const bool w4 = WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4);
-                            const uint32_t col = column_of(k, nb1);
+                            const uint32_t col = w4 ? column_of(k, nb1) : full_of(k, column_of(k, nb1));
                             const uint4 a = load4(col);
                             uint4 b = make_uint4(0, 0, 0, 0);
                             if (!w4) b = load4(col + 16u);
@@ -421,7 +432,7 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     for (int k = 0; k < P.nd; k++) {
         if (P.d_nb[k] == 0 || P.d_nb[k] > 16 || P.d_pw[k] == 0) return false;
         for (int q = 0; q < P.nd; q++)
-            if ((uint64_t)P.d_stride_cur[k][q] * P.d_pw[k] * 4u >= (1u << 24) || (uint64_t)P.d_stride_new[k][q] * P.d_pw[k] * 4u >= (1u << 24))
+            if ((uint64_t)P.d_stride_cur[k][q] * 16u >= (1u << 24) || (uint64_t)P.d_stride_new[k][q] * 16u >= (1u << 24))
                 return false; // 24-bit multiplies of the strides in bytes
         for (int a = 0; a < P.nact; a++)
             if (P.a_dyn[a] == k && P.a_R[a] >= 0xFFFF0000u) return false; // rate ~ 1 (R_h + 1 must fit 16 bits): older kernels
