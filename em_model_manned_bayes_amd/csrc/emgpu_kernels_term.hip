@@ -67,26 +67,30 @@ __device__ __forceinline__ int t_discretize8(double x, const double *__restrict_
 
 // The transition draws of the three dynamic variables of one attempt (select_random.m:17-20 on precompiled thresholds):
 // 1-based bin = 1 + #{t < rm1 : x' >= thr[t]} on a sorted threshold row.  Up to 8 thresholds are loaded together and counted;
-// more (bearing / heading: 35) take every 6th first, then the 6 of the group the draw falls in.  The first groups of all three
+// more (bearing / heading: 35) take the row's pivots first (every 6th threshold, kept as a row of their own), then the 6 of the
+// group the draw falls in.  The first groups of all three
 // variables are requested before any is used: one memory round trip for the lot, a second one only for the long rows.
 // Indices past a row's end are read (the table carries 64 words of slack) and masked, not clamped.
 typedef const uint32_t __attribute__((address_space(1))) *gptr_t;   // a global-memory pointer (the compiler cannot tell from a loaded one)
 typedef uint32_t uint4u_t __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t uint2u_t __attribute__((ext_vector_type(2), aligned(4)));
 struct Draw3 { int bin[3]; };
-__device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const int (&rm1)[3], const uint32_t (&x)[3]) {
+__device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&piv)[3], const int (&rm1)[3], const uint32_t (&x)[3]) {
     uint32_t first[3][8];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         if (rm1[k] <= 8) {                                    // wave-uniform
             // eight consecutive words from a 4-byte aligned address: two 16-byte loads
-            const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)row[k], b = *(const uint4u_t __attribute__((address_space(1))) *)(row[k] + 4);
+            const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)row[k];
+            uint4u_t b = {0u, 0u, 0u, 0u};
+            if (rm1[k] > 4) b = *(const uint4u_t __attribute__((address_space(1))) *)(row[k] + 4);   // (wave-uniform; masked below either way)
             first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
             first[k][4] = b.x; first[k][5] = b.y; first[k][6] = b.z; first[k][7] = b.w;
         } else {
-#pragma unroll
-            for (int q = 0; q < 7; q++) first[k][q] = row[k][6 * q + 5];
-            first[k][7] = 0u;
+            // the row's pivots (EmgpuPlan::d_pivoff): every 6th threshold of its full groups but the last, "never" elsewhere
+            const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)piv[k], b = *(const uint4u_t __attribute__((address_space(1))) *)(piv[k] + 4);
+            first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
+            first[k][4] = b.x; first[k][5] = b.y; first[k][6] = b.z; first[k][7] = b.w;
         }
     }
     Draw3 out;
@@ -99,10 +103,9 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const int (&rm1
             for (int q = 0; q < 8; q++) b += (q < rm1[k] && xp >= first[k][q]) ? 1 : 0;
             out.bin[k] = b + 1;
         } else if (rm1[k] <= 48) {
-            const int ngrp = (rm1[k] + 5) / 6;                // groups of 6 thresholds; pivot = last threshold of a group
-            int g = 0;
+            int g = 0;                                        // groups of 6 thresholds; pivot = last threshold of a group
 #pragma unroll
-            for (int q = 0; q < 7; q++) g += (q < ngrp - 1 && xp >= first[k][q]) ? 1 : 0;   // full groups entirely at or below x
+            for (int q = 0; q < 7; q++) g += (xp >= first[k][q]) ? 1 : 0;   // full groups entirely at or below x
             uint32_t t[6];
             {
                 const gptr_t gp = row[k] + 6 * g;
@@ -195,7 +198,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     // LDS instead, and row r leaves for memory -- one 256-byte store per field for the wave -- once every running lane is past it.
     // A lane more than kRing rows ahead of the slowest waits (the slowest lane sets the wave's run time either way).
     int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
-    gptr_t row[3] = {thr, thr, thr};
+    gptr_t row[3] = {thr, thr, thr}, piv[3] = {thr, thr, thr};
     double curr_hdg = 0, d_nm = 0;
     int flushed = 0; // wave-uniform: rows [0, flushed) of every lane are in memory
     while (__ballot(!done) != 0ull) {
@@ -234,6 +237,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
 #pragma unroll
                     for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)st[P.d_ivar[q]];
                     row[k] = thr + (P.d_off[k] - P.d_off[0]) + (size_t)c * (uint32_t)rm1[k];
+                    if (rm1[k] > 8 && rm1[k] <= 48) piv[k] = thr + (P.d_pivoff[k] - P.d_off[0]) + (size_t)c * 8u;   // wave-uniform
                 }
             }
             // ---- one attempt at the step's transition draw (attempt number in the Philox key)
@@ -242,7 +246,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
             uint32_t xw[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) xw[k] = word_of(rng.block(11u /* TERM_TRANS */, P.d_tvar[k], (uint32_t)ii >> 2), ii & 3);
-            const Draw3 nb = t_draw3(row, rm1, xw);
+            const Draw3 nb = t_draw3(row, piv, rm1, xw);
             // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude
             // or speed bin makes the step be drawn again -- the events applied before it stay applied, as in the reference's loop
             bool resample = false;

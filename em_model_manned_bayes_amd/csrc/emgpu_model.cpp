@@ -586,6 +586,18 @@ CompiledPlan compile_plan(const Model &m) {
     }
     P.nact = na;
     P.thr_total = (uint32_t)cp.thr.size();
+    for (int k = 0; k < nd; k++) {   // pivot rows (EmgpuPlan::d_pivoff), appended past thr_total
+        P.d_pivoff[k] = 0;
+        const int rm1 = (int)P.d_r[k] - 1;
+        if (rm1 <= 8 || rm1 > 48) continue;
+        const int64_t q = m.q_transition[P.d_tvar[k]];
+        const int ngrp = (rm1 + 5) / 6;
+        P.d_pivoff[k] = (uint32_t)cp.thr.size();
+        cp.thr.resize(cp.thr.size() + (size_t)q * 8);
+        for (int64_t j = 0; j < q; j++)
+            for (int g = 0; g < 8; g++)
+                cp.thr[P.d_pivoff[k] + (size_t)j * 8 + g] = (g < ngrp - 1) ? cp.thr[P.d_off[k] + (size_t)j * rm1 + 6 * g + 5] : 0xFFFFFFFFu;
+    }
     P.cthr_total = (uint32_t)cp.cthr.size();
     P.pthr_total = (uint32_t)cp.pthr.size();
     return cp;

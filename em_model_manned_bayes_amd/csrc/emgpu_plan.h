@@ -60,6 +60,10 @@ struct EmgpuPlan {
     uint8_t d_nb[EMGPU_MAX_ND], d_zero[EMGPU_MAX_ND];
     uint16_t d_boff[EMGPU_MAX_ND];
     uint32_t d_off[EMGPU_MAX_ND];
+    // rows of 9..48 thresholds also have a pivot row of 8 words in thr[] (offset d_pivoff, past thr_total; 0 = none): every 6th
+    // threshold (index 6q + 5) of the row's full groups but the last, 2^32-1 elsewhere -- k_terminal_propagate finds the group of a
+    // draw from two 16-byte loads instead of seven strided ones
+    uint32_t d_pivoff[EMGPU_MAX_ND];
     uint32_t d_stride_static[EMGPU_MAX_ND][EMGPU_MAX_NI]; // parents that never change, by position p
     uint32_t d_stride_cur[EMGPU_MAX_ND][EMGPU_MAX_ND];    // time-t node of dynamic var k' as parent
     uint32_t d_stride_new[EMGPU_MAX_ND][EMGPU_MAX_ND];    // (t+1) node of dynamic var k' (sampled earlier)
