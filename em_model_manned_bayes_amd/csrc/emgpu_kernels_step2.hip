@@ -48,6 +48,14 @@ __device__ __forceinline__ uint32_t mad24(uint32_t bin, uint32_t stride, uint32_
     return r;
 }
 
+template <uint32_t CUR, uint32_t NEW>
+constexpr bool s2_pre(int k) {
+    if (s2_level<NEW>(k) != 0) return false;
+    for (int q = 0; q < 4; q++)
+        if (((CUR >> (4 * k + q)) & 1u) && s2_level<NEW>(q) != 0) return false;
+    return true;
+}
+
 constexpr uint32_t kSelBase2 = 0x0c0c0c00u; // v_perm_b32 selector: bytes 1-3 zero, byte 0 <- table[borrows]
 
 // borrows of x_h - X_h over the thresholds of one padded column (SDWA reads the draw's halfword and the
@@ -219,6 +227,8 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
     constexpr int kLev[4] = {s2_level<NEW>(0), s2_level<NEW>(1), s2_level<NEW>(2), s2_level<NEW>(3)};
     constexpr int kMaxLev = kLev[0] > kLev[1] ? (kLev[0] > kLev[2] ? (kLev[0] > kLev[3] ? kLev[0] : kLev[3]) : (kLev[2] > kLev[3] ? kLev[2] : kLev[3]))
                                              : (kLev[1] > kLev[2] ? (kLev[1] > kLev[3] ? kLev[1] : kLev[3]) : (kLev[2] > kLev[3] ? kLev[2] : kLev[3]));
+    // level-0 nodes all of whose dynamic parents are level-0 nodes (through their current bins)
+    constexpr bool kPre[4] = {s2_pre<CUR, NEW>(0), s2_pre<CUR, NEW>(1), s2_pre<CUR, NEW>(2), s2_pre<CUR, NEW>(3)};
     const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
     for (int g8 = 0; g8 < G8; g8++) {
         uint4 th[ND];
@@ -269,7 +279,14 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
         };
         auto full_of = [&](int k, uint32_t col16) { return (col16 - P.d_poff16[k] * 4u) * 2u + P.d_poff[k] * 4u; };
         if (g8 >= 1 && 8 * g8 + 7 < T) {
-            // ---- interior block: every second is a draw, nothing is guarded
+            // ---- interior block: every second is a draw, nothing is guarded.
+            // A level-0 node whose parents are level-0 nodes' current bins only (kPre) knows its NEXT second's column as soon as
+            // this second's level 0 is decided: that gather is issued together with this second's level-1 gathers, so a second
+            // exposes one round trip less through L1/L2.
+            uint4 pre[ND];
+            uint32_t precol[ND];
+#pragma unroll
+            for (int k = 0; k < ND; k++) { pre[k] = make_uint4(0, 0, 0, 0); precol[k] = 0u; }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 uint32_t nb1[ND];
@@ -285,6 +302,7 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
 #pragma unroll
                     for (int k = 0; k < ND; k++) {
                         if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
+                        if (lev == 0 && j > 0 && kMaxLev >= 1 && kPre[k]) { colv[k] = precol[k]; ca[k] = pre[k]; continue; }   // requested a second ago
                         colv[k] = column_of(k, nb1);
                         ca[k] = load4(colv[k]);
                     }
@@ -325,6 +343,18 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                         if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
                         if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) nb1[k] = __builtin_amdgcn_perm(0u, ca[k].w, sel[k]);
                         else nb1[k] = __builtin_amdgcn_ubfe(ca[k].w, 4u * sel[k], 4u);   // nibble table indexed by the borrows
+                    }
+                    if (lev == 0 && j < 7 && kMaxLev >= 1) {
+#pragma unroll
+                        for (int k = 0; k < ND; k++) {
+                            if (!kPre[k] || (!REG && k >= P.nd)) continue;
+                            uint32_t col = basecol[k];     // the column of second j + 1: the new bins are its current ones
+#pragma unroll
+                            for (int q = 0; q < ND; q++)
+                                if ((CUR >> (4 * k + q)) & 1u) col = mad24(nb1[q], P.d_stride_cur[k][q] * wbytes[k], col);
+                            precol[k] = col;
+                            pre[k] = load4(col);
+                        }
                     }
                 }
 #pragma unroll
