@@ -896,6 +896,40 @@ print("fallback ok")
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_terminal_propagation_on_the_run_time_shape_instance(terminal_dir):
+    """k_terminal_propagate<0,0,0> (row lengths read from the plan: any trajectory-model shape) is never picked for the shipped
+    36/7/5-bin shape, which has its own instance; a child process with EMGPU_DEBUG_TERM_GENERIC runs it on that shape against
+    the oracle."""
+    import subprocess, sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle as O
+import em_model_manned_bayes_amd as E
+from em_model_manned_bayes_amd import native
+ctx = native.Context(0)
+t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=%r)
+n, seed = 500, 0x5EED0005
+_, samples = t.sample(n, seed=seed, ctx=ctx)
+geo, mo = t._geo_rows(samples)
+dl = t._dyn_rows()
+oms = []
+for m in t._traj:
+    pp = O.parse_model_txt(m.parameters_filename)
+    oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
+ref, ref_rows = O.propagate(oms, mo, geo, seed, dl, tmax_s=120.0)
+got, rows = native.propagate_terminal_host(ctx, [m.native for m in t._traj], geo, mo, seed, tmax_s=120.0, dyn_limits=dl)
+assert ctx.last_kernel() == "k_terminal_propagate", ctx.last_kernel()
+assert np.array_equal(rows, ref_rows)
+for L_ in range(4 * n):
+    np.testing.assert_allclose(got[L_, :rows[L_]], ref[L_, :rows[L_]], rtol=1e-6, atol=1e-6)
+print("generic ok")
+''' % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"), os.path.join(ROOT_DIR, "oracle"), str(terminal_dir))
+    env = dict(os.environ, EMGPU_DEBUG_TERM_GENERIC="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "generic ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("name", ["uncor_1200code_v2p1", "uncor_1200only_fwme_v1p2", "glider_v1", "cor_v1"])
 def test_every_short_length_matches_oracle(name, gpu_ctx, model_dir):
     """T = 1 .. 18 (every position of the 8-second block boundary, the 4-second output blocks and the
