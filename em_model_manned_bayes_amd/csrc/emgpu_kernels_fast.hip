@@ -159,7 +159,7 @@ __device__ __forceinline__ uint32_t eight_seconds_pk(const uint4 &th, const uint
         par |= acc;                                                                          // an odd count in either half: a tie
         uint32_t cnt;
         asm("v_pk_lshrrev_b16 %0, 1, %1 op_sel_hi:[0,1]" : "=v"(cnt) : "v"(acc));
-        nb2[p] = __builtin_amdgcn_perm(bnh, bnl, cnt | 0x0c000c00u);                         // dbn_sample.m:144: bins of 2p (byte 0) and 2p+1 (byte 2)
+        nb2[p] = __builtin_amdgcn_perm(bnh, bnl, cnt);                                       // dbn_sample.m:144: bins of 2p (byte 0) and 2p+1 (byte 2); bytes 1 and 3 (selector 0) are never read
         uint32_t u;                                                                          // resample_events.m:24: 0 no hit, 1 tie, 2 hit
         asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(u) : "s"(RR1), "v"(wr));
         asm("v_pk_min_u16 %0, %0, 2 op_sel_hi:[1,0]" : "+v"(u));
