@@ -106,8 +106,8 @@ __device__ __forceinline__ uint32_t zero_stream(uint32_t a, uint32_t b) { return
 //   * H_t = 0 has no T' (it would be -1): it gets T' = 0 and x_h = 0 is treated as a tie by a separate test of the
 //     draws themselves (p = 2^-16 per draw, like any other tie).
 // Thresholds beyond meff (the instance is built for M >= meff) get T' = 0xFFFF: never fired, never a tie.
-// The byte table is indexed by the number of FIRED thresholds n (entries 0-3 in bnl, 4-7 in bnh) and carries the
-// zero-bin flag in bit 7 like the by-borrows table of the exact pass.
+// The byte table is indexed by the number of FIRED thresholds n (entries 0-3 in bnl, 4-7 in bnh; for M <= 3 by 2n, the sum of
+// the min(d, 2) itself) and carries the zero-bin flag in bit 7 like the by-borrows table of the exact pass.
 template <int M>
 __device__ __forceinline__ void load_cthr_pk(uint32_t (&tp)[(M + 1) / 2], uint32_t &bnl, uint32_t &bnh, const uint32_t *__restrict__ p, int meff, uint32_t zbin1) {
     static_assert(M >= 1 && M <= 7, "the byte table has 8 entries");
@@ -132,7 +132,8 @@ __device__ __forceinline__ void load_cthr_pk(uint32_t (&tp)[(M + 1) / 2], uint32
     for (int n = 0; n <= M; n++) {
         uint32_t e = (map >> (4 * (n < meff ? n : meff))) & 15u;
         e |= (e == zbin1) ? kZeroFlag : 0u;
-        if (n < 4) lo |= e << (8 * n); else hi |= e << (8 * (n - 4));
+        const int at = (M <= 3) ? 2 * n : n;   // up to 3 thresholds: indexed by the sum itself (2 per fired threshold), no halving
+        if (at < 4) lo |= e << (8 * at); else hi |= e << (8 * (at - 4));
     }
     bnl = lo; bnh = hi;
 }
@@ -157,8 +158,8 @@ __device__ __forceinline__ uint32_t eight_seconds_pk(const uint4 &th, const uint
             if (t == 0) acc = d; else asm("v_pk_add_u16 %0, %0, %1" : "+v"(acc) : "v"(d));
         }
         par |= acc;                                                                          // an odd count in either half: a tie
-        uint32_t cnt;
-        asm("v_pk_lshrrev_b16 %0, 1, %1 op_sel_hi:[0,1]" : "=v"(cnt) : "v"(acc));
+        uint32_t cnt = acc;
+        if (M > 3) asm("v_pk_lshrrev_b16 %0, 1, %1 op_sel_hi:[0,1]" : "=v"(cnt) : "v"(acc));
         nb2[p] = __builtin_amdgcn_perm(bnh, bnl, cnt);                                       // dbn_sample.m:144: bins of 2p (byte 0) and 2p+1 (byte 2); bytes 1 and 3 (selector 0) are never read
         uint32_t u;                                                                          // resample_events.m:24: 0 no hit, 1 tie, 2 hit
         asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(u) : "s"(RR1), "v"(wr));
