@@ -1,5 +1,5 @@
 // emgpu_coop.h -- wave-cooperative dediscretize and the dense-trace store, shared by the
-// 8-second-block kernels (k_uncor_fast, k_dbn_step).
+// 8-second-block kernels (k_uncor_fast, k_dbn_step2, k_dbn_step).
 //
 // A dediscretize draw (dediscretize.m:39) is due only at an event (~0.3 per lane and 8-second
 // block), but a per-lane `if (event) philox()` makes the whole wave pay for a Philox call whenever

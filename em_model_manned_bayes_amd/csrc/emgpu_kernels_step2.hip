@@ -5,11 +5,14 @@
 //
 // What differs from the fast-branch kernel: a variable's CPT column changes every second with the
 // dynamic state (asub2ind.m:13-14 as strides over the current and the freshly drawn bins), so the
-// column -- padded to 4 or 8 words (EmgpuPlan::pthr: thresholds + byte map) -- is fetched per draw
-// with one or two 16-byte loads through L1/L2 (the tables are small: cor_v1 14 KB).  The secondary (low) halfword block of a variable is generated only at a second where
+// column is fetched per draw with ONE 16-byte gather through L1/L2 (a buffer resource, byte offsets): a 4-word column
+// {t0, t1, t2, byte map} as it is, an 8-word one in its 16-byte form (high halves two per word + nibble map; EmgpuPlan::d_poff16).
+// The columns of one dependency level are gathered together, the next second's level-0 columns as soon as this second's
+// level 0 is decided.  The secondary (low) halfword block of a variable is generated only at a second where
 // some lane of the wave met a tie between a draw's high halfword and a threshold's (p = 2^-16 per
 // compare); the draw is then redone with the full 32 bits, in place, because later seconds depend on it.
-// Bound: VALU issue (Philox + ~25 instructions per draw) and the dependent LDS round trips.
+// Interior blocks run unguarded; the first block of a trajectory and a partial last one take a rolled loop on full draws.
+// Bound: VALU issue (Philox + ~16 instructions per draw, 84 % of the cycles on cor_v1) and one exposed L1/L2 round trip per second.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
