@@ -7,8 +7,9 @@
 
 Same property and method names and argument meaning.  `.sample` runs on the GPU through
 libemgpu (there is no CPU path).  UncorEncounterModel.track runs on the GPU too, on a documented point-mass
-model in place of the un-vendored em-core dynamics ("dynamics unpinned"); its 'geodetic' branch and
-CorTerminalModel.track need em-core / DEM data and raise NotImplementedError.
+model in place of the un-vendored em-core dynamics ("dynamics unpinned"); its 'geodetic' branch needs em-core / DEM data
+and raises NotImplementedError.  CorTerminalModel.track (geometry draw -> createEncounter -> the filters of track.m) runs on
+the GPU as well, given the trajectory-model files.
 """
 import os
 
@@ -428,8 +429,9 @@ _DYN_LIMITS = {
 class CorTerminalModel(EncounterModel):
     """@CorTerminalModel: the encounter-geometry Bayesian network and its rejection sampler
     (CorTerminalModel.m:45-111, sample.m:1-82).  The 20 trajectory-model files are absent from the
-    reference mount (.MISSING_LARGE_BLOBS), so only the geometry model is loaded; .track needs them
-    and em-core and raises NotImplementedError."""
+    reference mount (.MISSING_LARGE_BLOBS): with only the geometry model in parameters_directory .sample works and
+    .createEncounter / .track raise NotImplementedError; with the files (or synthetic.write_terminal_directory's stand-ins)
+    they run on the GPU."""
 
     def __init__(self, srcData="terminalradar", parameters_directory=None, compatBackwardModels=True):
         """compatBackwardModels: CorTerminalModel.m:97,100 load the intruder LANDING reverse file as the
