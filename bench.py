@@ -48,6 +48,10 @@ CONFIGS = {
                 metric="encounter samples/sec (240 s correlated two-aircraft DBN)",
                 workload="%(model)s correlated two-aircraft joint network (stand-in for cor_v2p1, absent from the reference mount), "
                          "%(n)d encounters x %(T)d s per GPU"),
+    "cor_v2p1_like": dict(models=["cor_v2p1_like"], n=10_000_000, seed=0x5EED0003, unit="encounters/s",
+                          metric="encounter samples/sec (240 s correlated two-aircraft DBN)",
+                          workload="%(model)s: generator-made correlated network with cor_v2p1's table sizes (4x the columns of cor_v1; "
+                                   "em_model_manned_bayes_amd/synthetic.py, seed 0x5EED0003), %(n)d encounters x %(T)d s per GPU"),
     "mixed": dict(models=V1P2, n=6_250_000, seed=0x5EED0004, unit="trajectories/s",
                   metric="trajectory samples/sec (240 s uncor DBN, mixed batch over the six uncor_*_v1p2 files)",
                   workload="mixed batch over all uncor_*_v1p2 model files, model = contiguous block of the global index range, "
@@ -70,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--seconds", type=int, default=DEFAULT_T, help="trajectory length (the headline metric is quoted at 240)")
     ap.add_argument("--per-step", action="store_true", help="PER_STEP transition semantics instead of REFERENCE_AUTO")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `configs` object (BASELINE.json configs[2..4] measured in the same process after the headline)")
+    ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each entry of `configs` (2 warm-up steps before)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="minimum units timed on the CPU oracle (scaled up to ~10 s)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: allow more ranks than GPUs (ranks share devices, gloo barrier); the line says so")
@@ -79,11 +86,42 @@ def parse_args(argv=None):
 # ------------------------------------------------------------------------------------------------
 # launcher: --gpus N without a launcher's environment
 # ------------------------------------------------------------------------------------------------
+def visible_gpu_count():
+    """GPUs this process tree may use, counted WITHOUT loading a GPU runtime into this process: the KFD topology in sysfs
+    (a node with simd_count > 0 is a GPU), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES;
+    when sysfs is not readable, a child process asks the library (emgpu_device_count) and exits."""
+    import glob
+    import re
+    total = None
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if nodes:
+        total = 0
+        for f in nodes:
+            try:
+                m = re.search(r"^simd_count\s+(\d+)", open(f).read(), re.M)
+            except OSError:
+                total = None
+                break
+            total += 1 if (m and int(m.group(1)) > 0) else 0
+    if total is None:
+        code = ("import ctypes,sys; sys.path.insert(0, %r); from em_model_manned_bayes_amd import _lib as L; c = ctypes.c_int32(0); "
+                "L.lib().emgpu_device_count(ctypes.byref(c)); print(c.value)" % ROOT)
+        try:
+            total = int(subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300).stdout.decode().strip() or 0)
+        except Exception:
+            total = 0
+        return total   # the runtime already applied the *_VISIBLE_DEVICES masks
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            total = min(total, len([x for x in v.split(",") if x.strip() != ""]))
+    return total
+
+
 def launch_ranks(args, argv):
     """Start args.gpus rank processes of this script and relay rank 0's JSON line.  Nothing in this
-    process touches a GPU (torch.cuda.device_count() does not initialise one on this image)."""
-    import torch
-    have = torch.cuda.device_count()
+    process touches a GPU or imports torch: the devices are counted from sysfs (visible_gpu_count)."""
+    have = visible_gpu_count()
     if have < args.gpus and not args.oversubscribe:
         sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
         return 3
@@ -175,6 +213,12 @@ class TorchRocm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def release(self):
+        """Give the memory of dropped workloads back before the next one allocates."""
+        import gc
+        gc.collect()
+        self.torch.cuda.empty_cache()
+
     def finish(self):
         if self.world > 1:
             self.dist.destroy_process_group()
@@ -248,9 +292,10 @@ class DbnWorkload:
         total = n * self.world
         base = k * total
         blocks = [(m, base + f, c) for (m, f, c) in native.mixed_blocks(total, len(self.models), first - base, first - base + n)]
-        self.launches_per_step = max(self.launches_per_step, len(blocks))
         p, _ = native.make_params(n, self.T, self.seed, first_index=first, transition_mode=self.mode, **self.idx[0])
         native.sample_dbn_blocks_device(self.ctx, self.models, p, blocks, **self.ptrs())
+        self.blocks_per_step = max(getattr(self, "blocks_per_step", 0), len(blocks))
+        self.launches_per_step = max(self.launches_per_step, self.ctx.last_launches())   # models that share a kernel instance share ONE launch
 
     def sync(self):
         self.ctx.sync()  # surfaces deferred rejection-cap errors
@@ -272,7 +317,7 @@ class DbnWorkload:
                           "state (u8 + f32 per variable): %d B/unit; re-draws of static variables appear only in the "
                           "event-list output" % self.bytes_per_unit,
                 "values": "f32 at the boundary (f64 arithmetic inside, rounded on store); uniforms are 32-bit",
-                "models": self.names, "launches_per_step": self.launches_per_step,
+                "models": self.names, "launches_per_step": self.launches_per_step, "model_blocks_per_step": getattr(self, "blocks_per_step", 1),
                 "sharding": "global sample index, no collective"}
 
     def cpu_baseline(self, n_cpu):
@@ -290,15 +335,19 @@ class DbnWorkload:
         O.uncor_sample(om, n_cpu, T, seed, mode=O.RNG_PHILOX, per_step=self.per_step, want_events=False, want_dense=True)
         dt1 = time.perf_counter() - t0
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        n_mt = int(min(n_cpu * cores, 1_000_000))  # dense f64 outputs: 6.5 GB of host memory at 1 M
+        # all threads: thread-private output blocks (oracle/em_oracle.c em_uncor_sample_throughput_mt), about 10 s of work
+        n_cal = max(cores * 512, 4096)   # calibrate first: the sample is sized from the rate the threads really reach
         t0 = time.perf_counter()
-        O.uncor_sample_mt(om, n_mt, T, seed, cores, per_step=self.per_step)
+        O.uncor_sample_throughput_mt(om, n_cal, T, seed, cores, per_step=self.per_step)
+        n_mt = int(min(max(n_cal, n_cal / (time.perf_counter() - t0) * 10.0), 20_000_000))
+        t0 = time.perf_counter()
+        O.uncor_sample_throughput_mt(om, n_mt, T, seed, cores, per_step=self.per_step)
         dtm = time.perf_counter() - t0
         return {"value": n_mt / dtm, "unit": self.cfg["unit"], "cores": cores, "kind": "port",
-                "single_thread_value": n_cpu / dt1,
+                "single_thread_value": n_cpu / dt1, "thread_scaling": (n_mt / dtm) / (n_cpu / dt1),
                 "sample": "oracle/em_oracle.c (scalar port of the reference algorithm), Philox mode, model %s: %d units x %d s "
-                          "on %d threads in %.1f s; 1 thread: %d units in %.1f s; MATLAB itself is not installed and cannot be timed"
-                          % (self.names[0], n_mt, T, cores, dtm, n_cpu, dt1)}
+                          "on %d threads in %.1f s (thread-private dense outputs); 1 thread: %d units in %.1f s; MATLAB itself is not "
+                          "installed and cannot be timed" % (self.names[0], n_mt, T, cores, dtm, n_cpu, dt1)}
 
 
 class TerminalWorkload:
@@ -328,7 +377,8 @@ class TerminalWorkload:
         self.out = pl.empty((6, self.cap, 4 * self.n), "float32")
         self.rows = pl.empty((4 * self.n,), "int32")
         self.handles = (C.c_void_p * 10)(*[x.native._h for x in self.t._traj])
-        self.bytes_per_unit = 7335   # 75 B geometry + 2 x 2 x <=121 steps x 3 variables x 5 B
+        self.bytes_bound = 7335      # 75 B geometry + 2 x 2 x <=121 steps x 3 variables x 5 B
+        self.bytes_per_unit = self.bytes_bound   # replaced in check() by 75 + 15 B x the track-seconds the run really produced
         self.launches_per_step = 1
 
     def step(self, k):
@@ -352,12 +402,15 @@ class TerminalWorkload:
     def check(self):
         # rows < 0: a track whose inner re-draw loop hit max_resample (the reference would spin on it, createEncounter.m:218-262)
         self.failed = int((self.rows < 0).sum())
+        self.track_seconds = float(self.rows.clamp(min=0).sum().item()) / self.n
+        self.bytes_per_unit = 75.0 + 15.0 * self.track_seconds   # SURVEY.md 8d per-unit figure on the measured track lengths
         assert int(self.rows.max()) <= self.cap and int(self.rows.max()) >= 2 and self.failed <= 0.01 * 4 * self.n, (int(self.rows.min()), self.failed)
 
     def config(self):
-        return {"workload": self.cfg["workload"] % dict(n=self.n), "output": "tracks f32 [6][%d][4n] + rows; <=%d B/encounter algorithmic" % (self.cap, self.bytes_per_unit),
+        return {"workload": self.cfg["workload"] % dict(n=self.n), "output": "tracks f32 [6][%d][4n] + rows; algorithmic bytes = 75 + 15 B x track-seconds = %.0f B/encounter as measured (bound: %d)"
+                          % (self.cap, self.bytes_per_unit, self.bytes_bound),
                 "launches_per_step": 1, "sharding": "global encounter index, no collective",
-                "track_seconds_per_encounter": float(self.rows.clamp(min=0).sum().item()) / self.n,
+                "track_seconds_per_encounter": getattr(self, "track_seconds", None),
                 "tracks_over_the_redraw_cap": getattr(self, "failed", None)}
 
     def cpu_baseline(self, n_cpu):
@@ -387,19 +440,18 @@ def make_workload(args, pl, rank, world):
 
 
 # ------------------------------------------------------------------------------------------------
-def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
-    """One rank of the benchmark.  `pl` (plumbing) is TorchRocm unless a test injects its own."""
-    pl = pl or TorchRocm(rank, local_rank, world, args.oversubscribe)
-    w = make_workload(args, pl, rank, world)
-    for k in range(args.warmup):
+def measure(w, pl, args, warmup, steps):
+    """warmup untimed steps, then `steps` timed ones bracketed by barrier + device synchronisation on both sides; the launch
+    durations come from HIP events on the stream the kernels are launched on.  Returns (elapsed_s max over ranks, [ms per step])."""
+    for k in range(warmup):
         w.step(k)
     w.sync()
     pl.barrier()
-    ev = [(pl.event(), pl.event()) for _ in range(args.steps)]
+    ev = [(pl.event(), pl.event()) for _ in range(steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         pl.record(ev[k][0])
-        w.step(args.warmup + k)
+        w.step(warmup + k)
         pl.record(ev[k][1])
     pl.barrier()
     t1 = time.perf_counter()
@@ -407,33 +459,79 @@ def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
     elapsed = pl.max_over_ranks(t1 - t0)
     step_ms = [pl.elapsed_ms(a, b) for a, b in ev]
     w.check()
+    return elapsed, step_ms
+
+
+def roofline_of(w, step_ms, lib_version):
+    avg_step_s = (sum(step_ms) / len(step_ms)) * 1e-3
+    alg = w.bytes_per_unit * w.n
+    achieved = alg / avg_step_s / 1e9
+    kernel = w.kernel_name()
+    per_launch = alg / w.launches_per_step
+    per_launch = int(per_launch) if float(per_launch).is_integer() else per_launch
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+         "avg_launch_ms": avg_step_s * 1e3 / w.launches_per_step, "launches_per_step": w.launches_per_step,
+         "avg_step_ms": avg_step_s * 1e3, "algorithmic_bytes_per_launch": per_launch,
+         "algorithmic_bytes_per_unit": w.bytes_per_unit}
+    if w.launches_per_step > 1:   # blocks of different kernel instances: they run on the ctx stream and three side streams
+        r["launches_overlap"] = "avg_launch_ms is avg_step_ms / launches_per_step; single launches in a kernel trace overlap"
+    r.update(recorded_traffic(kernel, per_launch, lib_version))
+    return r
+
+
+OTHER_CONFIGS = ["cor", "cor_v2p1_like", "mixed", "terminal"]
+
+
+def other_configs(args, pl, lib_version):
+    """BASELINE.json configs[2..4] (+ the cor_v2p1-sized stand-in) at their full single-GPU sizes, measured in this process after
+    the headline: each entry carries its own ms_per_step, kernel and roofline on that config's algorithmic bytes."""
+    import copy
+    res = {}
+    for name in OTHER_CONFIGS:
+        a = copy.copy(args)
+        a.config, a.n, a.model, a.per_step = name, 0, None, False
+        cfg = CONFIGS[name]
+        try:
+            w = (TerminalWorkload if name == "terminal" else DbnWorkload)(a, cfg, pl, 0, 1)
+            elapsed, step_ms = measure(w, pl, a, 2, args.other_steps)
+            res[name] = {"metric": cfg["metric"], "value": w.n * args.other_steps / elapsed, "unit": cfg["unit"],
+                         "ms_per_step": elapsed / args.other_steps * 1e3, "steps": args.other_steps, "warmup": 2,
+                         "kernel": w.kernel_name(), "config": w.config(), "roofline": roofline_of(w, step_ms, lib_version)}
+        except Exception as e:   # an entry that cannot run says so; the headline line is still printed
+            res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        w = None
+        pl.release()
+    return res
+
+
+def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
+    """One rank of the benchmark.  `pl` (plumbing) is TorchRocm unless a test injects its own."""
+    pl = pl or TorchRocm(rank, local_rank, world, args.oversubscribe)
+    w = make_workload(args, pl, rank, world)
+    elapsed, step_ms = measure(w, pl, args, args.warmup, args.steps)
     line = None
     if rank == 0:
         from em_model_manned_bayes_amd import _lib as L
         cfg = CONFIGS[args.config]
         total = w.n * world * args.steps
-        avg_step_s = (sum(step_ms) / len(step_ms)) * 1e-3
-        alg = w.bytes_per_unit * w.n
-        achieved = alg / avg_step_s / 1e9
+        lib_version = L.lib().emgpu_version().decode()
         kernel = w.kernel_name()
         line = {
             "metric": cfg["metric"], "value": total / elapsed, "unit": cfg["unit"], "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 draws and compares; f64 dediscretize; f32 values stored", "data": "synthetic",
-            "config": dict(w.config(), kernel=kernel, lib=L.lib().emgpu_version().decode()),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
-                         "avg_launch_ms": avg_step_s * 1e3 / w.launches_per_step, "launches_per_step": w.launches_per_step,
-                         "avg_step_ms": avg_step_s * 1e3, "algorithmic_bytes_per_launch": alg // w.launches_per_step,
-                         "algorithmic_bytes_per_unit": w.bytes_per_unit},
+            "config": dict(w.config(), kernel=kernel, lib=lib_version),
+            "roofline": roofline_of(w, step_ms, lib_version),
         }
         if getattr(pl, "shared", False):
             line["oversubscribed"] = True
-        if w.launches_per_step > 1:   # a mixed batch: its blocks run on the ctx stream and three side streams
-            line["roofline"]["launches_overlap"] = "avg_launch_ms is avg_step_ms / launches_per_step; single launches in a kernel trace overlap"
-        line["roofline"].update(recorded_traffic(kernel, alg // w.launches_per_step, line["config"]["lib"]))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = w.cpu_baseline(args.cpu_sample)
+        if world == 1 and args.config == "uncor" and not args.no_other_configs and not args.model and not args.n and hasattr(pl, "release"):
+            w = None
+            pl.release()
+            line["configs"] = other_configs(args, pl, lib_version)
         out.write(json.dumps(line) + "\n")
         out.flush()
     pl.finish()

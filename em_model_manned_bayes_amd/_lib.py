@@ -122,7 +122,7 @@ SYMBOLS = [
     "emgpu_model_set_zero_bins", "emgpu_shard_range", "emgpu_device_count", "emgpu_mixed_blocks",
     "emgpu_sample_dbn_blocks_device", "emgpu_sample_dbn_multi_host", "emgpu_sample_dbn_multi_device",
     "emgpu_track_uncor_host", "emgpu_track_uncor_device", "emgpu_uncor_dynamic_limits", "emgpu_model_start_log_weight",
-    "emgpu_track_terminal_host", "emgpu_debug_parent_masks",
+    "emgpu_track_terminal_host", "emgpu_debug_parent_masks", "emgpu_last_launch_count",
 ]
 
 _lib = None
@@ -143,6 +143,8 @@ def lib():
     L.emgpu_version.restype = C.c_char_p
     L.emgpu_last_kernel_name.restype = C.c_char_p
     L.emgpu_last_kernel_name.argtypes = [C.c_void_p]
+    L.emgpu_last_launch_count.argtypes = [C.c_void_p]
+    L.emgpu_last_launch_count.restype = C.c_int32
     L.emgpu_model_load_txt.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.emgpu_model_from_arrays.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]
     L.emgpu_model_free.argtypes = [C.c_void_p]
@@ -170,7 +172,7 @@ def lib():
     L.emgpu_sample_dbn_multi_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(SampleParams), C.POINTER(SampleOut)]
     for f in (L.emgpu_track_uncor_host, L.emgpu_track_uncor_device):
         f.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(UTrackParams), C.c_void_p, C.c_void_p, C.c_void_p]
-    L.emgpu_track_terminal_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TTrackParams), C.c_void_p, C.c_void_p, C.c_int32,
+    L.emgpu_track_terminal_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(TTrackParams), C.c_void_p, C.c_void_p, C.c_int32,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
     L.emgpu_uncor_dynamic_limits.argtypes = [C.c_void_p, C.POINTER(UTrackParams), C.c_void_p] + [C.c_double] * 4 + [C.c_void_p]
     L.emgpu_ctx_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]

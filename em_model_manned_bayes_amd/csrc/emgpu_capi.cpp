@@ -52,6 +52,11 @@ struct Uploaded {
     uint32_t *d_cthr = nullptr;
     uint32_t *d_pthr = nullptr;
     double *d_bnd = nullptr;
+    void *d_planf = nullptr; // the plan itself (+ k_uncor_fast's resample thresholds) for launches that serve several models
+    void free_tables() {
+        (void)hipFree(d_thr); (void)hipFree(d_cthr); (void)hipFree(d_pthr); (void)hipFree(d_bnd); (void)hipFree(d_planf);
+        d_thr = d_cthr = d_pthr = nullptr; d_bnd = nullptr; d_planf = nullptr;
+    }
 };
 } // namespace
 
@@ -65,6 +70,7 @@ struct emgpu_ctx {
     std::map<uint64_t, Uploaded> cache; // by Model::uid
     uint64_t use_clock = 0;
     std::string last_kernel;
+    int32_t last_launches = 0;
     double *d_layers = nullptr;
     size_t d_layers_cap = 0;
     const uint32_t **d_thr_base = nullptr; // terminal propagation: per-model table pointers
@@ -388,7 +394,7 @@ int emgpu_ctx_sync(emgpu_ctx *ctx) {
 void emgpu_ctx_free(emgpu_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (auto &kv : ctx->cache) { (void)hipFree(kv.second.d_thr); (void)hipFree(kv.second.d_cthr); (void)hipFree(kv.second.d_pthr); (void)hipFree(kv.second.d_bnd); }
+    for (auto &kv : ctx->cache) kv.second.free_tables();
     (void)hipFree(ctx->d_status);
     (void)hipFree(ctx->d_layers);
     (void)hipFree(ctx->d_thr_base);
@@ -403,6 +409,7 @@ void emgpu_ctx_free(emgpu_ctx *ctx) {
 }
 
 const char *emgpu_last_kernel_name(const emgpu_ctx *ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
+int32_t emgpu_last_launch_count(const emgpu_ctx *ctx) { return ctx ? ctx->last_launches : 0; }
 
 } // extern "C"
 
@@ -420,8 +427,7 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h, const std::s
             if (!pinned || !pinned->count(kv.first)) byuse.push_back({kv.second.last_use, kv.first});
         std::sort(byuse.begin(), byuse.end());
         for (size_t q = 0; q < byuse.size() / 2; q++) {
-            Uploaded &old = ctx->cache[byuse[q].second];
-            (void)hipFree(old.d_thr); (void)hipFree(old.d_cthr); (void)hipFree(old.d_pthr); (void)hipFree(old.d_bnd);
+            ctx->cache[byuse[q].second].free_tables();
             ctx->cache.erase(byuse[q].second);
         }
     }
@@ -431,10 +437,7 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h, const std::s
     // (re)compile: tables depend on N, alpha, start, boundaries, rates
     CompiledPlan cp = emgpu::compile_plan(h->m);
     HIP_OK(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read the old tables
-    if (u.d_thr) { HIP_OK(hipFree(u.d_thr)); u.d_thr = nullptr; }
-    if (u.d_bnd) { HIP_OK(hipFree(u.d_bnd)); u.d_bnd = nullptr; }
-    if (u.d_cthr) { HIP_OK(hipFree(u.d_cthr)); u.d_cthr = nullptr; }
-    if (u.d_pthr) { HIP_OK(hipFree(u.d_pthr)); u.d_pthr = nullptr; }
+    u.free_tables();
     // 64 words of slack: k_terminal_propagate reads a row's thresholds in fixed groups (8, or every 6th up to index 41) and masks
     // the ones past the row's end instead of clamping every index
     const size_t nthr = cp.thr.size() + 64;
@@ -452,6 +455,12 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h, const std::s
     HIP_OK(hipMalloc((void **)&u.d_pthr, (u.cp.pthr.size() ? u.cp.pthr.size() : 4) * sizeof(uint32_t)));
     if (!u.cp.pthr.empty()) HIP_OK(hipMemcpy(u.d_pthr, u.cp.pthr.data(), u.cp.pthr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     u.cp.plan.pthr = u.d_pthr;
+    {   // the finished plan (device pointers in place) next to its tables, for k_uncor_fast_mixed
+        std::vector<char> pf(emgpu::plan_f_bytes());
+        emgpu::plan_f_fill(u.cp.plan, pf.data());
+        HIP_OK(hipMalloc(&u.d_planf, pf.size()));
+        HIP_OK(hipMemcpy(u.d_planf, pf.data(), pf.size(), hipMemcpyHostToDevice));
+    }
     u.version = h->m.version;
     return u;
 }
@@ -519,6 +528,7 @@ static void launch_dbn(emgpu_ctx *ctx, const Uploaded &u, const EmgpuRun &A, hip
     else if (emgpu::step_eligible(u.cp.plan, A)) e = emgpu::launch_dbn_step(u.cp.plan, A, stream, &name);
     else e = emgpu::launch_dbn_generic(u.cp.plan, A, stream, &name);
     ctx->last_kernel = name;
+    ctx->last_launches++;
     if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
 }
 
@@ -552,6 +562,7 @@ int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sa
     EmgpuRun A;
     fill_run(ctx, u, h->m, p, A);
     bind_outputs(A, h->m, p, out);
+    ctx->last_launches = 0;
     launch_dbn(ctx, u, A);
     return EMGPU_OK;
     EMGPU_CATCH
@@ -601,17 +612,60 @@ int emgpu_sample_dbn_blocks_device(emgpu_ctx *ctx, const emgpu_model *const *mod
     }
     emgpu_sample_out o = *out;
     if (!o.ld) o.ld = p->n;
-    // Blocks write disjoint columns: they go round-robin over the ctx stream and three side streams, forked from and joined
-    // back into the ctx stream with events (a caller sees one in-order operation).  Uploads happen before the fork:
-    // get_uploaded may synchronise the ctx stream.
-    int n_live = 0;
+    // Everything that can fail -- argument checks, table uploads (get_uploaded may synchronise the ctx stream), the runs and
+    // their output bindings -- happens before the first launch: an error leaves nothing in flight.
+    struct Live { const Uploaded *u; EmgpuRun A; int64_t col; int shape; };
+    std::vector<Live> live;
     for (int b = 0; b < n_blocks; b++) {
-        if (blocks[b].model < 0 || blocks[b].model >= n_models) return fail(EMGPU_ERR_ARG, "block names a model outside the list");
-        if (blocks[b].n > 0) { (void)get_uploaded(ctx, models[blocks[b].model], &pinned); n_live++; }
+        const emgpu_block &B = blocks[b];
+        if (B.model < 0 || B.model >= n_models) return fail(EMGPU_ERR_ARG, "block names a model outside the list");
+        if (B.n < 0 || B.first_index < p->first_index || B.first_index - p->first_index + (uint64_t)B.n > (uint64_t)p->n)
+            return fail(EMGPU_ERR_ARG, "block outside [first_index, first_index + n)");
+        if (B.n == 0) continue;
+        const emgpu_model *h = models[B.model];
+        const Uploaded &u = get_uploaded(ctx, h, &pinned);   // std::map: the reference stays valid, and nothing pinned is evicted
+        const int64_t col = (int64_t)(B.first_index - p->first_index);
+        emgpu_sample_params q = *p;
+        q.first_index = B.first_index; q.n = B.n;
+        if (p->indices) q.indices = p->indices + col;   // an index list covers the call's columns: block b draws its own entries
+        Live L;
+        L.u = &u; L.col = col;
+        fill_run(ctx, u, h->m, &q, L.A);
+        bind_outputs(L.A, h->m, &q, &o, col);
+        L.shape = emgpu::fast_uncor_eligible(u.cp.plan, L.A) ? emgpu::uncor_fast_shape(u.cp.plan) : -1;
+        live.push_back(L);
+    }
+    ctx->last_launches = 0;
+    if (live.empty()) return EMGPU_OK;
+    // Blocks whose models run on the same k_uncor_fast instance share ONE launch (model id per workgroup); every other block
+    // is its own launch.  With several launches they go round-robin over the ctx stream and three side streams, forked from
+    // and joined back into the ctx stream with events (a caller sees one in-order operation).
+    static const bool no_mixed = getenv("EMGPU_DEBUG_NO_MIXED_LAUNCH") != nullptr;
+    struct Launch { int shape; std::vector<int> members; };
+    std::vector<Launch> launches;
+    // the run of a shared launch is common to its blocks but for the index range and the columns: the rejection test's variables
+    // must sit at the same topological positions in every member
+    auto same_positions = [](const EmgpuRun &a, const EmgpuRun &b) { return a.pos_L == b.pos_L && a.pos_v == b.pos_v && a.pos_dh == b.pos_dh; };
+    for (int i = 0; i < (int)live.size(); i++) {
+        Launch *into = nullptr;
+        if (live[i].shape >= 0 && !no_mixed)
+            for (auto &g : launches)
+                if (g.shape == live[i].shape && (int)g.members.size() < EMGPU_MAX_MIXED && same_positions(live[g.members[0]].A, live[i].A)) { into = &g; break; }
+        if (into) into->members.push_back(i);
+        else launches.push_back(Launch{live[i].shape, {i}});
     }
     static const bool no_side = getenv("EMGPU_DEBUG_NO_SIDE_STREAMS") != nullptr;
-    const bool fork = n_live >= 2 && !no_side;
+    const bool fork = launches.size() >= 2 && !no_side;
     int used = 0; // side streams in use
+    struct Join {   // runs on every way out: side streams that were forked are joined back even when a launch fails
+        emgpu_ctx *ctx; int *used;
+        ~Join() {
+            for (int q = 0; q < *used; q++) {
+                (void)hipEventRecord(ctx->ev_join[q], ctx->side[q]);
+                (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join[q], 0);
+            }
+        }
+    } join{ctx, &used};
     if (fork) {
         if (!ctx->ev_fork) {
             HIP_OK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -622,34 +676,36 @@ int emgpu_sample_dbn_blocks_device(emgpu_ctx *ctx, const emgpu_model *const *mod
         }
         HIP_OK(hipEventRecord(ctx->ev_fork, ctx->stream));
     }
-    int live = 0;
-    for (int b = 0; b < n_blocks; b++) {
-        const emgpu_block &B = blocks[b];
-        if (B.model < 0 || B.model >= n_models) return fail(EMGPU_ERR_ARG, "block names a model outside the list");
-        if (B.n < 0 || B.first_index < p->first_index || B.first_index - p->first_index + (uint64_t)B.n > (uint64_t)p->n)
-            return fail(EMGPU_ERR_ARG, "block outside [first_index, first_index + n)");
-        if (B.n == 0) continue;
-        const emgpu_model *h = models[B.model];
-        Uploaded &u = get_uploaded(ctx, h, &pinned);
-        emgpu_sample_params q = *p;
-        q.first_index = B.first_index; q.n = B.n;
-        EmgpuRun A;
-        fill_run(ctx, u, h->m, &q, A);
-        bind_outputs(A, h->m, &q, &o, (int64_t)(B.first_index - p->first_index));
+    for (int g = 0; g < (int)launches.size(); g++) {
         hipStream_t st = ctx->stream;
         if (fork) {
-            const int lane = live % (emgpu_ctx::kSide + 1);
+            const int lane = g % (emgpu_ctx::kSide + 1);
             if (lane > 0) {
                 st = ctx->side[lane - 1];
                 if (lane > used) { HIP_OK(hipStreamWaitEvent(st, ctx->ev_fork, 0)); used = lane; }
             }
         }
-        live++;
-        launch_dbn(ctx, u, A, st);
-    }
-    for (int q = 0; q < used; q++) {
-        HIP_OK(hipEventRecord(ctx->ev_join[q], ctx->side[q]));
-        HIP_OK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[q], 0));
+        const Launch &G = launches[g];
+        if (G.members.size() == 1) { launch_dbn(ctx, *live[G.members[0]].u, live[G.members[0]].A, st); continue; }
+        // one launch for the group: the call's run with the outputs at column 0, the blocks as (plan, index range, column)
+        const void *planf[EMGPU_MAX_MIXED];
+        uint64_t first[EMGPU_MAX_MIXED];
+        int64_t nn[EMGPU_MAX_MIXED], col[EMGPU_MAX_MIXED];
+        for (size_t q = 0; q < G.members.size(); q++) {
+            const Live &L = live[G.members[q]];
+            planf[q] = L.u->d_planf; first[q] = L.A.first_index; nn[q] = L.A.n; col[q] = L.col;
+        }
+        const Live &L0 = live[G.members[0]];
+        EmgpuRun A = L0.A;
+        emgpu_sample_params q0 = *p;
+        q0.n = L0.A.n;   // bind_outputs checks col + n against ld: column 0 with the first member's n always fits
+        bind_outputs(A, models[0]->m, &q0, &o, 0);
+        A.ld = L0.A.ld;
+        const char *name = "";
+        hipError_t e = emgpu::launch_uncor_fast_mixed(A, (int)G.members.size(), planf, first, nn, col, G.shape, st, &name);
+        ctx->last_kernel = name;
+        ctx->last_launches++;
+        if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     }
     return EMGPU_OK;
     EMGPU_CATCH
@@ -665,6 +721,7 @@ int emgpu_sample_dbn_multi_device(emgpu_ctx *const *ctxs, int32_t n_ctx, const e
         emgpu_shard_range(p->n, d, n_ctx, &lo, &hi);
         emgpu_sample_params q = *p;
         q.first_index = p->first_index + (uint64_t)lo; q.n = hi - lo;
+        if (p->indices) q.indices = p->indices + lo;   // shard d draws entries [lo, hi) of the list (device pointer valid on every device: managed / peer memory is the caller's business)
         return emgpu_sample_dbn_device(ctxs[d], h, &q, &outs[d]);
     });
     EMGPU_CATCH
@@ -681,6 +738,7 @@ int emgpu_sample_dbn_multi_host(emgpu_ctx *const *ctxs, int32_t n_ctx, const emg
         emgpu_shard_range(p->n, d, n_ctx, &lo, &hi);
         emgpu_sample_params q = *p;
         q.first_index = p->first_index + (uint64_t)lo; q.n = hi - lo;
+        if (p->indices) q.indices = p->indices + lo;   // host list: shard d uploads and draws its own entries [lo, hi)
         emgpu_sample_out o = *out;
         o.ld = out->ld ? out->ld : p->n;
         o.col_offset = out->col_offset + lo;
@@ -895,10 +953,11 @@ int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int3
 // Upload / validate the trajectory models of a terminal call and publish their table pointers in ctx->d_thr_base.
 // Returns the first model's uploaded plan (the shapes every model shares).
 static uint32_t rel_piv(const EmgpuPlan &P, int k) { return P.d_pivoff[k] ? P.d_pivoff[k] - P.d_off[0] : 0u; } // pivot rows relative to the first dynamic table
-static const Uploaded *terminal_tables(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models) {
+static const Uploaded *terminal_tables(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models, const std::set<uint64_t> *also_pinned = nullptr) {
     std::vector<const uint32_t *> bases;
     const Uploaded *first = nullptr;
     std::set<uint64_t> pinned; // the table pointers collected below must survive the cache's LRU sweep
+    if (also_pinned) pinned = *also_pinned;
     for (int i = 0; i < n_models; i++) {
         if (!models[i]) throw Error(EMGPU_ERR_ARG, "null model");
         pinned.insert(models[i]->m.uid);
@@ -1004,13 +1063,16 @@ int emgpu_propagate_terminal_host(emgpu_ctx *ctx, const emgpu_model *const *mode
     EMGPU_CATCH
 }
 
-int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *gm, const emgpu_model *const *traj_models,
+int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *gm, const emgpu_model *const *traj_models, int32_t n_traj_models,
                               const emgpu_ttrack_params *p, double *sample, double *traj, int32_t cap2, int32_t *len,
                               double *meta, int32_t *attempts) {
     EMGPU_TRY
     if (!ctx || !gm || !traj_models || !p) return fail(EMGPU_ERR_ARG, "null argument");
     if (p->n < 0 || p->max_resample < 1 || p->max_track_attempts < 1 || p->max_attempts < 1 || !(p->tmax_s >= 1) || (traj && cap2 < 2))
         return fail(EMGPU_ERR_ARG, "bad n / caps / tmax_s");
+    // CheckCumTurn (CorTerminalModel.m:135-185) keeps the merged track's heading differences per lane: 2 (tmax_s + 3) - 2 <= 248
+    if (p->tmax_s > 122) return fail(EMGPU_ERR_UNSUPPORTED, "tmax_s > 122 (the reference default is 120)");
+    if (n_traj_models != 10) return fail(EMGPU_ERR_ARG, "the terminal model has 10 trajectory models (CorTerminalModel.m:84-100)");
     const Model &g = gm->m;
     for (int k = 0; k < 12; k++) if (p->idx[k] < 1 || p->idx[k] > g.n_initial) return fail(EMGPU_ERR_ARG, "geometry variable index out of range");
     CTX_LOCK(ctx);
@@ -1035,8 +1097,10 @@ int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *gm, const emgpu
         int32_t *d_len = len ? (int32_t *)dalloc(n * 2 * 4) : nullptr;
         double *d_meta = meta ? (double *)dalloc(n * 4 * 8) : nullptr;
         int32_t *d_att = (int32_t *)dalloc(n * 4);
-        const Uploaded *first = terminal_tables(ctx, traj_models, 10);
-        Uploaded &ug = get_uploaded(ctx, gm);
+        std::set<uint64_t> pinned{gm->m.uid};   // the trajectory tables' pointers are published before the geometry model's upload
+        for (int i = 0; i < n_traj_models; i++) if (traj_models[i]) pinned.insert(traj_models[i]->m.uid);
+        const Uploaded *first = terminal_tables(ctx, traj_models, n_traj_models, &pinned);
+        Uploaded &ug = get_uploaded(ctx, gm, &pinned);
         emgpu_bn_params bp;
         memset(&bp, 0, sizeof bp);
         bp.max_attempts = p->max_attempts; bp.bounds_sample = p->bounds_sample;

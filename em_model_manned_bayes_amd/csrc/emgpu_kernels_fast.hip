@@ -326,8 +326,10 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
     pbA &= 0x7F7F7F7Fu; pbB &= 0x7F7F7F7Fu;
 }
 
+// The whole kernel as a function of (plan, run, workgroup number within the run): k_uncor_fast runs it on the kernel's own arguments,
+// k_uncor_fast_mixed on the entry of the model block its workgroup belongs to.
 template <int NI, int M0, int M1, int M2>
-__global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
+__device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs &F, const int64_t wg) {
     // workers look the bin of a request up in LDS (the owner does not encode it into the request): -1.8 % on the
     // <7,4,6,6> instance too since the packed compare pass freed its registers
     constexpr bool LB = true;
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
     __shared__ double s_bnd[3][16];
     const int tid = threadIdx.x, lane = tid & 63;
     CoopLds<3, LB> &W = s_wave[tid >> 6];
-    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    const int64_t i = wg * 256 + tid;
     const bool valid = i < A.n; // lanes past the end stay alive: they serve as workers for their wave
     const uint64_t gidx = A.first_index + (uint64_t)i;
     Rng rng{(uint32_t)gidx, (uint32_t)(gidx >> 32), 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
@@ -423,9 +425,54 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
 #pragma unroll
         for (int k = 0; k < 3; k++)
             coop_fill_store_msb<3, LB>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
-                                   3u, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
+                                   3u, F.slot[k], wg * 256, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
         wave_sync(); // results of this block are consumed before the next block's workers overwrite them
     }
+}
+
+template <int NI, int M0, int M1, int M2>
+__global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
+    uncor_fast_body<NI, M0, M1, M2>(P, A, F, (int64_t)blockIdx.x);
+}
+
+// Mixed-model batch in ONE launch (RUN_1_emsample.m:13,24-47 shards by model file; SURVEY.md 8e: "model id per block"): the models
+// of the batch share this kernel instance, every model block of the batch owns a contiguous range of workgroups
+// [wg_begin[b], wg_begin[b+1]) -- ceil(n_b / 256) of them, so no workgroup meets two table sets.  What differs between the blocks
+// of one call travels in the kernel arguments (index range, first column in the shared trace); a model's plan and resample
+// thresholds sit in device memory next to its tables (uploaded once with them) and are read through the constant address space:
+// the same scalar loads that fetch a single-model launch's kernel arguments.
+struct PlanF {
+    EmgpuPlan P;
+    FastArgs F;
+};
+struct MixedBlock {
+    const PlanF *pf;
+    uint64_t first_index;
+    int64_t n, col; // trajectories; first column of the block in the call's trace
+};
+struct MixedHead {
+    EmgpuRun A; // the call's run: outputs at column 0, n / first_index unused
+    int32_t nb, _pad;
+    uint32_t wg_begin[EMGPU_MAX_MIXED + 1];
+    MixedBlock blk[EMGPU_MAX_MIXED];
+};
+template <int NI, int M0, int M1, int M2>
+__global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast_mixed(const MixedHead H) {
+    uint32_t b = 0;
+#pragma unroll
+    for (int q = 1; q < EMGPU_MAX_MIXED; q++) b += (q < H.nb && blockIdx.x >= H.wg_begin[q]) ? 1u : 0u;
+    const MixedBlock B = H.blk[b];
+    EmgpuRun A = H.A;
+    A.first_index = B.first_index; A.n = B.n;
+    const size_t c = (size_t)B.col;
+    A.init_bin = A.init_bin ? A.init_bin + c : nullptr;
+    A.init_val = A.init_val ? A.init_val + c : nullptr;
+    A.dyn_bin = A.dyn_bin ? A.dyn_bin + c : nullptr;
+    A.dyn_val = A.dyn_val ? A.dyn_val + 4 * c : nullptr;
+    A.attempts = A.attempts ? A.attempts + c : nullptr;
+    typedef const __attribute__((address_space(4))) PlanF *CPlanF;
+    const PlanF &E = *(const PlanF *)((CPlanF)B.pf);
+    uncor_fast_body<NI, M0, M1, M2>(E.P, A, E.F, (int64_t)(blockIdx.x - H.wg_begin[b]));
 }
 
 // Kernel instances by the number of DISTINCT thresholds per column of the three dynamic variables
@@ -465,8 +512,9 @@ static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs
     return hipGetLastError();
 }
 
-hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
-    if (A.n <= 0) return hipSuccess;
+int uncor_fast_shape(const EmgpuPlan &P) { return fast_shape_of(P); }
+
+static FastArgs fast_args_of(const EmgpuPlan &P) {
     FastArgs F{};
     for (int k = 0; k < 3; k++) {
         F.slot[k] = P.d_row[k];
@@ -474,6 +522,55 @@ hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t 
             if (P.a_dyn[a] == k) F.Rk[k] = P.a_R[a];
         F.RR1[k] = ((F.Rk[k] >> 16) + 1u) * 0x00010001u;
     }
+    return F;
+}
+
+size_t plan_f_bytes() { return sizeof(PlanF); }
+void plan_f_fill(const EmgpuPlan &P, void *host_buf) {
+    PlanF *pf = static_cast<PlanF *>(host_buf);
+    pf->P = P; pf->F = fast_args_of(P);
+}
+
+template <int NI, int M0, int M1, int M2>
+static hipError_t launch_mixed_t(const MixedHead &H, unsigned blocks, hipStream_t s) {
+    hipLaunchKernelGGL((k_uncor_fast_mixed<NI, M0, M1, M2>), dim3(blocks), dim3(256), 0, s, H);
+    return hipGetLastError();
+}
+
+// A: the call's run with the outputs bound at column 0; block b = n[b] trajectories from global index first[b] on, written from
+// column col[b] on, with the device-resident plan d_planf[b] (plan_f_fill); all of instance `shape`.
+hipError_t launch_uncor_fast_mixed(const EmgpuRun &A, int nb, const void *const *d_planf, const uint64_t *first, const int64_t *n, const int64_t *col,
+                                   int shape, hipStream_t s, const char **name) {
+    if (nb < 1 || nb > EMGPU_MAX_MIXED) return hipErrorInvalidValue;
+    MixedHead H{};
+    H.A = A;
+    H.nb = nb;
+    uint64_t wg = 0;
+    for (int b = 0; b < nb; b++) {
+        H.blk[b] = MixedBlock{static_cast<const PlanF *>(d_planf[b]), first[b], n[b], col[b]};
+        H.wg_begin[b] = (uint32_t)wg;
+        wg += (uint64_t)((n[b] + 255) / 256);
+    }
+    for (int b = nb; b <= EMGPU_MAX_MIXED; b++) H.wg_begin[b] = (uint32_t)wg;
+    for (int b = nb; b < EMGPU_MAX_MIXED; b++) H.blk[b] = H.blk[nb - 1];
+    if (wg == 0) return hipSuccess;
+    if (wg > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    switch (shape) {
+    case 0: *name = "k_uncor_fast_mixed<7,2,2,2>"; return launch_mixed_t<7, 2, 2, 2>(H, (unsigned)wg, s);
+    case 1: *name = "k_uncor_fast_mixed<7,2,4,2>"; return launch_mixed_t<7, 2, 4, 2>(H, (unsigned)wg, s);
+    case 2: *name = "k_uncor_fast_mixed<7,2,4,4>"; return launch_mixed_t<7, 2, 4, 4>(H, (unsigned)wg, s);
+    case 3: *name = "k_uncor_fast_mixed<7,4,2,4>"; return launch_mixed_t<7, 4, 2, 4>(H, (unsigned)wg, s);
+    case 4: *name = "k_uncor_fast_mixed<7,4,6,4>"; return launch_mixed_t<7, 4, 6, 4>(H, (unsigned)wg, s);
+    case 5: *name = "k_uncor_fast_mixed<7,4,6,6>"; return launch_mixed_t<7, 4, 6, 6>(H, (unsigned)wg, s);
+    case 6: *name = "k_uncor_fast_mixed<7,6,6,6>"; return launch_mixed_t<7, 6, 6, 6>(H, (unsigned)wg, s);
+    case 7: *name = "k_uncor_fast_mixed<9,6,6,6>"; return launch_mixed_t<9, 6, 6, 6>(H, (unsigned)wg, s);
+    default: *name = "none"; return hipErrorNotSupported;
+    }
+}
+
+hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
+    if (A.n <= 0) return hipSuccess;
+    const FastArgs F = fast_args_of(P);
     switch (fast_shape_of(P)) {
     case 0: *name = "k_uncor_fast<7,2,2,2>"; return launch_t<7, 2, 2, 2>(P, A, F, s);
     case 1: *name = "k_uncor_fast<7,2,4,2>"; return launch_t<7, 2, 4, 2>(P, A, F, s);

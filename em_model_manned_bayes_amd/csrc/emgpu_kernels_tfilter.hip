@@ -76,6 +76,7 @@ struct Track {
 __device__ bool f_check_cum_turn(const Track &T, double limit) {                             // CorTerminalModel.m:135-185
     if (!(limit < INFINITY) || T.n < 2) return false;                                        // |cumsum| > inf never holds
     const int m = T.n - 1;
+    if (m > 248) return true;   // cannot happen: emgpu_track_terminal_host refuses tmax_s > 122 (a merged track has <= 2 tmax_s + 3 rows); fail closed
     float hd[248];
     short ts[128], te[128];
     int nts = 0, nte = 0;

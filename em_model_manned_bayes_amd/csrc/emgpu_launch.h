@@ -10,6 +10,13 @@ hipError_t launch_bn(const EmgpuPlan &P, const EmgpuBnRun &A, hipStream_t s, con
 // Returns false when the (plan, run) pair is outside what the specialised kernel covers.
 bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A);
 hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
+// Mixed-model batch in one launch: nb <= EMGPU_MAX_MIXED blocks whose plans are fast-eligible and share the instance
+// uncor_fast_shape().  A model's plan lives in device memory (plan_f_bytes() bytes filled by plan_f_fill on the host, then uploaded).
+int uncor_fast_shape(const EmgpuPlan &P);
+size_t plan_f_bytes();
+void plan_f_fill(const EmgpuPlan &P, void *host_buf);
+hipError_t launch_uncor_fast_mixed(const EmgpuRun &A, int nb, const void *const *d_planf, const uint64_t *first, const int64_t *n, const int64_t *col,
+                                   int shape, hipStream_t s, const char **name);
 // The per-timestep DBN with dense output (dependent-branch models, EMGPU_TRANSITION_PER_STEP).
 bool step_eligible(const EmgpuPlan &P, const EmgpuRun &A);
 hipError_t launch_dbn_step(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);

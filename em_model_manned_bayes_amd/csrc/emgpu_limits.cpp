@@ -43,16 +43,18 @@ UncorLimits build_uncor_limits(const Model &m, const UncorTrackVars &tv) {
     const int rV = m.r_initial[tv.idxV - 1], rDH = m.r_initial[tv.idxDH - 1];
     const std::vector<double> &NV = m.N_initial[tv.idxV - 1], &NDH = m.N_initial[tv.idxDH - 1];
     const int64_t qV = m.q_initial[tv.idxV - 1], qDH = m.q_initial[tv.idxDH - 1];
-    auto cuts = [&](int idx, double *cut) {                                    // em_read.m:130-136
+    auto cuts = [&](int idx, double *cut, const char *what) {                  // em_read.m:130-136
         const std::vector<double> &b = m.boundaries[idx - 1];
+        // cut[] has 16 entries and the kernel's discretize reads cut[n - 1]: 1..15 cut points, one fewer than the variable has bins
+        if (b.size() < 3 || b.size() - 2 > 15) throw Error(EMGPU_ERR_UNSUPPORTED, std::string("track: ") + what + " needs 2..16 bins (3..17 boundaries)");
+        if ((int)b.size() - 1 != m.r_initial[idx - 1]) throw Error(EMGPU_ERR_UNSUPPORTED, std::string("track: the boundaries of ") + what + " do not match its number of bins");
         int n = 0;
         for (size_t i = 1; i + 1 < b.size(); i++) cut[n++] = b[i];
         return n;
     };
     L.discL = m.boundaries[tv.idxL - 1].empty(); L.discV = false;
-    L.ncL = L.discL ? 0 : cuts(tv.idxL, L.cutL);
-    L.ncV = cuts(tv.idxV, L.cutV);
-    if (L.ncL > 15 || L.ncV > 15) throw Error(EMGPU_ERR_UNSUPPORTED, "track: more than 16 bins in L or v");
+    L.ncL = L.discL ? 0 : cuts(tv.idxL, L.cutL, "L");
+    L.ncV = cuts(tv.idxV, L.cutV, "v");
     const bool is_idx = tv.idxG > 0 && tv.idxA > 0;
     L.ordered = is_idx && tv.idxG == 1 && tv.idxA == 2 && tv.idxL == 3 && tv.idxV == 4 && tv.idxDH == 6;   // :14,17
     std::vector<double> v_initial((size_t)rV), dh_initial((size_t)rDH);

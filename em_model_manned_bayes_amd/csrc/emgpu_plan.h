@@ -15,6 +15,7 @@
 #define EMGPU_MAX_NI 16 // initial-network variables
 #define EMGPU_MAX_ND 4  // dynamic variables (rows of the temporal map)
 #define EMGPU_MAX_R 64  // bins per variable
+#define EMGPU_MAX_MIXED 16 // model blocks of a mixed batch served by ONE launch (k_uncor_fast_mixed)
 
 // ---- RNG slot map -------------------------------------------------------
 // Philox4x32-10, key = {seed_lo, seed_hi},

@@ -523,7 +523,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         plhs[0] = mxCreateDoubleMatrix((mwSize)ni, (mwSize)n, mxREAL);
         mxArray *tr = mxCreateNumericArray(4, d4, mxDOUBLE_CLASS, mxREAL), *mt = mxCreateDoubleMatrix(4, (mwSize)n, mxREAL);
         int32_t *ln = (int32_t *)mxMalloc(sizeof(int32_t) * (2 * n + 1)), *att = (int32_t *)mxMalloc(sizeof(int32_t) * (n + 1));
-        const int rc = emgpu_track_terminal_host(ctx0(), gm, models, &p, mxGetPr(plhs[0]), mxGetPr(tr), cap2, ln, mxGetPr(mt), att);
+        const int rc = emgpu_track_terminal_host(ctx0(), gm, models, 10, &p, mxGetPr(plhs[0]), mxGetPr(tr), cap2, ln, mxGetPr(mt), att);
         if (bs) mxFree(bs);
         if (rc != EMGPU_ERR_REJECT_CAP) check(rc);           /* at the cap the accepted encounters are still returned: attempts = -1 marks the rest */
         if (nlhs > 1) plhs[1] = tr;

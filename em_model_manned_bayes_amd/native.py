@@ -175,6 +175,10 @@ class Context:
     def last_kernel(self):
         return L.lib().emgpu_last_kernel_name(self._h).decode()
 
+    def last_launches(self):
+        """Kernel launches of the last sample_dbn_*_device call on this context."""
+        return int(L.lib().emgpu_last_launch_count(self._h))
+
     def __del__(self):
         try:
             if self._h:
@@ -445,8 +449,10 @@ def track_terminal_host(ctx, geom_model, traj_models, n, seed, dyn_limits, max_c
     ni, cap2 = geom_model.n_initial, 2 * (int(tmax_s) + 3)
     sample = np.zeros((n, ni)); traj = np.zeros((n, 2, cap2, 6)); ln = np.zeros((n, 2), dtype=np.int32)
     meta = np.zeros((n, 4)); att = np.zeros(n, dtype=np.int32)
+    if len(traj_models) != 10:
+        raise ValueError("traj_models: the 10 trajectory models in CorTerminalModel.m:84-100 order")
     handles = (C.c_void_p * len(traj_models))(*[m._h for m in traj_models])
-    rc = L.lib().emgpu_track_terminal_host(ctx._h, geom_model._h, handles, C.byref(p), _p(sample), _p(traj), cap2, _p(ln), _p(meta), _p(att))
+    rc = L.lib().emgpu_track_terminal_host(ctx._h, geom_model._h, handles, len(traj_models), C.byref(p), _p(sample), _p(traj), cap2, _p(ln), _p(meta), _p(att))
     if not (allow_cap and rc == L.ERR_REJECT_CAP):   # the outputs of the encounters that were accepted are delivered either way (attempts -1 marks the rest)
         L.check(rc)
     return {"sample": sample, "traj": traj, "len": ln, "meta": meta, "attempts": att, "kernel": ctx.last_kernel()}

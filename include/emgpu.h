@@ -384,13 +384,16 @@ typedef struct {
     const double *bounds_sample;     /* n_initial x 2 row-major or NULL (sample.m:45-53)                   */
     int32_t idx[12];                 /* 1-based geometry variable ids: own {distance bearing alt speed heading intent}, then int */
 } emgpu_ttrack_params;
-int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *geom_model, const emgpu_model *const *traj_models,
+int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *geom_model, const emgpu_model *const *traj_models, int32_t n_traj_models,
                               const emgpu_ttrack_params *p, double *sample, double *traj, int32_t cap2, int32_t *len,
                               double *meta, int32_t *attempts);
 
 /* Introspection for benchmarks/tests: name of the kernel variant the last *_device call used and
  * the algorithmic output bytes per trajectory of that call (5*n_i + 5*T*n_d for dense output). */
 const char *emgpu_last_kernel_name(const emgpu_ctx *ctx);
+/* Kernel launches the last emgpu_sample_dbn_*_device call on this ctx issued (a mixed batch whose models share a kernel
+ * instance is ONE launch with the model id per workgroup; RUN_1_emsample.m:13,24-47 is the reference's per-file loop). */
+int32_t emgpu_last_launch_count(const emgpu_ctx *ctx);
 
 /* Test hooks into the plan compiler (host only): the u32 quantile thresholds of one CPT column
  * (r weights -> r-1 thresholds; bin = 1 + #{k : min(x, 2^32-2) >= out[k]} reproduces

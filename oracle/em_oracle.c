@@ -690,6 +690,42 @@ int64_t em_uncor_sample_batch_mt(const em_model_t *m, uint64_t seed, uint64_t fi
     return rc_all;
 }
 
+/* Throughput form of the same batch for bench.py's all-cores cpu_baseline leg: every thread samples chunks of `chunk`
+ * trajectories into ITS OWN dense buffers (allocated and first touched by the thread, reused chunk after chunk), so the
+ * threads do not contend on page faults of one shared multi-gigabyte output the way em_uncor_sample_batch_mt's callers made
+ * them (256 threads scaled 7.6x).  The arithmetic per trajectory is the same; *checksum (sum of all dense bins) shows the
+ * work was done and equals the sum over em_uncor_sample_batch's dense_bin for the same range. */
+int64_t em_uncor_sample_throughput_mt(const em_model_t *m, uint64_t seed, uint64_t first_index, int64_t n,
+                                      int sample_time, const em_uncor_opts_t *o, int threads, int64_t chunk, uint64_t *checksum) {
+    int64_t rc_all = 0;
+    uint64_t sum_all = 0;
+    const int nd = m->n_dyn, T = sample_time;
+    if (chunk < 1) chunk = 256;
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+#pragma omp parallel num_threads(threads) reduction(+ : sum_all)
+    {
+        uint8_t *db = (uint8_t *)malloc((size_t)chunk * (size_t)T * (size_t)nd);
+        double *dv = (double *)malloc(sizeof(double) * (size_t)chunk * (size_t)T * (size_t)nd);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t c = 0; c < n_chunks; c++) {
+            const int64_t lo = c * chunk, cnt = (lo + chunk <= n) ? chunk : n - lo;
+            int64_t rc = em_uncor_sample_batch(m, EM_RNG_PHILOX, seed, first_index + (uint64_t)lo, cnt, T, o, NULL, NULL,
+                                               NULL, NULL, NULL, NULL, NULL, 0, db, dv, NULL, NULL);
+            if (rc != 0) {
+#pragma omp critical
+                rc_all = rc;
+            } else {
+                uint64_t s = 0;
+                for (size_t q = 0; q < (size_t)cnt * (size_t)T * (size_t)nd; q++) s += db[q];
+                sum_all += s;
+            }
+        }
+        free(db); free(dv);
+    }
+    if (checksum) *checksum = sum_all;
+    return rc_all;
+}
+
 /* ------------------------------------------------------------------------- */
 /* a14 @CorTerminalModel/sample.m:29-77 -- geometry BN, one sample with its   */
 /* rejection loop: bn_sample + dediscretize (:34-42), bounds box (:45-53),    */

@@ -385,6 +385,22 @@ def uncor_sample_mt(om, n, T, seed, threads, first_index=0, per_step=False, max_
     return db, dv
 
 
+def uncor_sample_throughput_mt(om, n, T, seed, threads, first_index=0, per_step=False, max_attempts=1000, chunk=256):
+    """em_uncor_sample_throughput_mt: the dense batch on `threads` threads with thread-private output blocks; returns the
+    sum of all dense bins (equal to uncor_sample(...)['dense_bin'].sum() for the same range)."""
+    L = lib()
+    o = _UncorOpts()
+    o.idxL, o.idxV, o.idxDH = om.label_index("L"), om.label_index("v"), om.label_index("\\dot h")
+    o.max_attempts, o.per_step = int(max_attempts), int(bool(per_step))
+    chk = C.c_uint64(0)
+    L.em_uncor_sample_throughput_mt.restype = C.c_int64
+    rc = L.em_uncor_sample_throughput_mt(C.byref(om.c), C.c_uint64(seed), C.c_uint64(first_index), C.c_int64(n), C.c_int(T),
+                                         C.byref(o), C.c_int(int(threads)), C.c_int64(int(chunk)), C.byref(chk))
+    if rc != 0:
+        raise RuntimeError("em_uncor_sample_throughput_mt failed rc=%d" % rc)
+    return int(chk.value)
+
+
 def dbn_sample(om, n, t_max, seed, mode=RNG_PHILOX, first_index=0, per_step=False):
     """dbn_sample.m restated: returns init_bin [n,ni], list of raw events [K,3] (dt, var, bin)."""
     L = lib()

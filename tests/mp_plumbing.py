@@ -34,12 +34,16 @@ class _Ctx:
     def __init__(self):
         self.kernel = "oracle(em_uncor_sample_batch)"
         self.launches = []
+        self.last = 0   # oracle calls that answered the last sample_dbn_*_device call
 
     def sync(self):
         pass
 
     def last_kernel(self):
         return self.kernel
+
+    def last_launches(self):
+        return self.last
 
 
 class _Model:
@@ -79,11 +83,13 @@ class NativeShim:
     @staticmethod
     def sample_dbn_device(ctx, model, p, ld=0, col_offset=0, **ptrs):
         ctx.launches.append((0, int(p.first_index), int(p.n)))
+        ctx.last = 1
         NativeShim._write(model, int(p.n), int(p.first_index), int(p.sample_time), int(p.seed),
                           p.transition_mode == L.TRANSITION_PER_STEP, int(col_offset), ptrs)
 
     @staticmethod
     def sample_dbn_blocks_device(ctx, models, p, blocks, ld=0, col_offset=0, **ptrs):
+        ctx.last = len(blocks)
         for (m, first, cnt) in blocks:
             assert int(p.first_index) <= first and first + cnt <= int(p.first_index) + int(p.n)
             ctx.launches.append((m, first, cnt))

@@ -364,6 +364,124 @@ def test_mixed_model_batch_matches_oracle(gpu_ctx, model_dir):
 
 
 @pytest.mark.gpu
+def test_mixed_batch_is_one_launch_at_full_size_and_exact_across_every_block_boundary(model_dir):
+    """BASELINE.json configs[3] at one rank's full size: 6.25 M trajectories x 240 s over the six uncor_*_v1p2 files in ONE launch
+    (k_uncor_fast_mixed: model id per workgroup; RUN_1_emsample.m:13,24-47 is the reference's per-file loop).  Oracle slices
+    straddle every one of the five block boundaries, the two ends of the trace and the middle of every block; the
+    per-block-launch path (EMGPU_DEBUG_NO_MIXED_LAUNCH, in a child process: the switch is read once) writes the same bytes."""
+    import subprocess
+    import torch
+    from em_model_manned_bayes_amd import sharding
+    from bench import V1P2
+    pairs = [load_pair(nm_, model_dir) for nm_ in V1P2]
+    n, T, seed, first = 6_250_000, 240, 0x5EED0004, 3 * 6_250_000
+    dev = torch.device("cuda", 0)
+    ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    G4 = T // 4
+    ib = torch.zeros((7, n), dtype=torch.uint8, device=dev); iv = torch.zeros((7, n), dtype=torch.float32, device=dev)
+    db = torch.zeros((G4, 3, n), dtype=torch.int32, device=dev); dv = torch.zeros((G4, 3, n, 4), dtype=torch.float32, device=dev)
+    at = torch.zeros(n, dtype=torch.int32, device=dev)
+    # the rank's shard of a 50 M batch is itself cut at the model boundaries of the GLOBAL range; here the shard is its own batch
+    blocks = [(m, first + f, c) for (m, f, c) in native.mixed_blocks(n, 6, 0, n)]
+    p, _ = native.make_params(n, T, seed, first_index=first, **uncor_indices(pairs[0][1]))
+    native.sample_dbn_blocks_device(ctx, [pr[0] for pr in pairs], p, blocks, init_bin=ib.data_ptr(), init_val=iv.data_ptr(),
+                                    dyn_bin=db.data_ptr(), dyn_val=dv.data_ptr(), attempts=at.data_ptr())
+    ctx.sync()
+    assert ctx.last_launches() == 1 and ctx.last_kernel() == "k_uncor_fast_mixed<7,4,6,6>", (ctx.last_launches(), ctx.last_kernel())
+    oms = [O.OracleModel(pr[1]) for pr in pairs]
+
+    def check(lo, hi):   # columns [lo, hi) of the trace against the oracle, model by model
+        gb = native.unpack_dyn_bin(db[:, :, lo:hi].contiguous().cpu().numpy().view(np.uint32), T)
+        gv = native.unpack_dyn_val(dv[:, :, lo:hi].contiguous().cpu().numpy(), T)
+        gib, giv, gat = ib[:, lo:hi].cpu().numpy().T, iv[:, lo:hi].cpu().numpy().T, at[lo:hi].cpu().numpy()
+        for (m, f, c) in blocks:
+            a, b = max(lo, f - first), min(hi, f - first + c)
+            if b <= a:
+                continue
+            ref = O.uncor_sample(oms[m], b - a, T, seed, first_index=first + a, want_events=False)
+            sl = slice(a - lo, b - lo)
+            assert np.array_equal(gb[sl], ref["dense_bin"]) and np.array_equal(gv[sl], ref["dense_val"].astype(np.float32)), (m, a, b)
+            assert np.array_equal(gib[sl], ref["init_bin"]) and np.array_equal(giv[sl], ref["init_val"].astype(np.float32)), (m, a, b)
+            assert np.array_equal(gat[sl], ref["attempts"]), (m, a, b)
+    edges = [f - first for (_, f, _) in blocks[1:]]
+    for e in edges:
+        check(e - 300, e + 300)          # both sides of a model boundary: the last (partial) workgroup of one block, the first of the next
+    check(0, 300); check(n - 300, n)
+    for (_, f, c) in blocks:
+        check(f - first + c // 2, f - first + c // 2 + 200)
+    chk = (int(db.to(torch.int64).sum().item()), float(dv.double().sum().item()), int(ib.to(torch.int64).sum().item()))
+    code = r'''
+import os, sys, torch
+for q in ("", "tests", "oracle"):
+    sys.path.insert(0, os.path.join(os.environ["EMGPU_ROOT"], q))
+from em_model_manned_bayes_amd import native
+from util import load_pair, uncor_indices
+from bench import V1P2
+pairs = [load_pair(nm_, os.environ["EMGPU_MODEL_DIR"]) for nm_ in V1P2]
+n, T, seed, first = 6_250_000, 240, 0x5EED0004, 3 * 6_250_000
+dev = torch.device("cuda", 0)
+ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+ib = torch.zeros((7, n), dtype=torch.uint8, device=dev); iv = torch.zeros((7, n), dtype=torch.float32, device=dev)
+db = torch.zeros((T // 4, 3, n), dtype=torch.int32, device=dev); dv = torch.zeros((T // 4, 3, n, 4), dtype=torch.float32, device=dev)
+blocks = [(m, first + f, c) for (m, f, c) in native.mixed_blocks(n, 6, 0, n)]
+p, _ = native.make_params(n, T, seed, first_index=first, **uncor_indices(pairs[0][1]))
+native.sample_dbn_blocks_device(ctx, [pr[0] for pr in pairs], p, blocks, init_bin=ib.data_ptr(), init_val=iv.data_ptr(), dyn_bin=db.data_ptr(), dyn_val=dv.data_ptr())
+ctx.sync()
+print(ctx.last_launches(), int(db.to(torch.int64).sum().item()), repr(float(dv.double().sum().item())), int(ib.to(torch.int64).sum().item()))
+'''
+    del ib, iv, db, dv, at
+    torch.cuda.empty_cache()
+    env = dict(os.environ, EMGPU_DEBUG_NO_MIXED_LAUNCH="1", EMGPU_ROOT=ROOT, EMGPU_MODEL_DIR=str(model_dir))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    launches, s_db, s_dv, s_ib = out.stdout.decode().split()
+    assert int(launches) == 6 and (int(s_db), float(s_dv), int(s_ib)) == chk
+
+
+@pytest.mark.gpu
+def test_index_lists_are_cut_with_the_shards_and_blocks(gpu_ctx, model_dir):
+    """emgpu_sample_params.indices through the multi-context and the block entry points (ADVICE r2): shard d / block b draws ITS
+    entries of the list, not the list's head again."""
+    import torch
+    nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
+    idx = uncor_indices(pp)
+    n, T, seed = 1003, 29, 0xABCD
+    rng = np.random.default_rng(5)
+    pick = rng.permutation(50_000)[:n].astype(np.uint64) + 7
+    one = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, want_dense=True, want_events=True, indices=pick, **idx)
+    ctxs = [native.Context(0) for _ in range(3)]
+    multi = native.sample_dbn_host(ctxs, nm, n, T, seed, want_dense=True, want_events=True, indices=pick, **idx)
+    for k in ("init_bin", "init_val", "dyn_bin", "dyn_val", "attempts", "ev_count"):
+        assert np.array_equal(one[k], multi[k]), k
+    assert all(np.array_equal(a, b) for a, b in zip(one["events"], multi["events"]))
+    for q in (0, 334, 335, 669, n - 1):   # rows of the list against the oracle at their own global index
+        r1 = O.uncor_sample(O.OracleModel(pp), 1, T, seed, first_index=int(pick[q]), want_events=False)
+        assert np.array_equal(multi["dyn_bin"][q], r1["dense_bin"][0]) and np.array_equal(multi["init_bin"][q], r1["init_bin"][0])
+    # device variant and the block entry point with a device-resident list
+    dev = torch.device("cuda", 0)
+    G4 = (T + 3) // 4
+    dpick = torch.from_numpy(pick.view(np.int64)).to(dev)
+    bufs, outs = [], []
+    for d in range(3):
+        lo, hi = native.shard_range(n, d, 3)
+        b = torch.zeros((G4, 3, hi - lo), dtype=torch.int32, device=dev)
+        bufs.append(b); outs.append(dict(dyn_bin=b.data_ptr()))
+    torch.cuda.synchronize()
+    p, keep = native.make_params(n, T, seed, **idx)
+    p.indices = dpick.data_ptr()
+    native.sample_dbn_multi_device(ctxs, nm, p, outs)
+    for c in ctxs:
+        c.sync()
+    got = np.concatenate([native.unpack_dyn_bin(b.cpu().numpy().view(np.uint32), T) for b in bufs])
+    assert np.array_equal(got, one["dyn_bin"])
+    db = torch.zeros((G4, 3, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    native.sample_dbn_blocks_device(gpu_ctx, [nm, nm], p, [(0, 0, 400), (1, 400, n - 400)], dyn_bin=db.data_ptr())
+    gpu_ctx.sync()
+    assert np.array_equal(native.unpack_dyn_bin(db.cpu().numpy().view(np.uint32), T), one["dyn_bin"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,per_step", [("uncor_1200code_v2p1", False), ("cor_v1", False), ("uncor_1200only_fwme_v1p2", True), ("haa_v1", False)])
 def test_shards_written_into_one_trace_through_ld_and_col_offset(name, per_step, gpu_ctx, model_dir):
     """emgpu_sample_out.ld / col_offset on every dense kernel family and on the event-list kernel: three uneven shards of one
