@@ -74,6 +74,7 @@ def parse_args(argv=None):
     ap.add_argument("--seconds", type=int, default=DEFAULT_T, help="trajectory length (the headline metric is quoted at 240)")
     ap.add_argument("--per-step", action="store_true", help="PER_STEP transition semantics instead of REFERENCE_AUTO")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ld-pad", type=int, default=1024, help="pad the trace's leading dimension to a multiple of this many columns")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the `configs` object (BASELINE.json configs[2..4] measured in the same process after the headline)")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each entry of `configs` (2 warm-up steps before)")
@@ -244,6 +245,22 @@ def _label_indices(model):
     return dict(idx_L=lab("L"), idx_v=lab("v"), idx_dh=lab("\\dot h"))
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one (the GPU
+    boxes show 256 hardware threads behind a 16-CPU quota: 256 busy threads there are throttled to 16 cores' worth of time)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = "%d hardware threads in the affinity mask" % aff
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            if q < aff:
+                return q, note + ", cgroup cpu.max = %s/%s -> %d cores' worth of CPU time" % (quota, period, q)
+    except (OSError, ValueError):
+        pass
+    return aff, note
+
+
 class DbnWorkload:
     """uncor / cor / mixed: emgpu_sample_dbn_device (one model) or emgpu_sample_dbn_blocks_device (several
     models filling one shared trace), dense output."""
@@ -262,11 +279,13 @@ class DbnWorkload:
         m0 = self.models[0]
         self.ni, self.nd = m0.n_initial, m0.n_dyn
         G4 = (self.T + 3) // 4
-        n = self.n
-        self.init_bin = pl.empty((self.ni, n), "uint8")
-        self.init_val = pl.empty((self.ni, n), "float32")
-        self.dyn_bin = pl.empty((G4, self.nd, n), "int32")
-        self.dyn_val = pl.empty((G4, self.nd, n, 4), "float32")
+        # the trace's leading dimension (emgpu_sample_out.ld) is padded to a multiple of 1024 columns: every row of every array then
+        # starts on a 1 KiB boundary and no wave store straddles a 128-byte line (6.25 M columns unpadded cost 18 %)
+        self.ld = ld = -(-self.n // args.ld_pad) * args.ld_pad
+        self.init_bin = pl.empty((self.ni, ld), "uint8")
+        self.init_val = pl.empty((self.ni, ld), "float32")
+        self.dyn_bin = pl.empty((G4, self.nd, ld), "int32")
+        self.dyn_val = pl.empty((G4, self.nd, ld, 4), "float32")
         self.bytes_per_unit = 5 * self.ni + 5 * self.T * self.nd
         self.mode = L.TRANSITION_PER_STEP if args.per_step else L.TRANSITION_REFERENCE_AUTO
         self.per_step = args.per_step
@@ -276,7 +295,7 @@ class DbnWorkload:
 
     def ptrs(self):
         return dict(init_bin=self.init_bin.data_ptr(), init_val=self.init_val.data_ptr(),
-                    dyn_bin=self.dyn_bin.data_ptr(), dyn_val=self.dyn_val.data_ptr())
+                    dyn_bin=self.dyn_bin.data_ptr(), dyn_val=self.dyn_val.data_ptr(), ld=self.ld)
 
     def step(self, k):
         from em_model_manned_bayes_amd import sharding
@@ -307,8 +326,8 @@ class DbnWorkload:
         # size-independent sanity on the full-size output: every bin within 1..r, no NaN
         t = self.pl.torch if hasattr(self.pl, "torch") else None
         if t is not None:
-            assert int(self.init_bin.min()) >= 1 and bool(t.isfinite(self.dyn_val[:, :, : min(self.n, 100000)]).all())
-            assert int((self.dyn_bin[0] & 0xFF).min()) >= 1
+            assert int(self.init_bin[:, : self.n].min()) >= 1 and bool(t.isfinite(self.dyn_val[:, :, : min(self.n, 100000)]).all())
+            assert int((self.dyn_bin[0, :, : self.n] & 0xFF).min()) >= 1
 
     def config(self):
         return {"workload": self.cfg["workload"] % dict(model=self.names[0], n=self.n, T=self.T),
@@ -317,7 +336,7 @@ class DbnWorkload:
                           "state (u8 + f32 per variable): %d B/unit; re-draws of static variables appear only in the "
                           "event-list output" % self.bytes_per_unit,
                 "values": "f32 at the boundary (f64 arithmetic inside, rounded on store); uniforms are 32-bit",
-                "models": self.names, "launches_per_step": self.launches_per_step, "model_blocks_per_step": getattr(self, "blocks_per_step", 1),
+                "trace_ld": self.ld, "models": self.names, "launches_per_step": self.launches_per_step, "model_blocks_per_step": getattr(self, "blocks_per_step", 1),
                 "sharding": "global sample index, no collective"}
 
     def cpu_baseline(self, n_cpu):
@@ -334,7 +353,7 @@ class DbnWorkload:
         t0 = time.perf_counter()
         O.uncor_sample(om, n_cpu, T, seed, mode=O.RNG_PHILOX, per_step=self.per_step, want_events=False, want_dense=True)
         dt1 = time.perf_counter() - t0
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores, cores_note = usable_cores()
         # all threads: thread-private output blocks (oracle/em_oracle.c em_uncor_sample_throughput_mt), about 10 s of work
         n_cal = max(cores * 512, 4096)   # calibrate first: the sample is sized from the rate the threads really reach
         t0 = time.perf_counter()
@@ -344,7 +363,7 @@ class DbnWorkload:
         O.uncor_sample_throughput_mt(om, n_mt, T, seed, cores, per_step=self.per_step)
         dtm = time.perf_counter() - t0
         return {"value": n_mt / dtm, "unit": self.cfg["unit"], "cores": cores, "kind": "port",
-                "single_thread_value": n_cpu / dt1, "thread_scaling": (n_mt / dtm) / (n_cpu / dt1),
+                "single_thread_value": n_cpu / dt1, "thread_scaling": (n_mt / dtm) / (n_cpu / dt1), "cores_note": cores_note,
                 "sample": "oracle/em_oracle.c (scalar port of the reference algorithm), Philox mode, model %s: %d units x %d s "
                           "on %d threads in %.1f s (thread-private dense outputs); 1 thread: %d units in %.1f s; MATLAB itself is not "
                           "installed and cannot be timed" % (self.names[0], n_mt, T, cores, dtm, n_cpu, dt1)}

@@ -508,6 +508,7 @@ static void bind_outputs(EmgpuRun &A, const Model &m, const emgpu_sample_params 
     const int64_t ld = out->ld ? out->ld : A.n, off = out->col_offset + extra_offset;
     if (ld < 0 || off < 0 || off + A.n > ld) throw Error(EMGPU_ERR_ARG, "col_offset + n exceeds ld");
     A.ld = ld;
+    A.col0 = off;
     const size_t o = (size_t)off;
     A.init_bin = out->init_bin ? out->init_bin + o : nullptr;
     A.init_val = out->init_val ? out->init_val + o : nullptr;

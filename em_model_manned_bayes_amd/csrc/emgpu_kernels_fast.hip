@@ -328,8 +328,11 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
 
 // The whole kernel as a function of (plan, run, workgroup number within the run): k_uncor_fast runs it on the kernel's own arguments,
 // k_uncor_fast_mixed on the entry of the model block its workgroup belongs to.
-template <int NI, int M0, int M1, int M2>
-__device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs &F, const int64_t wg) {
+// MIXED: the plan is read from device memory (not from the kernel arguments): what the 8-second loop uses of it is pinned in
+// scalar registers up front (readfirstlane) -- left to the compiler these became vector loads inside the loop, each waiting
+// (vmcnt counts stores too on gfx9) for the block's trace stores.
+template <int NI, int M0, int M1, int M2, bool MIXED = false>
+__device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs &F, const int64_t i0 /* trajectory of lane 0: wave-uniform, may be < 0 */) {
     // workers look the bin of a request up in LDS (the owner does not encode it into the request): -1.8 % on the
     // <7,4,6,6> instance too since the packed compare pass freed its registers
     constexpr bool LB = true;
@@ -337,8 +340,8 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
     __shared__ double s_bnd[3][16];
     const int tid = threadIdx.x, lane = tid & 63;
     CoopLds<3, LB> &W = s_wave[tid >> 6];
-    const int64_t i = wg * 256 + tid;
-    const bool valid = i < A.n; // lanes past the end stay alive: they serve as workers for their wave
+    const int64_t i = i0 + tid;
+    const bool valid = i >= 0 && i < A.n; // lanes outside the run stay alive: they serve as workers for their wave
     const uint64_t gidx = A.first_index + (uint64_t)i;
     Rng rng{(uint32_t)gidx, (uint32_t)(gidx >> 32), 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
     const int T = A.T;
@@ -398,17 +401,27 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
     // from here on the current bin carries the zero-bin flag like the entries of the byte tables
 #pragma unroll
     for (int k = 0; k < 3; k++) cur1[k] |= (cur1[k] == (uint32_t)P.d_zero[k]) ? kZeroFlag : 0u;
-    const uint32_t iv0 = P.d_ivar[0], iv1 = P.d_ivar[1], iv2 = P.d_ivar[2];
+    auto U = [](uint32_t v) -> uint32_t { return MIXED ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v; };
+    const uint32_t iv0 = U(P.d_ivar[0]), iv1 = U(P.d_ivar[1]), iv2 = U(P.d_ivar[2]);
     const uint32_t ivs[3] = {iv0, iv1, iv2};
+    uint32_t h_tvar[3], h_meff[3], h_zero[3], h_Rk[3], h_RR1[3], h_slot[3];
+    const uint32_t *h_ctab[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        h_tvar[k] = U(P.d_tvar[k]); h_meff[k] = U(P.d_meff[k]); h_zero[k] = U(P.d_zero[k]);
+        h_Rk[k] = U(F.Rk[k]); h_RR1[k] = U(F.RR1[k]); h_slot[k] = U(F.slot[k]);
+        const uint64_t a = (uint64_t)(P.cthr + P.d_coff[k]);
+        h_ctab[k] = reinterpret_cast<const uint32_t *>(((uint64_t)U((uint32_t)(a >> 32)) << 32) | U((uint32_t)a));
+    }
     const uint32_t *col_slot = reinterpret_cast<const uint32_t *>(&W.res[lane * CoopLds<3, LB>::kStride + CoopLds<3, LB>::kSpare]);
     const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
     for (int g8 = 0; g8 < G8; g8++) {
         uint32_t pbA[3], pbB[3], need8[3], kind8[3], fill8[3];
         {
             uint32_t hit8[3], chg8[3], zer8[3];
-            eight_seconds<M0>(rng, P.d_tvar[0], iv0, g8, T, P.cthr + P.d_coff[0], P.d_meff[0], col_slot + 0, th0, bl0, bh0, (uint32_t)P.d_zero[0], F.Rk[0], F.RR1[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
-            eight_seconds<M1>(rng, P.d_tvar[1], iv1, g8, T, P.cthr + P.d_coff[1], P.d_meff[1], col_slot + 1, th1, bl1, bh1, (uint32_t)P.d_zero[1], F.Rk[1], F.RR1[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
-            eight_seconds<M2>(rng, P.d_tvar[2], iv2, g8, T, P.cthr + P.d_coff[2], P.d_meff[2], col_slot + 2, th2, bl2, bh2, (uint32_t)P.d_zero[2], F.Rk[2], F.RR1[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
+            eight_seconds<M0>(rng, h_tvar[0], iv0, g8, T, h_ctab[0], (int)h_meff[0], col_slot + 0, th0, bl0, bh0, h_zero[0], h_Rk[0], h_RR1[0], cur1[0], pbA[0], pbB[0], hit8[0], chg8[0], zer8[0]);
+            eight_seconds<M1>(rng, h_tvar[1], iv1, g8, T, h_ctab[1], (int)h_meff[1], col_slot + 1, th1, bl1, bh1, h_zero[1], h_Rk[1], h_RR1[1], cur1[1], pbA[1], pbB[1], hit8[1], chg8[1], zer8[1]);
+            eight_seconds<M2>(rng, h_tvar[2], iv2, g8, T, h_ctab[2], (int)h_meff[2], col_slot + 2, th2, bl2, bh2, h_zero[2], h_Rk[2], h_RR1[2], cur1[2], pbA[2], pbB[2], hit8[2], chg8[2], zer8[2]);
 #pragma unroll
             for (int k = 0; k < 3; k++) {      // the streams stay MSB-first: bit (7-j) <-> second j
                 need8[k] = (hit8[k] | chg8[k]) & ~zer8[k];   // a dediscretize draw is due (dediscretize.m:24-39)
@@ -425,19 +438,21 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
 #pragma unroll
         for (int k = 0; k < 3; k++)
             coop_fill_store_msb<3, LB>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
-                                   3u, F.slot[k], wg * 256, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
+                                   3u, h_slot[k], i0, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
         wave_sync(); // results of this block are consumed before the next block's workers overwrite them
     }
 }
 
 template <int NI, int M0, int M1, int M2>
 __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
-    uncor_fast_body<NI, M0, M1, M2>(P, A, F, (int64_t)blockIdx.x);
+    // workgroup w covers columns [256 w, 256 w + 256) of the TRACE: a shard that starts at column col0 leads with col0 mod 256 idle lanes
+    uncor_fast_body<NI, M0, M1, M2>(P, A, F, (int64_t)blockIdx.x * 256 - (A.col0 & 255));
 }
 
 // Mixed-model batch in ONE launch (RUN_1_emsample.m:13,24-47 shards by model file; SURVEY.md 8e: "model id per block"): the models
 // of the batch share this kernel instance, every model block of the batch owns a contiguous range of workgroups
-// [wg_begin[b], wg_begin[b+1]) -- ceil(n_b / 256) of them, so no workgroup meets two table sets.  What differs between the blocks
+// [wg_begin[b], wg_begin[b+1]) -- lined up with the trace's columns like a single-model launch, so a workgroup at a model
+// boundary exists twice with complementary live lanes and no workgroup meets two table sets.  What differs between the blocks
 // of one call travels in the kernel arguments (index range, first column in the shared trace); a model's plan and resample
 // thresholds sit in device memory next to its tables (uploaded once with them) and are read through the constant address space:
 // the same scalar loads that fetch a single-model launch's kernel arguments.
@@ -472,7 +487,7 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast_mixed(cons
     A.attempts = A.attempts ? A.attempts + c : nullptr;
     typedef const __attribute__((address_space(4))) PlanF *CPlanF;
     const PlanF &E = *(const PlanF *)((CPlanF)B.pf);
-    uncor_fast_body<NI, M0, M1, M2>(E.P, A, E.F, (int64_t)(blockIdx.x - H.wg_begin[b]));
+    uncor_fast_body<NI, M0, M1, M2, true>(E.P, A, E.F, (int64_t)(blockIdx.x - H.wg_begin[b]) * 256 - ((H.A.col0 + B.col) & 255));
 }
 
 // Kernel instances by the number of DISTINCT thresholds per column of the three dynamic variables
@@ -505,7 +520,7 @@ bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
 
 template <int NI, int M0, int M1, int M2>
 static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs &F, hipStream_t s) {
-    const int64_t blocks = (A.n + 255) / 256;
+    const int64_t blocks = (A.n + (A.col0 & 255) + 255) / 256;
     // EMGPU_DEBUG_EXTRA_LDS: bytes of unused dynamic LDS per workgroup, to study occupancy sensitivity
     static const int extra_lds = getenv("EMGPU_DEBUG_EXTRA_LDS") ? atoi(getenv("EMGPU_DEBUG_EXTRA_LDS")) : 0;
     hipLaunchKernelGGL((k_uncor_fast<NI, M0, M1, M2>), dim3((unsigned)blocks), dim3(256), (size_t)extra_lds, s, P, A, F);
@@ -549,7 +564,7 @@ hipError_t launch_uncor_fast_mixed(const EmgpuRun &A, int nb, const void *const 
     for (int b = 0; b < nb; b++) {
         H.blk[b] = MixedBlock{static_cast<const PlanF *>(d_planf[b]), first[b], n[b], col[b]};
         H.wg_begin[b] = (uint32_t)wg;
-        wg += (uint64_t)((n[b] + 255) / 256);
+        wg += (uint64_t)((n[b] + ((A.col0 + col[b]) & 255) + 255) / 256);   // lined up with the trace's columns (k_uncor_fast_mixed)
     }
     for (int b = nb; b <= EMGPU_MAX_MIXED; b++) H.wg_begin[b] = (uint32_t)wg;
     for (int b = nb; b < EMGPU_MAX_MIXED; b++) H.blk[b] = H.blk[nb - 1];

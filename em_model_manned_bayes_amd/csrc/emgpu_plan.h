@@ -103,6 +103,9 @@ struct EmgpuRun {
     uint64_t seed, first_index;
     int64_t n;
     int64_t ld; // trajectory dimension of the output arrays (>= n: a shard may be written into a larger shared trace)
+    int64_t col0; // column of the trace the output pointers below already point at: kernels that care line their workgroups up with
+                  // the TRACE's columns (multiples of 256), not with the shard's first one -- a wave store that straddles 128-byte lines
+                  // costs this write-bound path 20-35 % (measured: 6.25 M columns, shards at odd offsets)
     int32_t T, per_step;
     uint32_t flags;
     int32_t max_attempts;

@@ -632,7 +632,8 @@ def test_bench_launches_its_own_ranks(tmp_path):
     r = subprocess.run(cmd[:2] + ["--config", "mixed", "--steps", "2", "--warmup", "1", "--n", "300000", "--no-cpu-baseline"], env=env, capture_output=True, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    assert line["n_gpus"] == 1 and line["config"]["kernel"].startswith("k_uncor_fast<7,4,6,6>") and len(line["config"]["models"]) == 6
+    assert line["n_gpus"] == 1 and line["config"]["kernel"] == "k_uncor_fast_mixed<7,4,6,6>" and len(line["config"]["models"]) == 6
+    assert line["config"]["launches_per_step"] == 1 and line["config"]["model_blocks_per_step"] == 6
 
 
 @pytest.fixture(scope="module")

@@ -46,10 +46,11 @@ def _run(world, argv):
     return got
 
 
-def _unpack(bufs, T):
+def _unpack(bufs, T, n):
+    """the rank's trace (leading dimension padded by bench.py) -> its first n columns in user-facing shapes"""
     from em_model_manned_bayes_amd import native
     ib, iv, db, dv = bufs
-    return ib.T, iv.T, native.unpack_dyn_bin(db, T), native.unpack_dyn_val(dv, T)
+    return ib.T[:n], iv.T[:n], native.unpack_dyn_bin(db, T)[:n], native.unpack_dyn_val(dv, T)[:n]
 
 
 def test_two_rank_bench_runs_the_products_rank_logic(model_dir):
@@ -69,7 +70,7 @@ def test_two_rank_bench_runs_the_products_rank_logic(model_dir):
     k = warmup + steps - 1
     om = O.OracleModel(O.parse_model_txt(em_io.materialize_model("uncor_1200code_v2p1", model_dir)))
     full = O.uncor_sample(om, n * world, T, 0x5EED0002, first_index=k * world * n, want_events=False)
-    parts = [_unpack(g[3], T) for g in got]
+    parts = [_unpack(g[3], T, n) for g in got]
     assert np.array_equal(np.concatenate([p[0] for p in parts]), full["init_bin"])
     assert np.array_equal(np.concatenate([p[1] for p in parts]), full["init_val"].astype(np.float32))
     assert np.array_equal(np.concatenate([p[2] for p in parts]), full["dense_bin"])
@@ -93,7 +94,7 @@ def test_two_rank_mixed_batch_blocks(model_dir):
         lo, hi = sharding.shard_range(total, r, world)
         assert launches == sharding.mixed_batch_blocks(total, 6, lo, hi)
         assert sum(c for _, _, c in launches) == n and launches[0][1] == lo
-        ib, iv, db, dv = _unpack(got[r][3], T)
+        ib, iv, db, dv = _unpack(got[r][3], T, n)
         for (m, first, cnt) in launches:
             ref = O.uncor_sample(oms[m], cnt, T, 0x5EED0004, first_index=first, want_events=False)
             sl = slice(first - lo, first - lo + cnt)
@@ -128,7 +129,7 @@ def test_eight_rank_dry_run_covers_the_range_once(model_dir):
         assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))      # disjoint and gap-free
     for r in (0, 3, 7):   # the last step's trace of three ranks against the oracle, block by block
         lo, _ = sharding.shard_range(total, r, world)
-        ib, iv, db, dv = _unpack(got[r][3], T)
+        ib, iv, db, dv = _unpack(got[r][3], T, n)
         for (m, first, cnt) in [b for b in got[r][2] if b[1] >= 2 * total]:
             ref = O.uncor_sample(oms[m], cnt, T, 0x5EED0004, first_index=first, want_events=False)
             sl = slice(first - 2 * total - lo, first - 2 * total - lo + cnt)
