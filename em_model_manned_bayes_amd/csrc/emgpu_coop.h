@@ -83,7 +83,7 @@ __device__ __forceinline__ void coop_worker_pass(CoopLds<ND, LB> &W, int lane, u
         const uint64_t go = gidx - (uint64_t)lane + (uint64_t)owner;
         const uint32_t iv = (ivpack >> (8u * k)) & 0xFFu;
         const uint32_t sec = kind ? EMGPU_SEC_DEDISC_TRANS : EMGPU_SEC_DEDISC_RES;
-        const uint4 r4 = philox4x32_10((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner],
+        const uint4 r4 = philox4x32((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner],
                                        (sec << 28) | (iv << 20) | (uint32_t)(2 * g8 + (int)(j >> 2)), rng.k0, rng.k1);
         const uint32_t w = j & 3u;
         const uint32_t x = w == 0 ? r4.x : (w == 1 ? r4.y : (w == 2 ? r4.z : r4.w));

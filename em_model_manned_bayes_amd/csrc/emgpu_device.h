@@ -1,4 +1,4 @@
-// emgpu_device.h -- device-side primitives shared by every kernel: Philox4x32-10, the uniform,
+// emgpu_device.h -- device-side primitives shared by every kernel: Philox4x32 (EMGPU_PHILOX_ROUNDS rounds), the uniform,
 // the threshold draw and dediscretize.  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -9,11 +9,11 @@
 
 namespace emgpu {
 
-// Philox4x32-10 (Salmon et al. SC'11).  The key is wave-uniform (the seed), so the key schedule
+// Philox4x32-R, R = EMGPU_PHILOX_ROUNDS (Salmon et al. SC'11; emgpu_plan.h).  The key is wave-uniform (the seed), so the key schedule
 // lives in SGPRs / literals; each round is two v_mad_u64_u32 (32x32->64) and four XORs.
-__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+__device__ __forceinline__ uint4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < EMGPU_PHILOX_ROUNDS; r++) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         // three-input XOR in one v_bitop3_b32 (truth table 0x96), gfx950
@@ -31,7 +31,7 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 struct Rng {
     uint32_t c0, c1, attempt, k0, k1;
     __device__ __forceinline__ uint4 block(uint32_t section, uint32_t a, uint32_t blk) const {
-        return philox4x32_10(c0, c1, attempt, (section << 28) | (a << 20) | blk, k0, k1);
+        return philox4x32(c0, c1, attempt, (section << 28) | (a << 20) | blk, k0, k1);
     }
 };
 

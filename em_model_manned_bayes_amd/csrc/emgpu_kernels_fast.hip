@@ -4,7 +4,7 @@
 // loop iteration.
 //
 // Work per trajectory and 8-second block
-//   * 6 Philox4x32-10 calls: the PRIMARY (high) halfwords of the 24 transition draws
+//   * 6 Philox4x32 calls: the PRIMARY (high) halfwords of the 24 transition draws
 //     (dbn_sample.m:133,144) and 24 resample Bernoullis (resample_events.m:24) of the dynamic
 //     variables.  Variables that are not dynamic cannot change the dense trace.
 //     A draw is decided from its high 16 bits alone unless they tie with a threshold's high half
@@ -18,7 +18,7 @@
 //     across the 64 lanes of the wave through LDS and computed by "worker" lanes: one Philox call
 //     per wave serves them all instead of one divergent call per event.
 //   * 2 x (4-byte + 16-byte) stores per variable: time-blocked SoA, 1 KiB contiguous per wave store.
-// Bound: HBM writes (3635 B / trajectory) co-limited by the integer multiplies of Philox4x32-10
+// Bound: HBM writes (3635 B / trajectory) co-limited by the integer multiplies of Philox4x32
 // (DESIGN.md section 5).  No MFMA: there is no contraction on this path.
 #include <hip/hip_runtime.h>
 

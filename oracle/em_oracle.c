@@ -23,7 +23,7 @@
  * Two uniform sources:
  *   EM_RNG_MT19937 : one global MT19937 stream, genrand_res53 doubles, consumed in
  *                    exactly the order the reference calls rand.
- *   EM_RNG_PHILOX  : counter-based Philox4x32-10; every reference rand call site
+ *   EM_RNG_PHILOX  : counter-based Philox4x32-R (R = EM_PHILOX_ROUNDS); every reference rand call site
  *                    has a fixed SLOT (section, a, idx) so that the result does not
  *                    depend on draw order, GPU count or launch shape.
  */
@@ -80,12 +80,17 @@ static double mt_res53(em_mt_t *s) {
 }
 
 /* ------------------------------------------------------------------------- */
-/* Philox4x32-10 (Salmon et al., SC'11; Random123 v1.14 philox.h constants).  */
-/* ------------------------------------------------------------------------- */
-void em_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+/* Philox4x32-R (Salmon et al., SC'11; Random123 v1.14 philox.h constants).    */
+/* The generator runs EM_PHILOX_ROUNDS rounds -- the same number as the kernels' */
+/* EMGPU_PHILOX_ROUNDS (csrc/emgpu_plan.h); em_philox4x32_10 is kept for the     */
+/* published Random123 known-answer vectors, which pin the round function.       */
+#ifndef EM_PHILOX_ROUNDS
+#define EM_PHILOX_ROUNDS 7
+#endif
+void em_philox4x32_r(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
     uint32_t k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < rounds; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -97,6 +102,9 @@ void em_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+void em_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { em_philox4x32_r(ctr, key, 10, out); }
+int em_philox_rounds(void) { return EM_PHILOX_ROUNDS; }
+static void em_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { em_philox4x32_r(ctr, key, EM_PHILOX_ROUNDS, out); }
 
 /* Slot sections.  ctr = {gidx_lo, gidx_hi, attempt,
  * section<<28 | a<<20 | (idx>>2)}, word = idx & 3, key = {seed_lo, seed_hi}. */
@@ -160,7 +168,7 @@ uint32_t em_philox_word(em_rng_t *g, uint32_t section, uint32_t a, uint32_t idx)
     ctr[2] = g->attempt;
     ctr[3] = (section << 28) | (a << 20) | (idx >> 2);
     if (!g->cache_valid || memcmp(ctr, g->cache_ctr, sizeof ctr) != 0) {
-        em_philox4x32_10(ctr, g->key, g->cache_out);
+        em_philox4x32(ctr, g->key, g->cache_out);
         memcpy(g->cache_ctr, ctr, sizeof ctr);
         g->cache_valid = 1;
     }
@@ -174,7 +182,7 @@ static uint32_t em_philox_half(em_rng_t *g, uint32_t section, uint32_t a, uint32
     ctr[1] = (uint32_t)(g->gidx >> 32);
     ctr[2] = g->attempt;
     ctr[3] = (section << 28) | (a << 20) | (idx >> 3);
-    em_philox4x32_10(ctr, g->key, out);
+    em_philox4x32(ctr, g->key, out);
     return (h & 1u) ? (out[h >> 1] >> 16) : (out[h >> 1] & 0xFFFFu);
 }
 

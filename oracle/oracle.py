@@ -440,9 +440,35 @@ def geom_sample(om, n, seed, mode=RNG_PHILOX, first_index=0, bounds_sample=None,
 
 
 def philox4x32_10(ctr, key):
+    """Random123's default (10 rounds): the function the published known-answer vectors pin."""
     out = (C.c_uint32 * 4)()
     lib().em_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
-    return [int(x) for x in out]
+    return list(out)
+
+
+def philox4x32_r(ctr, key, rounds):
+    out = (C.c_uint32 * 4)()
+    lib().em_philox4x32_r((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), C.c_int(int(rounds)), out)
+    return list(out)
+
+
+def philox_rounds():
+    """Rounds the oracle's generator runs (EM_PHILOX_ROUNDS; the kernels' EMGPU_PHILOX_ROUNDS must agree)."""
+    return int(lib().em_philox_rounds())
+
+
+def philox4x32_np(c0, c1, c2, c3, k0, k1, rounds):
+    """Vectorised numpy Philox4x32-`rounds` (an independent restatement used by the statistical tests): arrays of uint32 counters."""
+    c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint64) for x in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    M = np.uint64(0xFFFFFFFF)
+    for _ in range(int(rounds)):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = (p1 >> np.uint64(32)) ^ c1 ^ k0, p1 & M, (p0 >> np.uint64(32)) ^ c3 ^ k1, p0 & M
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M
+    return tuple(x.astype(np.uint32) for x in (c0, c1, c2, c3))
 
 
 def mt_doubles(seed, n):
