@@ -803,12 +803,33 @@ int64_t em_dbn_sample_batch(const em_model_t *m, int mode, uint64_t seed, uint64
 }
 
 /* ------------------------------------------------------------------------- */
+/* Decision margins (test infrastructure for the .track parity tests): while em_margin_ptr points at a number, every        */
+/* discrete decision of the track paths -- a discretize, a limit test, a rounding, an argmin -- records how close it came   */
+/* to going the other way, |value - threshold| / scale, and the smallest such distance of the attempt is left there.        */
+/* A GPU result that parts from this restatement at some attempt is only excusable when that number is at rounding level.   */
+/* ------------------------------------------------------------------------- */
+static _Thread_local double *em_margin_ptr = NULL;
+static void em_note_s(double v, double thr, double scale) {
+    if (!em_margin_ptr || isnan(v) || isnan(thr) || isinf(v) || isinf(thr)) return;
+    if (v == thr) return;   /* an exact tie is structural (a speed clamped to its limit, an altitude of exactly 0): the same constant on both sides */
+    const double s = fmax(fmax(fabs(v), fabs(thr)), scale);
+    const double r = s > 0 ? fabs(v - thr) / s : 0.0;
+    if (r < *em_margin_ptr) *em_margin_ptr = r;
+}
+static void em_note(double v, double thr) { em_note_s(v, thr, 0.0); }
+
+/* ------------------------------------------------------------------------- */
 /* a16 discretize_bayes.m:14-22                                               */
 /* ------------------------------------------------------------------------- */
 int em_discretize_bayes(double x, const double *thresholds, int n) {
-    if (x >= thresholds[n - 1]) return n + 1;
-    for (int i = 0; i < n; i++) if (x < thresholds[i]) return i + 1;
-    return n + 1;
+    int b = n + 1;
+    if (!(x >= thresholds[n - 1]))
+        for (int i = 0; i < n; i++) if (x < thresholds[i]) { b = i + 1; break; }
+    if (em_margin_ptr) {   /* the two cut points that bound the chosen bin */
+        if (b >= 2) em_note(x, thresholds[b - 2]);
+        if (b <= n) em_note(x, thresholds[b - 1]);
+    }
+    return b;
 }
 
 /* a17 bn_dirichlet_prior.m:18-37 ('dbe' => 1/(r*q); numeric => constant), one node */
@@ -1198,7 +1219,8 @@ void em_point_mass_dynamics(const double ic[8], const double *ctrl, int T, const
 /* f32_inputs: round the sampled values to f32 first (what the GPU path's boundary hands its dynamics kernel).    */
 int em_uncor_track_one(const em_model_t *m, int mode, uint64_t *seed_io, uint64_t gidx, int T, const em_uncor_opts_t *o,
                        const em_track_vars_t *tv, int max_track_attempts, int f32_inputs,
-                       double *out /* (10T+1) x 8 or NULL */, double limits[3], int32_t *attempts_out, int32_t *sample_attempts_out) {
+                       double *out /* (10T+1) x 8 or NULL */, double limits[3], int32_t *attempts_out, int32_t *sample_attempts_out,
+                       double *margins /* mcap per-attempt decision margins, or NULL */, int mcap) {
     int ni = m->n_initial;
     int cap = (ni + m->n_dyn + 1) * T + 8; if (cap < 64) cap = 64;
     em_event_t *ev = (em_event_t *)malloc(sizeof(em_event_t) * (size_t)cap);
@@ -1240,7 +1262,11 @@ int em_uncor_track_one(const em_model_t *m, int mode, uint64_t *seed_io, uint64_
         const double ic[8] = {v_ft_s, 0, 0, h_ft, 0, asin(dh_ft_s / v_ft_s), atan(v_ft_s * dpsi / 32.2), dv_ft_ss}; /* :441-446 */
         double mm[5];
         em_point_mass_dynamics(ic, ctrl, T, dyn, out, mm);
-        em_uncor_dynamic_limits(m, tv, iv, mm[0], mm[1], mm[2], mm[3], limits);                           /* :459 */
+        if (margins && j < mcap) { margins[j] = 1e300; em_margin_ptr = &margins[j]; }
+        em_uncor_dynamic_limits(m, tv, iv, mm[0], mm[1], mm[2], mm[3], limits);                           /* :459 (its discretize calls note their margins) */
+        em_note(mm[0], min_alt); em_note(mm[1], max_alt); em_note(mm[2], limits[0]); em_note(mm[3], limits[1]);
+        em_note_s(mm[4], limits[2], fabs(h_ft));   /* a difference of altitudes: rounding scales with the altitude */
+        em_margin_ptr = NULL;
         const int viol_L = mm[0] < min_alt || mm[1] > max_alt;                                            /* :462-464 */
         const int viol_V = mm[2] < limits[0] || mm[3] > limits[1];
         const int viol_DH = mm[4] > limits[2];
@@ -1252,12 +1278,14 @@ int em_uncor_track_one(const em_model_t *m, int mode, uint64_t *seed_io, uint64_
 
 int64_t em_uncor_track_batch(const em_model_t *m, int mode, uint64_t seed, uint64_t first_index, int64_t n, int T,
                              const em_uncor_opts_t *o, const em_track_vars_t *tv, int max_track_attempts, int f32_inputs,
-                             double *out /* n x (10T+1) x 8 or NULL */, double *limits /* n x 3 */, int32_t *attempts) {
+                             double *out /* n x (10T+1) x 8 or NULL */, double *limits /* n x 3 */, int32_t *attempts,
+                             double *margins /* n x mcap or NULL */, int mcap) {
     uint64_t running = seed;   /* MT19937: one seed counter across samples AND attempts, like the reference's loop */
     for (int64_t i = 0; i < n; i++) {
         uint64_t s = mode == EM_RNG_MT19937 ? running : seed;
         int rc = em_uncor_track_one(m, mode, &s, first_index + (uint64_t)i, T, o, tv, max_track_attempts, f32_inputs,
-                                    out ? out + (size_t)i * (size_t)(10 * T + 1) * 8 : NULL, limits + 3 * i, attempts + i, NULL);
+                                    out ? out + (size_t)i * (size_t)(10 * T + 1) * 8 : NULL, limits + 3 * i, attempts + i, NULL,
+                                    margins ? margins + (size_t)i * (size_t)mcap : NULL, mcap);
         if (rc != 0) { if (rc == -3) { attempts[i] = -1; continue; } return rc; }
         if (mode == EM_RNG_MT19937) running = s;
     }
@@ -1292,10 +1320,17 @@ static double em_round1(double x) { return round(x * 10.0) / 10.0; }
 
 /* CorTerminalModel.m:135-185.  heading: degrees, n values.  Returns is_reject. */
 int em_check_cum_turn(const double *heading_in, int n, double limit) {
-    if (n < 2) return 0;
+    if (n < 2 || !(limit < INFINITY)) return 0;   /* |cumsum| > inf never holds: nothing below decides anything */
     double hd[260];
     const int m = n - 1;
-    for (int i = 0; i < m; i++) hd[i] = em_round1(em_wrapTo180(heading_in[i + 1]) - em_wrapTo180(heading_in[i]));
+    for (int i = 0; i < m; i++) {
+        const double a = em_wrapTo180(heading_in[i + 1]), b = em_wrapTo180(heading_in[i]);
+        hd[i] = em_round1(a - b);
+        if (em_margin_ptr) {   /* the rounding to one decimal: distance of 10 (a - b) to the nearest half-integer, at the headings' scale */
+            const double x = (a - b) * 10.0;
+            em_note_s(x, floor(x) + 0.5, 10.0 * fmax(fabs(a), fabs(b)));
+        }
+    }
     int ts[260], te[260], nts = 0, nte = 0;
     for (int i = 0; i + 1 < m; i++) {
         if (hd[i] == 0 && hd[i + 1] != 0) ts[nts++] = i + 2;   /* find(...) + 1, 1-based */
@@ -1316,6 +1351,7 @@ int em_check_cum_turn(const double *heading_in, int n, double limit) {
         for (int q = 0; q < k; q++) {
             if (any_break && q > seg0 && em_sign(h[q]) != em_sign(h[q - 1])) { seg0 = q; cum = 0; }
             cum += h[q];
+            em_note(fabs(cum), limit);
             if (fabs(cum) > limit) return 1;
         }
     }
@@ -1339,15 +1375,26 @@ int em_check_dynamic_limits(const em_traj_t *tr, const em_dynlims_t *dl, double 
         const int is_alt = tr->z[i] > 0 && tr->z[i] <= dl->maxAltitude_ft;
         const int is_spd = tr->v[i] >= dl->minVel_ft_s && tr->v[i] <= dl->maxVel_ft_s;
         const int is_vr = fabs(dh[i]) <= dl->maxVertRate_ft_s;
+        if (em_margin_ptr) {
+            em_note_s(tr->z[i], 0.0, 1.0); em_note(tr->z[i], dl->maxAltitude_ft);
+            em_note(tr->v[i], dl->minVel_ft_s); em_note(tr->v[i], dl->maxVel_ft_s);
+            em_note_s(fabs(dh[i]), dl->maxVertRate_ft_s, fabs(tr->z[i]));
+        }
         double rate;
         {   /* computeHeadingRate(deg2rad(heading), 1:n) */
             const int k = i + 1 < n ? i : n - 2;
             rate = em_wrapToPi(tr->hdg[k + 1] * (3.14159265358979323846 / 180.0) - tr->hdg[k] * (3.14159265358979323846 / 180.0));
         }
         const int is_turn = fabs(rate) <= dl->maxTurnRate_deg_s;
+        em_note_s(fabs(rate), dl->maxTurnRate_deg_s, 6.3);   /* a difference of headings in radians */
         int is_pitch = 1;
         if (i > 0) {
             const double ratio = fabs(tr->z[i] - tr->z[i - 1]) / tr->v[i];
+            if (em_margin_ptr) {
+                const double zs = fabs(tr->z[i]) / fmax(tr->v[i], 1e-300);   /* the ratio's rounding scales with z / v */
+                em_note_s(ratio, 1.0, zs);
+                if (ratio <= 1) em_note_s(ratio, sin(pitch_deg * (3.14159265358979323846 / 180.0)), zs);
+            }
             /* abs(asind(r)): for r > 1 MATLAB returns a complex number whose magnitude exceeds 90 */
             is_pitch = ratio <= 1 ? fabs(asin(ratio) * (180.0 / 3.14159265358979323846)) <= pitch_deg : (pitch_deg == INFINITY);
         }
@@ -1371,6 +1418,13 @@ int em_terminal_filters(const em_traj_t *tr, int own_intent, int int_intent, con
         const double d = sqrt(dx * dx + dy * dy) * 6076.1154855643;
         if (d < hmd) { hmd = d; best = k; }
     }
+    if (em_margin_ptr)   /* the argmin: how close the runner-up came, at the scale of the positions the distances are differences of */
+        for (int k = 0; k < nc; k++) {
+            if (k == best) continue;
+            const double dx = tr[0].x[ia + k] - tr[1].x[ib + k], dy = tr[0].y[ia + k] - tr[1].y[ib + k];
+            const double ps = fmax(fmax(fabs(tr[0].x[ia + k]), fabs(tr[1].x[ib + k])), fmax(fabs(tr[0].y[ia + k]), fabs(tr[1].y[ib + k])));
+            em_note_s(sqrt(dx * dx + dy * dy) * 6076.1154855643, hmd, ps * 6076.1154855643);
+        }
     meta[0] = tr[0].t[ia + best]; meta[1] = hmd; meta[2] = tr[1].z[ib + best] - tr[0].z[ia + best];
     if (!(fabs(meta[0]) <= 10)) return 0;                                                    /* :84-87 */
     const int is_long = nc >= o->min_enc_time_s;                                             /* :90-91 */
@@ -1379,15 +1433,21 @@ int em_terminal_filters(const em_traj_t *tr, int own_intent, int int_intent, con
         close[a] = low[a] = 0;
         for (int i = 0; i < tr[a].n; i++) {
             const double d_ft = hypot(tr[a].x[i], tr[a].y[i]) * 1.68781;
-            if (d_ft <= o->thres_dist_ft) { close[a] = 1; if (tr[a].z[i] <= o->thres_alt_low_ft) low[a] = 1; }
+            em_note(d_ft, o->thres_dist_ft);
+            if (d_ft <= o->thres_dist_ft) { close[a] = 1; em_note(tr[a].z[i], o->thres_alt_low_ft); if (tr[a].z[i] <= o->thres_alt_low_ft) low[a] = 1; }
         }
         double dh[260], zmax = tr[a].z[0], zmin = tr[a].z[0];                                /* CheckIntentVertical :228-266 */
         em_forward_rate(tr[a].z, tr[a].n, dh);
         for (int i = 1; i < tr[a].n; i++) { zmax = fmax(zmax, tr[a].z[i]); zmin = fmin(zmin, tr[a].z[i]); }
         const double thr_time = (zmax - zmin) / o->thres_vertrate_ft_s, pth = fmin(0.2, thr_time / (double)tr[a].n);
         int nclimb = 0, ndesc = 0;
-        for (int i = 0; i < tr[a].n; i++) { nclimb += dh[i] >= o->thres_vertrate_ft_s; ndesc += dh[i] <= -o->thres_vertrate_ft_s; }
+        for (int i = 0; i < tr[a].n; i++) {
+            nclimb += dh[i] >= o->thres_vertrate_ft_s; ndesc += dh[i] <= -o->thres_vertrate_ft_s;
+            em_note_s(dh[i], o->thres_vertrate_ft_s, fabs(tr[a].z[i])); em_note_s(dh[i], -o->thres_vertrate_ft_s, fabs(tr[a].z[i]));
+        }
         climb[a] = (double)nclimb / tr[a].n >= pth; descend[a] = (double)ndesc / tr[a].n >= pth;
+        em_note((double)nclimb / tr[a].n, pth); em_note((double)ndesc / tr[a].n, pth);
+        em_note(0.2, thr_time / (double)tr[a].n);
     }
     const int prox1 = (close[0] && low[0]) || !close[0];                                     /* :98-112 */
     const int prox2 = int_intent == 3 ? !(close[1] && low[1]) : ((close[1] && low[1]) || !close[1]);
@@ -1396,7 +1456,7 @@ int em_terminal_filters(const em_traj_t *tr, int own_intent, int int_intent, con
     if (own_intent == 1 || own_intent == 2) {
         const double c = own_intent == 1 ? 90.0 : 270.0;
         int ok = 0;
-        for (int i = 0; i < tr[0].n; i++) ok += tr[0].hdg[i] >= c - 30 && tr[0].hdg[i] <= c + 30;
+        for (int i = 0; i < tr[0].n; i++) { ok += tr[0].hdg[i] >= c - 30 && tr[0].hdg[i] <= c + 30; em_note(tr[0].hdg[i], c - 30); em_note(tr[0].hdg[i], c + 30); }
         own_ok = (own_intent == 1 ? descend[0] : climb[0]) && ((double)ok / tr[0].n >= .95);
     }
     const int dyn1 = em_check_dynamic_limits(&tr[0], &dl[0], o->max_cum_turn_deg[0], o->pitch_deg[0]);   /* :140-141 */
@@ -1428,15 +1488,20 @@ static void em_merge_tracks(const double *fwd, int rf, const double *bck, int rb
 /* sample [n][n_i], traj [n][2][cap2][6] (cap2 >= 2*(tmax+2)), len [n][2], meta [n][4], attempts [n] (-1: cap).           */
 int64_t em_terminal_track_batch(const em_model_t *const *models, uint64_t seed, uint64_t first_index, int64_t n, const em_geom_opts_t *go,
                                 const em_dynlims_t *dl, const em_ttrack_opts_t *o, double tmax_s, int max_resample, int max_track_attempts,
-                                int f32, double *sample, double *traj, int32_t *len, double *meta, int32_t *attempts, int cap2) {
+                                int f32, double *sample, double *traj, int32_t *len, double *meta, int32_t *attempts, int cap2,
+                                double *margins /* n x mcap per-attempt decision margins, or NULL */, int mcap) {
     const em_model_t *gm = models[0];
     const int ni = gm->n_initial, cap = (int)tmax_s + 3;
-    double *out4 = (double *)malloc(sizeof(double) * 4 * (size_t)cap * 6);
+    int64_t rc_all = 0;
+#pragma omp parallel for schedule(dynamic, 4)
     for (int64_t i = 0; i < n; i++) {
+        double *out4 = (double *)malloc(sizeof(double) * 4 * (size_t)cap * 6);
         attempts[i] = -1;
         for (int j = 0; j < max_track_attempts; j++) {
             double v[128]; int32_t S[128], att;
-            if (em_geom_sample_batch(gm, EM_RNG_PHILOX, seed + (uint64_t)j, first_index + (uint64_t)i, 1, go, S, v, &att) != 0) { free(out4); return -3; }
+            double *mg = (margins && j < mcap) ? &margins[(size_t)i * (size_t)mcap + j] : NULL;
+            if (mg) *mg = 1e300;
+            if (em_geom_sample_batch(gm, EM_RNG_PHILOX, seed + (uint64_t)j, first_index + (uint64_t)i, 1, go, S, v, &att) != 0) { rc_all = -3; break; }
             if (f32) for (int k = 0; k < ni; k++) v[k] = (float)v[k];
             double geo[12]; int32_t mo[4]; int32_t rows[4];
             for (int a = 0; a < 2; a++) {                                                   /* createEncounter.m:21-49 */
@@ -1448,11 +1513,15 @@ int64_t em_terminal_track_batch(const em_model_t *const *models, uint64_t seed, 
             }
             const int oi = (int)geo[5], ii_ = (int)geo[11];
             mo[0] = 2 * (oi - 1); mo[1] = mo[0] + 1; mo[2] = 4 + 2 * (ii_ - 1); mo[3] = mo[2] + 1;
-            if (em_propagate_batch(models + 1, mo, EM_RNG_PHILOX, seed + (uint64_t)j, first_index + (uint64_t)i, 1, geo, dl, tmax_s, max_resample, out4, rows, cap) != 0) continue;
+            em_margin_ptr = mg;   /* the discretize calls of the propagation and every test of the filters note their margins */
+            const int prc = em_propagate_batch(models + 1, mo, EM_RNG_PHILOX, seed + (uint64_t)j, first_index + (uint64_t)i, 1, geo, dl, tmax_s, max_resample, out4, rows, cap);
+            if (prc != 0) { em_margin_ptr = NULL; continue; }
             em_traj_t tr[2];
             for (int a = 0; a < 2; a++) em_merge_tracks(out4 + (size_t)(2 * a) * cap * 6, rows[2 * a], out4 + (size_t)(2 * a + 1) * cap * 6, rows[2 * a + 1], f32, &tr[a]);
             double mt[4];
-            if (!em_terminal_filters(tr, oi, ii_, dl, o, mt)) continue;
+            const int good = em_terminal_filters(tr, oi, ii_, dl, o, mt);
+            em_margin_ptr = NULL;
+            if (!good) continue;
             attempts[i] = j + 1;
             for (int k = 0; k < ni; k++) sample[i * ni + k] = v[k];
             for (int a = 0; a < 2; a++) {
@@ -1465,7 +1534,7 @@ int64_t em_terminal_track_batch(const em_model_t *const *models, uint64_t seed, 
             for (int k = 0; k < 4; k++) meta[4 * i + k] = mt[k];
             break;
         }
+        free(out4);
     }
-    free(out4);
-    return 0;
+    return rc_all;
 }

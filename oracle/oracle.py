@@ -615,7 +615,7 @@ def point_mass_dynamics(ic, ctrl, dyn):
 
 
 def uncor_track(om, n, T, seed, mode=RNG_PHILOX, first_index=0, is_quantize500=False, is_rotorcraft=False,
-                max_track_attempts=200, max_attempts=1000, f32_inputs=True, want_tracks=True):
+                max_track_attempts=200, max_attempts=1000, f32_inputs=True, want_tracks=True, margin_cap=64):
     """UncorEncounterModel.track restated (UncorEncounterModel.m:318-471, coordSys 'NEU') on the documented point-mass
     dynamics.  Returns dict: tracks [n, 10T+1, 8], limits [n, 3], attempts [n] (-1: cap hit)."""
     L = lib()
@@ -626,12 +626,13 @@ def uncor_track(om, n, T, seed, mode=RNG_PHILOX, first_index=0, is_quantize500=F
     tv = _track_vars(om, is_rotorcraft)
     tracks = np.zeros((n, 10 * T + 1, 8)) if want_tracks else None
     limits = np.zeros((n, 3)); attempts = np.zeros(n, dtype=np.int32)
+    margins = np.full((n, margin_cap), np.inf)   # [i, j]: how close attempt j + 1 of trajectory i came to deciding differently (em_note)
     rc = L.em_uncor_track_batch(C.byref(om.c), C.c_int(mode), C.c_uint64(seed), C.c_uint64(first_index), C.c_int64(n), C.c_int(T),
                                 C.byref(o), C.byref(tv), C.c_int(max_track_attempts), C.c_int(int(f32_inputs)),
-                                _ptr(tracks) if want_tracks else None, _ptr(limits), _ptr(attempts))
+                                _ptr(tracks) if want_tracks else None, _ptr(limits), _ptr(attempts), _ptr(margins), C.c_int(margin_cap))
     if rc != 0:
         raise RuntimeError("em_uncor_track_batch failed rc=%d" % rc)
-    return {"tracks": tracks, "limits": limits, "attempts": attempts}
+    return {"tracks": tracks, "limits": limits, "attempts": attempts, "margins": margins}
 
 
 class _TTrackOpts(C.Structure):
@@ -647,7 +648,7 @@ def check_cum_turn(heading_deg, limit):
 
 def terminal_track(gom, oms, n, seed, dyn_limits, max_cum_turn_deg, pitch_deg, first_index=0, tmax_s=120.0, min_enc_time_s=30.0,
                    thres_dist_ft=2.5 * 6076, thres_alt_low_ft=750.0, thres_vertrate_ft_s=5.0, bounds_sample=None, max_track_attempts=500,
-                   max_attempts=100000, max_resample=100000, f32=True):
+                   max_attempts=100000, max_resample=100000, f32=True, margin_cap=None):
     """CorTerminalModel.track restated (track.m:45-150), Philox mode.  gom: geometry OracleModel; oms: the 10 trajectory OracleModels with the
     stay prior.  Returns dict like native.track_terminal_host."""
     L = lib()
@@ -676,9 +677,11 @@ def terminal_track(gom, oms, n, seed, dyn_limits, max_cum_turn_deg, pitch_deg, f
     ni, cap2 = gom.n_initial, 2 * (int(tmax_s) + 3)
     sample = np.zeros((n, ni)); traj = np.zeros((n, 2, cap2, 6)); ln = np.zeros((n, 2), dtype=np.int32)
     meta = np.zeros((n, 4)); att = np.zeros(n, dtype=np.int32)
+    mcap = int(max_track_attempts if margin_cap is None else margin_cap)
+    margins = np.full((n, mcap), np.inf)   # [i, j]: how close attempt j + 1 of encounter i came to deciding differently (em_note)
     rc = L.em_terminal_track_batch(ptrs, C.c_uint64(seed), C.c_uint64(first_index), C.c_int64(n), C.byref(go), dl, C.byref(o), C.c_double(tmax_s),
                                    C.c_int(max_resample), C.c_int(max_track_attempts), C.c_int(int(f32)), _ptr(sample), _ptr(traj), _ptr(ln), _ptr(meta),
-                                   _ptr(att), C.c_int(cap2))
+                                   _ptr(att), C.c_int(cap2), _ptr(margins), C.c_int(mcap))
     if rc != 0:
         raise RuntimeError("em_terminal_track_batch failed rc=%d" % rc)
-    return {"sample": sample, "traj": traj, "len": ln, "meta": meta, "attempts": att}
+    return {"sample": sample, "traj": traj, "len": ln, "meta": meta, "attempts": att, "margins": margins}

@@ -7,7 +7,7 @@ import pytest
 
 import oracle as O
 from em_model_manned_bayes_amd import native, _lib as L
-from util import load_pair, uncor_indices, assert_uncor_parity
+from util import load_pair, uncor_indices, assert_uncor_parity, assert_parting_only_on_a_threshold
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -732,12 +732,19 @@ def test_terminal_ten_million_encounters_properties(terminal_dir):
     assert 300 < total_seconds / (5 * n) < 488        # mean track-seconds per encounter (4 tracks x <= 122)
 
 
-@pytest.mark.parametrize("actypes", [("GENERIC", "GENERIC"), ("GENERIC", "RTCA228_A1"), ("RTCA228_A3", "RTCA228_A2")])
-def test_terminal_track_matches_oracle(actypes, terminal_dir, gpu_ctx):
+@pytest.mark.parametrize("actypes,n,cap,cum_override", [(("GENERIC", "GENERIC"), 2000, 150, None), (("GENERIC", "RTCA228_A1"), 120, 600, None),
+                                                        (("RTCA228_A3", "RTCA228_A2"), 120, 600, None), (("GENERIC", "GENERIC"), 600, 150, (40.0, 40.0))])
+def test_terminal_track_matches_oracle(actypes, n, cap, cum_override, terminal_dir, gpu_ctx):
     """CorTerminalModel.track (track.m:45-150) on the GPU -- rounds of geometry draw -> createEncounter inputs -> propagation ->
     the filters of CorTerminalModel.m:117-316 -- against the oracle's per-encounter loop on the same Philox keys (attempt j:
-    seed + j).  The accepted attempt, the geometry sample and the CPA metadata must be identical; the tracks are the f32 values
-    the propagation kernel stores (1e-6: device and host libm differ in the last bits before that rounding)."""
+    seed + j).  EVERY encounter must accept the same attempt (or stay rejected through the cap on both sides), except where the
+    oracle's decision margin of the parting attempt is at rounding level: the filters read the tracks as the f32 values the
+    propagation stores, and those agree between device and host to 1e-6 only (libm's last bits before the rounding), so a value
+    may sit on a threshold to within two f32 ulps (tolerance 2^-22 relative to the value's own scale; oracle em_note covers
+    every discretize of the propagation, every limit test, the CPA argmin, the fractions and the rounding of CheckCumTurn).
+    The geometry sample, lengths and CPA metadata of agreeing encounters are identical, the tracks agree to 1e-6.
+    cum_override: GENERIC limits with a 40 degree cumulative-turn limit -- CheckCumTurn (CorTerminalModel.m:135-185) becomes the
+    deciding filter for a good part of the encounters (checked against a run without it)."""
     t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=terminal_dir)
     t.acType1, t.acType2 = actypes
     gom = O.OracleModel(O.parse_model_txt(t.parameters_filename))
@@ -747,23 +754,29 @@ def test_terminal_track_matches_oracle(actypes, terminal_dir, gpu_ctx):
         oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
     d = (t.dynLimits1, t.dynLimits2)
     cum, pitch = [x["maxCumTurn_deg"] for x in d], [x["pitch_deg"] for x in d]
-    n, seed, cap = 120, 0xF2, 600
+    if cum_override:
+        cum = list(cum_override)
+    seed = 0xF2
     ref = O.terminal_track(gom, oms, n, seed, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap)
     got = native.track_terminal_host(gpu_ctx, t.native, [m.native for m in t._traj], n, seed, t._dyn_rows(), cum, pitch, first_index=5,
                                      max_track_attempts=cap, allow_cap=True)   # encounters still rejected after `cap` attempts: -1 on both sides
-    if (ref["attempts"] < 0).any():
+    if (ref["attempts"] < 0).any() and n <= 200:
         with pytest.raises(L.EmgpuError) as ei:
             native.track_terminal_host(gpu_ctx, t.native, [m.native for m in t._traj], n, seed, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap)
         assert ei.value.code == L.ERR_REJECT_CAP
     assert "k_terminal_filter" in got["kernel"] and "k_terminal_propagate" in got["kernel"]
-    same = got["attempts"] == ref["attempts"]
-    assert same.mean() >= 0.98, (got["attempts"], ref["attempts"])
+    same = assert_parting_only_on_a_threshold(got["attempts"], ref["attempts"], ref["margins"], 2.0 ** -22, "encounter")
+    assert same.sum() >= n - max(2, n // 500), "more threshold coincidences than %d encounters can explain: %d" % (n, (~same).sum())
     ok = same & (ref["attempts"] > 0)
     if actypes == ("GENERIC", "GENERIC"):   # (the RTCA limits -- pitch 15 deg, cumulative turn 180 deg, narrow speed bands -- reject most synthetic tracks:
-        assert ok.sum() >= n // 4 and (ref["attempts"][ok] > 1).any()   #  there the test is that both sides reject the same attempts)
+        assert ok.sum() >= n // 5 and (ref["attempts"][ok] > 1).any()   #  there the test is that both sides reject the same attempts)
+    if cum_override:   # CheckCumTurn decides: without the limit the same encounters accept an earlier attempt
+        free = O.terminal_track(gom, oms, n, seed, t._dyn_rows(), [np.inf, np.inf], pitch, first_index=5, max_track_attempts=cap)
+        decided = (free["attempts"] > 0) & (free["attempts"] != ref["attempts"])
+        assert decided.sum() >= n // 20, decided.sum()
     assert np.array_equal(got["sample"][ok], ref["sample"][ok]) and np.array_equal(got["len"][ok], ref["len"][ok])
     np.testing.assert_allclose(got["meta"][ok], ref["meta"][ok], rtol=1e-5, atol=1e-3)
-    for i in np.flatnonzero(ok):
+    for i in np.flatnonzero(ok)[:400]:
         for a in range(2):
             k = ref["len"][i, a]
             np.testing.assert_allclose(got["traj"][i, a, :k], ref["traj"][i, a, :k], rtol=1e-6, atol=1e-5)
@@ -998,7 +1011,7 @@ import sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
 import oracle as O
 from em_model_manned_bayes_amd import native
-from util import load_pair, uncor_indices, assert_uncor_parity
+from util import load_pair, uncor_indices, assert_uncor_parity, assert_parting_only_on_a_threshold
 ctx = native.Context(0)
 for name, T, n in [("glider_v1", 61, 600), ("cor_v1", 24, 300)]:
     nm, pp, _ = load_pair(name, %r)
@@ -1169,8 +1182,10 @@ def test_sample2track_kernel_reproduces_the_committed_golden(gpu_ctx):
 def test_uncor_track_matches_oracle(name, rot, T, gpu_ctx, model_dir):
     """UncorEncounterModel.track on the GPU (UncorEncounterModel.m:419-471): rounds of sample -> point-mass dynamics ->
     getDynamicLimits rejection, against the oracle's per-trajectory loop on the same Philox keys (attempt j: seed + j).
-    Accepted attempt and limits must be identical; the f64 track agrees to 1e-9 relative (device vs host libm differ in
-    the last bits of asin / atan / tan / sin / cos, and 600 steps accumulate them)."""
+    Accepted attempt and limits must be identical -- a trajectory may part only at an attempt whose decision margin (oracle em_note:
+    altitude / speed / vertical-rate against their limits, the min / max altitude and speed against the cut points that pick the limits)
+    is below 1e-9 --; the f64 track agrees to 1e-9 relative (device vs host libm differ in the last bits of asin / atan / tan / sin /
+    cos, and 600 steps accumulate them)."""
     nm, pp, _ = load_pair(name, model_dir)
     om = O.OracleModel(pp)
     n, seed = 3000, 0xF1
@@ -1178,8 +1193,10 @@ def test_uncor_track_matches_oracle(name, rot, T, gpu_ctx, model_dir):
     ref = O.uncor_track(om, n, T, seed, first_index=77, is_rotorcraft=rot)
     assert "k_uncor_track" in got["kernel"]
     assert (ref["attempts"] > 1).sum() > 10, "the case must exercise the retry rounds"
-    same = got["attempts"] == ref["attempts"]
-    assert same.mean() > 0.999, "accept/reject decisions differ beyond libm noise: %d of %d" % ((~same).sum(), n)
+    # every trajectory accepts the same attempt, or parted where a value of that attempt sat within 1e-9 (relative) of the limit or
+    # cut point it was tested against (the f64 tracks of the two sides agree to 1e-9: asserted below)
+    same = assert_parting_only_on_a_threshold(got["attempts"], ref["attempts"], ref["margins"], 1e-9, "trajectory")
+    assert same.sum() >= n - 3, "more threshold coincidences than 3000 trajectories can explain: %d" % (~same).sum()
     assert np.array_equal(got["limits"][same], ref["limits"][same])
     np.testing.assert_allclose(got["tracks"][same], ref["tracks"][same], rtol=1e-9, atol=1e-6)
     # the sampled part is bit-exact: time 0 row = the initial state of the accepted attempt

@@ -125,3 +125,21 @@ def random_model(rs, dependent=None, nd=None):
     return {"n_initial": ni, "n_transition": nt, "labels_initial": labels_initial, "labels_transition": labels_transition,
             "G_initial": Gi, "G_transition": Gt, "r_initial": r, "r_transition": rt, "N_initial": N_initial,
             "N_transition": N_transition, "boundaries": boundaries, "resample_rates": rates}
+
+
+def assert_parting_only_on_a_threshold(got_attempts, ref_attempts, margins, tol, what):
+    """.track parity, exact about every disagreement: GPU and oracle must accept the SAME attempt of every unit, except where the
+    oracle's own decision margin of the attempt at which the two part (one side accepted it, the other rejected it) is below `tol`
+    -- some value of that attempt sat on a threshold to within the last bits in which device and host arithmetic differ.
+    margins[i, j]: smallest |value - threshold| / scale over every discrete decision of attempt j + 1 of unit i (oracle em_note).
+    Returns the boolean mask of units that agree."""
+    got_attempts, ref_attempts = np.asarray(got_attempts), np.asarray(ref_attempts)
+    same = got_attempts == ref_attempts
+    for i in np.flatnonzero(~same):
+        g, r = int(got_attempts[i]), int(ref_attempts[i])
+        j = min(x for x in (g, r) if x > 0)   # the earlier acceptance: the other side rejected this attempt (or never accepted)
+        assert j - 1 < margins.shape[1], "%s %d: parted at attempt %d, beyond the recorded margins" % (what, i, j)
+        m = margins[i, j - 1]
+        assert m < tol, ("%s %d: GPU accepted attempt %d, oracle attempt %d, but no decision of attempt %d was closer than %.3g "
+                         "to its threshold (tolerance %.3g): a real accept/reject difference" % (what, i, g, r, j, m, tol))
+    return same

@@ -1,0 +1,43 @@
+"""tools/track_disagreements.py -- how often do the GPU .track paths and the CPU checker part, and at what decision margin?
+Diagnostic companion of tests/test_gpu_parity.py::test_terminal_track_matches_oracle / test_uncor_track_matches_oracle (which
+assert that every parting sits on a threshold).  Needs a GPU; prints one line per case."""
+import os, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for q in ("", "tests", "oracle"):
+    sys.path.insert(0, os.path.join(ROOT, q))
+import numpy as np
+import oracle as O
+import em_model_manned_bayes_amd as E
+from em_model_manned_bayes_amd import native, synthetic
+from util import load_pair
+
+ctx = native.Context(0)
+tmp = tempfile.mkdtemp()
+for name, rot, T in (("uncor_1200code_v2p1", False, 60), ("uncor_1200only_rotorcraft_v1p2", True, 45), ("glider_v1", False, 37)):
+    nm, pp, _ = load_pair(name, tmp)
+    n = 20000
+    got = native.track_uncor_host(ctx, nm, n, T, 0xF1, first_index=77, is_rotorcraft=rot, want_tracks=False) if "want_tracks" in native.track_uncor_host.__code__.co_varnames else native.track_uncor_host(ctx, nm, n, T, 0xF1, first_index=77, is_rotorcraft=rot)
+    ref = O.uncor_track(O.OracleModel(pp), n, T, 0xF1, first_index=77, is_rotorcraft=rot, want_tracks=False)
+    d = np.flatnonzero(got["attempts"] != ref["attempts"])
+    print("uncor.track %s: %d of %d part; margins at the parting attempt: %s" % (name, len(d), n,
+          [float(ref["margins"][i, min(x for x in (got["attempts"][i], ref["attempts"][i]) if x > 0) - 1]) for i in d]))
+tdir = synthetic.write_terminal_directory(tempfile.mkdtemp())
+t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=tdir)
+gom = O.OracleModel(O.parse_model_txt(t.parameters_filename))
+oms = []
+for m in t._traj:
+    pp = O.parse_model_txt(m.parameters_filename)
+    oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
+for act, cum_override in ((("GENERIC", "GENERIC"), None), (("GENERIC", "RTCA228_A1"), None), (("RTCA228_A3", "RTCA228_A2"), None), (("GENERIC", "GENERIC"), (40.0, 40.0))):
+    t.acType1, t.acType2 = act
+    dd = (t.dynLimits1, t.dynLimits2)
+    cum, pitch = [x["maxCumTurn_deg"] for x in dd], [x["pitch_deg"] for x in dd]
+    if cum_override:
+        cum = list(cum_override)
+    n, cap = 4000, 150
+    ref = O.terminal_track(gom, oms, n, 0xF2, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap)
+    got = native.track_terminal_host(ctx, t.native, [m.native for m in t._traj], n, 0xF2, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap, allow_cap=True)
+    d = np.flatnonzero(got["attempts"] != ref["attempts"])
+    print("terminal.track %s cum %s: %d of %d part (%d accepted, %d attempt-encounters); margins: %s" % (act, cum, len(d), n, (ref["attempts"] > 0).sum(),
+          np.where(ref["attempts"] > 0, ref["attempts"], cap).sum(),
+          [float(ref["margins"][i, min(x for x in (got["attempts"][i], ref["attempts"][i]) if x > 0) - 1]) for i in d]))
