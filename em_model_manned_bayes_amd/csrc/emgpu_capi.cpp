@@ -1092,7 +1092,7 @@ int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *gm, const emgpu
         uint8_t *d_acc = (uint8_t *)dalloc(n);
         uint64_t *d_gidx[2] = {(uint64_t *)dalloc(n * 8), (uint64_t *)dalloc(n * 8)};
         int64_t *d_slot[2] = {(int64_t *)dalloc(n * 8), (int64_t *)dalloc(n * 8)};
-        uint32_t *d_count = (uint32_t *)dalloc(4);
+        uint32_t *d_count = (uint32_t *)dalloc(4 * emgpu::compact_scratch_words((int64_t)n));
         double *d_sample = sample ? (double *)dalloc(n * ni * 8) : nullptr;
         double *d_traj = traj ? (double *)dalloc(n * 2 * (size_t)cap2 * 6 * 8) : nullptr;
         int32_t *d_len = len ? (int32_t *)dalloc(n * 2 * 4) : nullptr;
@@ -1325,7 +1325,7 @@ static int track_uncor_rounds(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_
         uint8_t *d_acc = (uint8_t *)dalloc(n);
         uint64_t *d_gidx[2] = {(uint64_t *)dalloc(n * 8), (uint64_t *)dalloc(n * 8)};
         int64_t *d_slot[2] = {(int64_t *)dalloc(n * 8), (int64_t *)dalloc(n * 8)};
-        uint32_t *d_count = (uint32_t *)dalloc(4);
+        uint32_t *d_count = (uint32_t *)dalloc(4 * emgpu::compact_scratch_words((int64_t)n));
         HIP_OK(hipMemcpyAsync(d_lim, L.table.data(), L.table.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         HIP_OK(hipStreamSynchronize(ctx->stream)); // L.table is a local
         Uploaded &u = get_uploaded(ctx, h);

@@ -41,6 +41,56 @@ __device__ __forceinline__ void ut_sincos(double x, double &s, double &c) {
     c = (q == 0) ? cr : ((q == 1) ? -sr : ((q == 2) ? -cr : sr));
 }
 
+// 1 / d to about one ulp: v_rcp_f64 and two Newton steps (5 instructions; the IEEE-exact division the compiler emits for `/`
+// takes ~35).  The dynamics divide six times per 0.1 s step as written; here they share ONE reciprocal, 1 / (v cos(phi)).
+__device__ __forceinline__ double ut_rcp(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    return fma(x, e, x);
+}
+// atan on fdlibm's breakpoints (s_atan.c: 7/16, 11/16, 19/16, 39/16) and kernel polynomial, the reduced argument's division through
+// ut_rcp, selects instead of branches; within 2 ulp of the library's (checked against numpy in tests/test_host.py's restatement).
+__device__ __forceinline__ double ut_atan(double x) {
+    const double ax = fabs(x);
+    double num = ax, den = 1.0, c = 0.0;
+    if (ax >= 0.4375) { num = fma(2.0, ax, -1.0); den = 2.0 + ax; c = 4.63647609000806093515e-01; }      // atan(0.5)
+    if (ax >= 0.6875) { num = ax - 1.0; den = ax + 1.0; c = 7.85398163397448278999e-01; }                 // atan(1)
+    if (ax >= 1.1875) { num = ax - 1.5; den = fma(1.5, ax, 1.0); c = 9.82793723247329054082e-01; }        // atan(1.5)
+    if (ax >= 2.4375) { num = -1.0; den = ax; c = 1.57079632679489655800e+00; }                           // atan(inf)
+    const double t = num * ut_rcp(den);
+    const double z = t * t, w = z * z;
+    double s1 = fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02);
+    s1 = fma(w, s1, 6.66107313738753120669e-02);
+    s1 = fma(w, s1, 9.09088713343650656196e-02);
+    s1 = fma(w, s1, 1.42857142725034663711e-01);
+    s1 = fma(w, s1, 3.33333333333329318027e-01);
+    s1 = z * s1;
+    double s2 = fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02);
+    s2 = fma(w, s2, -7.69187620504482999495e-02);
+    s2 = fma(w, s2, -1.11111104054623557880e-01);
+    s2 = fma(w, s2, -1.99999999998764832476e-01);
+    s2 = w * s2;
+    const double r = c + (t - t * (s1 + s2));
+    return x < 0 ? -r : r;
+}
+// asin for |x| < 0.5 (a climb angle below 30 degrees): fdlibm's rational kernel (e_asin.c), its division through ut_rcp
+__device__ __forceinline__ double ut_asin_small(double x) {
+    const double t = x * x;
+    double p = fma(t, 3.47933107596021167570e-05, 7.91534994289814532176e-04);
+    p = fma(t, p, -4.00555345006794114027e-02);
+    p = fma(t, p, 2.01212532134862925881e-01);
+    p = fma(t, p, -3.25565818622400915405e-01);
+    p = fma(t, p, 1.66666666666666657415e-01);
+    p = t * p;
+    double q = fma(t, 7.70381505559019352791e-02, -6.88283971605453293030e-01);
+    q = fma(t, q, 2.02094576023350569471e+00);
+    q = fma(t, q, -2.40339491173441421878e+00);
+    q = fma(t, q, 1.0);
+    return fma(x, p * ut_rcp(q), x);
+}
+
 __device__ __forceinline__ int ut_discretize(double x, const double *cut, int n) { // discretize_bayes.m:14-22
     if (x >= cut[n - 1]) return n + 1;
     int d = n + 1;
@@ -79,19 +129,26 @@ __global__ void __launch_bounds__(256) k_uncor_track(const EmgpuUTrackRun A) {
             for (int s = 0; s < 10; s++) {
                 double a = acmd;
                 if ((v >= A.dyn[1] && a > 0) || (v <= A.dyn[0] && a < 0)) a = 0;
-                double sn = hd / v; sn = sn < -1 ? -1 : (sn > 1 ? 1 : sn);
-                double q = (asin(sn) - theta) / dt; q = q < -A.dyn[4] ? -A.dyn[4] : (q > A.dyn[4] ? A.dyn[4] : q);
-                theta = theta + q * dt;
-                double r = (atan(v * psidot / g) - phi) / dt; r = r < -A.dyn[5] ? -A.dyn[5] : (r > A.dyn[5] ? A.dyn[5] : r);
+                // the step as the header states it, with its six divisions folded into one reciprocal, 1 / (v cos(phi)): 1 / v is its
+                // product with cos(phi), tan(phi) / v its product with sin(phi); `/ dt` is `* 10`, `/ g` a multiplication by 1 / g.
+                // Every rewrite moves a result by an ulp or two -- the tracks are compared with the oracle's at 1e-9 (same as before).
+                double r = (ut_atan(v * psidot * (1.0 / 32.2)) - phi) * 10.0; r = r < -A.dyn[5] ? -A.dyn[5] : (r > A.dyn[5] ? A.dyn[5] : r);
                 phi = phi + r * dt;
                 double ct, st, cp, sp, cb, sb;
+                ut_sincos(phi, sb, cb);
+                const double rcv = ut_rcp(v * cb), inv_v = cb * rcv;
+                double sn = hd * inv_v; sn = sn < -1 ? -1 : (sn > 1 ? 1 : sn);
+                double as;   // chosen per lane by the lane's own value: a result never depends on which trajectories share its wave
+                if (fabs(sn) < 0.5) as = ut_asin_small(sn);
+                else as = asin(sn);                                                            // steeper than 30 degrees: the library's
+                double q = (as - theta) * 10.0; q = q < -A.dyn[4] ? -A.dyn[4] : (q > A.dyn[4] ? A.dyn[4] : q);
+                theta = theta + q * dt;
                 ut_sincos(theta, st, ct);
                 ut_sincos(psi, sp, cp);
-                ut_sincos(phi, sb, cb);
                 n = n + v * ct * cp * dt;
                 e = e + v * ct * sp * dt;
                 h = h + v * st * dt;
-                psi = psi + g * (sb / cb) / v * dt;
+                psi = psi + g * (sb * rcv) * dt;
                 v = v + a * dt; v = v < A.dyn[0] ? A.dyn[0] : (v > A.dyn[1] ? A.dyn[1] : v);
                 step++;
                 if (++since_rec == A.stride) {   // every stride-th step is kept
@@ -131,11 +188,48 @@ __global__ void __launch_bounds__(256) k_uncor_track(const EmgpuUTrackRun A) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_compact_rejected(int64_t n, uint64_t first_index, const uint8_t *accepted, const uint64_t *gidx_in, const int64_t *slot_in,
-                                                          uint64_t *gidx_out, int64_t *slot_out, uint32_t *count) {
+// Rejected lanes of a round -> the next round's index lists, IN ORDER (lane i before lane i' > i: the launch order of a later round
+// does not depend on which workgroup finished first): per-workgroup counts (ballot + population count), one exclusive scan over
+// the workgroups, then every rejected lane writes at its workgroup's offset + its rank among the rejected lanes before it.
+// scratch: count[0] = total, count[1 + b] = rejected lanes of workgroup b, then their exclusive scan in place.
+__global__ void __launch_bounds__(256) k_count_rejected(int64_t n, const uint8_t *accepted, uint32_t *count) {
+    __shared__ uint32_t s_w[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || accepted[i]) return;
-    const uint32_t k = atomicAdd(count, 1u);
+    const bool rej = i < n && !accepted[i];
+    const unsigned long long bal = __ballot(rej);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) count[1 + blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ void __launch_bounds__(1024) k_scan_rejected(uint32_t nb, uint32_t *count) {
+    __shared__ uint32_t s_part[1024];
+    const uint32_t t = threadIdx.x, per = (nb + 1023u) / 1024u, lo = t * per, hi = min(lo + per, nb);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) sum += count[1 + b];
+    s_part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {   // inclusive scan of the thread sums
+        const uint32_t v = t >= d ? s_part[t - d] : 0u;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[t] - sum;
+    for (uint32_t b = lo; b < hi; b++) { const uint32_t c = count[1 + b]; count[1 + b] = run; run += c; }
+    if (t == 1023u) count[0] = s_part[1023];
+}
+__global__ void __launch_bounds__(256) k_scatter_rejected(int64_t n, uint64_t first_index, const uint8_t *accepted, const uint64_t *gidx_in, const int64_t *slot_in,
+                                                          uint64_t *gidx_out, int64_t *slot_out, const uint32_t *count) {
+    __shared__ uint32_t s_w[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool rej = i < n && !accepted[i];
+    const unsigned long long bal = __ballot(rej);
+    const uint32_t w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) s_w[w] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (!rej) return;
+    uint32_t k = count[1 + blockIdx.x] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    for (uint32_t q = 0; q < w; q++) k += s_w[q];
     gidx_out[k] = gidx_in ? gidx_in[i] : first_index + (uint64_t)i;   // round 0 covers the contiguous range
     slot_out[k] = slot_in ? slot_in[i] : i;
 }
@@ -147,10 +241,15 @@ hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char
     return hipGetLastError();
 }
 
+size_t compact_scratch_words(int64_t n) { return 2 + (size_t)((n + 255) / 256); }
+
 hipError_t launch_compact_rejected(int64_t n, uint64_t first_index, const uint8_t *accepted, const uint64_t *gidx_in, const int64_t *slot_in,
-                                   uint64_t *gidx_out, int64_t *slot_out, uint32_t *count, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_compact_rejected, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, first_index, accepted, gidx_in, slot_in, gidx_out, slot_out, count);
+                                   uint64_t *gidx_out, int64_t *slot_out, uint32_t *count /* compact_scratch_words(n) words; [0] receives the total */, hipStream_t s) {
+    if (n <= 0) return hipMemsetAsync(count, 0, sizeof(uint32_t), s);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_count_rejected, dim3(nb), dim3(256), 0, s, n, accepted, count);
+    hipLaunchKernelGGL(k_scan_rejected, dim3(1), dim3(1024), 0, s, (uint32_t)nb, count);
+    hipLaunchKernelGGL(k_scatter_rejected, dim3(nb), dim3(256), 0, s, n, first_index, accepted, gidx_in, slot_in, gidx_out, slot_out, count);
     return hipGetLastError();
 }
 

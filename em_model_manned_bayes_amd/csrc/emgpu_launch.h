@@ -29,7 +29,9 @@ hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, 
 hipError_t launch_terminal_geo(const EmgpuTGeoRun &A, hipStream_t s);
 hipError_t launch_terminal_filter(const EmgpuTFilterRun &A, hipStream_t s, const char **name);
 hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char **name);
-// rejected lanes of a round -> the next round's index lists (order is not defined; results are keyed by index)
+// rejected lanes of a round -> the next round's index lists, in lane order; count: compact_scratch_words(n) words of device
+// scratch, count[0] receives the number of rejected lanes
+size_t compact_scratch_words(int64_t n);
 hipError_t launch_compact_rejected(int64_t n, uint64_t first_index, const uint8_t *accepted, const uint64_t *gidx_in, const int64_t *slot_in,
                                    uint64_t *gidx_out, int64_t *slot_out, uint32_t *count, hipStream_t s);
 hipError_t launch_sample2track(const EmgpuTrackRun &A, bool dense, hipStream_t s, const char **name);
