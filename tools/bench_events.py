@@ -1,7 +1,8 @@
 """tools/bench_events.py -- the event-list output (what UncorEncounterModel.sample returns: [dt, variable, value, bin] rows per
 trajectory, dbn_hierarchical_sample.m:33-60) on one GPU: k_dbn_generic, 1 M trajectories x 240 s, event_cap 256."""
 import sys, time, tempfile
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np, ctypes as C
 from em_model_manned_bayes_amd import em_io, native, _lib as L
 dev = torch.device("cuda", 0)
