@@ -951,6 +951,18 @@ int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int3
     EMGPU_CATCH
 }
 
+int emgpu_debug_pk_column(const emgpu_model *m, int32_t k, int64_t col, uint32_t *words) {
+    EMGPU_TRY
+    if (!m || !words) return fail(EMGPU_ERR_ARG, "null argument");
+    const emgpu::CompiledPlan cp = emgpu::compile_plan(m->m);
+    const EmgpuPlan &P = cp.plan;
+    if (k < 0 || k >= P.nd || P.d_pw[k] == 0) return fail(EMGPU_ERR_ARG, "no such padded dynamic variable");
+    if (col < 0 || col >= m->m.q_transition[P.d_tvar[k]]) return fail(EMGPU_ERR_ARG, "no such column");
+    for (int t = 0; t < 4; t++) words[t] = cp.pthr[P.d_poffpk[k] + (size_t)col * 4 + t];
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
 // Upload / validate the trajectory models of a terminal call and publish their table pointers in ctx->d_thr_base.
 // Returns the first model's uploaded plan (the shapes every model shares).
 static uint32_t rel_piv(const EmgpuPlan &P, int k) { return P.d_pivoff[k] ? P.d_pivoff[k] - P.d_off[0] : 0u; } // pivot rows relative to the first dynamic table

@@ -78,22 +78,6 @@ __device__ __forceinline__ void load_cthr(uint32_t (&tp)[(M + 1) / 2], uint32_t 
     bml = lo; bmh = hi;
 }
 
-// Bit B (4..7) of the 8 packed bytes (seconds 0-3 in a, 4-7 in b) as an MSB-first stream: bit 7-j <-> second j.  One mask and
-// one v_mul_hi_u32 per word: the multiplier moves bit 8i + B of the masked word to bit 35 - i of the 64-bit product (the 16
-// partial products land on 16 different bits: no carries), so the low nibble of the high word is the stream of that word.
-template <int B>
-__device__ __forceinline__ uint32_t byte_bit_stream(uint32_t a, uint32_t b) {
-    static_assert(B >= 4 && B <= 7, "the shifts 35 - B - 9i must fit a 32-bit multiplier");
-    constexpr uint32_t K = (1u << (35 - B)) | (1u << (26 - B)) | (1u << (17 - B)) | (1u << (8 - B));
-#ifdef EMGPU_OLD_STREAM
-    const uint32_t na = (((a >> B) & 0x01010101u) * 0x80402010u) >> 28, nb = (((b >> B) & 0x01010101u) * 0x80402010u) >> 28;
-    return (na << 4) | nb;
-#endif
-    const uint32_t ha = __umulhi(a & (0x01010101u << B), K), hb = __umulhi(b & (0x01010101u << B), K);
-    uint32_t t;
-    asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(t) : "v"(ha), "v"(hb)); // (the compiler splits the mask over both operands: one more instruction)
-    return t & 0xFFu; // other partial products sit at bits >= 9 of the high words
-}
 __device__ __forceinline__ uint32_t zero_stream(uint32_t a, uint32_t b) { return byte_bit_stream<7>(a, b); }
 
 // ---- the packed (two seconds per instruction) form of the same column ------------------------------------

@@ -103,6 +103,50 @@ __device__ __forceinline__ uint32_t chain6p(uint32_t w, uint32_t t01, uint32_t t
 #undef EMGPU_S2_FIRST
 #undef EMGPU_S2_NEXT
 
+// ---- the packed compare of an interior second (EmgpuPlan::d_poffpk) ------------------------------------------------------
+// One draw against a column's T' pairs: x_h = the half ODD of w goes to BOTH halves of a packed subtract, each against its own
+// threshold; d = min(sat(x_h - T'), 2) is 0 not fired, 1 the low halfword decides, 2 fired; the pairs are added up and the two
+// halves folded: the result is 2 * (thresholds fired), odd exactly when the draw needs its low halfword.  Six (NW = 3) or four
+// (NW = 2: columns of at most 3 thresholds; T'3 = 0xFFFF never fires) thresholds in 3 NW + 1 instructions, no carry, no VCC,
+// no wait states (the carry chain: 3 per threshold plus a min per threshold for the tie).
+template <bool ODD, int NW>
+__device__ __forceinline__ uint32_t pk_fired2(uint32_t w, uint32_t t01, uint32_t t23, uint32_t t45) {
+    uint32_t d0, d1, d2 = 0u, acc;
+    if (ODD) {
+        asm("v_pk_sub_u16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] clamp" : "=v"(d0) : "v"(w), "v"(t01));
+        asm("v_pk_sub_u16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] clamp" : "=v"(d1) : "v"(w), "v"(t23));
+        if (NW == 3) asm("v_pk_sub_u16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] clamp" : "=v"(d2) : "v"(w), "v"(t45));
+    } else {
+        asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] clamp" : "=v"(d0) : "v"(w), "v"(t01));
+        asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] clamp" : "=v"(d1) : "v"(w), "v"(t23));
+        if (NW == 3) asm("v_pk_sub_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] clamp" : "=v"(d2) : "v"(w), "v"(t45));
+    }
+    asm("v_pk_min_u16 %0, %0, 2 op_sel_hi:[1,0]" : "+v"(d0));
+    asm("v_pk_min_u16 %0, %0, 2 op_sel_hi:[1,0]" : "+v"(d1));
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(acc) : "v"(d0), "v"(d1));
+    if (NW == 3) {
+        asm("v_pk_min_u16 %0, %0, 2 op_sel_hi:[1,0]" : "+v"(d2));
+        asm("v_pk_add_u16 %0, %0, %1" : "+v"(acc) : "v"(d2));
+    }
+    uint32_t s;
+    asm("v_add_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(s) : "v"(acc));
+    return s;
+}
+// s | (the half ODD of z): z carries a 1 in the halves whose x_h is 0 (a tie with any threshold whose high half is 0)
+template <bool ODD>
+__device__ __forceinline__ uint32_t or_half(uint32_t s, uint32_t z) {
+    uint32_t r;
+    if (ODD) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(s), "v"(z));
+    else asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(s), "v"(z));
+    return r;
+}
+// bin * stride + acc, everything in vector registers (no scalar operand: no wait states to respect)
+__device__ __forceinline__ uint32_t mad24v(uint32_t bin, uint32_t stride, uint32_t acc) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(bin), "v"(stride), "v"(acc));
+    return r;
+}
+
 // resample Bernoulli on the high halfword: hit8 = hit8 + hit8 + (x_h < R_h); returns x_h - R_h.
 // The leading s_nop keeps two wait states between a VALU that may just have written the SGPR
 // (v_readlane of a spilled register) and its read here.
@@ -216,9 +260,19 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
     uint32_t wbytes[ND];
 #pragma unroll
     for (int k = 0; k < ND; k++) {
-        wbytes[k] = 16u; // a 4-word column, or the 16-byte form of an 8-word one (EmgpuPlan::d_poff16)
-        basecol[k] = ((WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) ? P.d_poff[k] : P.d_poff16[k]) * 4u + basecol[k] * 16u; // wave-uniform choice
+        wbytes[k] = 16u; // the packed-compare form: 16 bytes per column (EmgpuPlan::d_poffpk)
+        basecol[k] = P.d_poffpk[k] * 4u + basecol[k] * 16u;
     }
+    // the strides of the parents that exist, in bytes, in vector registers (mad24v)
+    uint32_t svc[ND][ND], svn[ND][ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+#pragma unroll
+        for (int q = 0; q < ND; q++) {
+            svc[k][q] = svn[k][q] = 0u;
+            if ((CUR >> (4 * k + q)) & 1u) asm volatile("v_mov_b32 %0, %1" : "=v"(svc[k][q]) : "s"(P.d_stride_cur[k][q] * 16u));
+            if (q < k && ((NEW >> (4 * k + q)) & 1u)) asm volatile("v_mov_b32 %0, %1" : "=v"(svn[k][q]) : "s"(P.d_stride_new[k][q] * 16u));
+        }
     uint32_t ivs[ND];
 #pragma unroll
     for (int k = 0; k < ND; k++) ivs[k] = P.d_ivar[k];
@@ -274,13 +328,17 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
             uint32_t col = basecol[k];
 #pragma unroll
             for (int q = 0; q < ND; q++)
-                if ((CUR >> (4 * k + q)) & 1u) col = mad24(cur1[q], P.d_stride_cur[k][q] * wbytes[k], col);
+                if ((CUR >> (4 * k + q)) & 1u) col = mad24v(cur1[q], svc[k][q], col);
 #pragma unroll
             for (int q = 0; q < k; q++)
-                if ((NEW >> (4 * k + q)) & 1u) col = mad24(nb1[q], P.d_stride_new[k][q] * wbytes[k], col);
+                if ((NEW >> (4 * k + q)) & 1u) col = mad24v(nb1[q], svn[k][q], col);
             return col;
         };
-        auto full_of = [&](int k, uint32_t col16) { return (col16 - P.d_poff16[k] * 4u) * 2u + P.d_poff[k] * 4u; };
+        // the same column in the padded table of full thresholds (4 or 8 words per column)
+        auto full_of = [&](int k, uint32_t colpk) {
+            const bool w4 = WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4);
+            return (colpk - P.d_poffpk[k] * 4u) * (w4 ? 1u : 2u) + P.d_poff[k] * 4u;
+        };
         if (g8 >= 1 && 8 * g8 + 7 < T) {
             // ---- interior block: every second is a draw, nothing is guarded.
             // A level-0 node whose parents are level-0 nodes' current bins only (kPre) knows its NEXT second's column as soon as
@@ -290,6 +348,18 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
             uint32_t precol[ND];
 #pragma unroll
             for (int k = 0; k < ND; k++) { pre[k] = make_uint4(0, 0, 0, 0); precol[k] = 0u; }
+            uint32_t cur_in[ND];   // the bins the block starts from (the "changed" stream of second 0 compares with them)
+#pragma unroll
+            for (int k = 0; k < ND; k++) cur_in[k] = cur1[k];
+            // a 1 in every half of the block's draws that is 0: such a draw ties with any threshold whose high half is 0 (it has no T')
+            uint4 zt[ND];
+#pragma unroll
+            for (int k = 0; k < ND; k++) {
+                uint32_t z[4];
+#pragma unroll
+                for (int p2 = 0; p2 < 4; p2++) asm("v_pk_sub_u16 %0, 1, %1 op_sel_hi:[0,1] clamp" : "=v"(z[p2]) : "v"(word_of(th[k], p2)));
+                zt[k] = make_uint4(z[0], z[1], z[2], z[3]);
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 uint32_t nb1[ND];
@@ -309,43 +379,44 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                         colv[k] = column_of(k, nb1);
                         ca[k] = load4(colv[k]);
                     }
-                    // ---- the draws of this level from the high halfwords (dbn_sample.m:77)
-                    uint32_t dlev = 0xFFFFFFFFu;
+                    // ---- the draws of this level from the high halfwords (dbn_sample.m:77): twice the number of thresholds that fired,
+                    // bit 0 raised when the low halfword is needed
+                    uint32_t tlev = 0u;
 #pragma unroll
                     for (int k = 0; k < ND; k++) {
                         if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
-                        const uint32_t wt = word_of(th[k], j >> 1);
-                        if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) {
-                            const uint4 a = ca[k];
-                            sel[k] = (j & 1) ? chain3<true>(wt, a.x, a.y, a.z, selbase, dmin[k]) : chain3<false>(wt, a.x, a.y, a.z, selbase, dmin[k]);
-                        } else {
-                            const uint4 a = ca[k];
-                            sel[k] = (j & 1) ? chain6p<true>(wt, a.x, a.y, a.z, dmin[k]) : chain6p<false>(wt, a.x, a.y, a.z, dmin[k]);
-                        }
-                        dlev = min(dlev, dmin[k]);
+                        const uint32_t wt = word_of(th[k], j >> 1), wz = word_of(zt[k], j >> 1);
+                        const uint4 a = ca[k];
+                        uint32_t s2;
+                        if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) s2 = (j & 1) ? pk_fired2<true, 2>(wt, a.x, a.y, a.z) : pk_fired2<false, 2>(wt, a.x, a.y, a.z);
+                        else s2 = (j & 1) ? pk_fired2<true, 3>(wt, a.x, a.y, a.z) : pk_fired2<false, 3>(wt, a.x, a.y, a.z);
+                        sel[k] = (j & 1) ? or_half<true>(s2, wz) : or_half<false>(s2, wz);
+                        tlev |= sel[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < ND; k++) {
+                        if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
+                        nb1[k] = __builtin_amdgcn_ubfe(ca[k].w, sel[k] << 1, 4u);   // nibble (fired) of the column's map; overwritten below on a tie
                     }
                     // one tie test per level; the draws that tied (in some lane) are repeated on the full 32-bit draw, out of line
-                    if (__ballot(dlev == 0u) != 0ull) {
+                    if (__ballot((tlev & 1u) != 0u) != 0ull) {
 #pragma unroll
                         for (int k = 0; k < ND; k++) {
                             if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
-                            if (__ballot(dmin[k] == 0u) == 0ull) continue;
+                            if (__ballot((sel[k] & 1u) != 0u) == 0ull) continue;
+                            const uint32_t cf = full_of(k, colv[k]);   // the full thresholds of the column, from the padded table
                             if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) {
-                                sel[k] = kSelBase2 + exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, word_of(th[k], j >> 1), P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
-                                                                   ca[k].x, ca[k].y, ca[k].z, 0u, 0u, 0u);
-                            } else {   // the full thresholds of the column, from the 8-word table
-                                const uint32_t cf = full_of(k, colv[k]);
+                                const uint4 fa = load4(cf);
+                                const uint32_t b = exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, word_of(th[k], j >> 1), P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
+                                                                 fa.x, fa.y, fa.z, 0u, 0u, 0u);
+                                nb1[k] = __builtin_amdgcn_perm(0u, fa.w, kSelBase2 + b);
+                            } else {
                                 const uint4 fa = load4(cf), fb = load4(cf + 16u);
-                                sel[k] = exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, word_of(th[k], j >> 1), P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
-                                                       fa.x, fa.y, fa.z, fa.w, fb.x, fb.y);
+                                const uint32_t b = exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, word_of(th[k], j >> 1), P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
+                                                                 fa.x, fa.y, fa.z, fa.w, fb.x, fb.y);
+                                nb1[k] = __builtin_amdgcn_perm(fb.w, fb.z, kSelBase2 + b);
                             }
                         }
-                    }
-#pragma unroll
-                    for (int k = 0; k < ND; k++) {
-                        if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
-                        if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) nb1[k] = __builtin_amdgcn_perm(0u, ca[k].w, sel[k]);
-                        else nb1[k] = __builtin_amdgcn_ubfe(ca[k].w, 4u * sel[k], 4u);   // nibble table indexed by the borrows
                     }
                     if (lev == 0 && j < 7 && kMaxLev >= 1) {
 #pragma unroll
@@ -354,7 +425,7 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                             uint32_t col = basecol[k];     // the column of second j + 1: the new bins are its current ones
 #pragma unroll
                             for (int q = 0; q < ND; q++)
-                                if ((CUR >> (4 * k + q)) & 1u) col = mad24(nb1[q], P.d_stride_cur[k][q] * wbytes[k], col);
+                                if ((CUR >> (4 * k + q)) & 1u) col = mad24v(nb1[q], svc[k][q], col);
                             precol[k] = col;
                             pre[k] = load4(col);
                         }
@@ -363,13 +434,21 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
 #pragma unroll
                 for (int k = 0; k < ND; k++) {
                     if (!REG && k >= P.nd) continue;
-                    asm("v_cmp_ne_u32 vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
-                        "v_cmp_eq_u32 vcc, %4, %2\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
-                        : "+v"(chg8[k]), "+v"(zer8[k]) : "v"(nb1[k]), "v"(cur1[k]), "s"((uint32_t)P.d_zero[k]) : "vcc");
                     cur1[k] = nb1[k];                                                               // map back, dbn_sample.m:82
-                    const uint32_t b = cur1[k] << (8 * (j & 3));
-                    if (j < 4) pbA[k] |= b; else pbB[k] |= b;
+                    if (j < 4) pbA[k] = j ? (pbA[k] | (cur1[k] << (8 * (j & 3)))) : cur1[k];
+                    else pbB[k] = (j & 3) ? (pbB[k] | (cur1[k] << (8 * (j & 3)))) : cur1[k];
                 }
+            }
+            // the block's "changed" and "zero bin" streams from the packed bins (MSB-first: bit 7 - j <-> second j): a bin differs from
+            // the second before it when the XOR's low nibble is not 0 (bins are < 16: + 0x0F carries into bit 4); it is the zero bin when
+            // the XOR with that bin is 0 (+ 0x7F leaves bit 7 clear).  One multiply per word gathers the bits (byte_bit_stream).
+#pragma unroll
+            for (int k = 0; k < ND; k++) {
+                if (!REG && k >= P.nd) continue;
+                const uint32_t prevA = (pbA[k] << 8) | cur_in[k], prevB = __builtin_amdgcn_alignbit(pbB[k], pbA[k], 24);
+                chg8[k] = byte_bit_stream<4>((pbA[k] ^ prevA) + 0x0F0F0F0Fu, (pbB[k] ^ prevB) + 0x0F0F0F0Fu);
+                const uint32_t zz = (uint32_t)P.d_zero[k] * 0x01010101u;
+                zer8[k] = ~byte_bit_stream<7>((pbA[k] ^ zz) + 0x7F7F7F7Fu, (pbB[k] ^ zz) + 0x7F7F7F7Fu) & 0xFFu;
             }
         } else {
             // ---- the first block of a trajectory (second 0 is the initial state, not a draw) and a partial last block: one rolled
@@ -393,7 +472,7 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                         for (int k = 0; k < ND; k++) {
                             if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
                             const bool w4 = WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4);
-                            const uint32_t col = w4 ? column_of(k, nb1) : full_of(k, column_of(k, nb1));
+                            const uint32_t col = full_of(k, column_of(k, nb1));   // the plain thresholds of the padded table
                             const uint4 a = load4(col);
                             uint4 b = make_uint4(0, 0, 0, 0);
                             if (!w4) b = load4(col + 16u);

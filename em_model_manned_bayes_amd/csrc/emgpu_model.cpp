@@ -556,6 +556,32 @@ CompiledPlan compile_plan(const Model &m) {
                     o[mfix] = lo;
                     if (W == 8) o[7] = hi;
                 }
+                {   // the packed-compare form (EmgpuPlan::d_poffpk): T' pairs + the nibble map by fired count
+                    P.d_poffpk[k] = (uint32_t)cp.pthr.size();
+                    cp.pthr.resize(cp.pthr.size() + (size_t)q * 4);
+                    C = cp.cthr.data() + P.d_coff[k];
+                    uint32_t *Pk = cp.pthr.data() + P.d_poffpk[k];
+                    for (int64_t j = 0; j < q; j++) {
+                        const uint32_t *c = C + (size_t)j * (meff + 1);
+                        uint32_t *o = Pk + (size_t)j * 4;
+                        uint32_t tq[6], prev = 0u;
+                        for (int t = 0; t < 6; t++) {
+                            uint32_t v = 0xFFFFu;
+                            if (t < meff) {
+                                const uint32_t h = c[t] >> 16;
+                                v = h ? h - 1u : 0u;
+                                if (t > 0 && v <= prev) v = prev + 1u;
+                                v = v > 0xFFFFu ? 0xFFFFu : v;
+                            }
+                            tq[t] = v; prev = v;
+                        }
+                        for (int w = 0; w < 3; w++) o[w] = tq[2 * w] | (tq[2 * w + 1] << 16);
+                        uint32_t nib = 0u;
+                        for (int n = 0; n <= 6; n++) nib |= ((c[meff] >> (4 * (n < meff ? n : meff))) & 15u) << (4 * n);
+                        o[3] = nib;
+                    }
+                }
+                Pd = cp.pthr.data() + P.d_poff[k];   // (the resize above may have moved the buffer)
                 P.d_poff16[k] = 0;
                 if (W == 8) {   // the 16-byte form (EmgpuPlan::d_poff16)
                     P.d_poff16[k] = (uint32_t)cp.pthr.size();

@@ -99,6 +99,14 @@ struct EmgpuPlan {
     // word {t0h | t1h << 16, t2h | t3h << 16, t4h | t5h << 16} and the bin table as nibbles indexed by the number of borrows --
     // one gather per draw instead of two for the hot compare; the full column is only read on a tie and in a trajectory's edge blocks.
     uint32_t d_poff16[EMGPU_MAX_ND];
+    // every padded variable also has the PACKED-COMPARE form (word offset d_poffpk, 4 words per column):
+    // {T'0 | T'1 << 16, T'2 | T'3 << 16, T'4 | T'5 << 16, nibble map}.  T'_t is the 16-bit value for which d = sat(x_h - T'_t) reads
+    // 0: threshold t not fired, 1: the low halfword decides (a tie with the threshold's high half), >= 2: fired -- H_t - 1, made
+    // strictly increasing along the column, 0 for H_t = 0 (x_h = 0 is then a tie by a separate test), 0xFFFF beyond the column's
+    // thresholds (exactly load_cthr_pk of the fast kernel, built on the host because the column changes every second here).
+    // The sum of min(d, 2) over the thresholds is 2 * fired, odd exactly when some compare needs the low halfword; nibble n of the
+    // map is the 1-based bin when n thresholds fired.  Two or three v_pk_sub_u16 / v_pk_min_u16 pairs decide a draw: no carries.
+    uint32_t d_poffpk[EMGPU_MAX_ND];
     uint32_t pthr_total, _pad1;
     const uint32_t *pthr;
     // ---- device tables

@@ -412,6 +412,11 @@ int emgpu_debug_dynamic_column(const emgpu_model *m, int32_t k, int64_t col, int
  * 8 words {t0..t5, map_lo, map_hi} (0: the variable has no padded table); unused thresholds repeat the last real one (2^32-1 if none);
  * the map is a byte table: entry b = 1-based bin when b of the 3 (6) thresholds did NOT fire. */
 int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int32_t *width, uint32_t *words);
+/* The same column in the packed-compare form of the per-timestep kernel (4 words): {T'0 | T'1 << 16, T'2 | T'3 << 16, T'4 | T'5 << 16,
+ * nibble map}.  With x_h the draw's high halfword and d_t = min(sat16(x_h - T'_t), 2): the sum over t is 2 * (thresholds fired),
+ * odd exactly when the draw's low halfword decides some compare; nibble (sum / 2) of the map is the 1-based bin
+ * (select_random.m:17-20 on the high halfword alone; x_h = 0 is always referred to the full 32-bit compare). */
+int emgpu_debug_pk_column(const emgpu_model *m, int32_t k, int64_t col, uint32_t *words);
 
 /* Which dynamic variables are parents of which (t+1) node, in plan order k = 0..n_dyn-1: bit 4k+q of cur_mask = the time-t
  * node of dynamic variable q is a parent of k's (t+1) node; of new_mask = its (t+1) node is (dbn_sample.m:65-93: the

@@ -241,6 +241,48 @@ def test_compacted_columns_select_the_same_bin(name, model_dir):
     assert lib.emgpu_debug_dynamic_column(h, nd, 0, *([C.byref(C.c_int64())] * 7)) == L.ERR_ARG   # no such variable
 
 
+@pytest.mark.parametrize("name", ["cor_v1", "glider_v1", "uncor_1200code_v1", "uncor_1200code_v2p1", "haa_v1", "cor_v2p1_like"])
+def test_packed_compare_columns_decide_like_select_random(name, model_dir):
+    """EmgpuPlan::d_poffpk, the form k_dbn_step2 decides a draw from: for EVERY high halfword x_h of a column, either the packed
+    rule flags the draw for the full 32-bit compare (an odd sum of min(sat16(x_h - T'), 2), or x_h == 0), or the bin it reads off
+    (nibble sum / 2) is the bin of select_random.m:17-20 for every low halfword -- checked at the two extreme low halfwords and
+    against the plain thresholds; whenever the low halfword can change the bin the draw IS flagged."""
+    from em_model_manned_bayes_amd import synthetic
+    path = synthetic.write_correlated_v2p1_like(model_dir) if name == "cor_v2p1_like" else em_io.materialize_model(name, model_dir)
+    p = E.em_read(path)
+    pp = O.parse_model_txt(path)
+    lib = L.lib()
+    h = p["native"]._h
+    rng = np.random.RandomState(5)
+    xh = np.arange(65536, dtype=np.int64)
+    checked = 0
+    for k in range(len(pp["temporal_map"])):
+        tvar, r, q, meff, mp = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32(), C.c_uint32()
+        thr = np.zeros(15, dtype=np.uint32); cthr = np.zeros(7, dtype=np.uint32)
+        args = lambda col: (h, k, col, C.byref(tvar), C.byref(r), C.byref(q), thr.ctypes.data, C.byref(meff), cthr.ctypes.data, C.byref(mp))
+        assert lib.emgpu_debug_dynamic_column(*args(0)) == 0
+        if meff.value == 0 or meff.value > 6:
+            continue
+        for col in sorted(set(int(c) for c in rng.randint(0, q.value, 25)) | {0, q.value - 1}):
+            assert lib.emgpu_debug_dynamic_column(*args(col)) == 0
+            pk = np.zeros(4, dtype=np.uint32)
+            assert lib.emgpu_debug_pk_column(h, k, col, pk.ctypes.data) == 0
+            tq = np.array([(int(pk[w]) >> (16 * hh)) & 0xFFFF for w in range(3) for hh in range(2)], dtype=np.int64)
+            assert np.all(np.diff(tq[tq < 0xFFFF]) > 0)                      # strictly increasing where real
+            d = np.minimum(np.maximum(xh[:, None] - tq[None, :], 0), 2)      # min(sat16(x_h - T'), 2)
+            ssum = d.sum(axis=1)
+            flagged = (ssum % 2 == 1) | (xh == 0)
+            t = thr[: r.value - 1].astype(np.int64)
+            lo_bin = 1 + (np.minimum((xh << 16), 2**32 - 2)[:, None] >= t[None, :]).sum(axis=1)              # low halfword 0x0000
+            hi_bin = 1 + (np.minimum((xh << 16) | 0xFFFF, 2**32 - 2)[:, None] >= t[None, :]).sum(axis=1)     # low halfword 0xFFFF
+            pk_bin = (int(pk[3]) >> (4 * (ssum // 2))) & 15
+            assert np.all(flagged | ((pk_bin == lo_bin) & (pk_bin == hi_bin))), (name, k, col)
+            assert np.all(flagged[lo_bin != hi_bin]), (name, k, col)       # the low halfword matters => referred to the exact compare
+            assert flagged.mean() < 0.02, (name, k, col, flagged.mean())     # and that stays rare
+            checked += 1
+    assert checked > 0
+
+
 def test_shard_ranges_cover_exactly():
     for n, w in [(10, 3), (50_000_000, 8), (7, 8), (0, 2), (1, 1)]:
         ranges = [sharding.shard_range(n, r, w) for r in range(w)]
