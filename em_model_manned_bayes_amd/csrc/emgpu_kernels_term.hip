@@ -9,6 +9,10 @@
 // the recorded rows in a per-lane LDS ring that is flushed row by row with coalesced stores, the velocity's direction carried
 // as an angle, sin/cos of the reduced angle as Horner sums, an instance for the terminal model's row shapes.
 // em-core's local_smooth (createEncounter.m:88-89) is not applied: un-vendored dependency.
+// Round 3: ONE Philox call per attempt serves the transition draws of all three dynamic variables (slot map: block = the step,
+// word = the variable's row of the temporal map; the same for the dediscretize draws, made only when the lane has an event);
+// the bearing bin comes from an f32 guess of the angle walked to the exact bin with f64 cross products against the cut directions
+// (no atan2); distance is compared squared and the speed is carried (no square roots in the loop).
 // Bound: vector instruction issue at two waves per SIMD (256 registers of f64 state) + dependent gathers; output 24 B per second.
 #include <hip/hip_runtime.h>
 
@@ -55,6 +59,35 @@ __device__ __forceinline__ int t_discretize(double x, const double *__restrict__
     k = k < 0 ? 0 : (k > gd.n ? gd.n : k);
     while (k > 0 && x < cut[k - 1]) k--;
     while (k < gd.n && x >= cut[k]) k++;
+    return k + 1;
+}
+
+// The bearing bin of createEncounter.m:277-279, discretize_bayes(wrapTo360(atan2d(y, x)), cut) = 1 + #{q : angle >= cut[q]}, without the
+// atan2: the half-plane is exact from the sign of y (atan2d < 0 <=> y < 0, its wrap adds 360), a 20-instruction f32 estimate of the
+// angle inside it guesses the count, and the guess is walked to the exact count by testing the neighbouring cut directions with f64
+// cross products: angle >= cut  <=>  cos(cut) y - sin(cut) x >= 0 for a cut within 180 degrees of the angle (the walk only ever
+// looks at the guess's neighbours).  s_dir[q] = (cosd, sind)(cut[q]) with MATLAB's exact zeros at the multiples of 90.
+__device__ __forceinline__ int t_bearing_bin(double x, double y, const double *__restrict__ cut, const double2 *__restrict__ s_dir, int n, double lo, double inv_step) {
+    const float fx = fabsf((float)x), fy = fabsf((float)y);
+    const float mx = fmaxf(fx, fy), mn = fminf(fx, fy);
+    const float t = mx > 0.f ? mn * __builtin_amdgcn_rcpf(mx) : 0.f, t2 = t * t;
+    float a = t * (0.99997726f + t2 * (-0.33262347f + t2 * (0.19354346f + t2 * (-0.11643287f + t2 * (0.05265332f - t2 * 0.01172120f)))));   // atan(t), 1e-5 rad
+    a *= 57.29578f;
+    a = fy > fx ? 90.f - a : a;                       // first-quadrant angle of (|x|, |y|)
+    a = x < 0 ? 180.f - a : a;                        // upper half-plane angle of (x, |y|)
+    a = y < 0 ? 360.f - a : a;                        // exact half: y < 0 <=> the angle is in (180, 360]
+    double kd = ((double)a - lo) * inv_step;          // candidate number of cut points <= angle, minus one
+    kd = kd < -1.0 ? -1.0 : (kd > (double)n ? (double)n : kd);
+    int k = (int)kd + 1;
+    k = k < 0 ? 0 : (k > n ? n : k);
+    if (x == 0.0 && y == 0.0) {                       // atan2d(0, 0) = 0: only cut points at or below 0 count
+        k = 0;
+        while (k < n && 0.0 >= cut[k]) k++;
+        return k + 1;
+    }
+    auto ge = [&](int q) { const double2 d = s_dir[q]; return d.x * y - d.y * x >= 0.0; };
+    while (k > 0 && !ge(k - 1)) k--;
+    while (k < n && ge(k)) k++;
     return k + 1;
 }
 
@@ -143,6 +176,17 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     __shared__ CutGrid s_grid[5];
     __shared__ double s_cut8[5][8];   // the cut points of a grid with at most 8 of them, padded with +inf
     __shared__ float s_ring[4][kRing][6][64];   // per wave: the last kRing recorded rows of every lane, field-major (conflict-free)
+    __shared__ double2 s_dir[kBndStride];       // (cosd, sind) of the bearing variable's cut points
+    __shared__ double s_cut8sq[8];              // squares of the distance variable's cut points (when it has at most 8)
+    for (int q = threadIdx.x; q < (int)P.i_nb[2] - 2; q += 256) {
+        double sd, cd;
+        sincosd_small(P.bnd[P.i_boff[2] + 1 + q], sd, cd);
+        s_dir[q] = make_double2(cd, sd);
+    }
+    if (threadIdx.x < 8) {
+        const double c = ((int)threadIdx.x < (int)P.i_nb[1] - 2) ? P.bnd[P.i_boff[1] + 1 + threadIdx.x] : __builtin_inf();
+        s_cut8sq[threadIdx.x] = c * c;   // (cut points of a distance are >= 0: d >= c <=> d^2 >= c^2)
+    }
     for (int v = 2; v <= 6; v++) {
         const int nbv = P.i_nb[v - 1], n = nbv - 2;
         for (int q = threadIdx.x; q < nbv; q += 256) s_bnd[(v - 2) * kBndStride + q] = P.bnd[P.i_boff[v - 1] + q];
@@ -164,13 +208,22 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     const double *g = A.geo + e * 12 + ac * 6;
     const int intent = (int)g[5];
     const gptr_t thr = (gptr_t)A.thr_base[A.model_of[L]];
-    const double minVel = A.dl[ac][0], maxVel = A.dl[ac][1], maxTurn = A.dl[ac][2], maxAlt = A.dl[ac][3], maxVert = A.dl[ac][4];
-    const CutGrid gDist = s_grid[0], gBear = s_grid[1], gHead = s_grid[2], gAlt = s_grid[3], gSpd = s_grid[4];
+    // the aircraft's limits are picked from the kernel arguments where they are used (kept per lane they cost ten registers)
+#define T_LIM(q) (ac ? A.dl[1][q] : A.dl[0][q])
+    const double maxAlt = T_LIM(3);
+    // the grids are wave-uniform: pinned in scalar registers (read back from LDS they would sit in 30 vector registers)
+    auto sgrid = [&](int q) {
+        const CutGrid gq = s_grid[q];
+        auto u32 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+        auto f64 = [&](double d) { const uint64_t b = (uint64_t)__double_as_longlong(d); return __longlong_as_double((long long)(((uint64_t)u32((uint32_t)(b >> 32)) << 32) | u32((uint32_t)b))); };
+        return CutGrid{(int)u32((uint32_t)gq.off), (int)u32((uint32_t)gq.n), f64(gq.lo), f64(gq.inv_step)};
+    };
+    const CutGrid gDist = sgrid(0), gBear = sgrid(1), gHead = sgrid(2), gAlt = sgrid(3), gSpd = sgrid(4);
     int alt_last = 0, spd_first = 0, spd_last = 0;     // discreteValidAlt / discreteValidV as bin ranges (createEncounter.m:118-126)
     {
         const double *bA = s_bnd + 3 * kBndStride, *bS = s_bnd + 4 * kBndStride;
         for (int q = 0; q < (int)P.i_nb[4]; q++) if (bA[q] <= maxAlt) alt_last = q + 1;
-        for (int q = 0; q < (int)P.i_nb[5]; q++) { if (!(bS[q] >= minVel)) spd_first = q + 1; if (bS[q] <= maxVel) spd_last = q + 1; }
+        for (int q = 0; q < (int)P.i_nb[5]; q++) { if (!(bS[q] >= T_LIM(0))) spd_first = q + 1; if (bS[q] <= T_LIM(1)) spd_last = q + 1; }
     }
     const double bounds_dist_hi = s_bnd[P.i_nb[1] - 1];
     const int rm1[3] = {RM1_0 ? RM1_0 : (int)P.d_r[0] - 1, RM1_1 ? RM1_1 : (int)P.d_r[1] - 1, RM1_2 ? RM1_2 : (int)P.d_r[2] - 1};
@@ -186,6 +239,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     double sh, chh;
     t_sincosd(heading_deg, sh, chh);
     double v0 = chh * g[3], v1 = sh * g[3];
+    double speed = g[3];   // norm(v_ft_s), carried: the velocity is only ever speed * (cosd, sind) rotated (its norm to 1e-16)
     // The direction of the velocity, carried as an angle: the velocity is only ever set to speed * (cosd, sind)(heading) and rotated
     // by the step's turn, so atan2d(v) is this angle up to rounding (1e-14 degrees) -- the reference's per-step atan2d
     // (createEncounter.m:163) costs a hundred instructions here.  (v = 0 would give atan2d = 0: speeds are clamped to minVel > 0.)
@@ -201,14 +255,14 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     // A lane more than kRing rows ahead of the slowest waits (the slowest lane sets the wave's run time either way).
     int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
     gptr_t row[3] = {thr, thr, thr}, piv[3] = {thr, thr, thr};
-    double curr_hdg = 0, d_nm = 0;
+    double curr_hdg = 0, d2_nm = 0;
+    const bool dist8 = gDist.n <= 8;   // wave-uniform: the distance grid is compared squared
     int flushed = 0; // wave-uniform: rows [0, flushed) of every lane are in memory
     while (__ballot(!done) != 0ull) {
         if (!done && (att != 0 || rows - flushed < kRing)) do {
             if (att == 0) {
                 // ---- the step begins: record the state, move, discretize (createEncounter.m:156-200)
                 if (rows >= A.cap) { failed = true; done = true; break; }
-                const double speed = sqrt(v0 * v0 + v1 * v1);
                 float *rec = &s_ring[threadIdx.x >> 6][rows % kRing][0][lane];
                 rec[0 * 64] = (float)t_s; rec[1 * 64] = (float)xy0; rec[2 * 64] = (float)xy1; rec[5 * 64] = (float)speed;
                 xy0 += (v0 * dt_s) * (1.0 / 6076.1154855643);
@@ -217,16 +271,16 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 double rec_z = z_ft;
                 if (ii > 1) {
                     const double alt_diff = z_ft - prev_z_rec;
-                    rec_z = prev_z_rec + t_sign(alt_diff) * fmin(maxVert, fabs(alt_diff));
+                    rec_z = prev_z_rec + t_sign(alt_diff) * fmin(T_LIM(4), fabs(alt_diff));
                 }
                 prev_z_rec = rec_z;
                 rec[3 * 64] = (float)rec_z; rec[4 * 64] = (float)curr_hdg;
                 rows++;
                 // CreateStartDistribution (0-based bins), createEncounter.m:268-294
-                d_nm = sqrt(xy0 * xy0 + xy1 * xy1);
+                d2_nm = xy0 * xy0 + xy1 * xy1;
                 st[0] = intent - 1;
-                st[1] = (gDist.n <= 8 ? t_discretize8(d_nm, s_cut8[0]) : t_discretize(d_nm, s_bnd, gDist)) - 1;     // wave-uniform choices
-                st[2] = t_discretize(t_wrap_atan2d(xy1, xy0), s_bnd, gBear) - 1;
+                st[1] = (dist8 ? t_discretize8(d2_nm, s_cut8sq) : t_discretize(sqrt(d2_nm), s_bnd, gDist)) - 1;     // wave-uniform choices
+                st[2] = t_bearing_bin(xy0, xy1, s_bnd + gBear.off + 1, s_dir, gBear.n, gBear.lo, gBear.inv_step) - 1;
                 st[3] = t_discretize(heading_deg, s_bnd, gHead) - 1;
                 st[4] = (gAlt.n <= 8 ? t_discretize8(z_ft, s_cut8[3]) : t_discretize(z_ft, s_bnd, gAlt)) - 1;
                 st[5] = (gSpd.n <= 8 ? t_discretize8(speed, s_cut8[4]) : t_discretize(speed, s_bnd, gSpd)) - 1;      // norm(v_ft_s): the velocity has not changed since `speed`
@@ -246,42 +300,42 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
             if (att >= A.max_resample) { failed = true; done = true; break; }
             rng.attempt = (uint32_t)role + 4u * (uint32_t)att;
             uint32_t xw[3];
+            {   // block = the step, word = the variable's row of the temporal map: one Philox call for the three draws
+                const uint4 tw = rng.block(11u /* TERM_TRANS */, 0u, (uint32_t)ii);
 #pragma unroll
-            for (int k = 0; k < 3; k++) xw[k] = word_of(rng.block(11u /* TERM_TRANS */, P.d_tvar[k], (uint32_t)ii >> 2), ii & 3);
+                for (int k = 0; k < 3; k++) xw[k] = word_of(tw, (int)P.d_row[k]);
+            }
             const Draw3 nb = t_draw3(row, piv, rm1, xw);
             // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude
             // or speed bin makes the step be drawn again -- the events applied before it stay applied, as in the reference's loop
             bool resample = false;
-            {
-                const int d = kh == 0 ? nb.bin[0] : (kh == 1 ? nb.bin[1] : nb.bin[2]);
-                if (d != st[3] + 1) heading_deg = t_dedisc(s_bnd + 2 * kBndStride, d, word_of(rng.block(12u /* TERM_DEDISC */, 3u, (uint32_t)ii >> 2), ii & 3));
+            const int dH = kh == 0 ? nb.bin[0] : (kh == 1 ? nb.bin[1] : nb.bin[2]), dA = ka == 0 ? nb.bin[0] : (ka == 1 ? nb.bin[1] : nb.bin[2]),
+                      dS = ks == 0 ? nb.bin[0] : (ks == 1 ? nb.bin[1] : nb.bin[2]);
+            uint4 dw = make_uint4(0u, 0u, 0u, 0u);   // the step's dediscretize draws (one Philox call, made by the lanes that have an event)
+            if (dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1) dw = rng.block(12u /* TERM_DEDISC */, 0u, (uint32_t)ii);
+            if (dH != st[3] + 1) heading_deg = t_dedisc(s_bnd + 2 * kBndStride, dH, word_of(dw, (int)P.d_row[kh]));
+            if (dA != st[4] + 1) {
+                // MATLAB: 1:[] is empty, so with no boundary at or below the limit no altitude event is valid
+                if (alt_last >= 1 && dA >= 1 && dA <= alt_last) z_ft = t_dedisc(s_bnd + 3 * kBndStride, dA, word_of(dw, (int)P.d_row[ka]));
+                else resample = true;
             }
-            {
-                const int d = ka == 0 ? nb.bin[0] : (ka == 1 ? nb.bin[1] : nb.bin[2]);
-                if (d != st[4] + 1) {
-                    // MATLAB: 1:[] is empty, so with no boundary at or below the limit no altitude event is valid
-                    if (alt_last >= 1 && d >= 1 && d <= alt_last) z_ft = t_dedisc(s_bnd + 3 * kBndStride, d, word_of(rng.block(12u, 4u, (uint32_t)ii >> 2), ii & 3));
-                    else resample = true;
-                }
-            }
-            if (!resample) {
-                const int d = ks == 0 ? nb.bin[0] : (ks == 1 ? nb.bin[1] : nb.bin[2]);
-                if (d != st[5] + 1) {
-                    if (spd_first >= 1 && d >= spd_first && d <= spd_last) {
-                        double s1 = t_dedisc(s_bnd + 4 * kBndStride, d, word_of(rng.block(12u, 5u, (uint32_t)ii >> 2), ii & 3));
-                        if (s1 < minVel) s1 = minVel;
-                        if (s1 > maxVel) s1 = maxVel;
-                        t_sincosd(heading_deg, sh, chh);
-                        v0 = chh * s1; v1 = sh * s1;
-                        vang = heading_deg;
-                    } else resample = true;
-                }
+            if (!resample && dS != st[5] + 1) {
+                if (spd_first >= 1 && dS >= spd_first && dS <= spd_last) {
+                    double s1 = t_dedisc(s_bnd + 4 * kBndStride, dS, word_of(dw, (int)P.d_row[ks]));
+                    const double minVel = T_LIM(0), maxVel = T_LIM(1);
+                    if (s1 < minVel) s1 = minVel;
+                    if (s1 > maxVel) s1 = maxVel;
+                    t_sincosd(heading_deg, sh, chh);
+                    v0 = chh * s1; v1 = sh * s1;
+                    vang = heading_deg;
+                    speed = s1;
+                } else resample = true;
             }
             if (resample) { att++; break; }
             att = 0;
             // ---- the step ends: turn towards the new heading, advance the clock, stop conditions
             const double turn1 = round((heading_deg - curr_hdg) * 100.0) * 0.01;
-            const double delta = fmin(fabs(turn1), maxTurn) * t_sign(turn1);
+            const double delta = fmin(fabs(turn1), T_LIM(2)) * t_sign(turn1);
             if (delta != 0.0) {                                  // rotationmatrix(0) is the identity
                 t_sincosd(delta, sh, chh);
                 const double vx = chh * v0 - sh * v1, vy = sh * v0 + chh * v1;
@@ -289,7 +343,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 vang += delta;
             }
             t_s += dt_s; ii++;
-            done = (fabs(t_s) > A.tmax_s) || (d_nm > bounds_dist_hi) || ((intent == 1 || intent == 2) && d_nm <= 0.25) || (is_ownship && xy1 > 0.25);
+            done = (fabs(t_s) > A.tmax_s) || (d2_nm > bounds_dist_hi * bounds_dist_hi) || ((intent == 1 || intent == 2) && d2_nm <= 0.0625) || (is_ownship && xy1 > 0.25);
         } while (false);
         // ---- rows that every running lane has produced leave for memory
         for (;;) {

@@ -130,8 +130,9 @@ enum {
     EM_SEC_RES_LO = 10,
     /* terminal trajectory propagation (createEncounter.m:93-265): counter word 2 ("attempt") carries
      * role + 4*resample_attempt with role = 2*(aircraft-1) + (direction == backward); idx = step ii */
-    EM_SEC_TERM_TRANS = 11,  /* dbn_sample(...,2,start) transition draw: a = tvar-1, idx = ii   */
-    EM_SEC_TERM_DEDISC = 12  /* dediscretize of an accepted event:       a = var-1,  idx = ii   */
+    EM_SEC_TERM_TRANS = 11,  /* dbn_sample(...,2,start) transition draw: a = 0, idx = 4 ii + row: block ii holds the step's   */
+    EM_SEC_TERM_DEDISC = 12  /* dediscretize of an accepted event: the same     draws of all three dynamic variables (word =  */
+                             /* the variable's row of the temporal map): one Philox call per step and section                  */
 };
 
 enum { EM_RNG_MT19937 = 0, EM_RNG_PHILOX = 1 };
@@ -943,8 +944,8 @@ int em_propagate_trajectory(const em_model_t *m, em_rng_t *g, int role, int is_o
                 const int r = m->r_transition[tv - 1];
                 const int64_t j = parent_config(m->G_transition, nt, m->r_transition, x, tv);
                 column_weights(m->N_transition, m->A_transition, m->off_transition[tv - 1], r, j, w);
-                if (g->mode == EM_RNG_MT19937) (void)em_rand(g, EM_SEC_TERM_TRANS, (uint32_t)(tv - 1), 0);
-                newbin[k] = em_select_random_r(w, r, em_rand(g, EM_SEC_TERM_TRANS, (uint32_t)(tv - 1), (uint32_t)ii));
+                if (g->mode == EM_RNG_MT19937) (void)em_rand(g, EM_SEC_TERM_TRANS, 0u, 0);
+                newbin[k] = em_select_random_r(w, r, em_rand(g, EM_SEC_TERM_TRANS, 0u, 4u * (uint32_t)ii + (uint32_t)k));
             }
             is_resample = 0;
             /* events rows in ascending variable id: 4 heading, 5 altitude, 6 speed (:198-238) */
@@ -954,17 +955,17 @@ int em_propagate_trajectory(const em_model_t *m, em_rng_t *g, int role, int is_o
                 const int d = newbin[k];
                 if (var == IDX_HEAD) {
                     if (d != heading_discrete) {
-                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, (uint32_t)(var - 1), (uint32_t)ii);
+                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, 0u, 4u * (uint32_t)ii + (uint32_t)k);
                         heading_deg = bnd[var][d - 1] + (bnd[var][d] - bnd[var][d - 1]) * u;
                     }
                 } else if (var == IDX_ALT) {
                     if (alt_last >= 1 && d >= 1 && d <= alt_last) {      /* 1:[] is empty in MATLAB */
-                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, (uint32_t)(var - 1), (uint32_t)ii);
+                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, 0u, 4u * (uint32_t)ii + (uint32_t)k);
                         z_ft = bnd[var][d - 1] + (bnd[var][d] - bnd[var][d - 1]) * u;
                     } else is_resample = 1;
                 } else if (var == IDX_SPD) {
                     if (spd_first >= 1 && d >= spd_first && d <= spd_last) { /* []:1:e is empty: no speed event is ever valid */
-                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, (uint32_t)(var - 1), (uint32_t)ii);
+                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, 0u, 4u * (uint32_t)ii + (uint32_t)k);
                         double s1 = bnd[var][d - 1] + (bnd[var][d] - bnd[var][d - 1]) * u;
                         if (s1 < dl->minVel_ft_s) s1 = dl->minVel_ft_s;
                         if (s1 > dl->maxVel_ft_s) s1 = dl->maxVel_ft_s;
