@@ -966,6 +966,7 @@ int emgpu_debug_pk_column(const emgpu_model *m, int32_t k, int64_t col, uint32_t
 // Upload / validate the trajectory models of a terminal call and publish their table pointers in ctx->d_thr_base.
 // Returns the first model's uploaded plan (the shapes every model shares).
 static uint32_t rel_piv(const EmgpuPlan &P, int k) { return P.d_pivoff[k] ? P.d_pivoff[k] - P.d_off[0] : 0u; } // pivot rows relative to the first dynamic table
+static uint32_t rel_c8(const EmgpuPlan &P, int k) { return P.d_c8off[k] ? P.d_c8off[k] - P.d_off[0] : 0u; }     // compact rows likewise
 static const Uploaded *terminal_tables(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models, const std::set<uint64_t> *also_pinned = nullptr) {
     std::vector<const uint32_t *> bases;
     const Uploaded *first = nullptr;
@@ -997,6 +998,7 @@ static const Uploaded *terminal_tables(emgpu_ctx *ctx, const emgpu_model *const 
             // the initial networks may differ (2 or 3 intents): only the dynamic tables' relative layout must agree
             bool same = (P.d_off[1] - P.d_off[0]) == (Q.d_off[1] - Q.d_off[0]) && (P.d_off[2] - P.d_off[0]) == (Q.d_off[2] - Q.d_off[0]) &&
                         memcmp(P.d_r, Q.d_r, sizeof P.d_r) == 0 && rel_piv(P, 0) == rel_piv(Q, 0) && rel_piv(P, 1) == rel_piv(Q, 1) && rel_piv(P, 2) == rel_piv(Q, 2) &&
+                        rel_c8(P, 0) == rel_c8(Q, 0) && rel_c8(P, 1) == rel_c8(Q, 1) && rel_c8(P, 2) == rel_c8(Q, 2) &&
                         memcmp(P.d_stride_static, Q.d_stride_static, sizeof P.d_stride_static) == 0 &&
                         memcmp(P.d_stride_cur, Q.d_stride_cur, sizeof P.d_stride_cur) == 0 && u.cp.bnd == first->cp.bnd && memcmp(P.i_boff, Q.i_boff, sizeof P.i_boff) == 0 &&
                         memcmp(P.d_ivar, Q.d_ivar, sizeof P.d_ivar) == 0 && memcmp(P.d_tvar, Q.d_tvar, sizeof P.d_tvar) == 0;

@@ -110,11 +110,17 @@ typedef const uint32_t __attribute__((address_space(1))) *gptr_t;   // a global-
 typedef uint32_t uint4u_t __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t uint2u_t __attribute__((ext_vector_type(2), aligned(4)));
 struct Draw3 { int bin[3]; };
-__device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&piv)[3], const int (&rm1)[3], const uint32_t (&x)[3]) {
+// c8: the compact form of a long row (EmgpuPlan::d_c8off; null: the variable has none): six distinct thresholds + the byte map decide
+// the draw from ONE 32-byte gather; a row with more than six (flag byte) sends its lane down the pivot path
+__device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&piv)[3], const gptr_t (&c8)[3], const bool (&has_c8)[3], const int (&rm1)[3], const uint32_t (&x)[3]) {
     uint32_t first[3][8];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        if (rm1[k] <= 8) {                                    // wave-uniform
+        if (has_c8[k]) {                                      // wave-uniform
+            const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)c8[k], b = *(const uint4u_t __attribute__((address_space(1))) *)(c8[k] + 4);
+            first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
+            first[k][4] = b.x; first[k][5] = b.y; first[k][6] = b.z; first[k][7] = b.w;
+        } else if (rm1[k] <= 8) {                             // wave-uniform
             // eight consecutive words from a 4-byte aligned address: two 16-byte loads
             const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)row[k];
             uint4u_t b = {0u, 0u, 0u, 0u};
@@ -132,12 +138,31 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const uint32_t xp = clamp32(x[k]);
-        if (rm1[k] <= 8) {
+        if (rm1[k] <= 8 && has_c8[k]) {                       // a 5- or 6-threshold row in its aligned compact form: six always fit
+            int nf = 0;
+#pragma unroll
+            for (int q = 0; q < 6; q++) nf += (xp >= first[k][q]) ? 1 : 0;
+            out.bin[k] = (int)((nf < 4 ? first[k][6] >> (8 * nf) : first[k][7] >> (8 * (nf - 4))) & 0xFFu);
+        } else if (rm1[k] <= 8) {
             int b = 0;
 #pragma unroll
             for (int q = 0; q < 8; q++) b += (q < rm1[k] && xp >= first[k][q]) ? 1 : 0;
             out.bin[k] = b + 1;
         } else if (rm1[k] <= 48) {
+            bool pivots = true;
+            if (has_c8[k]) {
+                int nf = 0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) nf += (xp >= first[k][q]) ? 1 : 0;
+                out.bin[k] = (int)((nf < 4 ? first[k][6] >> (8 * nf) : first[k][7] >> (8 * (nf - 4))) & 0xFFu);
+                pivots = (first[k][7] >> 24) != 0u;            // a row with more than six distinct thresholds (none in sparse tables)
+                if (pivots) {
+                    const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)piv[k], b = *(const uint4u_t __attribute__((address_space(1))) *)(piv[k] + 4);
+                    first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
+                    first[k][4] = b.x; first[k][5] = b.y; first[k][6] = b.z; first[k][7] = b.w;
+                }
+            }
+            if (pivots) {
             int g = 0;                                        // groups of 6 thresholds; pivot = last threshold of a group
 #pragma unroll
             for (int q = 0; q < 7; q++) g += (xp >= first[k][q]) ? 1 : 0;   // full groups entirely at or below x
@@ -152,6 +177,7 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
 #pragma unroll
             for (int q = 0; q < 6; q++) b += (6 * g + q < rm1[k] && xp >= t[q]) ? 1 : 0;
             out.bin[k] = b + 1;
+            }
         } else {                                              // beyond 48 thresholds (none of the shipped shapes): plain search
             int lo = 0, hi = rm1[k];
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (xp >= row[k][mid]) lo = mid + 1; else hi = mid; }
@@ -254,7 +280,8 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     // LDS instead, and row r leaves for memory -- one 256-byte store per field for the wave -- once every running lane is past it.
     // A lane more than kRing rows ahead of the slowest waits (the slowest lane sets the wave's run time either way).
     int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
-    gptr_t row[3] = {thr, thr, thr}, piv[3] = {thr, thr, thr};
+    gptr_t row[3] = {thr, thr, thr}, piv[3] = {thr, thr, thr}, c8[3] = {thr, thr, thr};
+    const bool has_c8[3] = {P.d_c8off[0] != 0u, P.d_c8off[1] != 0u, P.d_c8off[2] != 0u};   // wave-uniform
     double curr_hdg = 0, d2_nm = 0;
     const bool dist8 = gDist.n <= 8;   // wave-uniform: the distance grid is compared squared
     int flushed = 0; // wave-uniform: rows [0, flushed) of every lane are in memory
@@ -294,6 +321,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                     for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)st[P.d_ivar[q]];
                     row[k] = thr + (P.d_off[k] - P.d_off[0]) + (size_t)c * (uint32_t)rm1[k];
                     if (rm1[k] > 8 && rm1[k] <= 48) piv[k] = thr + (P.d_pivoff[k] - P.d_off[0]) + (size_t)c * 8u;   // wave-uniform
+                    if (has_c8[k]) c8[k] = thr + (P.d_c8off[k] - P.d_off[0]) + (size_t)c * 8u;
                 }
             }
             // ---- one attempt at the step's transition draw (attempt number in the Philox key)
@@ -305,7 +333,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
 #pragma unroll
                 for (int k = 0; k < 3; k++) xw[k] = word_of(tw, (int)P.d_row[k]);
             }
-            const Draw3 nb = t_draw3(row, piv, rm1, xw);
+            const Draw3 nb = t_draw3(row, piv, c8, has_c8, rm1, xw);
             // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude
             // or speed bin makes the step be drawn again -- the events applied before it stay applied, as in the reference's loop
             bool resample = false;

@@ -72,6 +72,12 @@ struct EmgpuPlan {
     // threshold (index 6q + 5) of the row's full groups but the last, 2^32-1 elsewhere -- k_terminal_propagate finds the group of a
     // draw from two 16-byte loads instead of seven strided ones
     uint32_t d_pivoff[EMGPU_MAX_ND];
+    // the same rows also have a COMPACT form of 8 words in thr[] (offset d_c8off, after the pivot rows; 0 = none): a row's distinct
+    // thresholds that can fire (0 < X < 2^32-1), ascending, padded with 2^32-1 to six, then the byte map "n of them fired -> 1-based
+    // bin" (7 bytes); byte 7 = 0xFF when the row has more than six (the kernel then takes the pivot path for that lane).  Zero-count
+    // bins make most thresholds of a 36-bin row coincide (a heading moves to a neighbouring bin or stays): one 32-byte gather
+    // decides the draw where pivots + group take two dependent ones, from a table a quarter of the size.
+    uint32_t d_c8off[EMGPU_MAX_ND];
     uint32_t d_stride_static[EMGPU_MAX_ND][EMGPU_MAX_NI]; // parents that never change, by position p
     uint32_t d_stride_cur[EMGPU_MAX_ND][EMGPU_MAX_ND];    // time-t node of dynamic var k' as parent
     uint32_t d_stride_new[EMGPU_MAX_ND][EMGPU_MAX_ND];    // (t+1) node of dynamic var k' (sampled earlier)
