@@ -32,8 +32,38 @@ __device__ __forceinline__ double t_wrap_atan2d(double y, double x) {
     const double a = t_atan2d(y, x);
     return a < 0.0 ? a + 360.0 : a + 0.0;
 }
-// cosd / sind: MATLAB's reduction in degrees + Horner sums on the reduced angle (sincosd_small, emgpu_device.h)
-__device__ __forceinline__ void t_sincosd(double deg, double &s, double &c) { sincosd_small(deg, s, c); }
+// A constant held in a SCALAR register pair at its use: the Horner coefficients below are loop invariants, and left to the compiler
+// they are materialised once and then occupy ~34 vector registers through the whole step loop of a kernel that is short of them.
+__device__ __forceinline__ double t_k(double c) { asm volatile("" : "+s"(c)); return c; }
+// cosd / sind: MATLAB's reduction in degrees (n = round(x/90), x - 90 n in [-45, 45], quadrant mod(n, 4)) + the Horner sums of
+// sincos_small (emgpu_device.h: same coefficients, same order of operations => the same bits), coefficients as scalar operands
+__device__ __forceinline__ void t_sincosd(double deg, double &s, double &c) {
+    const double n = round(deg * t_k(1.0 / 90.0));
+    const double x = t_k(3.14159265358979323846 / 180.0) * (deg - n * 90.0);
+    const int m = (int)((long long)n & 3ll);
+    const double z = x * x;
+    double ps = t_k(-1.0 / 121645100408832000.0);
+    ps = fma(ps, z, t_k(1.0 / 355687428096000.0));
+    ps = fma(ps, z, t_k(-1.0 / 1307674368000.0));
+    ps = fma(ps, z, t_k(1.0 / 6227020800.0));
+    ps = fma(ps, z, t_k(-1.0 / 39916800.0));
+    ps = fma(ps, z, t_k(1.0 / 362880.0));
+    ps = fma(ps, z, t_k(-1.0 / 5040.0));
+    ps = fma(ps, z, t_k(1.0 / 120.0));
+    ps = fma(ps, z, t_k(-1.0 / 6.0));
+    const double sx = fma(x * z, ps, x);
+    double pc = t_k(-1.0 / 6402373705728000.0);
+    pc = fma(pc, z, t_k(1.0 / 20922789888000.0));
+    pc = fma(pc, z, t_k(-1.0 / 87178291200.0));
+    pc = fma(pc, z, t_k(1.0 / 479001600.0));
+    pc = fma(pc, z, t_k(-1.0 / 3628800.0));
+    pc = fma(pc, z, t_k(1.0 / 40320.0));
+    pc = fma(pc, z, t_k(-1.0 / 720.0));
+    pc = fma(pc, z, t_k(1.0 / 24.0));
+    const double cx = (1.0 - 0.5 * z) + (z * z) * pc;
+    s = (m == 0) ? sx : ((m == 1) ? cx : ((m == 2) ? -sx : -cx));
+    c = (m == 0) ? cx : ((m == 1) ? -sx : ((m == 2) ? -cx : sx));
+}
 // dediscretize.m:33-39 on the two boundaries of 1-based bin d (LDS), f64 without contraction
 __device__ __forceinline__ double t_dedisc(const double *__restrict__ bnd, int d, uint32_t x) {
 #pragma clang fp contract(off)
