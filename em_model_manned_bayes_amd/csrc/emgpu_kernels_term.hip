@@ -23,8 +23,11 @@
 
 namespace emgpu {
 
+// A constant held in a SCALAR register pair at its use: the f64 constants of the step loop are loop invariants, and left to the compiler
+// they are materialised once and then occupy ~60 vector registers through the whole loop of a kernel that is short of them.
+__device__ __forceinline__ double t_k(double c) { asm volatile("" : "+s"(c)); return c; }
 // the carried direction angle brought into [0, 360): what wrapTo360(atan2d(v)) gives for the same direction
-__device__ __forceinline__ double t_mod360(double lon) { return lon - floor(lon * (1.0 / 360.0)) * 360.0; }
+__device__ __forceinline__ double t_mod360(double lon) { return lon - floor(lon * t_k(1.0 / 360.0)) * t_k(360.0); }
 __device__ __forceinline__ double t_atan2d(double y, double x) { return atan2(y, x) * (180.0 / 3.14159265358979323846); }
 // wrapTo360(atan2d(y, x)): the angle is in [-180, 180], where lon - floor(lon / 360) * 360 is lon + 360 below zero and lon from
 // zero up (the same roundings: floor is -1 or 0), and the "== 0 && positive" rule never fires
@@ -32,9 +35,6 @@ __device__ __forceinline__ double t_wrap_atan2d(double y, double x) {
     const double a = t_atan2d(y, x);
     return a < 0.0 ? a + 360.0 : a + 0.0;
 }
-// A constant held in a SCALAR register pair at its use: the Horner coefficients below are loop invariants, and left to the compiler
-// they are materialised once and then occupy ~34 vector registers through the whole step loop of a kernel that is short of them.
-__device__ __forceinline__ double t_k(double c) { asm volatile("" : "+s"(c)); return c; }
 // cosd / sind: MATLAB's reduction in degrees (n = round(x/90), x - 90 n in [-45, 45], quadrant mod(n, 4)) + the Horner sums of
 // sincos_small (emgpu_device.h: same coefficients, same order of operations => the same bits), coefficients as scalar operands
 __device__ __forceinline__ void t_sincosd(double deg, double &s, double &c) {
@@ -78,7 +78,10 @@ __device__ __forceinline__ double t_sign(double x) { return (double)((x > 0) - (
 // cut = boundaries(2:end-1).  The answer is guessed from the grid's first point and mean spacing (exact for the 10-degree bearing /
 // heading grids) and then walked to the true bin: any sorted grid gives the reference's answer, a uniform one in one or two LDS
 // reads instead of a scan.
-constexpr int kRing = 8;       // rows a lane may run ahead of the slowest lane of its wave
+#ifndef EMGPU_TERM_RING
+#define EMGPU_TERM_RING 6
+#endif
+constexpr int kRing = EMGPU_TERM_RING;       // rows a lane may run ahead of the slowest lane of its wave
 constexpr int kBndStride = 68; // boundaries per variable in LDS (the host checks i_nb <= 66)
 struct CutGrid { int off, n; double lo, inv_step; };
 __device__ __forceinline__ int t_discretize(double x, const double *__restrict__ s_bnd, const CutGrid &gd) {
@@ -154,7 +157,8 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
             // eight consecutive words from a 4-byte aligned address: two 16-byte loads
             const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)row[k];
             uint4u_t b = {0u, 0u, 0u, 0u};
-            if (rm1[k] > 4) b = *(const uint4u_t __attribute__((address_space(1))) *)(row[k] + 4);   // (wave-uniform; masked below either way)
+            if (rm1[k] > 6) b = *(const uint4u_t __attribute__((address_space(1))) *)(row[k] + 4);   // (wave-uniform; masked below either way)
+            else if (rm1[k] > 4) { const uint2u_t b2 = *(const uint2u_t __attribute__((address_space(1))) *)(row[k] + 4); b.x = b2.x; b.y = b2.y; }
             first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
             first[k][4] = b.x; first[k][5] = b.y; first[k][6] = b.z; first[k][7] = b.w;
         } else {
@@ -218,7 +222,7 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
 }
 
 #ifndef EMGPU_TERM_WAVES
-#define EMGPU_TERM_WAVES 2
+#define EMGPU_TERM_WAVES 4
 #endif
 // RM1_k: thresholds per row of dynamic variable k as a compile-time constant (0: read from the plan).  The instance built for the
 // terminal model's shape (36 headings, 7 altitude and 5 speed bins) folds every "is this index inside the row" test; left to run
@@ -231,7 +235,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     __shared__ double s_bnd[5 * kBndStride];
     __shared__ CutGrid s_grid[5];
     __shared__ double s_cut8[5][8];   // the cut points of a grid with at most 8 of them, padded with +inf
-    __shared__ float s_ring[4][kRing][6][64];   // per wave: the last kRing recorded rows of every lane, field-major (conflict-free)
+    __shared__ float s_ring[4][kRing][5][64];   // per wave: the last kRing recorded rows of every lane (x y z heading speed; the time is the row number), field-major (conflict-free)
     __shared__ double2 s_dir[kBndStride];       // (cosd, sind) of the bearing variable's cut points
     __shared__ double s_cut8sq[8];              // squares of the distance variable's cut points (when it has at most 8)
     for (int q = threadIdx.x; q < (int)P.i_nb[2] - 2; q += 256) {
@@ -287,11 +291,8 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     const int kh = P.d_ivar[0] == 3 ? 0 : (P.d_ivar[1] == 3 ? 1 : 2), ka = P.d_ivar[0] == 4 ? 0 : (P.d_ivar[1] == 4 ? 1 : 2),
               ks = P.d_ivar[0] == 5 ? 0 : (P.d_ivar[1] == 5 ? 1 : 2);
     // the part of a column index that never changes along a track: the intent (variable 1)
-    uint32_t col_static[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) col_static[k] = P.d_stride_static[k][0] * (uint32_t)(intent - 1);
 
-    double xy0 = g[0], xy1 = g[1], z_ft = g[2], heading_deg = g[4], t_s = 0, prev_z_rec = 0;
+    double xy0 = g[0], xy1 = g[1], z_ft = g[2], heading_deg = g[4], prev_z_rec = 0;
     double sh, chh;
     t_sincosd(heading_deg, sh, chh);
     double v0 = chh * g[3], v1 = sh * g[3];
@@ -310,9 +311,9 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     // LDS instead, and row r leaves for memory -- one 256-byte store per field for the wave -- once every running lane is past it.
     // A lane more than kRing rows ahead of the slowest waits (the slowest lane sets the wave's run time either way).
     int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
-    gptr_t row[3] = {thr, thr, thr}, piv[3] = {thr, thr, thr}, c8[3] = {thr, thr, thr};
+    uint32_t colk[3] = {0u, 0u, 0u};   // the step's CPT columns; the row addresses are formed at the draw (nine 64-bit pointers kept per lane cost 18 registers)
     const bool has_c8[3] = {P.d_c8off[0] != 0u, P.d_c8off[1] != 0u, P.d_c8off[2] != 0u};   // wave-uniform
-    double curr_hdg = 0, d2_nm = 0;
+    double curr_hdg = 0;
     const bool dist8 = gDist.n <= 8;   // wave-uniform: the distance grid is compared squared
     int flushed = 0; // wave-uniform: rows [0, flushed) of every lane are in memory
     while (__ballot(!done) != 0ull) {
@@ -321,9 +322,9 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 // ---- the step begins: record the state, move, discretize (createEncounter.m:156-200)
                 if (rows >= A.cap) { failed = true; done = true; break; }
                 float *rec = &s_ring[threadIdx.x >> 6][rows % kRing][0][lane];
-                rec[0 * 64] = (float)t_s; rec[1 * 64] = (float)xy0; rec[2 * 64] = (float)xy1; rec[5 * 64] = (float)speed;
-                xy0 += (v0 * dt_s) * (1.0 / 6076.1154855643);
-                xy1 += (v1 * dt_s) * (1.0 / 6076.1154855643);
+                rec[0 * 64] = (float)xy0; rec[1 * 64] = (float)xy1; rec[4 * 64] = (float)speed;
+                xy0 += (v0 * dt_s) * t_k(1.0 / 6076.1154855643);
+                xy1 += (v1 * dt_s) * t_k(1.0 / 6076.1154855643);
                 curr_hdg = (speed > 0.0) ? t_mod360(vang) : 0.0;
                 double rec_z = z_ft;
                 if (ii > 1) {
@@ -331,10 +332,10 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                     rec_z = prev_z_rec + t_sign(alt_diff) * fmin(T_LIM(4), fabs(alt_diff));
                 }
                 prev_z_rec = rec_z;
-                rec[3 * 64] = (float)rec_z; rec[4 * 64] = (float)curr_hdg;
+                rec[2 * 64] = (float)rec_z; rec[3 * 64] = (float)curr_hdg;
                 rows++;
                 // CreateStartDistribution (0-based bins), createEncounter.m:268-294
-                d2_nm = xy0 * xy0 + xy1 * xy1;
+                const double d2_nm = xy0 * xy0 + xy1 * xy1;
                 st[0] = intent - 1;
                 st[1] = (dist8 ? t_discretize8(d2_nm, s_cut8sq) : t_discretize(sqrt(d2_nm), s_bnd, gDist)) - 1;     // wave-uniform choices
                 st[2] = t_bearing_bin(xy0, xy1, s_bnd + gBear.off + 1, s_dir, gBear.n, gBear.lo, gBear.inv_step) - 1;
@@ -344,14 +345,12 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 // CPT column of each dynamic variable (asub2ind.m:13-14 as strides); topological position == variable id
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    uint32_t c = col_static[k];
+                    uint32_t c = 0u;
 #pragma unroll
-                    for (int p = 1; p < 6; p++) c += P.d_stride_static[k][p] * (uint32_t)st[p];
+                    for (int p = 0; p < 6; p++) c += P.d_stride_static[k][p] * (uint32_t)st[p];   // st[0]: the intent, which never changes
 #pragma unroll
                     for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)st[P.d_ivar[q]];
-                    row[k] = thr + (P.d_off[k] - P.d_off[0]) + (size_t)c * (uint32_t)rm1[k];
-                    if (rm1[k] > 8 && rm1[k] <= 48) piv[k] = thr + (P.d_pivoff[k] - P.d_off[0]) + (size_t)c * 8u;   // wave-uniform
-                    if (has_c8[k]) c8[k] = thr + (P.d_c8off[k] - P.d_off[0]) + (size_t)c * 8u;
+                    colk[k] = c;
                 }
             }
             // ---- one attempt at the step's transition draw (attempt number in the Philox key)
@@ -362,6 +361,13 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 const uint4 tw = rng.block(11u /* TERM_TRANS */, 0u, (uint32_t)ii);
 #pragma unroll
                 for (int k = 0; k < 3; k++) xw[k] = word_of(tw, (int)P.d_row[k]);
+            }
+            gptr_t row[3], piv[3], c8[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                row[k] = thr + (P.d_off[k] - P.d_off[0]) + (size_t)colk[k] * (uint32_t)rm1[k];
+                piv[k] = (rm1[k] > 8 && rm1[k] <= 48) ? thr + (P.d_pivoff[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;   // wave-uniform
+                c8[k] = has_c8[k] ? thr + (P.d_c8off[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;
             }
             const Draw3 nb = t_draw3(row, piv, c8, has_c8, rm1, xw);
             // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude
@@ -392,7 +398,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
             if (resample) { att++; break; }
             att = 0;
             // ---- the step ends: turn towards the new heading, advance the clock, stop conditions
-            const double turn1 = round((heading_deg - curr_hdg) * 100.0) * 0.01;
+            const double turn1 = round((heading_deg - curr_hdg) * t_k(100.0)) * t_k(0.01);
             const double delta = fmin(fabs(turn1), T_LIM(2)) * t_sign(turn1);
             if (delta != 0.0) {                                  // rotationmatrix(0) is the identity
                 t_sincosd(delta, sh, chh);
@@ -400,8 +406,9 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 v0 = vx; v1 = vy;
                 vang += delta;
             }
-            t_s += dt_s; ii++;
-            done = (fabs(t_s) > A.tmax_s) || (d2_nm > bounds_dist_hi * bounds_dist_hi) || ((intent == 1 || intent == 2) && d2_nm <= 0.0625) || (is_ownship && xy1 > 0.25);
+            ii++;
+            const double d2_nm = xy0 * xy0 + xy1 * xy1;   // (the position has not moved since the step began: recomputed, not carried)
+            done = ((double)(ii - 1) > A.tmax_s) || (d2_nm > bounds_dist_hi * bounds_dist_hi) || ((intent == 1 || intent == 2) && d2_nm <= 0.0625) || (is_ownship && xy1 > 0.25);
         } while (false);
         // ---- rows that every running lane has produced leave for memory
         for (;;) {
@@ -411,8 +418,9 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 const float *rec = &s_ring[threadIdx.x >> 6][flushed % kRing][0][lane];
                 float *o = A.out + (size_t)flushed * nl + (size_t)L;
                 const size_t fs = (size_t)A.cap * nl;
+                o[0] = (float)(dt_s * (double)flushed);   // t_s = +-row: whole seconds, exact
 #pragma unroll
-                for (int f = 0; f < 6; f++) o[f * fs] = rec[f * 64];
+                for (int f = 1; f < 6; f++) o[f * fs] = rec[(f - 1) * 64];
             }
             flushed++;
         }
