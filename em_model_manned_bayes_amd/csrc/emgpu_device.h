@@ -78,26 +78,33 @@ __device__ __forceinline__ double dedisc_f64(const double *__restrict__ bnd, int
 // sin and cos of |x| <= pi/4 (a reduced angle): Taylor sums to x^19 / x^18 in Horner form on explicit fma -- truncation below
 // 1e-19, about two ulp of rounding.  The library's sin() / cos() spend three times the instructions on a range reduction that
 // such an argument never needs.  Used where outputs are compared at a tolerance (tracks), never on the sampling path.
+// A constant held in a SCALAR register pair at its use.  The f64 coefficients of a loop body are loop invariants: left to the compiler they are
+// materialised once, ahead of the loop, and then sit in vector registers for its whole length -- 60 of them in k_terminal_propagate, a third
+// of its budget and a whole wave of occupancy.  As scalar operands (one per VALU instruction) they cost two s_mov each at the use.
+__device__ __forceinline__ double sk64(double c) { asm volatile("" : "+s"(c)); return c; }
+// SK: the coefficients as scalar operands (sk64)
+template <bool SK = false>
 __device__ __forceinline__ void sincos_small(double x, double &s, double &c) {
+    auto K = [](double v) { return SK ? sk64(v) : v; };
     const double z = x * x;
-    double ps = -1.0 / 121645100408832000.0;          // -1/19!
-    ps = fma(ps, z, 1.0 / 355687428096000.0);         //  1/17!
-    ps = fma(ps, z, -1.0 / 1307674368000.0);          // -1/15!
-    ps = fma(ps, z, 1.0 / 6227020800.0);              //  1/13!
-    ps = fma(ps, z, -1.0 / 39916800.0);               // -1/11!
-    ps = fma(ps, z, 1.0 / 362880.0);                  //  1/9!
-    ps = fma(ps, z, -1.0 / 5040.0);                   // -1/7!
-    ps = fma(ps, z, 1.0 / 120.0);                     //  1/5!
-    ps = fma(ps, z, -1.0 / 6.0);                      // -1/3!
+    double ps = K(-1.0 / 121645100408832000.0);          // -1/19!
+    ps = fma(ps, z, K(1.0 / 355687428096000.0));         //  1/17!
+    ps = fma(ps, z, K(-1.0 / 1307674368000.0));          // -1/15!
+    ps = fma(ps, z, K(1.0 / 6227020800.0));              //  1/13!
+    ps = fma(ps, z, K(-1.0 / 39916800.0));               // -1/11!
+    ps = fma(ps, z, K(1.0 / 362880.0));                  //  1/9!
+    ps = fma(ps, z, K(-1.0 / 5040.0));                   // -1/7!
+    ps = fma(ps, z, K(1.0 / 120.0));                     //  1/5!
+    ps = fma(ps, z, K(-1.0 / 6.0));                      // -1/3!
     s = fma(x * z, ps, x);
-    double pc = -1.0 / 6402373705728000.0;            // -1/18!
-    pc = fma(pc, z, 1.0 / 20922789888000.0);          //  1/16!
-    pc = fma(pc, z, -1.0 / 87178291200.0);            // -1/14!
-    pc = fma(pc, z, 1.0 / 479001600.0);               //  1/12!
-    pc = fma(pc, z, -1.0 / 3628800.0);                // -1/10!
-    pc = fma(pc, z, 1.0 / 40320.0);                   //  1/8!
-    pc = fma(pc, z, -1.0 / 720.0);                    // -1/6!
-    pc = fma(pc, z, 1.0 / 24.0);                      //  1/4!
+    double pc = K(-1.0 / 6402373705728000.0);            // -1/18!
+    pc = fma(pc, z, K(1.0 / 20922789888000.0));          //  1/16!
+    pc = fma(pc, z, K(-1.0 / 87178291200.0));            // -1/14!
+    pc = fma(pc, z, K(1.0 / 479001600.0));               //  1/12!
+    pc = fma(pc, z, K(-1.0 / 3628800.0));                // -1/10!
+    pc = fma(pc, z, K(1.0 / 40320.0));                   //  1/8!
+    pc = fma(pc, z, K(-1.0 / 720.0));                    // -1/6!
+    pc = fma(pc, z, K(1.0 / 24.0));                      //  1/4!
     c = (1.0 - 0.5 * z) + (z * z) * pc;
 }
 // cosd / sind with MATLAB's reduction in degrees: n = round(x/90), x - 90 n in [-45, 45], quadrant m = mod(n, 4)
@@ -106,7 +113,7 @@ __device__ __forceinline__ void sincosd_small(double deg, double &s, double &c) 
     const double x = (3.14159265358979323846 / 180.0) * (deg - n * 90.0);
     const int m = (int)((long long)n & 3ll);
     double sx, cx;
-    sincos_small(x, sx, cx);
+    sincos_small<false>(x, sx, cx);
     s = (m == 0) ? sx : ((m == 1) ? cx : ((m == 2) ? -sx : -cx));
     c = (m == 0) ? cx : ((m == 1) ? -sx : ((m == 2) ? -cx : sx));
 }

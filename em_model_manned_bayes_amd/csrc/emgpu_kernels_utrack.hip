@@ -35,7 +35,7 @@ __device__ __forceinline__ void ut_sincos(double x, double &s, double &c) {
     double r = fma(-k, 1.57079632673412561417, x);                     // pi/2, first 33 bits
     r = fma(-k, 6.07710050650619224932e-11, r);                        // pi/2 - the above
     double sr, cr;
-    sincos_small(r, sr, cr);
+    sincos_small<false>(r, sr, cr);   // (coefficients as scalar operands -- three waves instead of two -- were measured: +4 %, this kernel is issue-bound)
     const int q = (int)((long long)k & 3ll);
     s = (q == 0) ? sr : ((q == 1) ? cr : ((q == 2) ? -sr : -cr));
     c = (q == 0) ? cr : ((q == 1) ? -sr : ((q == 2) ? -cr : sr));
