@@ -190,8 +190,12 @@ __device__ __attribute__((noinline)) uint32_t exact_hit(uint32_t c0, uint32_t c1
 // instances drop the wave-uniform tests and the code behind them (cor_v1: 25.2 -> 20.8 ms).
 // CUR / NEW: which dynamic variables are parents of which (t+1) node (bit 4k+q; step_parent_masks): an instance built for a
 // model's masks multiplies only the strides that exist (cor_v1: 6 of 22) and fetches the columns of a dependency level together.
-template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW>
+// FRZ: the FAST branch of dbn_sample.m:95-166 on this kernel -- the parent configuration of every transition is frozen at the
+// initial state (the column of a variable never changes along a trajectory).  For the fast-branch models k_uncor_fast does not
+// take (four dynamic variables: littoral_cor_v1); the per-second gathers then hit the same line every time.
+template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW, bool FRZ = false>
 __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
+    static_assert(!FRZ || NEW == 0u, "a fast-branch model has no (t+1) parents");
     __shared__ CoopLds<ND, true> s_wave[4];
     __shared__ double s_bnd[ND][16];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -276,6 +280,9 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
     uint32_t ivs[ND];
 #pragma unroll
     for (int k = 0; k < ND; k++) ivs[k] = P.d_ivar[k];
+    uint32_t frz[ND];   // FRZ: the initial bins, the only "current" bins a column ever sees (dbn_sample.m:110-135)
+#pragma unroll
+    for (int k = 0; k < ND; k++) frz[k] = cur1[k];
     uint32_t selbase; // kSelBase2 held in a VGPR (the first v_addc of every compare chain reads it)
     asm volatile("v_mov_b32 %0, %1" : "=v"(selbase) : "s"(kSelBase2));
 
@@ -328,7 +335,7 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
             uint32_t col = basecol[k];
 #pragma unroll
             for (int q = 0; q < ND; q++)
-                if ((CUR >> (4 * k + q)) & 1u) col = mad24v(cur1[q], svc[k][q], col);
+                if ((CUR >> (4 * k + q)) & 1u) col = mad24v(FRZ ? frz[q] : cur1[q], svc[k][q], col);
 #pragma unroll
             for (int q = 0; q < k; q++)
                 if ((NEW >> (4 * k + q)) & 1u) col = mad24v(nb1[q], svn[k][q], col);
@@ -538,7 +545,7 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     static const bool off = getenv("EMGPU_DEBUG_NO_STEP2") != nullptr;
     if (off) return false;
     if (P.nd < 1 || P.nd > 4) return false;
-    if (!(P.depend || A.per_step)) return false;
+    if (!(P.depend || A.per_step) && P.nd != 4) return false;   // a fast-branch model: only the four-variable ones (frozen columns, FRZ)
     if (A.ev_count != nullptr || A.events != nullptr) return false;
     if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
     for (int k = 0; k < P.nd; k++) {
@@ -589,6 +596,7 @@ static bool launch_masked(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args
 hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
     if (A.n <= 0) return hipSuccess;
     Step2Args F{};
+    const bool frozen = !(P.depend || A.per_step);
     bool all_res = true;
     int wmode = P.d_pw[0];
     for (int k = 0; k < P.nd; k++) {
@@ -607,6 +615,20 @@ hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s
         {"k_dbn_step2<16,4,w4,reg>", "k_dbn_step2<16,4,w8,reg>", "k_dbn_step2<16,4,reg>", "k_dbn_step2<16,4>"}};
     const int shape = (P.ni <= 7 && P.nd <= 3) ? 0 : ((P.ni <= 9 && P.nd <= 3) ? 1 : 2);
     const bool reg = all_res && P.nd == (shape == 2 ? 4 : 3);
+    if (frozen) {   // fast branch, four dynamic variables
+        const dim3 g((unsigned)((A.n + 255) / 256)), b(256);
+        uint32_t cur, nw;
+        step_parent_masks(P, &cur, &nw);
+        if (nw != 0u) return hipErrorNotSupported;   // (cannot be: is_dynvar_depend would be set)
+        if (reg && wmode == 4 && P.ni <= 16 && cur == 0x8421u) {
+            *name = "k_dbn_step2<16,4,w4,reg>[frozen]";   // littoral_cor_v1: every variable's only dynamic parent is its own current bin
+            hipLaunchKernelGGL((k_dbn_step2<16, 4, 4, true, 0x8421u, 0u, true>), g, b, 0, s, P, A, F);
+        } else {
+            *name = "k_dbn_step2<16,4>[frozen]";
+            hipLaunchKernelGGL((k_dbn_step2<16, 4, 0, false, kCurAll4, 0u, true>), g, b, 0, s, P, A, F);
+        }
+        return hipGetLastError();
+    }
     static const bool no_masks = getenv("EMGPU_DEBUG_NO_STEP2_MASKS") != nullptr;
     if (reg && !no_masks) {
         uint32_t cur, nw;

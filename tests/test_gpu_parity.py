@@ -130,6 +130,12 @@ def test_correlated_model_matches_oracle(name, gpu_ctx, model_dir):
     ref = O.uncor_sample(om, n, T, seed)           # no "v"/"\dot h" labels -> rejection test disabled on both sides
     got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, want_dense=True, want_events=True)
     assert_uncor_parity(got, ref, T)
+    # dense only: the per-timestep kernel -- for the fast-branch model with its columns frozen at the initial state (dbn_sample.m:110-135)
+    for T2, n2 in ((120, 1500), (7, 300), (8, 257), (1, 64)):
+        ref2 = O.uncor_sample(om, n2, T2, seed + 1, first_index=2**33, want_events=False)
+        got2 = native.sample_dbn_host(gpu_ctx, nm, n2, T2, seed + 1, first_index=2**33, want_dense=True, want_events=False)
+        assert got2["kernel"].startswith("k_dbn_step2<16,4,") and (("[frozen]" in got2["kernel"]) == (name == "littoral_cor_v1")), got2["kernel"]
+        assert_uncor_parity(got2, ref2, T2)
 
 
 def test_start_presets_prior_layers_quantize(gpu_ctx, model_dir):
