@@ -26,6 +26,7 @@
 
 #include "emgpu_coop.h"
 #include "emgpu_device.h"
+#include "emgpu_events.h"
 #include "emgpu_launch.h"
 
 namespace emgpu {
@@ -310,112 +311,6 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
     pbA &= 0x7F7F7F7Fu; pbB &= 0x7F7F7F7Fu;
 }
 
-// ---- event lists from the fast kernel --------------------------------------------------------------------------------------
-// What UncorEncounterModel.sample returns (UncorEncounterModel.m:283-300) is the event list of dbn_hierarchical_sample.m:16-37:
-// per second c = 1..T first the resample rows of resample_events.m:16-37 in ascending variable id -- of EVERY variable with a
-// rate, also the static ones that the dense trace never shows -- then, for c < T, the transition rows of dbn_sample.m:151-161 in
-// ascending variable id, and the terminator row.  The 8-second block already holds all of it but two things: the re-draws of
-// static variables (their own RES slots: one more Philox call per such variable and block, the same packed compare) and the
-// value of a resample row that a transition of the same second hides in the dense trace (its DEDISC_RES draw is made here, by
-// the lane that needs it; ~1 per trajectory).  The flag streams of a block -- up to 5 resample streams, 3 transition streams,
-// MSB-first -- are transposed into one 64-bit mask whose leading bit is the lane's next event in list order.
-constexpr int kEvRes = 5;   // resample streams per block: bits 0-4 of a second's byte; bits 5-7: the three transition streams
-
-// 8 x 8 bit-matrix transpose (bit 8r + c <-> bit 8c + r): three delta swaps
-__device__ __forceinline__ uint64_t transpose8x8(uint64_t x) {
-    uint64_t t;
-    t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull; x ^= t ^ (t << 7);
-    t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x ^= t ^ (t << 14);
-    t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x ^= t ^ (t << 28);
-    return x;
-}
-
-// the eight resample Bernoullis of one block of a STATIC variable (resample_events.m:24): high halfwords two seconds per
-// instruction like eight_seconds_pk; a tie with R's high half anywhere in the wave redoes the lane's eight on 32 bits.
-__device__ __forceinline__ uint32_t static_hits8(const Rng &rng, uint32_t var, int g8, uint32_t R, uint32_t RR1) {
-    const uint4 rh = rng.block(EMGPU_SEC_RES, var, (uint32_t)g8);
-    uint32_t hitA = 0u;
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        uint32_t u;
-        asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(u) : "s"(RR1), "v"(word_of(rh, p)));
-        asm("v_pk_min_u16 %0, %0, 2 op_sel_hi:[1,0]" : "+v"(u));
-        hitA = p ? ((hitA << 2) | u) : u;
-    }
-    uint32_t hit8 = (hitA & 0xAAu) | ((hitA >> 17) & 0x55u);
-    if (__ballot((hitA & 0x00550055u) != 0u) != 0ull) {
-        const uint4 rl = rng.block(EMGPU_SEC_RES_LO, var, (uint32_t)g8);
-        hit8 = 0u;
-#pragma unroll
-        for (int j = 0; j < 8; j++) hit8 = (hit8 << 1) | (clamp32(split_draw(rh, rl, j)) < R ? 1u : 0u);
-    }
-    return hit8;
-}
-
-// wave-uniform description of the (up to) eight event streams of a block, byte b of every word for stream b: resample of the
-// b-th variable with a rate (b < 5, ascending variable id), transition of the (b - 5)-th dynamic variable in ascending variable id
-struct EvPlan {
-    uint64_t var1;  // 1-based variable id of the row
-    uint64_t kdyn;  // dynamic-variable index k (0..2), 0xFF: a static variable (or no stream)
-    uint64_t zero;  // zero bin (0: none)
-    uint64_t nb;    // number of boundaries (0: categorical, the value is the bin)
-    uint64_t boff;  // boundaries offset of streams 0-3 (16 bits each); boff4: of stream 4
-    uint32_t boff4, nact;
-    uint32_t R[kEvRes];    // resample hit thresholds
-    uint32_t RR1[kEvRes];  // (R >> 16) + 1 in both halfwords
-};
-template <int NI>
-__device__ __forceinline__ EvPlan ev_plan_of(const EmgpuPlan &P) {
-    EvPlan E{};
-    E.nact = (uint32_t)P.nact;
-#pragma unroll
-    for (int b = 0; b < kEvRes; b++) {
-        E.R[b] = 0u; E.RR1[b] = 0x00010001u;
-        uint64_t kd = 0xFFull;
-        if (b < P.nact) {
-            const uint32_t pos = P.a_pos[b];
-            E.var1 |= (uint64_t)(P.a_var[b] + 1u) << (8 * b);
-            kd = (uint64_t)(uint8_t)P.a_dyn[b];
-            E.zero |= (uint64_t)P.i_zero[pos] << (8 * b);
-            E.nb |= (uint64_t)P.i_nb[pos] << (8 * b);
-            if (b < 4) E.boff |= (uint64_t)P.i_boff[pos] << (16 * b); else E.boff4 = P.i_boff[pos];
-            E.R[b] = P.a_R[b]; E.RR1[b] = ((P.a_R[b] >> 16) + 1u) * 0x00010001u;
-        }
-        E.kdyn |= kd << (8 * b);
-    }
-#pragma unroll
-    for (int e = 0; e < 3; e++) {
-        const uint32_t k = P.d_emit[e];
-        E.var1 |= (uint64_t)(P.d_ivar[k] + 1u) << (8 * (kEvRes + e));
-        E.kdyn |= (uint64_t)k << (8 * (kEvRes + e));
-        E.zero |= (uint64_t)P.d_zero[k] << (8 * (kEvRes + e));
-        E.nb |= (uint64_t)P.d_nb[k] << (8 * (kEvRes + e));
-    }
-    return E;
-}
-
-// per-lane state of the event list
-struct EvState {
-    uint64_t *ev;      // the lane's list
-    uint32_t count, last_t, cap;
-    uint64_t sbins;    // byte b: 1-based bin of static stream b
-    __device__ __forceinline__ void emit(uint32_t at, uint32_t var1, uint32_t bin1, float v) {   // dbn_hierarchical_sample.m:33-37 row [dt var value], bin alongside
-        const uint32_t dt = at - last_t;
-        last_t = at;
-        if (count < cap) ev[count] = (uint64_t)(dt & 0xFFFFu) | ((uint64_t)var1 << 16) | ((uint64_t)bin1 << 24) | ((uint64_t)__float_as_uint(v) << 32);
-        count++;
-    }
-};
-
-// dediscretize.m:33-39 for a resample row whose draw the cooperative pass did not make (a static variable, or a row hidden by a
-// transition of the same second): slot (DEDISC_RES, variable, second c), made by the lane itself
-__device__ __attribute__((noinline)) float ev_draw(uint32_t c0, uint32_t c1, uint32_t attempt, uint32_t k0, uint32_t k1, const double *bnd,
-                                                   uint32_t var0, uint32_t c, uint32_t bin0, uint32_t boff) {
-    const uint4 r4 = philox4x32(c0, c1, attempt, (EMGPU_SEC_DEDISC_RES << 28) | (var0 << 20) | (c >> 2), k0, k1);
-    const uint32_t w = c & 3u;
-    return (float)dedisc_f64(bnd, (int)boff, (int)bin0, w == 0 ? r4.x : (w == 1 ? r4.y : (w == 2 ? r4.z : r4.w)));
-}
-
 // The whole kernel as a function of (plan, run, workgroup number within the run): k_uncor_fast runs it on the kernel's own arguments,
 // k_uncor_fast_mixed on the entry of the model block its workgroup belongs to.
 // MIXED: the plan is read from device memory (not from the kernel arguments): what the 8-second loop uses of it is pinned in
@@ -508,12 +403,8 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
     EvPlan E{};
     EvState S{};
     if constexpr (EV) {
-        E = ev_plan_of<NI>(P);
-        S.ev = A.events + (size_t)(valid ? i : 0) * (size_t)A.event_cap;
-        S.cap = valid ? (uint32_t)A.event_cap : 0u;
-#pragma unroll
-        for (int b = 0; b < kEvRes; b++)
-            if (b < P.nact && P.a_dyn[b] < 0) S.sbins |= (uint64_t)(uint32_t)(pick<NI>(bin, P.a_pos[b]) + 1) << (8 * b);
+        E = ev_plan_of<NI, 3>(P);
+        S = ev_state_of<NI, 3>(P, A, bin, valid, i);
     }
     const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
     for (int g8 = 0; g8 < G8; g8++) {
@@ -543,85 +434,12 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
         for (int k = 0; k < 3; k++)
             coop_fill_store_msb<3, LB>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
                                    3u, h_slot[k], i0, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
-        if constexpr (EV) {
-            // ---- the block's rows of the event list
-            // streams: byte 7 - b of `in` = stream b, bit 7 - j = second j; after the transpose bit 63 - (8 j + b) is event (j, b)
-            const uint32_t live8 = (g8 == 0 ? 0x7Fu : 0xFFu) & (8 * g8 + 7 < T ? 0xFFu : (0xFF00u >> (T - 8 * g8)) & 0xFFu);   // seconds 1 <= c < T
-            uint64_t in = 0ull;
-#pragma unroll
-            for (int b = 0; b < kEvRes; b++) {
-                if (b >= (int)E.nact) continue;                       // wave-uniform
-                const uint32_t kd = (uint32_t)(E.kdyn >> (8 * b)) & 0xFFu;
-                uint32_t st;
-                if (kd != 0xFFu) st = (hit24 >> (8u * kd)) & 0xFFu;   // a dynamic variable: decided by its 8-second pass
-                else st = static_hits8(rng, ((uint32_t)(E.var1 >> (8 * b)) & 0xFFu) - 1u, g8, E.R[b], E.RR1[b]) & live8;
-                in |= (uint64_t)st << (8 * (7 - b));
-            }
-#pragma unroll
-            for (int e = 0; e < 3; e++) {
-                const uint32_t kd = (uint32_t)(E.kdyn >> (8 * (kEvRes + e))) & 0xFFu;
-                in |= (uint64_t)((kind24 >> (8u * kd)) & 0xFFu) << (8 * (7 - (kEvRes + e)));
-            }
-            uint64_t pend = valid ? transpose8x8(in) : 0ull;
-            const uint8_t *bins8 = reinterpret_cast<const uint8_t *>(&W.res[lane * CoopLds<3, LB>::kStride + CoopLds<3, LB>::kBins]);
-            const float *res32 = &W.res[lane * CoopLds<3, LB>::kStride];
-            while (__ballot(pend != 0ull) != 0ull) {
-                if (pend != 0ull) {
-                    const uint32_t pos = (uint32_t)__clzll((long long)pend);
-                    pend &= ~(0x8000000000000000ull >> pos);
-                    const uint32_t j = pos >> 3, b = pos & 7u, sh = 8u * b;
-                    const uint32_t var1 = (uint32_t)(E.var1 >> sh) & 0xFFu, kd = (uint32_t)(E.kdyn >> sh) & 0xFFu, zb = (uint32_t)(E.zero >> sh) & 0xFFu;
-                    const uint32_t c = 8u * (uint32_t)g8 + j;
-                    uint32_t bin1;
-                    float v = 0.f;
-                    bool draw = false;
-                    if (b >= (uint32_t)kEvRes) {                        // a transition row (dbn_sample.m:151-161): the new bin and its value
-                        bin1 = bins8[8u * kd + j];
-                        if (bin1 != zb) v = res32[8u * kd + j];
-                    } else if (kd != 0xFFu) {                           // a resample row of a dynamic variable: the bin BEFORE this second's transition
-                        bin1 = j ? bins8[8u * kd + j - 1u] : ((prevw >> (8u * kd)) & 0xFFu);
-                        const bool hidden = ((kind24 >> (8u * kd + 7u - j)) & 1u) != 0u;
-                        if (bin1 != zb) { if (hidden) draw = true; else v = res32[8u * kd + j]; }
-                    } else {                                            // a resample row of a static variable
-                        bin1 = (uint32_t)(S.sbins >> sh) & 0xFFu;
-                        const uint32_t nb = (uint32_t)(E.nb >> sh) & 0xFFu;
-                        if (nb == 0u) v = (float)bin1; else if (bin1 != zb) draw = true;
-                    }
-                    if (draw) {
-                        const uint32_t boff = b < 4u ? (uint32_t)(E.boff >> (16u * b)) & 0xFFFFu : E.boff4;
-                        v = ev_draw(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, P.bnd, var1 - 1u, c, bin1 - 1u, boff);
-                    }
-                    S.emit(c, var1, bin1, v);
-                }
-            }
-        }
+        if constexpr (EV) ev_emit_block<3, LB>(W, lane, E, S, rng, P.bnd, g8, T, valid, hit24, kind24, prevw);
         wave_sync(); // results of this block are consumed before the next block's workers overwrite them
     }
     if constexpr (EV) {
-        // resample_events.m:16-37 also covers second T (the list runs to sum(dt) = T; the dense trace has no column T)
-        const uint32_t Tu = (uint32_t)T;
-#pragma unroll
-        for (int b = 0; b < kEvRes; b++) {
-            if (b >= (int)E.nact) continue;
-            const uint32_t var0 = ((uint32_t)(E.var1 >> (8 * b)) & 0xFFu) - 1u, kd = (uint32_t)(E.kdyn >> (8 * b)) & 0xFFu;
-            const uint4 rh = rng.block(EMGPU_SEC_RES, var0, Tu >> 3), rl = rng.block(EMGPU_SEC_RES_LO, var0, Tu >> 3);
-            uint32_t x = 0u;
-#pragma unroll
-            for (int j = 0; j < 8; j++) x = ((Tu & 7u) == (uint32_t)j) ? split_draw(rh, rl, j) : x;
-            if (clamp32(x) < E.R[b]) {
-                const uint32_t zb = (uint32_t)(E.zero >> (8 * b)) & 0xFFu, nb = (uint32_t)(E.nb >> (8 * b)) & 0xFFu;
-                const uint32_t bin1 = kd != 0xFFu ? (pick_word<3>(cur1, kd) & 0x7Fu) : ((uint32_t)(S.sbins >> (8 * b)) & 0xFFu);
-                float v = 0.f;
-                if (nb == 0u) v = (float)bin1;
-                else if (bin1 != zb) v = ev_draw(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, P.bnd, var0, Tu, bin1 - 1u, b < 4 ? (uint32_t)(E.boff >> (16 * b)) & 0xFFFFu : E.boff4);
-                S.emit(Tu, var0 + 1u, bin1, v);
-            }
-        }
-        if (!(A.flags & EMGPU_FLAG_NO_TERMINATOR)) S.emit(Tu, 0u, 0u, 0.f);   // dbn_hierarchical_sample.m:15-19
-        if (valid) {
-            A.ev_count[i] = S.count;
-            if (S.count > (uint32_t)A.event_cap) atomicOr(A.status, 2u);
-        }
+        const uint32_t curp = (cur1[0] & 0x7Fu) | ((cur1[1] & 0x7Fu) << 8) | ((cur1[2] & 0x7Fu) << 16);
+        ev_tail<3>(E, S, rng, P.bnd, T, curp, A, valid, i);
     }
 }
 
@@ -695,18 +513,10 @@ static int fast_shape_of(const EmgpuPlan &P) {
     return -1;
 }
 
-// event lists (k_uncor_fast_ev): at most kEvRes variables with a resample rate, every rate below the packed compare's limit
-static bool fast_events_ok(const EmgpuPlan &P, const EmgpuRun &A) {
-    if (P.nact > kEvRes || A.event_cap < 1) return false;
-    for (int a = 0; a < P.nact; a++)
-        if (P.a_R[a] >= 0xFFFF0000u) return false;
-    return true;
-}
-
 bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     if (A.indices != nullptr) return false; // an index list goes through the generic kernel
     if (P.nd != 3 || P.depend || A.per_step) return false;
-    if ((A.ev_count != nullptr || A.events != nullptr) && !fast_events_ok(P, A)) return false;
+    if ((A.ev_count != nullptr || A.events != nullptr) && !ev_plan_ok(P, A)) return false;
     if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
     for (int k = 0; k < 3; k++) {
         if (P.d_nb[k] == 0 || P.d_nb[k] > 16 || P.d_meff[k] == 0) return false;

@@ -20,6 +20,7 @@
 
 #include "emgpu_coop.h"
 #include "emgpu_device.h"
+#include "emgpu_events.h"
 #include "emgpu_launch.h"
 
 namespace emgpu {
@@ -193,8 +194,9 @@ __device__ __attribute__((noinline)) uint32_t exact_hit(uint32_t c0, uint32_t c1
 // FRZ: the FAST branch of dbn_sample.m:95-166 on this kernel -- the parent configuration of every transition is frozen at the
 // initial state (the column of a variable never changes along a trajectory).  For the fast-branch models k_uncor_fast does not
 // take (four dynamic variables: littoral_cor_v1); the per-second gathers then hit the same line every time.
-template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW, bool FRZ = false>
-__global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
+// EV: the event list as well (emgpu_events.h): what UncorEncounterModel.sample / dbn_hierarchical_sample return for these models.
+template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW, bool FRZ = false, bool EV = false>
+__global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
     static_assert(!FRZ || NEW == 0u, "a fast-branch model has no (t+1) parents");
     __shared__ CoopLds<ND, true> s_wave[4];
     __shared__ double s_bnd[ND][16];
@@ -214,6 +216,8 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
 
     uint32_t cur1[ND], basecol[ND];
     float cval[ND];
+    EvPlan E{};
+    EvState S{};
     {
         int bin[NI];
         double val[NI];
@@ -230,6 +234,10 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
                     if (A.init_val) A.init_val[(size_t)P.i_var[p] * A.ld + i] = (float)val[p];
                 }
             }
+        }
+        if constexpr (EV) {
+            E = ev_plan_of<NI, ND>(P);
+            S = ev_state_of<NI, ND>(P, A, bin, valid, i);
         }
 #pragma unroll
         for (int k = 0; k < ND; k++) {
@@ -297,6 +305,11 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
     for (int g8 = 0; g8 < G8; g8++) {
         uint4 th[ND];
         uint32_t pbA[ND], pbB[ND], hit8[ND], chg8[ND], zer8[ND]; // flag streams MSB-first: bit 7-j <-> second j
+        uint32_t prevp = 0u;                                     // EV: the bins the block starts from, one byte per variable
+        if constexpr (EV) {
+#pragma unroll
+            for (int k = 0; k < ND; k++) prevp |= cur1[k] << (8 * k);
+        }
         // seconds of this block that are draws at all (1 <= c < T), as an MSB-first mask
         uint32_t live8 = 0u;
 #pragma unroll
@@ -525,7 +538,19 @@ __global__ void __launch_bounds__(256, ND == 4 ? 3 : 4) k_dbn_step2(const EmgpuP
             if (k < P.nd)
                 coop_fill_store_msb<ND, true>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
                                               (uint32_t)P.nd, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
+        if constexpr (EV) {
+            uint32_t hitp = 0u;
+#pragma unroll
+            for (int k = 0; k < ND; k++) hitp |= (hit8[k] & 0xFFu) << (8 * k);
+            ev_emit_block<ND, true>(W, lane, E, S, rng, P.bnd, g8, T, valid, hitp, kind, prevp);
+        }
         wave_sync();
+    }
+    if constexpr (EV) {
+        uint32_t curp = 0u;
+#pragma unroll
+        for (int k = 0; k < ND; k++) curp |= cur1[k] << (8 * k);
+        ev_tail<ND>(E, S, rng, P.bnd, T, curp, A, valid, i);
     }
 }
 
@@ -546,7 +571,7 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     if (off) return false;
     if (P.nd < 1 || P.nd > 4) return false;
     if (!(P.depend || A.per_step) && P.nd != 4) return false;   // a fast-branch model: only the four-variable ones (frozen columns, FRZ)
-    if (A.ev_count != nullptr || A.events != nullptr) return false;
+    if ((A.ev_count != nullptr || A.events != nullptr) && !ev_plan_ok(P, A)) return false;
     if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
     for (int k = 0; k < P.nd; k++) {
         if (P.d_nb[k] == 0 || P.d_nb[k] > 16 || P.d_pw[k] == 0) return false;
@@ -562,10 +587,22 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
 // every parent / the full chain of dependencies: the instance any model can run on
 constexpr uint32_t kCurAll3 = 0x0777u, kNewAll3 = 0x0310u, kCurAll4 = 0xFFFFu, kNewAll4 = 0x7310u;
 
+// one instance, with or without the event list
+#define EMGPU_S2_LAUNCH(NI_, ND_, W_, REG_, C_, N_, FRZ_)                                                                      \
+    do {                                                                                                                       \
+        if (A.ev_count != nullptr) hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, true>), g, b, 0, s, P, A, F); \
+        else hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, false>), g, b, 0, s, P, A, F);                    \
+    } while (0)
+
 template <int NI, int ND>
 static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args &F, hipStream_t s, int wmode, bool reg) {
     const dim3 g((unsigned)((A.n + 255) / 256)), b(256);
     constexpr uint32_t C = ND == 4 ? kCurAll4 : kCurAll3, N = ND == 4 ? kNewAll4 : kNewAll3;
+    if (A.ev_count != nullptr) {   // event lists: the per-variable-width instances only (half the instances for the rarer output)
+        if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N, false, true>), g, b, 0, s, P, A, F);
+        else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false, C, N, false, true>), g, b, 0, s, P, A, F);
+        return hipGetLastError();
+    }
     if (reg && wmode == 4) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 4, true, C, N>), g, b, 0, s, P, A, F);
     else if (reg && wmode == 8) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 8, true, C, N>), g, b, 0, s, P, A, F);
     else if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N>), g, b, 0, s, P, A, F);
@@ -578,7 +615,7 @@ static bool launch_masked(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args
     const dim3 g((unsigned)((A.n + 255) / 256)), b(256);
 #define EMGPU_S2_CASE(NI_, ND_, W_, C_, N_, TAG_)                                                                  \
     if (P.ni <= NI_ && P.nd == ND_ && (W_ == 0 || wmode == W_) && cur == C_ && nw == N_) {                         \
-        hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, true, C_, N_>), g, b, 0, s, P, A, F);                        \
+        EMGPU_S2_LAUNCH(NI_, ND_, W_, true, C_, N_, false);                                                        \
         *tag = TAG_;                                                                                               \
         return true;                                                                                               \
     }
@@ -593,7 +630,17 @@ static bool launch_masked(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args
     return false;
 }
 
+static hipError_t launch_dbn_step2_inner(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
 hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
+    const hipError_t e = launch_dbn_step2_inner(P, A, s, name);
+    if (A.ev_count != nullptr) {   // the same kernel with the event list written as well
+        static thread_local char evname[96];
+        snprintf(evname, sizeof evname, "%s+events", *name);
+        *name = evname;
+    }
+    return e;
+}
+static hipError_t launch_dbn_step2_inner(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
     if (A.n <= 0) return hipSuccess;
     Step2Args F{};
     const bool frozen = !(P.depend || A.per_step);
@@ -622,10 +669,10 @@ hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s
         if (nw != 0u) return hipErrorNotSupported;   // (cannot be: is_dynvar_depend would be set)
         if (reg && wmode == 4 && P.ni <= 16 && cur == 0x8421u) {
             *name = "k_dbn_step2<16,4,w4,reg>[frozen]";   // littoral_cor_v1: every variable's only dynamic parent is its own current bin
-            hipLaunchKernelGGL((k_dbn_step2<16, 4, 4, true, 0x8421u, 0u, true>), g, b, 0, s, P, A, F);
+            EMGPU_S2_LAUNCH(16, 4, 4, true, 0x8421u, 0u, true);
         } else {
             *name = "k_dbn_step2<16,4>[frozen]";
-            hipLaunchKernelGGL((k_dbn_step2<16, 4, 0, false, kCurAll4, 0u, true>), g, b, 0, s, P, A, F);
+            EMGPU_S2_LAUNCH(16, 4, 0, false, kCurAll4, 0u, true);
         }
         return hipGetLastError();
     }

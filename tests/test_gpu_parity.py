@@ -29,12 +29,14 @@ def test_uncor_sample_matches_oracle(name, T, gpu_ctx, model_dir):
     assert_uncor_parity(got, ref, T)
     if name in FAST_MODELS:   # event lists of fast-branch models come from the fast kernel itself (up to 5 variables with a resample rate)
         assert got["kernel"].startswith("k_dbn_generic" if name == "haa_v1" else "k_uncor_fast_ev"), got["kernel"]
+    else:                     # ... and those of dependent-branch models from the per-timestep kernel
+        assert got["kernel"].startswith("k_dbn_step2") and got["kernel"].endswith("+events"), got["kernel"]
 
 
-@pytest.mark.parametrize("name", FAST_MODELS)
+@pytest.mark.parametrize("name", FAST_MODELS + DEP_MODELS + ["cor_v1", "littoral_cor_v1"])
 @pytest.mark.parametrize("T,n,cap", [(240, 4000, 256), (8, 700, 64), (16, 500, 64), (1, 100, 8), (7, 300, 3), (33, 2500, 4096)])
 def test_event_lists_from_the_fast_kernel_match_oracle(name, T, n, cap, gpu_ctx, model_dir):
-    """k_uncor_fast_ev: events only (no dense trace asked for), lengths that are multiples of the 8-second block and not (the
+    """k_uncor_fast_ev and k_dbn_step2<...>+events: events only (no dense trace asked for), lengths that are multiples of the 8-second block and not (the
     resample rows of second T come from the tail, dbn_hierarchical_sample.m:16-37 / resample_events.m:16-37), a list capacity that
     some trajectories overrun (EMGPU_ERR_EVENT_CAP, counts still exact) -- against the oracle's lists row for row: [dt, variable,
     bin] identical, values equal to the oracle's f64 rounded to f32, static-variable re-draws and rows hidden by a transition included."""
@@ -50,7 +52,7 @@ def test_event_lists_from_the_fast_kernel_match_oracle(name, T, n, cap, gpu_ctx,
         return
     got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, first_index=first, want_dense=False, want_events=True, event_cap=cap, **idx)
     if name != "haa_v1":
-        assert got["kernel"].startswith("k_uncor_fast_ev"), got["kernel"]
+        assert got["kernel"].startswith("k_uncor_fast_ev") or got["kernel"].endswith("+events"), got["kernel"]
     assert np.array_equal(got["ev_count"], ref_cnt)
     for i in range(n):
         g, r = got["events"][i], ref["events"][i]
