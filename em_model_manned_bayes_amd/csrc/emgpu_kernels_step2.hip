@@ -1,12 +1,12 @@
 // emgpu_kernels_step2.hip -- the per-timestep DBN (dbn_sample.m:65-93: dependent-branch models such as
 // cor_v1 and the glider family, and EMGPU_TRANSITION_PER_STEP) with dense output, built like
-// k_uncor_fast: one lane = one trajectory, 8 seconds per loop iteration, carry-arithmetic compare
-// chains on the primary (high) halfwords, MSB-first flag streams, wave-cooperative dediscretize.
+// k_uncor_fast: one lane = one trajectory, 8 seconds per loop iteration, packed 16-bit compares
+// on the primary (high) halfwords, MSB-first flag streams, wave-cooperative dediscretize.
 //
 // What differs from the fast-branch kernel: a variable's CPT column changes every second with the
 // dynamic state (asub2ind.m:13-14 as strides over the current and the freshly drawn bins), so the
-// column is fetched per draw with ONE 16-byte gather through L1/L2 (a buffer resource, byte offsets): a 4-word column
-// {t0, t1, t2, byte map} as it is, an 8-word one in its 16-byte form (high halves two per word + nibble map; EmgpuPlan::d_poff16).
+// column is fetched per draw with ONE 16-byte gather through L1/L2 (a buffer resource, byte offsets): its packed-compare form
+// (EmgpuPlan::d_poffpk: three T' pairs + the nibble map by fired count), whatever the column's width.
 // The columns of one dependency level are gathered together, the next second's level-0 columns as soon as this second's
 // level 0 is decided.  The secondary (low) halfword block of a variable is generated only at a second where
 // some lane of the wave met a tie between a draw's high halfword and a threshold's (p = 2^-16 per
@@ -43,15 +43,6 @@ constexpr int s2_level(int k) {
     return l;
 }
 
-// bin * stride + acc with the 24-bit multiplier.  Written out: the compiler masks an operand of __umul24 it cannot prove to fit
-// 24 bits (one more instruction per parent).  The stride is a scalar register that a VALU may just have written (v_readlane of a
-// spilled one), and gfx950 wants two wait states before a VALU reads it; the assembler does not look into asm blocks.
-__device__ __forceinline__ uint32_t mad24(uint32_t bin, uint32_t stride, uint32_t acc) {
-    uint32_t r;
-    asm("s_nop 1\n\tv_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(bin), "s"(stride), "v"(acc));
-    return r;
-}
-
 template <uint32_t CUR, uint32_t NEW>
 constexpr bool s2_pre(int k) {
     if (s2_level<NEW>(k) != 0) return false;
@@ -61,48 +52,6 @@ constexpr bool s2_pre(int k) {
 }
 
 constexpr uint32_t kSelBase2 = 0x0c0c0c00u; // v_perm_b32 selector: bytes 1-3 zero, byte 0 <- table[borrows]
-
-// borrows of x_h - X_h over the thresholds of one padded column (SDWA reads the draw's halfword and the
-// thresholds' high halves in place); d[] receives the differences (0 <=> the low halfword decides).
-// Two wait states separate every VCC write from its read (the assembler does not look into asm blocks).
-#define EMGPU_S2_FIRST(SELX)                                                                                       \
-    asm("v_sub_co_u32_sdwa %0, vcc, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:WORD_1\n\t" \
-        "s_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %4, vcc"                                                              \
-        : "=&v"(d0), "=&v"(sel) : "v"(w), "v"(t0), "v"(selbase) : "vcc")
-#define EMGPU_S2_NEXT(SELX, D, TH)                                                                                 \
-    asm("v_sub_co_u32_sdwa %0, vcc, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:WORD_1\n\t" \
-        "s_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"                                                              \
-        : "=&v"(D), "+v"(sel) : "v"(w), "v"(TH) : "vcc")
-
-template <bool ODD>
-__device__ __forceinline__ uint32_t chain3(uint32_t w, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t selbase, uint32_t &dmin) {
-    uint32_t d0, d1, d2, sel;
-    if (ODD) { EMGPU_S2_FIRST("WORD_1"); EMGPU_S2_NEXT("WORD_1", d1, t1); EMGPU_S2_NEXT("WORD_1", d2, t2); }
-    else { EMGPU_S2_FIRST("WORD_0"); EMGPU_S2_NEXT("WORD_0", d1, t1); EMGPU_S2_NEXT("WORD_0", d2, t2); }
-    dmin = min(min(d0, d1), d2);
-    return sel;
-}
-// six thresholds whose high halves sit two per word (the 16-byte column form): the borrow count starts at 0 (it indexes nibbles)
-#define EMGPU_S2_PK(SELX, SELT, D, TW, FIRST)                                                                       \
-    asm("v_sub_co_u32_sdwa %0, vcc, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SELX " src1_sel:" SELT "\n\t"   \
-        "s_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"                                                              \
-        : "=&v"(D), "+v"(sel) : "v"(w), "v"(TW) : "vcc")
-template <bool ODD>
-__device__ __forceinline__ uint32_t chain6p(uint32_t w, uint32_t t01, uint32_t t23, uint32_t t45, uint32_t &dmin) {
-    uint32_t d0, d1, d2, d3, d4, d5, sel = 0u;
-    if (ODD) {
-        EMGPU_S2_PK("WORD_1", "WORD_0", d0, t01, 1); EMGPU_S2_PK("WORD_1", "WORD_1", d1, t01, 0); EMGPU_S2_PK("WORD_1", "WORD_0", d2, t23, 0);
-        EMGPU_S2_PK("WORD_1", "WORD_1", d3, t23, 0); EMGPU_S2_PK("WORD_1", "WORD_0", d4, t45, 0); EMGPU_S2_PK("WORD_1", "WORD_1", d5, t45, 0);
-    } else {
-        EMGPU_S2_PK("WORD_0", "WORD_0", d0, t01, 1); EMGPU_S2_PK("WORD_0", "WORD_1", d1, t01, 0); EMGPU_S2_PK("WORD_0", "WORD_0", d2, t23, 0);
-        EMGPU_S2_PK("WORD_0", "WORD_1", d3, t23, 0); EMGPU_S2_PK("WORD_0", "WORD_0", d4, t45, 0); EMGPU_S2_PK("WORD_0", "WORD_1", d5, t45, 0);
-    }
-    dmin = min(min(min(d0, d1), d2), min(min(d3, d4), d5));
-    return sel;
-}
-#undef EMGPU_S2_PK
-#undef EMGPU_S2_FIRST
-#undef EMGPU_S2_NEXT
 
 // ---- the packed compare of an interior second (EmgpuPlan::d_poffpk) ------------------------------------------------------
 // One draw against a column's T' pairs: x_h = the half ODD of w goes to BOTH halves of a packed subtract, each against its own
@@ -146,21 +95,6 @@ __device__ __forceinline__ uint32_t mad24v(uint32_t bin, uint32_t stride, uint32
     uint32_t r;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(bin), "v"(stride), "v"(acc));
     return r;
-}
-
-// resample Bernoulli on the high halfword: hit8 = hit8 + hit8 + (x_h < R_h); returns x_h - R_h.
-// The leading s_nop keeps two wait states between a VALU that may just have written the SGPR
-// (v_readlane of a spilled register) and its read here.
-template <bool ODD>
-__device__ __forceinline__ uint32_t res_hit(uint32_t w, uint32_t R, uint32_t &hit8) {
-    uint32_t d;
-    if (ODD)
-        asm("s_nop 1\n\tv_subrev_co_u32_sdwa %0, vcc, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"
-            "s_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc" : "=&v"(d), "+v"(hit8) : "v"(w), "s"(R) : "vcc");
-    else
-        asm("s_nop 1\n\tv_subrev_co_u32_sdwa %0, vcc, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
-            "s_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc" : "=&v"(d), "+v"(hit8) : "v"(w), "s"(R) : "vcc");
-    return d;
 }
 
 // The rare exact redo of one draw, out of line so that the 32 copies of the hot per-second body stay small:
@@ -291,8 +225,6 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
     uint32_t frz[ND];   // FRZ: the initial bins, the only "current" bins a column ever sees (dbn_sample.m:110-135)
 #pragma unroll
     for (int k = 0; k < ND; k++) frz[k] = cur1[k];
-    uint32_t selbase; // kSelBase2 held in a VGPR (the first v_addc of every compare chain reads it)
-    asm volatile("v_mov_b32 %0, %1" : "=v"(selbase) : "s"(kSelBase2));
 
     // dependency levels as compile-time constants (a constexpr call with the loop variable is only folded after unrolling, too late
     // for the register allocator: the level loop would index its arrays dynamically)

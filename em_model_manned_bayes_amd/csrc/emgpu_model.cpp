@@ -582,21 +582,6 @@ CompiledPlan compile_plan(const Model &m) {
                     }
                 }
                 Pd = cp.pthr.data() + P.d_poff[k];   // (the resize above may have moved the buffer)
-                P.d_poff16[k] = 0;
-                if (W == 8) {   // the 16-byte form (EmgpuPlan::d_poff16)
-                    P.d_poff16[k] = (uint32_t)cp.pthr.size();
-                    cp.pthr.resize(cp.pthr.size() + (size_t)q * 4);
-                    Pd = cp.pthr.data() + P.d_poff[k];
-                    uint32_t *Pq = cp.pthr.data() + P.d_poff16[k];
-                    for (int64_t j = 0; j < q; j++) {
-                        const uint32_t *o = Pd + (size_t)j * 8;
-                        uint32_t *h = Pq + (size_t)j * 4;
-                        for (int t = 0; t < 3; t++) h[t] = (o[2 * t] >> 16) | (o[2 * t + 1] & 0xFFFF0000u);
-                        uint32_t nib = 0u;
-                        for (int b = 0; b <= 6; b++) nib |= (((b < 4 ? o[6] >> (8 * b) : o[7] >> (8 * (b - 4))) & 15u)) << (4 * b);
-                        h[3] = nib;
-                    }
-                }
             }
         }
     }

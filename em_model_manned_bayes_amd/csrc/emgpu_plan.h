@@ -101,10 +101,6 @@ struct EmgpuPlan {
     // for v_perm_b32.  d_pw[k] == 0 => no padded table for this variable.
     uint8_t d_pw[EMGPU_MAX_ND];
     uint32_t d_poff[EMGPU_MAX_ND];
-    // 8-word variables also have a 16-byte form in the same buffer (word offset d_poff16): the six thresholds' HIGH halves two per
-    // word {t0h | t1h << 16, t2h | t3h << 16, t4h | t5h << 16} and the bin table as nibbles indexed by the number of borrows --
-    // one gather per draw instead of two for the hot compare; the full column is only read on a tie and in a trajectory's edge blocks.
-    uint32_t d_poff16[EMGPU_MAX_ND];
     // every padded variable also has the PACKED-COMPARE form (word offset d_poffpk, 4 words per column):
     // {T'0 | T'1 << 16, T'2 | T'3 << 16, T'4 | T'5 << 16, nibble map}.  T'_t is the 16-bit value for which d = sat(x_h - T'_t) reads
     // 0: threshold t not fired, 1: the low halfword decides (a tie with the threshold's high half), >= 2: fired -- H_t - 1, made
