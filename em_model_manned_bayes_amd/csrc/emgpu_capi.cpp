@@ -78,6 +78,10 @@ struct emgpu_ctx {
     // Side streams for the blocks of a mixed batch (created on first use): independent launches that share the ctx stream's
     // ordering at both ends, so that one block's tail runs under the next block's head instead of in front of it.
     static constexpr int kSide = 3;
+    // Device scratch of the round drivers (UncorEncounterModel.track / CorTerminalModel.track), kept between calls and grown on demand:
+    // a fresh hipMalloc + hipFree of several gigabytes per call cost tens of milliseconds, at random (measured: 29 vs 127 ms per call)
+    struct Scratch { void *p = nullptr; size_t cap = 0; };
+    std::vector<Scratch> scratch;
     hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr, nullptr};
 };
@@ -395,6 +399,7 @@ void emgpu_ctx_free(emgpu_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->cache) kv.second.free_tables();
+    for (auto &sc : ctx->scratch) (void)hipFree(sc.p);
     (void)hipFree(ctx->d_status);
     (void)hipFree(ctx->d_layers);
     (void)hipFree(ctx->d_thr_base);
@@ -463,6 +468,20 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h, const std::s
     }
     u.version = h->m.version;
     return u;
+}
+
+// slot-th scratch buffer of the ctx, at least `bytes` long (contents undefined; valid until the next request for the same slot)
+static void *ctx_scratch(emgpu_ctx *ctx, size_t slot, size_t bytes) {
+    if (ctx->scratch.size() <= slot) ctx->scratch.resize(slot + 1);
+    emgpu_ctx::Scratch &sc = ctx->scratch[slot];
+    if (sc.cap < bytes || !sc.p) {
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        if (sc.p) { HIP_OK(hipFree(sc.p)); sc.p = nullptr; sc.cap = 0; }
+        const size_t want = bytes + bytes / 8 + 256;   // some headroom: batch sizes that wobble do not reallocate
+        HIP_OK(hipMalloc(&sc.p, want));
+        sc.cap = want;
+    }
+    return sc.p;
 }
 
 static void fill_run(emgpu_ctx *ctx, const Uploaded &u, const Model &m, const emgpu_sample_params *p, EmgpuRun &A) {
@@ -1095,8 +1114,8 @@ int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *gm, const emgpu
     const size_t n = (size_t)p->n, ni = (size_t)g.n_initial;
     if (n == 0) return EMGPU_OK;
     const int cap = (int)p->tmax_s + 3;
-    std::vector<void *> allocs;
-    auto dalloc = [&](size_t bytes) { void *q = nullptr; HIP_OK(hipMalloc(&q, bytes ? bytes : 1)); allocs.push_back(q); return q; };
+    size_t slot = 0;
+    auto dalloc = [&](size_t bytes) { return ctx_scratch(ctx, slot++, bytes ? bytes : 1); };   // kept by the ctx between calls
     int rc = EMGPU_OK;
     try {
         float *d_val = (float *)dalloc(ni * n * 4);
@@ -1184,11 +1203,9 @@ int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *gm, const emgpu
         else if (count > 0) rc = fail(EMGPU_ERR_REJECT_CAP, "terminal track: " + std::to_string(count) + " encounters were still rejected after max_track_attempts");
     } catch (...) {
         (void)hipStreamSynchronize(ctx->stream);
-        for (void *q : allocs) (void)hipFree(q);
         throw;
     }
     (void)hipStreamSynchronize(ctx->stream);
-    for (void *q : allocs) (void)hipFree(q);
     return rc;
     EMGPU_CATCH
 }
@@ -1330,8 +1347,8 @@ static int track_uncor_rounds(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_
     const int sDV = row_of(p->idx_dv), sDH = row_of(p->idx_dh), sDPsi = row_of(p->idx_dpsi);
     const size_t n = (size_t)p->n, ni = (size_t)m.n_initial, nd = (size_t)m.n_dyn(), T = (size_t)p->sample_time, G4 = (T + 3) / 4;
     if (n == 0) return EMGPU_OK;
-    std::vector<void *> allocs;
-    auto dalloc = [&](size_t bytes) { void *q = nullptr; HIP_OK(hipMalloc(&q, bytes ? bytes : 1)); allocs.push_back(q); return q; };
+    size_t slot = 0;
+    auto dalloc = [&](size_t bytes) { return ctx_scratch(ctx, slot++, bytes ? bytes : 1); };   // kept by the ctx between calls
     int rc = EMGPU_OK;
     try {
         float *d_iv = (float *)dalloc(ni * n * 4), *d_dv = (float *)dalloc(G4 * nd * n * 16);
@@ -1396,11 +1413,9 @@ static int track_uncor_rounds(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_
         if (rc == EMGPU_OK && count > 0) rc = fail(EMGPU_ERR_REJECT_CAP, "track: " + std::to_string(count) + " trajectories were still rejected after max_track_attempts");
     } catch (...) {
         (void)hipStreamSynchronize(ctx->stream);
-        for (void *q : allocs) (void)hipFree(q);
         throw;
     }
     (void)hipStreamSynchronize(ctx->stream);
-    for (void *q : allocs) (void)hipFree(q);
     return rc;
 }
 

@@ -19,6 +19,8 @@
 // Bound: f64 issue (asin, atan and three sin/cos pairs on Horner sums per 0.1 s step); 64 B per recorded step.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "emgpu_device.h"
 #include "emgpu_launch.h"
 #include "emgpu_plan.h"
@@ -29,13 +31,14 @@ namespace emgpu {
 // x - k * pi/2 taken in two pieces of pi/2 (the first has 33 significant bits: k * hi is exact), Horner sums on the remainder
 // (sincos_small, emgpu_device.h), the quadrant from k.  About 45 instructions for both
 // where the library's sin() + cos() take 180; results within 2 ulp of them (the tracks are compared at 1e-9).
+template <bool SK = false>   // SK: coefficients as scalar operands (sk64): for the variant that evaluates these once per recorded row only
 __device__ __forceinline__ void ut_sincos(double x, double &s, double &c) {
     if (!(fabs(x) < 1.0e5)) { s = sin(x); c = cos(x); return; }
     const double k = rint(x * 0.63661977236758134308);                 // 2/pi
     double r = fma(-k, 1.57079632673412561417, x);                     // pi/2, first 33 bits
     r = fma(-k, 6.07710050650619224932e-11, r);                        // pi/2 - the above
     double sr, cr;
-    sincos_small<false>(r, sr, cr);   // (coefficients as scalar operands -- three waves instead of two -- were measured: +4 %, this kernel is issue-bound)
+    sincos_small<SK>(r, sr, cr);   // (scalar-operand coefficients in the literal step -- three waves instead of two -- were measured: +4 %, it is issue-bound)
     const int q = (int)((long long)k & 3ll);
     s = (q == 0) ? sr : ((q == 1) ? cr : ((q == 2) ? -sr : -cr));
     c = (q == 0) ? cr : ((q == 1) ? -sr : ((q == 2) ? -cr : sr));
@@ -52,7 +55,9 @@ __device__ __forceinline__ double ut_rcp(double d) {
 }
 // atan on fdlibm's breakpoints (s_atan.c: 7/16, 11/16, 19/16, 39/16) and kernel polynomial, the reduced argument's division through
 // ut_rcp, selects instead of branches; within 2 ulp of the library's (checked against numpy in tests/test_host.py's restatement).
+template <bool SK = false>
 __device__ __forceinline__ double ut_atan(double x) {
+    auto K = [](double v) { return SK ? sk64(v) : v; };
     const double ax = fabs(x);
     double num = ax, den = 1.0, c = 0.0;
     if (ax >= 0.4375) { num = fma(2.0, ax, -1.0); den = 2.0 + ax; c = 4.63647609000806093515e-01; }      // atan(0.5)
@@ -61,33 +66,35 @@ __device__ __forceinline__ double ut_atan(double x) {
     if (ax >= 2.4375) { num = -1.0; den = ax; c = 1.57079632679489655800e+00; }                           // atan(inf)
     const double t = num * ut_rcp(den);
     const double z = t * t, w = z * z;
-    double s1 = fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02);
-    s1 = fma(w, s1, 6.66107313738753120669e-02);
-    s1 = fma(w, s1, 9.09088713343650656196e-02);
-    s1 = fma(w, s1, 1.42857142725034663711e-01);
-    s1 = fma(w, s1, 3.33333333333329318027e-01);
+    double s1 = fma(w, K(1.62858201153657823623e-02), K(4.97687799461593236017e-02));
+    s1 = fma(w, s1, K(6.66107313738753120669e-02));
+    s1 = fma(w, s1, K(9.09088713343650656196e-02));
+    s1 = fma(w, s1, K(1.42857142725034663711e-01));
+    s1 = fma(w, s1, K(3.33333333333329318027e-01));
     s1 = z * s1;
-    double s2 = fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02);
-    s2 = fma(w, s2, -7.69187620504482999495e-02);
-    s2 = fma(w, s2, -1.11111104054623557880e-01);
-    s2 = fma(w, s2, -1.99999999998764832476e-01);
+    double s2 = fma(w, K(-3.65315727442169155270e-02), K(-5.83357013379057348645e-02));
+    s2 = fma(w, s2, K(-7.69187620504482999495e-02));
+    s2 = fma(w, s2, K(-1.11111104054623557880e-01));
+    s2 = fma(w, s2, K(-1.99999999998764832476e-01));
     s2 = w * s2;
     const double r = c + (t - t * (s1 + s2));
     return x < 0 ? -r : r;
 }
 // asin for |x| < 0.5 (a climb angle below 30 degrees): fdlibm's rational kernel (e_asin.c), its division through ut_rcp
+template <bool SK = false>
 __device__ __forceinline__ double ut_asin_small(double x) {
+    auto K = [](double v) { return SK ? sk64(v) : v; };
     const double t = x * x;
-    double p = fma(t, 3.47933107596021167570e-05, 7.91534994289814532176e-04);
-    p = fma(t, p, -4.00555345006794114027e-02);
-    p = fma(t, p, 2.01212532134862925881e-01);
-    p = fma(t, p, -3.25565818622400915405e-01);
-    p = fma(t, p, 1.66666666666666657415e-01);
+    double p = fma(t, K(3.47933107596021167570e-05), K(7.91534994289814532176e-04));
+    p = fma(t, p, K(-4.00555345006794114027e-02));
+    p = fma(t, p, K(2.01212532134862925881e-01));
+    p = fma(t, p, K(-3.25565818622400915405e-01));
+    p = fma(t, p, K(1.66666666666666657415e-01));
     p = t * p;
-    double q = fma(t, 7.70381505559019352791e-02, -6.88283971605453293030e-01);
-    q = fma(t, q, 2.02094576023350569471e+00);
-    q = fma(t, q, -2.40339491173441421878e+00);
-    q = fma(t, q, 1.0);
+    double q = fma(t, K(7.70381505559019352791e-02), K(-6.88283971605453293030e-01));
+    q = fma(t, q, K(2.02094576023350569471e+00));
+    q = fma(t, q, K(-2.40339491173441421878e+00));
+    q = fma(t, q, K(1.0));
     return fma(x, p * ut_rcp(q), x);
 }
 
@@ -98,6 +105,18 @@ __device__ __forceinline__ int ut_discretize(double x, const double *cut, int n)
     return d;
 }
 
+// FASTBANK: the bank-rate limit r_max can never bind (|atan(..) - phi| / dt <= 10 pi < r_max; the reference passes 1e6, :414), so the bank
+// angle IS its command after every step, phi = atan(v psidot / g), and the step simplifies algebraically:
+//   * g tan(phi) / v dt = psidot dt: the heading advances by the commanded rate -- no atan, no sin/cos of phi, no division by cos(phi);
+//     within a second psidot is constant, so (cos psi, sin psi) are ROTATED by the second's (cos, sin)(psidot dt) instead of evaluated
+//   * the pitch either reaches its command, theta = asin(sn) with sn = hd / v -- then sin(theta) = sn and cos(theta) = sqrt(1 - sn^2) -- or
+//     turns towards it by q_max dt: a rotation of (cos theta, sin theta) by that fixed angle; which of the two, |asin(sn) - theta| <=
+//     q_max dt, is read off sin(asin(sn) - theta) = sn cos(theta) - sqrt(1 - sn^2) sin(theta): no asin
+//   * phi and theta themselves are only needed in the recorded rows (atan / asin once per recorded step).
+// One reciprocal, one square root and ~60 other f64 operations per 0.1 s step where the literal form takes three sin/cos pairs, an
+// atan and an asin; every quantity differs from the literal form's by rounding (1e-16 per step, accumulated 1e-13: the tracks are
+// compared with the oracle's literal form at 1e-9).  The literal form below stays for other r_max.
+template <bool FASTBANK>
 __global__ void __launch_bounds__(256) k_uncor_track(const EmgpuUTrackRun A) {
 #pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -115,6 +134,60 @@ __global__ void __launch_bounds__(256) k_uncor_track(const EmgpuUTrackRun A) {
     if (out) { out[0] = 0.0; out[1] = n; out[2] = e; out[3] = h; out[4] = v; out[5] = phi; out[6] = theta; out[7] = psi; }
     const float4 *dv4 = reinterpret_cast<const float4 *>(A.dyn_val);
     int step = 0, since_rec = 0, rec = 0;
+    if constexpr (FASTBANK) {
+        double st, ct, cp = 1.0, sp = 0.0, cdl, sdl;   // (sin, cos) theta, (cos, sin) psi, (cos, sin)(q_max dt)
+        ut_sincos<true>(theta, st, ct);
+        sincos_small<false>(A.dyn[4] * dt, sdl, cdl);
+        for (int c4 = 0; c4 * 4 < A.T; c4++) {
+            const float4 qDH = dv4[((size_t)c4 * A.nd + A.sDH) * ld + (size_t)i];
+            const float4 qDP = dv4[((size_t)c4 * A.nd + A.sDPsi) * ld + (size_t)i];
+            const float4 qDV = dv4[((size_t)c4 * A.nd + A.sDV) * ld + (size_t)i];
+            const float fDH[4] = {qDH.x, qDH.y, qDH.z, qDH.w}, fDP[4] = {qDP.x, qDP.y, qDP.z, qDP.w}, fDV[4] = {qDV.x, qDV.y, qDV.z, qDV.w};
+#pragma unroll 1
+            for (int w = 0; w < 4 && 4 * c4 + w < A.T; w++) {
+                const double hdot = (double)fDH[w] / 60.0, psidot = (double)fDP[w] * kPi180, acmd = (double)fDV[w] * 1.68780972222222;
+                const double hd = hdot < A.dyn[2] ? A.dyn[2] : (hdot > A.dyn[3] ? A.dyn[3] : hdot);
+                const double dpsi = psidot * dt;   // the heading step of this second: g tan(atan(v psidot / g)) / v dt
+                double cd, sd;
+                ut_sincos<true>(dpsi, sd, cd);
+#pragma unroll 1
+                for (int s = 0; s < 10; s++) {
+                    double a = acmd;
+                    if ((v >= A.dyn[1] && a > 0) || (v <= A.dyn[0] && a < 0)) a = 0;
+                    const double v_in = v;
+                    double sn = hd * ut_rcp(v); sn = sn < -1 ? -1 : (sn > 1 ? 1 : sn);
+                    const double cn = sqrt(fma(-sn, sn, 1.0));
+                    const double dd = sn * ct - cn * st;                       // sin(asin(sn) - theta)
+                    if (fabs(dd) <= sdl) { st = sn; ct = cn; }                 // the pitch reaches its command
+                    else {                                                     // ... or turns towards it at q_max
+                        const double sg = dd < 0 ? -sdl : sdl, s2 = st * cdl + ct * sg, c2 = ct * cdl - st * sg;
+                        st = s2; ct = c2;
+                    }
+                    n = n + v * ct * cp * dt;
+                    e = e + v * ct * sp * dt;
+                    h = h + v * st * dt;
+                    psi = psi + dpsi;
+                    { const double c2 = cp * cd - sp * sd, s2 = sp * cd + cp * sd; cp = c2; sp = s2; }
+                    v = v + a * dt; v = v < A.dyn[0] ? A.dyn[0] : (v > A.dyn[1] ? A.dyn[1] : v);
+                    step++;
+                    if (++since_rec == A.stride) {   // every stride-th step is kept: the two angles of the row are evaluated here only
+                        since_rec = 0; rec++;
+                        if (out) {
+                            double *o = out + (size_t)rec * 8;
+                            theta = fabs(st) < 0.5 ? ut_asin_small<true>(st) : asin(st);
+                            phi = ut_atan<true>(v_in * psidot * (1.0 / 32.2));
+                            o[0] = (double)step / 10.0; o[1] = n; o[2] = e; o[3] = h; o[4] = v; o[5] = phi; o[6] = theta; o[7] = psi;
+                        }
+                    }
+                    up_min = h < up_min ? h : up_min; up_max = h > up_max ? h : up_max;
+                    v_min = v < v_min ? v : v_min; v_max = v > v_max ? v : v_max;
+                }
+                const double vr = fabs(h - h_sec);
+                vr_max = vr > vr_max ? vr : vr_max;
+                h_sec = h;
+            }
+        }
+    } else
     for (int c4 = 0; c4 * 4 < A.T; c4++) {
         const float4 qDH = dv4[((size_t)c4 * A.nd + A.sDH) * ld + (size_t)i];
         const float4 qDP = dv4[((size_t)c4 * A.nd + A.sDPsi) * ld + (size_t)i];
@@ -235,9 +308,12 @@ __global__ void __launch_bounds__(256) k_scatter_rejected(int64_t n, uint64_t fi
 }
 
 hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char **name) {
-    *name = "k_uncor_track";
+    static const bool literal = getenv("EMGPU_DEBUG_UTRACK_LITERAL") != nullptr;   // tests: the literal step on the shipped limits
+    const bool fast = A.dyn[5] >= 32.0 && !literal;   // |atan - phi| / dt <= 10 pi: a bank-rate limit above that never binds
+    *name = fast ? "k_uncor_track<fastbank>" : "k_uncor_track";
     if (A.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_uncor_track, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, s, A);
+    if (fast) hipLaunchKernelGGL(k_uncor_track<true>, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL(k_uncor_track<false>, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, s, A);
     return hipGetLastError();
 }
 

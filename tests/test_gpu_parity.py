@@ -477,6 +477,87 @@ print(ctx.last_launches(), int(db.to(torch.int64).sum().item()), repr(float(dv.d
 
 
 @pytest.mark.gpu
+def test_mixed_launch_groups_blocks_by_kernel_instance(gpu_ctx, model_dir):
+    """emgpu_sample_dbn_blocks_device: blocks whose models share a k_uncor_fast instance are one launch of at most 16 blocks; models
+    of other instances or kernel families get launches of their own -- 20 blocks of one v1.2 model (16 + 4), then v2p1 (another
+    instance), a dependent-branch model (k_dbn_step2) and empty blocks in between; every column against the oracle."""
+    import torch
+    names = ["uncor_1200only_fwse_v1p2", "uncor_1200code_v2p1", "uncor_1200code_v1"]
+    pairs = [load_pair(nm_, model_dir) for nm_ in names]
+    T, seed, first = 40, 0xB10C, 2**34 + 3
+    sizes = [257, 1, 300, 255, 256, 511, 64, 63, 700, 2, 100, 333, 256, 257, 90, 10, 500, 129, 128, 1]   # 20 blocks of model 0 (odd offsets throughout)
+    blocks, col = [], 0
+    for c in sizes:
+        blocks.append((0, first + col, c)); col += c
+    blocks.append((1, first + col, 0))                         # an empty block
+    blocks.append((1, first + col, 1000)); col += 1000         # another instance: its own launch
+    blocks.append((2, first + col, 777)); col += 777           # dependent branch: k_dbn_step2
+    n = col
+    dev = torch.device("cuda", 0)
+    ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    G4 = T // 4
+    ld = n + 57   # a padded leading dimension
+    ib = torch.zeros((7, ld), dtype=torch.uint8, device=dev); iv = torch.zeros((7, ld), dtype=torch.float32, device=dev)
+    db = torch.zeros((G4, 3, ld), dtype=torch.int32, device=dev); dv = torch.zeros((G4, 3, ld, 4), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    # (uncor_1200code_v1 has 6 initial variables: the three models do not share a trace shape)
+    p, _ = native.make_params(n, T, seed, first_index=first, **uncor_indices(pairs[0][1]))
+    with pytest.raises(L.EmgpuError):
+        native.sample_dbn_blocks_device(ctx, [pr[0] for pr in pairs], p, blocks, dyn_bin=db.data_ptr(), ld=ld)
+    pairs, blocks, n = pairs[:2], blocks[:-1], n - 777
+    p, _ = native.make_params(n, T, seed, first_index=first, **uncor_indices(pairs[0][1]))
+    native.sample_dbn_blocks_device(ctx, [pr[0] for pr in pairs], p, blocks, init_bin=ib.data_ptr(), init_val=iv.data_ptr(),
+                                    dyn_bin=db.data_ptr(), dyn_val=dv.data_ptr(), ld=ld)
+    ctx.sync()
+    assert ctx.last_launches() == 3, ctx.last_launches()      # 16 + 4 blocks of the v1.2 instance, 1 of the v2p1 instance
+    gb = native.unpack_dyn_bin(db.cpu().numpy().view(np.uint32), T)
+    gv = native.unpack_dyn_val(dv.cpu().numpy(), T)
+    for (m, f, c) in blocks:
+        if c == 0:
+            continue
+        ref = O.uncor_sample(O.OracleModel(pairs[m][1]), c, T, seed, first_index=f, want_events=False)
+        sl = slice(f - first, f - first + c)
+        assert np.array_equal(gb[sl], ref["dense_bin"]) and np.array_equal(gv[sl], ref["dense_val"].astype(np.float32)), (m, f, c)
+        assert np.array_equal(ib[:, sl].cpu().numpy().T, ref["init_bin"])
+    assert not gb[n:].any() and not gv[n:].any()              # nothing written past the batch
+
+
+@pytest.mark.gpu
+def test_event_lists_at_two_million_trajectories_properties(model_dir):
+    """k_uncor_fast_ev at 2 M x 240 s, device resident: every list's dt column sums to T (the terminator closes it,
+    dbn_hierarchical_sample.m:15-19), variable ids and bins are in range, no list overruns its capacity, the mean list length is the
+    CPU oracle's for the same index range (a slice), and a second launch writes the same bytes."""
+    import torch
+    nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
+    idx = uncor_indices(pp)
+    n, T, seed, cap = 2_000_000, 240, 0x5EED0002, 256
+    dev = torch.device("cuda", 0)
+    ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    ec = torch.zeros(n, dtype=torch.int32, device=dev); ev = torch.zeros((n, cap, 2), dtype=torch.int32, device=dev)
+    p, _ = native.make_params(n, T, seed, event_cap=cap, **idx)
+    native.sample_dbn_device(ctx, nm, p, ev_count=ec.data_ptr(), events=ev.data_ptr())
+    ctx.sync()
+    assert ctx.last_kernel().startswith("k_uncor_fast_ev")
+    w0 = ev[:, :, 0]                                             # dt u16 | var u8 << 16 | bin u8 << 24
+    live = torch.arange(cap, device=dev)[None, :] < ec[:, None]
+    dt = torch.where(live, w0 & 0xFFFF, torch.zeros_like(w0))
+    assert int(ec.max()) <= cap and int(ec.min()) >= 1
+    assert bool((dt.sum(dim=1) == T).all())
+    var = torch.where(live, (w0 >> 16) & 0xFF, torch.zeros_like(w0))
+    assert int(var.max()) <= 7
+    last = ev[torch.arange(n, device=dev), (ec - 1).long(), 0]
+    assert bool((((last >> 16) & 0xFF) == 0).all())             # the terminator row: variable 0
+    chk = (int(ec.sum().item()), int(ev.to(torch.int64).sum().item()))
+    ec.zero_(); ev.zero_()
+    native.sample_dbn_device(ctx, nm, p, ev_count=ec.data_ptr(), events=ev.data_ptr())
+    ctx.sync()
+    assert chk == (int(ec.sum().item()), int(ev.to(torch.int64).sum().item()))
+    lo, m = 1_234_567, 3000
+    ref = O.uncor_sample(O.OracleModel(pp), m, T, seed, first_index=lo)
+    assert np.array_equal(ec[lo: lo + m].cpu().numpy(), np.array([len(e) for e in ref["events"]]))
+
+
+@pytest.mark.gpu
 def test_index_lists_are_cut_with_the_shards_and_blocks(gpu_ctx, model_dir):
     """emgpu_sample_params.indices through the multi-context and the block entry points: shard d / block b draws ITS
     entries of the list, not the list's head again."""
@@ -1244,6 +1325,36 @@ def test_uncor_track_matches_oracle(name, rot, T, gpu_ctx, model_dir):
     assert np.array_equal(one_hz["tracks"], got["tracks"][:500, ::10])
     part = native.track_uncor_host(gpu_ctx, nm, 300, T, seed, first_index=77 + 200, is_rotorcraft=rot)
     assert np.array_equal(part["tracks"], got["tracks"][200:500]) and np.array_equal(part["attempts"], got["attempts"][200:500])
+    assert "k_uncor_track<fastbank>" in got["kernel"]   # r_max = 1e6 (:414) can never bind: the algebraically reduced step
+
+
+@pytest.mark.gpu
+def test_uncor_track_reduced_step_equals_the_literal_step(model_dir, tmp_path):
+    """k_uncor_track<fastbank> (bank angle = its command, heading and pitch by rotation) against the literal step of the same kernel
+    (EMGPU_DEBUG_UTRACK_LITERAL, read once per process: a child runs it): the same accepted attempts and limits, tracks equal to 1e-10
+    relative (both are compared with the oracle's literal form in test_uncor_track_matches_oracle)."""
+    import pickle
+    import subprocess
+    code = r'''
+import os, sys, pickle
+for q in ("", "tests", "oracle"):
+    sys.path.insert(0, os.path.join(os.environ["EMGPU_ROOT"], q))
+from em_model_manned_bayes_amd import native
+from util import load_pair
+nm, pp, _ = load_pair("uncor_1200code_v2p1", os.environ["EMGPU_MODEL_DIR"])
+got = native.track_uncor_host(native.Context(0), nm, 4000, 80, 0xF7, first_index=5)
+pickle.dump((got["tracks"], got["attempts"], got["limits"], got["kernel"]), open(os.environ["EMGPU_OUT"], "wb"))
+'''
+    res = {}
+    for tag, extra in (("fast", {}), ("literal", {"EMGPU_DEBUG_UTRACK_LITERAL": "1"})):
+        out = str(tmp_path / (tag + ".pkl"))
+        env = dict(os.environ, EMGPU_ROOT=ROOT, EMGPU_MODEL_DIR=str(model_dir), EMGPU_OUT=out, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        res[tag] = pickle.load(open(out, "rb"))
+    assert "fastbank" in res["fast"][3] and "fastbank" not in res["literal"][3]
+    assert np.array_equal(res["fast"][1], res["literal"][1]) and np.array_equal(res["fast"][2], res["literal"][2])
+    np.testing.assert_allclose(res["fast"][0], res["literal"][0], rtol=1e-10, atol=1e-7)
 
 
 @pytest.mark.gpu
