@@ -660,7 +660,8 @@ int emgpu_sample_dbn_blocks_device(emgpu_ctx *ctx, const emgpu_model *const *mod
     // Blocks whose models run on the same k_uncor_fast instance share ONE launch (model id per workgroup); every other block
     // is its own launch.  With several launches they go round-robin over the ctx stream and three side streams, forked from
     // and joined back into the ctx stream with events (a caller sees one in-order operation).
-    static const bool no_mixed = getenv("EMGPU_DEBUG_NO_MIXED_LAUNCH") != nullptr;
+    static const bool no_mixed_env = getenv("EMGPU_DEBUG_NO_MIXED_LAUNCH") != nullptr;
+    const bool no_mixed = no_mixed_env || p->indices != nullptr;   // (an index list: one launch per block, k_uncor_fast_idx)
     struct Launch { int shape; std::vector<int> members; };
     std::vector<Launch> launches;
     // the run of a shared launch is common to its blocks but for the index range and the columns: the rejection test's variables
@@ -779,13 +780,8 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_samp
     const size_t ld = out->ld ? (size_t)out->ld : n, off = (size_t)out->col_offset;
     if (out->ld < 0 || out->col_offset < 0 || off + n > ld) return fail(EMGPU_ERR_ARG, "col_offset + n exceeds ld");
     emgpu_sample_out d{};
-    std::vector<void *> allocs;
-    auto dalloc = [&](size_t bytes) -> void * {
-        void *ptr = nullptr;
-        HIP_OK(hipMalloc(&ptr, bytes ? bytes : 1));
-        allocs.push_back(ptr);
-        return ptr;
-    };
+    size_t slot = 0;
+    auto dalloc = [&](size_t bytes) -> void * { return ctx_scratch(ctx, slot++, bytes ? bytes : 1); };   // kept by the ctx between calls
     int rc = EMGPU_OK;
     try {
         const size_t b_ib = ni * n, b_iv = ni * n * 4, b_db = G4 * nd * n * 4, b_dv = G4 * nd * n * 16;
@@ -839,11 +835,9 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_samp
         }
     } catch (...) {
         (void)hipStreamSynchronize(ctx->stream);
-        for (void *ptr : allocs) (void)hipFree(ptr);
         throw;
     }
     (void)hipStreamSynchronize(ctx->stream);
-    for (void *ptr : allocs) (void)hipFree(ptr);
     return rc;
     EMGPU_CATCH
 }

@@ -50,6 +50,10 @@ struct CoopLds {
     static constexpr int kKind = kSpare + 3;                      // the lane's kind mask of the block, read by the workers (LB)
     static constexpr int kStride = ((kSpare + 3 + 3) / 8) * 8 + 4; // words per lane; = 4 (mod 8) keeps the b128 reads conflict-free
     static_assert(kStride % 8 == 4 && kStride >= kSpare + 4, "lane stride");
+    // the lane's global sample index (two words), read by the worker that serves one of its requests: with an index list
+    // (emgpu_sample_params.indices) a neighbour's index is not this lane's plus the lane distance.  After the kind word where the
+    // row has room (3 variables), else in the column slots (only k_uncor_fast, a 3-variable kernel, uses those).
+    static constexpr int kGidx = (kSpare + 6 <= kStride) ? kSpare + 4 : kSpare;
     static constexpr int kCap = LB ? 256 : 128;                   // requests per compaction round
     using Request = typename std::conditional<LB, uint16_t, uint32_t>::type;
     Request queue[kCap];
@@ -84,7 +88,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t x) {
 // One worker pass: lanes 0..cnt-1 each serve the request queue[q0 + lane].  A request is owner | sb << 6 (sb = the
 // bit of the owner's need mask); with LB the worker reads the owner's bin and kind word from the owner's LDS row,
 // without it the owner encoded them (kind << 11, bin << 12).
-template <int ND, bool MSBFIRST, bool LB>
+template <int ND, bool MSBFIRST, bool LB, bool IDX = false>
 __device__ __forceinline__ void coop_worker_pass(CoopLds<ND, LB> &W, int lane, uint32_t q0, uint32_t cnt, uint64_t gidx, const Rng &rng, int g8,
                                                  uint32_t ivpack, const double (*s_bnd)[16]) {
     using L = CoopLds<ND, LB>;
@@ -96,7 +100,8 @@ __device__ __forceinline__ void coop_worker_pass(CoopLds<ND, LB> &W, int lane, u
         const uint32_t kind = LB ? ((reinterpret_cast<const uint32_t *>(&W.res[owner * L::kStride + L::kKind])[0] >> sb) & 1u) : ((d >> 11) & 1u);
         const uint32_t b1 = LB ? reinterpret_cast<const uint8_t *>(&W.res[owner * L::kStride + L::kBins])[s] : ((d >> 12) & 63u);
         const uint32_t k = s >> 3, j = s & 7u;
-        const uint64_t go = gidx - (uint64_t)lane + (uint64_t)owner;
+        uint64_t go = gidx - (uint64_t)lane + (uint64_t)owner;
+        if constexpr (LB && IDX) go = *reinterpret_cast<const uint64_t *>(&W.res[owner * L::kStride + L::kGidx]);   // an index list may be in use (coop_publish_gidx)
         const uint32_t iv = (ivpack >> (8u * k)) & 0xFFu;
         const uint32_t sec = kind ? EMGPU_SEC_DEDISC_TRANS : EMGPU_SEC_DEDISC_RES;
         const uint4 r4 = philox4x32((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner],
@@ -123,7 +128,7 @@ __device__ __forceinline__ void coop_worker_pass(CoopLds<ND, LB> &W, int lane, u
 // lane then writes its own requests to consecutive slots (find-first-set, one LDS store, clear the bit: no ballot
 // or rank per request), kCap positions per round, and the workers serve exactly ceil(requests / 64) passes.
 // Without LB (k_dbn_step, the fallback kernel) the round-1 scheme stays: one ballot + rank per compaction step.
-template <int ND, bool MSBFIRST = false, bool LB = false>
+template <int ND, bool MSBFIRST = false, bool LB = false, bool IDX = false>
 __device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64_t gidx, const Rng &rng, int g8,
                                             uint32_t needmask, uint32_t kindmask, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND],
                                             const uint32_t (&ivar)[ND], const double (*s_bnd)[16]) {
@@ -157,7 +162,7 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64
             wave_sync();
             for (uint32_t q0 = 0u; q0 < total; q0 += 64u) {
                 EMGPU_COUNT(3, lane, 1);
-                coop_worker_pass<ND, MSBFIRST, LB>(W, lane, q0, total, gidx, rng, g8, ivpack, s_bnd);
+                coop_worker_pass<ND, MSBFIRST, LB, IDX>(W, lane, q0, total, gidx, rng, g8, ivpack, s_bnd);
             }
             wave_sync();
         } else {
@@ -178,7 +183,7 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64
                 const uint32_t cnt = min(total - rb, (uint32_t)L::kCap);
                 for (uint32_t q0 = 0u; q0 < cnt; q0 += 64u) {
                     EMGPU_COUNT(3, lane, 1);
-                    coop_worker_pass<ND, MSBFIRST, LB>(W, lane, q0, cnt, gidx, rng, g8, ivpack, s_bnd);
+                    coop_worker_pass<ND, MSBFIRST, LB, IDX>(W, lane, q0, cnt, gidx, rng, g8, ivpack, s_bnd);
                 }
                 wave_sync();
             }
@@ -253,6 +258,12 @@ __device__ __forceinline__ void coop_zero_results(CoopLds<ND, LB> &W, int lane) 
     float4 *rp = reinterpret_cast<float4 *>(&W.res[lane * CoopLds<ND, LB>::kStride]);
 #pragma unroll
     for (int q = 0; q < 2 * ND; q++) rp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// once per trajectory: the lane's global sample index for the workers (CoopLds<ND, true>::kGidx)
+template <int ND>
+__device__ __forceinline__ void coop_publish_gidx(CoopLds<ND, true> &W, int lane, uint64_t gidx) {
+    *reinterpret_cast<uint64_t *>(&W.res[lane * CoopLds<ND, true>::kStride + CoopLds<ND, true>::kGidx]) = gidx;
 }
 
 // publish the packed bins of this lane's block for the workers (CoopLds<ND, true>)

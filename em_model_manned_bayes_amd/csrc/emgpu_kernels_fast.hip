@@ -317,7 +317,9 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
 // scalar registers up front (readfirstlane) -- left to the compiler these became vector loads inside the loop, each waiting
 // (vmcnt counts stores too on gfx9) for the block's trace stores.
 // EV: the event list of dbn_hierarchical_sample.m:33-60 is written as well (uncor_fast_events below).
-template <int NI, int M0, int M1, int M2, bool MIXED = false, bool EV = false>
+// IDX: an index list may be in use (emgpu_sample_params.indices): the workers read the owner's global index from LDS instead of
+// deriving it from their own (kept out of the plain instance: the benchmark kernel pays 1 % for the possibility).
+template <int NI, int M0, int M1, int M2, bool MIXED = false, bool EV = false, bool IDX = false>
 __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs &F, const int64_t i0 /* trajectory of lane 0: wave-uniform, may be < 0 */) {
     // workers look the bin of a request up in LDS (the owner does not encode it into the request): -1.8 % on the
     // <7,4,6,6> instance too since the packed compare pass freed its registers
@@ -328,7 +330,11 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
     CoopLds<3, LB> &W = s_wave[tid >> 6];
     const int64_t i = i0 + tid;
     const bool valid = i >= 0 && i < A.n; // lanes outside the run stay alive: they serve as workers for their wave
-    const uint64_t gidx = A.first_index + (uint64_t)i;
+    uint64_t gidx = A.first_index + (uint64_t)i;
+    if constexpr (IDX) {
+        if (A.indices != nullptr && valid) gidx = A.indices[i];   // (wave-uniform pointer test)
+        coop_publish_gidx<3>(W, lane, gidx);
+    }
     Rng rng{(uint32_t)gidx, (uint32_t)(gidx >> 32), 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
     const int T = A.T;
 #pragma unroll
@@ -429,7 +435,7 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
         const uint32_t kind24 = kind8[0] | (kind8[1] << 8) | (kind8[2] << 16);
         coop_zero_results<3, LB>(W, lane);
         if constexpr (LB) coop_publish_bins<3>(W, lane, pbA, pbB);
-        coop_dedisc<3, true, LB>(W, lane, gidx, rng, g8, need24, kind24, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
+        coop_dedisc<3, true, LB, IDX>(W, lane, gidx, rng, g8, need24, kind24, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
 #pragma unroll
         for (int k = 0; k < 3; k++)
             coop_fill_store_msb<3, LB>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
@@ -454,7 +460,12 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
 // dense instance's 128 registers.
 template <int NI, int M0, int M1, int M2>
 __global__ void __launch_bounds__(256, 3) k_uncor_fast_ev(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
-    uncor_fast_body<NI, M0, M1, M2, false, true>(P, A, F, (int64_t)blockIdx.x * 256 - (A.col0 & 255));
+    uncor_fast_body<NI, M0, M1, M2, false, true, true>(P, A, F, (int64_t)blockIdx.x * 256 - (A.col0 & 255));
+}
+// the dense kernel for an index list (the later rounds of UncorEncounterModel.track: the trajectories still rejected)
+template <int NI, int M0, int M1, int M2>
+__global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast_idx(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
+    uncor_fast_body<NI, M0, M1, M2, false, false, true>(P, A, F, (int64_t)blockIdx.x * 256 - (A.col0 & 255));
 }
 
 // Mixed-model batch in ONE launch (RUN_1_emsample.m:13,24-47 shards by model file; SURVEY.md 8e: "model id per block"): the models
@@ -514,7 +525,6 @@ static int fast_shape_of(const EmgpuPlan &P) {
 }
 
 bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
-    if (A.indices != nullptr) return false; // an index list goes through the generic kernel
     if (P.nd != 3 || P.depend || A.per_step) return false;
     if ((A.ev_count != nullptr || A.events != nullptr) && !ev_plan_ok(P, A)) return false;
     if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
@@ -598,9 +608,29 @@ static hipError_t launch_ev_t(const EmgpuPlan &P, const EmgpuRun &A, const FastA
     return hipGetLastError();
 }
 
+template <int NI, int M0, int M1, int M2>
+static hipError_t launch_idx_t(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs &F, hipStream_t s) {
+    const int64_t blocks = (A.n + (A.col0 & 255) + 255) / 256;
+    hipLaunchKernelGGL((k_uncor_fast_idx<NI, M0, M1, M2>), dim3((unsigned)blocks), dim3(256), 0, s, P, A, F);
+    return hipGetLastError();
+}
+
 hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
     if (A.n <= 0) return hipSuccess;
     const FastArgs F = fast_args_of(P);
+    if (A.indices != nullptr && A.ev_count == nullptr) {
+        switch (fast_shape_of(P)) {
+        case 0: *name = "k_uncor_fast_idx<7,2,2,2>"; return launch_idx_t<7, 2, 2, 2>(P, A, F, s);
+        case 1: *name = "k_uncor_fast_idx<7,2,4,2>"; return launch_idx_t<7, 2, 4, 2>(P, A, F, s);
+        case 2: *name = "k_uncor_fast_idx<7,2,4,4>"; return launch_idx_t<7, 2, 4, 4>(P, A, F, s);
+        case 3: *name = "k_uncor_fast_idx<7,4,2,4>"; return launch_idx_t<7, 4, 2, 4>(P, A, F, s);
+        case 4: *name = "k_uncor_fast_idx<7,4,6,4>"; return launch_idx_t<7, 4, 6, 4>(P, A, F, s);
+        case 5: *name = "k_uncor_fast_idx<7,4,6,6>"; return launch_idx_t<7, 4, 6, 6>(P, A, F, s);
+        case 6: *name = "k_uncor_fast_idx<7,6,6,6>"; return launch_idx_t<7, 6, 6, 6>(P, A, F, s);
+        case 7: *name = "k_uncor_fast_idx<9,6,6,6>"; return launch_idx_t<9, 6, 6, 6>(P, A, F, s);
+        default: *name = "none"; return hipErrorNotSupported;
+        }
+    }
     if (A.ev_count != nullptr) {
         switch (fast_shape_of(P)) {
         case 0: *name = "k_uncor_fast_ev<7,2,2,2>"; return launch_ev_t<7, 2, 2, 2>(P, A, F, s);

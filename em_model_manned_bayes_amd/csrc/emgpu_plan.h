@@ -139,7 +139,7 @@ struct EmgpuRun {
     uint64_t *events; // emgpu_event rows as packed 64-bit words
     int32_t *attempts;
     uint32_t *status; // device word: bit0 = rejection cap hit, bit1 = event cap hit
-    const uint64_t *indices; // optional: global index of lane i (instead of first_index + i); generic kernel only
+    const uint64_t *indices; // optional: global index of lane i (instead of first_index + i); every DBN kernel but the round-1 k_dbn_step
 };
 
 struct EmgpuBnRun {

@@ -127,6 +127,9 @@ int emgpu_model_set_zero_bins(emgpu_model *m, const int32_t *zero_bins, int32_t 
 /* ------------------------------------------------------------------------------------------------
  * Context
  * ---------------------------------------------------------------------------------------------- */
+/* A ctx owns: a stream, the uploaded tables of the models it has sampled (an LRU cache of ~48) and the device scratch of the
+ * host-pointer and .track entry points (kept between calls and grown on demand -- a fresh hipMalloc / hipFree of gigabytes per call
+ * costs up to 100 ms; emgpu_ctx_free releases everything). */
 int emgpu_ctx_create(int32_t device, emgpu_ctx **out);
 /* Launch on a caller stream (a hipStream_t passed as void*; NULL = the HIP default stream).
  * A new ctx launches on its own non-blocking stream until this is called. */
