@@ -82,6 +82,18 @@ __device__ __forceinline__ uint32_t pk_fired2(uint32_t w, uint32_t t01, uint32_t
     asm("v_add_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(s) : "v"(acc));
     return s;
 }
+// The same decision for a column of at most 3 thresholds in its PLAIN form {H0, H1, H2, map} (EmgpuPlan::d_poffpk): a_t = H_t - x_h with plain
+// subtracts; fired <=> a_t < 0, tie <=> a_t == 0 (x_h = 0 against H = 0 included).  Returns the bin's bit offset in the map (7 * fired);
+// tie receives min(a_t) as unsigned: 0 exactly on a tie.
+template <bool ODD>
+__device__ __forceinline__ uint32_t plain_fired7(uint32_t w, uint32_t h0, uint32_t h1, uint32_t h2, uint32_t &tie) {
+    const uint32_t xh = ODD ? (w >> 16) : (w & 0xFFFFu);
+    const uint32_t a0 = h0 - xh, a1 = h1 - xh, a2 = h2 - xh;
+    uint32_t off;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(off) : "v"(a0 >> 29), "v"(a1 >> 29), "v"(a2 >> 29));
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(tie) : "v"(a0), "v"(a1), "v"(a2));
+    return off;
+}
 // s | (the half ODD of z): z carries a 1 in the halves whose x_h is 0 (a tie with any threshold whose high half is 0)
 template <bool ODD>
 __device__ __forceinline__ uint32_t or_half(uint32_t s, uint32_t z) {
@@ -307,6 +319,8 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
             uint4 zt[ND];
 #pragma unroll
             for (int k = 0; k < ND; k++) {
+                zt[k] = make_uint4(0u, 0u, 0u, 0u);
+                if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) continue;   // (the plain form sees x_h = 0 against H = 0 as the tie it is)
                 uint32_t z[4];
 #pragma unroll
                 for (int p2 = 0; p2 < 4; p2++) asm("v_pk_sub_u16 %0, 1, %1 op_sel_hi:[0,1] clamp" : "=v"(z[p2]) : "v"(word_of(th[k], p2)));
@@ -339,16 +353,17 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
                         if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
                         const uint32_t wt = word_of(th[k], j >> 1), wz = word_of(zt[k], j >> 1);
                         const uint4 a = ca[k];
-                        uint32_t s2;
-                        if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) s2 = (j & 1) ? pk_fired2<true, 2>(wt, a.x, a.y, a.z) : pk_fired2<false, 2>(wt, a.x, a.y, a.z);
-                        else s2 = (j & 1) ? pk_fired2<true, 3>(wt, a.x, a.y, a.z) : pk_fired2<false, 3>(wt, a.x, a.y, a.z);
-                        sel[k] = (j & 1) ? or_half<true>(s2, wz) : or_half<false>(s2, wz);
+                        if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) {   // the plain form: sel = 1 on a tie (the map offset goes straight to the lookup)
+                            uint32_t tie;
+                            const uint32_t off = (j & 1) ? plain_fired7<true>(wt, a.x, a.y, a.z, tie) : plain_fired7<false>(wt, a.x, a.y, a.z, tie);
+                            nb1[k] = __builtin_amdgcn_ubfe(a.w, off, 4u);
+                            sel[k] = tie == 0u ? 1u : 0u;
+                        } else {
+                            const uint32_t s2 = (j & 1) ? pk_fired2<true, 3>(wt, a.x, a.y, a.z) : pk_fired2<false, 3>(wt, a.x, a.y, a.z);
+                            sel[k] = (j & 1) ? or_half<true>(s2, wz) : or_half<false>(s2, wz);
+                            nb1[k] = __builtin_amdgcn_ubfe(a.w, sel[k] << 1, 4u);   // nibble (fired) of the column's map; overwritten below on a tie
+                        }
                         tlev |= sel[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < ND; k++) {
-                        if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
-                        nb1[k] = __builtin_amdgcn_ubfe(ca[k].w, sel[k] << 1, 4u);   // nibble (fired) of the column's map; overwritten below on a tie
                     }
                     // one tie test per level; the draws that tied (in some lane) are repeated on the full 32-bit draw, out of line
                     if (__ballot((tlev & 1u) != 0u) != 0ull) {

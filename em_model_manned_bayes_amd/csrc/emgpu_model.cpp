@@ -575,6 +575,18 @@ CompiledPlan compile_plan(const Model &m) {
                             }
                             tq[t] = v; prev = v;
                         }
+                        if (W == 4) {
+                            // columns of at most 3 thresholds: the PLAIN form {H0, H1, H2, map} -- the thresholds' high halves as 32-bit
+                            // words (0x10000 beyond the column's: never reached), the bins 7 bits apart.  With a_t = H_t - x_h (plain
+                            // subtracts): a_t < 0 <=> threshold t fired, a_t == 0 <=> the low halfword decides; (a_t >>> 29) is 7 or 0,
+                            // their sum is the bit offset of the bin.  Three subtracts, three shifts, v_add3, v_bfe, v_min3: the packed
+                            // form of the same decision costs a third more issue cycles (VOP3P / SDWA ops issue at half the rate).
+                            for (int t = 0; t < 3; t++) o[t] = t < meff ? (c[t] >> 16) : 0x10000u;
+                            uint32_t m7 = 0u;
+                            for (int n = 0; n <= 3; n++) m7 |= ((c[meff] >> (4 * (n < meff ? n : meff))) & 15u) << (7 * n);
+                            o[3] = m7;
+                            continue;
+                        }
                         for (int w = 0; w < 3; w++) o[w] = tq[2 * w] | (tq[2 * w + 1] << 16);
                         uint32_t nib = 0u;
                         for (int n = 0; n <= 6; n++) nib |= ((c[meff] >> (4 * (n < meff ? n : meff))) & 15u) << (4 * n);

@@ -107,7 +107,10 @@ struct EmgpuPlan {
     // strictly increasing along the column, 0 for H_t = 0 (x_h = 0 is then a tie by a separate test), 0xFFFF beyond the column's
     // thresholds (exactly load_cthr_pk of the fast kernel, built on the host because the column changes every second here).
     // The sum of min(d, 2) over the thresholds is 2 * fired, odd exactly when some compare needs the low halfword; nibble n of the
-    // map is the 1-based bin when n thresholds fired.  Two or three v_pk_sub_u16 / v_pk_min_u16 pairs decide a draw: no carries.
+    // map is the 1-based bin when n thresholds fired.  Three v_pk_sub_u16 / v_pk_min_u16 pairs decide a draw: no carries.
+    // A 4-word variable (at most 3 thresholds) holds the PLAIN form in the same place: {H0, H1, H2, map}, H_t = the threshold's high half as a
+    // 32-bit word (0x10000: none), bins 7 bits apart in the map: a_t = H_t - x_h is negative when threshold t fired and 0 on a tie;
+    // sum of (a_t >>> 29) = 7 * fired = the bin's bit offset.  Plain VOP2 subtracts and shifts issue at twice the rate of the packed ops.
     uint32_t d_poffpk[EMGPU_MAX_ND];
     uint32_t pthr_total, _pad1;
     const uint32_t *pthr;

@@ -418,7 +418,10 @@ int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int3
 /* The same column in the packed-compare form of the per-timestep kernel (4 words): {T'0 | T'1 << 16, T'2 | T'3 << 16, T'4 | T'5 << 16,
  * nibble map}.  With x_h the draw's high halfword and d_t = min(sat16(x_h - T'_t), 2): the sum over t is 2 * (thresholds fired),
  * odd exactly when the draw's low halfword decides some compare; nibble (sum / 2) of the map is the 1-based bin
- * (select_random.m:17-20 on the high halfword alone; x_h = 0 is always referred to the full 32-bit compare). */
+ * (select_random.m:17-20 on the high halfword alone; x_h = 0 is always referred to the full 32-bit compare).
+ * A variable whose padded width is 4 (at most 3 thresholds) holds the PLAIN form instead: {H0, H1, H2, map}, H_t = the threshold's high
+ * half (0x10000: no such threshold); with a_t = H_t - x_h: a_t < 0 <=> threshold t fired, a_t == 0 <=> the low halfword decides; the
+ * 1-based bin is (map >> 7 * fired) & 15. */
 int emgpu_debug_pk_column(const emgpu_model *m, int32_t k, int64_t col, uint32_t *words);
 
 /* Which dynamic variables are parents of which (t+1) node, in plan order k = 0..n_dyn-1: bit 4k+q of cur_mask = the time-t

@@ -267,6 +267,20 @@ def test_packed_compare_columns_decide_like_select_random(name, model_dir):
             assert lib.emgpu_debug_dynamic_column(*args(col)) == 0
             pk = np.zeros(4, dtype=np.uint32)
             assert lib.emgpu_debug_pk_column(h, k, col, pk.ctypes.data) == 0
+            if meff.value <= 3:   # the PLAIN form {H0, H1, H2, map}: a_t = H_t - x_h, fired <=> a_t < 0, tie <=> a_t == 0, bins 7 bits apart
+                H = pk[:3].astype(np.int64)
+                a = H[None, :] - xh[:, None]
+                flagged = (a == 0).any(axis=1)
+                off = 7 * (a < 0).sum(axis=1)
+                t = thr[: r.value - 1].astype(np.int64)
+                lo_bin = 1 + (np.minimum((xh << 16), 2**32 - 2)[:, None] >= t[None, :]).sum(axis=1)
+                hi_bin = 1 + (np.minimum((xh << 16) | 0xFFFF, 2**32 - 2)[:, None] >= t[None, :]).sum(axis=1)
+                pk_bin = (int(pk[3]) >> off) & 15
+                assert np.all(flagged | ((pk_bin == lo_bin) & (pk_bin == hi_bin))), (name, k, col)
+                assert np.all(flagged[lo_bin != hi_bin]), (name, k, col)
+                assert flagged.mean() < 0.02, (name, k, col, flagged.mean())
+                checked += 1
+                continue
             tq = np.array([(int(pk[w]) >> (16 * hh)) & 0xFFFF for w in range(3) for hh in range(2)], dtype=np.int64)
             assert np.all(np.diff(tq[tq < 0xFFFF]) > 0)                      # strictly increasing where real
             d = np.minimum(np.maximum(xh[:, None] - tq[None, :], 0), 2)      # min(sat16(x_h - T'), 2)
