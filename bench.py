@@ -572,9 +572,14 @@ def recorded_traffic(kernel_name, algorithmic_bytes, lib_version):
         except Exception:
             continue
         line = s.get("bench_line", {})
+        theirs = line.get("roofline", {}).get("algorithmic_bytes_per_launch")
+        # the same launch size: equal bytes -- or, where the bytes are a property of the sampled data (terminal: 75 + 15 B x the track-seconds
+        # the batch happened to produce, which moves in the fourth digit with the step's index range), within half a percent
+        same_size = theirs == algorithmic_bytes or (isinstance(theirs, (int, float)) and not float(algorithmic_bytes).is_integer()
+                                                    and abs(theirs - algorithmic_bytes) <= 0.005 * algorithmic_bytes)
         same = (line.get("config", {}).get("kernel") == kernel_name      # the summary's own bench line ran this kernel variant ...
-                and line.get("roofline", {}).get("algorithmic_bytes_per_launch") == algorithmic_bytes   # ... on this launch size ...
-                and line.get("config", {}).get("lib") == lib_version)                                     # ... from these sources
+                and same_size                                            # ... on this launch size ...
+                and line.get("config", {}).get("lib") == lib_version)     # ... from these sources
         if same and "hbm_traffic_bytes_per_launch" in s:
             best = (s["hbm_traffic_bytes_per_launch"], os.path.basename(f))
     if best is None:
