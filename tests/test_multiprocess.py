@@ -168,3 +168,24 @@ def test_shard_arithmetic_matches_the_library():
             assert native.shard_range(n_total, r, world) == sharding.shard_range(n_total, r, world)
     for n_total, nm, lo, hi in ((50, 6, 10, 30), (50_000_000, 6, 6_250_000, 12_500_000), (5, 6, 0, 5)):
         assert native.mixed_blocks(n_total, nm, lo, hi) == sharding.mixed_batch_blocks(n_total, nm, lo, hi)
+
+
+def test_bench_host_side_helpers(tmp_path, monkeypatch):
+    """bench.usable_cores honours a cgroup CPU quota; bench.recorded_traffic matches a profile summary only for the same kernel, library
+    build and launch size -- exactly, or within half a percent where the size is a property of the sampled data (terminal)."""
+    import bench
+    cores, note = bench.usable_cores()
+    assert 1 <= cores <= (os.cpu_count() or 1) and "hardware threads" in note
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    line = {"config": {"kernel": "k_x<1>", "lib": "emgpu test src:abc"}, "roofline": {"algorithmic_bytes_per_launch": 1000}}
+    json.dump({"bench_line": line, "hbm_traffic_bytes_per_launch": 1234.0}, open(prof / "t1_summary.json", "w"))
+    line2 = {"config": {"kernel": "k_t", "lib": "emgpu test src:abc"}, "roofline": {"algorithmic_bytes_per_launch": 5000.25}}
+    json.dump({"bench_line": line2, "hbm_traffic_bytes_per_launch": 9999.0}, open(prof / "t2_summary.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.recorded_traffic("k_x<1>", 1000, "emgpu test src:abc")["traffic"] == 1234.0
+    assert bench.recorded_traffic("k_x<1>", 1001, "emgpu test src:abc")["traffic"] is None        # another launch size
+    assert bench.recorded_traffic("k_x<1>", 1000, "emgpu test src:def")["traffic"] is None        # another build
+    assert bench.recorded_traffic("k_y<1>", 1000, "emgpu test src:abc")["traffic"] is None        # another kernel
+    assert bench.recorded_traffic("k_t", 5010.5, "emgpu test src:abc")["traffic"] == 9999.0       # data-dependent bytes: 0.2 % apart
+    assert bench.recorded_traffic("k_t", 5100.5, "emgpu test src:abc")["traffic"] is None         # 2 % apart
