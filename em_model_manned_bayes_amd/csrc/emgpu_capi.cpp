@@ -652,7 +652,8 @@ int emgpu_sample_dbn_blocks_device(emgpu_ctx *ctx, const emgpu_model *const *mod
         L.u = &u; L.col = col;
         fill_run(ctx, u, h->m, &q, L.A);
         bind_outputs(L.A, h->m, &q, &o, col);
-        L.shape = emgpu::fast_uncor_eligible(u.cp.plan, L.A) ? emgpu::uncor_fast_shape(u.cp.plan) : -1;
+        // (event lists: k_uncor_fast_ev, one launch per block -- the shared launch writes the dense trace only)
+        L.shape = (emgpu::fast_uncor_eligible(u.cp.plan, L.A) && L.A.ev_count == nullptr) ? emgpu::uncor_fast_shape(u.cp.plan) : -1;
         live.push_back(L);
     }
     ctx->last_launches = 0;

@@ -520,6 +520,21 @@ def test_mixed_launch_groups_blocks_by_kernel_instance(gpu_ctx, model_dir):
         assert np.array_equal(gb[sl], ref["dense_bin"]) and np.array_equal(gv[sl], ref["dense_val"].astype(np.float32)), (m, f, c)
         assert np.array_equal(ib[:, sl].cpu().numpy().T, ref["init_bin"])
     assert not gb[n:].any() and not gv[n:].any()              # nothing written past the batch
+    # event lists through the block entry point: one k_uncor_fast_ev launch per block, lists in the call's columns
+    cap = 128
+    ec = torch.zeros(n, dtype=torch.int32, device=dev); ev = torch.zeros((n, cap, 2), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    p2, _ = native.make_params(n, T, seed, first_index=first, event_cap=cap, **uncor_indices(pairs[0][1]))
+    sub = [b for b in blocks if b[2] > 0][:3] + [blocks[-1]]
+    native.sample_dbn_blocks_device(ctx, [pr[0] for pr in pairs], p2, sub, ev_count=ec.data_ptr(), events=ev.data_ptr())
+    ctx.sync()
+    assert ctx.last_launches() == len(sub) and ctx.last_kernel().startswith("k_uncor_fast_ev")
+    cnt = ec.cpu().numpy(); evh = ev.cpu().numpy().reshape(n, cap * 2).view(native.EVENT_DTYPE)
+    for (m, f, c) in sub:
+        ref = O.uncor_sample(O.OracleModel(pairs[m][1]), c, T, seed, first_index=f)
+        for q in range(0, c, 37):
+            r = ref["events"][q]; g = evh[f - first + q, : cnt[f - first + q]]
+            assert len(g) == len(r) and np.array_equal(g["dt"], r[:, 0]) and np.array_equal(g["var"], r[:, 1]) and np.array_equal(g["value"], r[:, 2].astype(np.float32))
 
 
 @pytest.mark.gpu
