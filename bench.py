@@ -77,6 +77,8 @@ def parse_args(argv=None):
     ap.add_argument("--ld-pad", type=int, default=1024, help="pad the trace's leading dimension to a multiple of this many columns")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the `configs` object (BASELINE.json configs[2..4] measured in the same process after the headline)")
+    ap.add_argument("--step-gap-ms", type=float, default=0.0,
+                    help="DIAGNOSTIC (tools/power_probe.sh): idle this long after every launch; the line then says so and is no benchmark line")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each entry of `configs` (2 warm-up steps before)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="minimum units timed on the CPU oracle (scaled up to ~10 s)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -397,6 +399,7 @@ class TerminalWorkload:
         self.rows = pl.empty((4 * self.n,), "int32")
         self.handles = (C.c_void_p * 10)(*[x.native._h for x in self.t._traj])
         self.bytes_bound = 7335      # 75 B geometry + 2 x 2 x <=121 steps x 3 variables x 5 B
+        self.bytes_data_dependent = True
         self.bytes_per_unit = self.bytes_bound   # replaced in check() by 75 + 15 B x the track-seconds the run really produced
         self.launches_per_step = 1
 
@@ -472,6 +475,9 @@ def measure(w, pl, args, warmup, steps):
         pl.record(ev[k][0])
         w.step(warmup + k)
         pl.record(ev[k][1])
+        if getattr(args, "step_gap_ms", 0.0) > 0.0:   # diagnostic only: what the kernel does when it is NOT launched back to back
+            w.sync()
+            time.sleep(args.step_gap_ms * 1e-3)
     pl.barrier()
     t1 = time.perf_counter()
     w.sync()
@@ -491,11 +497,11 @@ def roofline_of(w, step_ms, lib_version):
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
          "avg_launch_ms": avg_step_s * 1e3 / w.launches_per_step, "launches_per_step": w.launches_per_step,
-         "avg_step_ms": avg_step_s * 1e3, "algorithmic_bytes_per_launch": per_launch,
+         "avg_step_ms": avg_step_s * 1e3, "step_ms": [round(x, 3) for x in step_ms], "algorithmic_bytes_per_launch": per_launch,
          "algorithmic_bytes_per_unit": w.bytes_per_unit}
     if w.launches_per_step > 1:   # blocks of different kernel instances: they run on the ctx stream and three side streams
         r["launches_overlap"] = "avg_launch_ms is avg_step_ms / launches_per_step; single launches in a kernel trace overlap"
-    r.update(recorded_traffic(kernel, per_launch, lib_version))
+    r.update(recorded_traffic(kernel, per_launch, lib_version, data_dependent=getattr(w, "bytes_data_dependent", False)))
     return r
 
 
@@ -545,6 +551,8 @@ def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
         }
         if getattr(pl, "shared", False):
             line["oversubscribed"] = True
+        if args.step_gap_ms > 0.0:
+            line["diagnostic"] = "idle gaps of %g ms between the launches (--step-gap-ms): value and ms_per_step include them" % args.step_gap_ms
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = w.cpu_baseline(args.cpu_sample)
         if world == 1 and args.config == "uncor" and not args.no_other_configs and not args.model and not args.n and hasattr(pl, "release"):
@@ -557,7 +565,7 @@ def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
     return line
 
 
-def recorded_traffic(kernel_name, algorithmic_bytes, lib_version):
+def recorded_traffic(kernel_name, algorithmic_bytes, lib_version, data_dependent=False):
     """roofline.traffic: HBM bytes per launch from the PMC passes (WRITE_SIZE + 2 x FETCH_SIZE, the
     gfx950 correction of MI355X_MICROARCH.md) of a committed profile of the SAME kernel, launch size
     AND library build (profiles/*_summary.json, produced by tools/profile_bench.sh: counters need
@@ -575,7 +583,7 @@ def recorded_traffic(kernel_name, algorithmic_bytes, lib_version):
         theirs = line.get("roofline", {}).get("algorithmic_bytes_per_launch")
         # the same launch size: equal bytes -- or, where the bytes are a property of the sampled data (terminal: 75 + 15 B x the track-seconds
         # the batch happened to produce, which moves in the fourth digit with the step's index range), within half a percent
-        same_size = theirs == algorithmic_bytes or (isinstance(theirs, (int, float)) and not float(algorithmic_bytes).is_integer()
+        same_size = theirs == algorithmic_bytes or (data_dependent and isinstance(theirs, (int, float))
                                                     and abs(theirs - algorithmic_bytes) <= 0.005 * algorithmic_bytes)
         same = (line.get("config", {}).get("kernel") == kernel_name      # the summary's own bench line ran this kernel variant ...
                 and same_size                                            # ... on this launch size ...

@@ -187,5 +187,6 @@ def test_bench_host_side_helpers(tmp_path, monkeypatch):
     assert bench.recorded_traffic("k_x<1>", 1001, "emgpu test src:abc")["traffic"] is None        # another launch size
     assert bench.recorded_traffic("k_x<1>", 1000, "emgpu test src:def")["traffic"] is None        # another build
     assert bench.recorded_traffic("k_y<1>", 1000, "emgpu test src:abc")["traffic"] is None        # another kernel
-    assert bench.recorded_traffic("k_t", 5010.5, "emgpu test src:abc")["traffic"] == 9999.0       # data-dependent bytes: 0.2 % apart
-    assert bench.recorded_traffic("k_t", 5100.5, "emgpu test src:abc")["traffic"] is None         # 2 % apart
+    assert bench.recorded_traffic("k_t", 5010, "emgpu test src:abc", data_dependent=True)["traffic"] == 9999.0   # data-dependent bytes: 0.2 % apart
+    assert bench.recorded_traffic("k_t", 5010, "emgpu test src:abc")["traffic"] is None           # ... only for a workload that says so
+    assert bench.recorded_traffic("k_t", 5100, "emgpu test src:abc", data_dependent=True)["traffic"] is None      # 2 % apart
