@@ -6,6 +6,7 @@ EmgpuError(EMGPU_ERR_NO_DEVICE).
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # EMGPU_LIB: alternative build of the same library (A/B timing of kernel variants on one box)
@@ -126,6 +127,33 @@ SYMBOLS = [
 ]
 
 _lib = None
+_hip_runtime = None
+
+
+def _share_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (soname
+    libamdhip64.so.7, like the system's).  Loaded first, libemgpu.so binds the system copy, and a later `import torch` brings a
+    SECOND runtime into the process (torch's loader asks for the file name, which no loaded soname matches): two HSA instances on
+    one GPU, a torch stream handed to emgpu_ctx_create is a foreign handle, and on some boxes the second initialisation fails
+    ("No HIP GPUs are available").  So when a torch wheel with a bundled runtime is installed, that copy is loaded first (the
+    wheel is located, not imported): libemgpu.so's NEEDED soname resolves to it, and so does torch's own load, whenever it comes.
+    EMGPU_HIP_RUNTIME=system keeps the system runtime (a process that never imports torch)."""
+    global _hip_runtime
+    if _hip_runtime is not None or os.environ.get("EMGPU_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            _hip_runtime = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            _hip_runtime = None
 
 
 def lib():
@@ -136,6 +164,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libemgpu.so not found at %s: build it with `make -C em_model_manned_bayes_amd/csrc` "
                           "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    _share_hip_runtime()
     L = C.CDLL(LIB_PATH)
     for s in SYMBOLS:
         getattr(L, s)  # AttributeError if the ABI is incomplete

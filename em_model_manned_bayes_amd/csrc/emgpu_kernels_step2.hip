@@ -303,8 +303,9 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
             const bool w4 = WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4);
             return (colpk - P.d_poffpk[k] * 4u) * (w4 ? 1u : 2u) + P.d_poff[k] * 4u;
         };
-        if (g8 >= 1 && 8 * g8 + 7 < T) {
-            // ---- interior block: every second is a draw, nothing is guarded.
+        if (8 * g8 + 7 < T) {
+            // ---- full block: every second is a draw, nothing is guarded -- but second 0 of the trajectory (block 0), which is the
+            // initial state and no draw (dbn_sample.m:77 starts at t = 2): a wave-uniform branch around that one second.
             // A level-0 node whose parents are level-0 nodes' current bins only (kPre) knows its NEXT second's column as soon as
             // this second's level 0 is decided: that gather is issued together with this second's level-1 gathers, so a second
             // exposes one round trip less through L1/L2.
@@ -330,9 +331,11 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
             for (int j = 0; j < 8; j++) {
                 uint32_t nb1[ND];
 #pragma unroll
-                for (int k = 0; k < ND; k++) nb1[k] = 1u;
+                for (int k = 0; k < ND; k++) nb1[k] = (j == 0) ? cur1[k] : 1u;
+                const bool draw = j > 0 || g8 != 0;   // wave-uniform; folded for j > 0
 #pragma unroll
                 for (int lev = 0; lev <= kMaxLev; lev++) {
+                    if (draw) {
                     uint4 ca[ND];   // live only across this level's gathers and draws
                     uint32_t sel[ND], dmin[ND], colv[ND];
 #pragma unroll
@@ -385,6 +388,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
                             }
                         }
                     }
+                    }   // draw
                     if (lev == 0 && j < 7 && kMaxLev >= 1) {
 #pragma unroll
                         for (int k = 0; k < ND; k++) {

@@ -4,6 +4,7 @@ presets, error behaviour, the plan compiler's integer thresholds, and the shardi
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -619,3 +620,26 @@ def test_start_log_weight(model_dir):
     with pytest.raises(E.EmgpuError) as ei:
         mdl.start_log_weight
     assert ei.value.code == L.ERR_PRESET
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """_lib._share_hip_runtime: a process that loads libemgpu.so and imports torch (in either order) holds ONE libamdhip64 /
+    libhsa-runtime64, not the system's next to the wheel's (two HSA instances on one GPU: foreign stream handles, and on some
+    boxes `No HIP GPUs are available` from the second one)."""
+    import subprocess
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+order = sys.argv[1]
+if order == "torch-first":
+    import torch
+from em_model_manned_bayes_amd import _lib
+_lib.lib()
+import torch
+libs = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l or "libhsa-runtime64" in l})
+print(len([x for x in libs if "libamdhip64" in x]), len([x for x in libs if "libhsa-runtime64" in x]))
+''' % ROOT
+    for order in ("emgpu-first", "torch-first"):
+        out = subprocess.run([sys.executable, "-c", code, order], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.split() == ["1", "1"], (order, out.stdout)
