@@ -1,8 +1,8 @@
-"""tools/track_disagreements.py -- how often do the GPU .track paths and the CPU checker part, and at what decision margin?
+"""tests/soak/track_disagreements.py (checker-side diagnostic: it runs the CPU oracle, so it lives under tests/) -- how often do the GPU .track paths and the CPU checker part, and at what decision margin?
 Diagnostic companion of tests/test_gpu_parity.py::test_terminal_track_matches_oracle / test_uncor_track_matches_oracle (which
 assert that every parting sits on a threshold).  Needs a GPU; prints one line per case."""
 import os, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for q in ("", "tests", "oracle"):
     sys.path.insert(0, os.path.join(ROOT, q))
 import numpy as np
