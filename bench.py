@@ -331,6 +331,30 @@ class DbnWorkload:
             assert int(self.init_bin[:, : self.n].min()) >= 1 and bool(t.isfinite(self.dyn_val[:, :, : min(self.n, 100000)]).all())
             assert int((self.dyn_bin[0, :, : self.n] & 0xFF).min()) >= 1
 
+    def streaming_write(self, reps=20):
+        """What a kernel that does nothing but store reaches on THIS box: hipMemset (torch zero_) of the trace buffers the step just filled,
+        median of `reps` after 3 untimed ones, HIP events.  The roofline's `peak` stays the guide's 8 TB/s; this is the ceiling a write
+        stream meets in practice (tools/ubench/store_ubench.hip: a store-only twin of the sampler's own store pattern reaches the same)."""
+        t = getattr(self.pl, "torch", None)
+        if t is None:
+            return None
+        bufs = [self.dyn_bin, self.dyn_val]
+        nbytes = sum(b.numel() * b.element_size() for b in bufs)
+        ms = []
+        for r in range(reps + 3):
+            a, b = self.pl.event(), self.pl.event()
+            self.pl.record(a)
+            for x in bufs:
+                x.zero_()
+            self.pl.record(b)
+            t.cuda.synchronize()
+            if r >= 3:
+                ms.append(self.pl.elapsed_ms(a, b))
+        ms.sort()
+        med = ms[len(ms) // 2]
+        return {"GB/s": nbytes / med / 1e6, "bytes": nbytes, "median_ms": med,
+                "how": "hipMemset (torch zero_) of the step's own dyn_bin + dyn_val buffers on this box, median of %d" % reps}
+
     def config(self):
         return {"workload": self.cfg["workload"] % dict(model=self.names[0], n=self.n, T=self.T),
                 "transition_mode": "PER_STEP" if self.per_step else "REFERENCE_AUTO",
@@ -502,6 +526,10 @@ def roofline_of(w, step_ms, lib_version):
     if w.launches_per_step > 1:   # blocks of different kernel instances: they run on the ctx stream and three side streams
         r["launches_overlap"] = "avg_launch_ms is avg_step_ms / launches_per_step; single launches in a kernel trace overlap"
     r.update(recorded_traffic(kernel, per_launch, lib_version, data_dependent=getattr(w, "bytes_data_dependent", False)))
+    sw = w.streaming_write() if hasattr(w, "streaming_write") else None
+    if sw:   # measured AFTER the timed region (the buffers' contents were checked by then)
+        r["streaming_write"] = sw
+        r["frac_of_streaming_write"] = achieved / sw["GB/s"]
     return r
 
 
