@@ -46,6 +46,27 @@ __global__ void __launch_bounds__(256, 4) k_twin(uint32_t *dyn_bin, float4 *dyn_
     }
 }
 
+// the same stores in a TILE-major layout: everything a workgroup (256 trajectories) writes is one contiguous range that it fills from
+// front to back ([tile][4-second block][variable][256]): does the order of the planes cost anything?
+__global__ void __launch_bounds__(256, 4) k_twin_tile(uint32_t *dyn_bin, float4 *dyn_val, int64_t n, int G4, uint32_t seedish) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = (uint32_t)i * 2654435761u + seedish;
+    const size_t base = (size_t)blockIdx.x * (size_t)G4 * 3 * 256 + threadIdx.x;
+    for (int g8 = 0; g8 < G4 / 2; g8++) {
+        x = x * 1664525u + 1013904223u;
+        const float f = __uint_as_float(0x3f800000u | (x >> 9));
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const size_t o = base + ((size_t)(2 * g8) * 3 + k) * 256;
+            dyn_bin[o] = x + k;
+            dyn_val[o] = make_float4(f, f + k, f, f);
+            dyn_bin[o + 3 * 256] = x ^ k;
+            dyn_val[o + 3 * 256] = make_float4(f, f, f + k, f);
+        }
+    }
+}
+
 template <bool NT>
 __global__ void __launch_bounds__(256, 4) k_flat(float4 *p, size_t n16, uint32_t seedish) {
     const float f = __uint_as_float(0x3f800000u | (seedish >> 9));
@@ -78,6 +99,7 @@ int main() {
     const unsigned blocks = (unsigned)((n + 255) / 256);
     run("twin", bytes, [&](int r) { hipLaunchKernelGGL(k_twin<false>, dim3(blocks), dim3(256), 0, 0, db, dv, n, ld, G4, (uint32_t)r); });
     run("twin+nt", bytes, [&](int r) { hipLaunchKernelGGL(k_twin<true>, dim3(blocks), dim3(256), 0, 0, db, dv, n, ld, G4, (uint32_t)r); });
+    run("twin tile", bytes, [&](int r) { hipLaunchKernelGGL(k_twin_tile, dim3(blocks), dim3(256), 0, 0, db, dv, n, G4, (uint32_t)r); });
     const size_t n16 = nb;                 // the value planes as one contiguous range (28.8 GB)
     const double fbytes = (double)n16 * 16;
     run("flat", fbytes, [&](int r) { hipLaunchKernelGGL(k_flat<false>, dim3(256 * 32), dim3(256), 0, 0, dv, n16, (uint32_t)r); });
