@@ -768,6 +768,8 @@ def test_bench_launches_its_own_ranks(tmp_path):
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["config"]["kernel"] == "k_uncor_fast_mixed<7,4,6,6>" and len(line["config"]["models"]) == 6
     assert line["config"]["launches_per_step"] == 1 and line["config"]["model_blocks_per_step"] == 6
+    rf = line["roofline"]   # every timed launch listed; the write ceiling of this box measured on the step's own buffers
+    assert len(rf["step_ms"]) == 2 and rf["streaming_write"]["GB/s"] > 1000 and 0 < rf["frac_of_streaming_write"] < 1.5
 
 
 @pytest.fixture(scope="module")
