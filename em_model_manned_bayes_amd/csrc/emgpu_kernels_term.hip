@@ -288,8 +288,12 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     const double bounds_dist_hi = s_bnd[P.i_nb[1] - 1];
     const int rm1[3] = {RM1_0 ? RM1_0 : (int)P.d_r[0] - 1, RM1_1 ? RM1_1 : (int)P.d_r[1] - 1, RM1_2 ? RM1_2 : (int)P.d_r[2] - 1};
     // which dynamic variable is heading / altitude / speed (the host checks that all three are there)
-    const int kh = P.d_ivar[0] == 3 ? 0 : (P.d_ivar[1] == 3 ? 1 : 2), ka = P.d_ivar[0] == 4 ? 0 : (P.d_ivar[1] == 4 ? 1 : 2),
-              ks = P.d_ivar[0] == 5 ? 0 : (P.d_ivar[1] == 5 ? 1 : 2);
+    // (the instance built for the shipped shape also knows the order: heading, altitude, speed with temporal-map rows 0, 1, 2 --
+    // launch_terminal_propagate checks it; the selects below then fold)
+    constexpr bool kShipped = RM1_0 == 35 && RM1_1 == 6 && RM1_2 == 4;
+    const int kh = kShipped ? 0 : (P.d_ivar[0] == 3 ? 0 : (P.d_ivar[1] == 3 ? 1 : 2)), ka = kShipped ? 1 : (P.d_ivar[0] == 4 ? 0 : (P.d_ivar[1] == 4 ? 1 : 2)),
+              ks = kShipped ? 2 : (P.d_ivar[0] == 5 ? 0 : (P.d_ivar[1] == 5 ? 1 : 2));
+    const int drow[3] = {kShipped ? 0 : (int)P.d_row[0], kShipped ? 1 : (int)P.d_row[1], kShipped ? 2 : (int)P.d_row[2]};
     // the part of a column index that never changes along a track: the intent (variable 1)
 
     double xy0 = g[0], xy1 = g[1], z_ft = g[2], heading_deg = g[4], prev_z_rec = 0;
@@ -310,6 +314,19 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     // row written straight to the [6][cap][4n] output would be 64 scattered 4-byte stores; each lane keeps its last kRing rows in
     // LDS instead, and row r leaves for memory -- one 256-byte store per field for the wave -- once every running lane is past it.
     // A lane more than kRing rows ahead of the slowest waits (the slowest lane sets the wave's run time either way).
+    // asub2ind.m:13-14 over the step's start state: the strides of a transition node's current-bin parents (heading, altitude, speed
+    // in the model's order) folded into the strides of the same variables as initial-state parents, once (wave-uniform, scalar) --
+    // per step the column is then six multiply-adds per node instead of nine plus three 6-way selects
+    uint32_t cstr[3][6];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            uint32_t sv = P.d_stride_static[k][p];
+#pragma unroll
+            for (int q = 0; q < 3; q++) sv += ((int)P.d_ivar[q] == p) ? P.d_stride_cur[k][q] : 0u;
+            cstr[k][p] = sv;
+        }
     int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
     uint32_t colk[3] = {0u, 0u, 0u};   // the step's CPT columns; the row addresses are formed at the draw (nine 64-bit pointers kept per lane cost 18 registers)
     const bool has_c8[3] = {P.d_c8off[0] != 0u, P.d_c8off[1] != 0u, P.d_c8off[2] != 0u};   // wave-uniform
@@ -347,9 +364,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 for (int k = 0; k < 3; k++) {
                     uint32_t c = 0u;
 #pragma unroll
-                    for (int p = 0; p < 6; p++) c += P.d_stride_static[k][p] * (uint32_t)st[p];   // st[0]: the intent, which never changes
-#pragma unroll
-                    for (int q = 0; q < 3; q++) c += P.d_stride_cur[k][q] * (uint32_t)st[P.d_ivar[q]];
+                    for (int p = 0; p < 6; p++) c += cstr[k][p] * (uint32_t)st[p];   // st[0]: the intent, which never changes
                     colk[k] = c;
                 }
             }
@@ -360,7 +375,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
             {   // block = the step, word = the variable's row of the temporal map: one Philox call for the three draws
                 const uint4 tw = rng.block(11u /* TERM_TRANS */, 0u, (uint32_t)ii);
 #pragma unroll
-                for (int k = 0; k < 3; k++) xw[k] = word_of(tw, (int)P.d_row[k]);
+                for (int k = 0; k < 3; k++) xw[k] = word_of(tw, drow[k]);
             }
             gptr_t row[3], piv[3], c8[3];
 #pragma unroll
@@ -377,15 +392,15 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                       dS = ks == 0 ? nb.bin[0] : (ks == 1 ? nb.bin[1] : nb.bin[2]);
             uint4 dw = make_uint4(0u, 0u, 0u, 0u);   // the step's dediscretize draws (one Philox call, made by the lanes that have an event)
             if (dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1) dw = rng.block(12u /* TERM_DEDISC */, 0u, (uint32_t)ii);
-            if (dH != st[3] + 1) heading_deg = t_dedisc(s_bnd + 2 * kBndStride, dH, word_of(dw, (int)P.d_row[kh]));
+            if (dH != st[3] + 1) heading_deg = t_dedisc(s_bnd + 2 * kBndStride, dH, word_of(dw, kh == 0 ? drow[0] : (kh == 1 ? drow[1] : drow[2])));
             if (dA != st[4] + 1) {
                 // MATLAB: 1:[] is empty, so with no boundary at or below the limit no altitude event is valid
-                if (alt_last >= 1 && dA >= 1 && dA <= alt_last) z_ft = t_dedisc(s_bnd + 3 * kBndStride, dA, word_of(dw, (int)P.d_row[ka]));
+                if (alt_last >= 1 && dA >= 1 && dA <= alt_last) z_ft = t_dedisc(s_bnd + 3 * kBndStride, dA, word_of(dw, ka == 0 ? drow[0] : (ka == 1 ? drow[1] : drow[2])));
                 else resample = true;
             }
             if (!resample && dS != st[5] + 1) {
                 if (spd_first >= 1 && dS >= spd_first && dS <= spd_last) {
-                    double s1 = t_dedisc(s_bnd + 4 * kBndStride, dS, word_of(dw, (int)P.d_row[ks]));
+                    double s1 = t_dedisc(s_bnd + 4 * kBndStride, dS, word_of(dw, ks == 0 ? drow[0] : (ks == 1 ? drow[1] : drow[2])));
                     const double minVel = T_LIM(0), maxVel = T_LIM(1);
                     if (s1 < minVel) s1 = minVel;
                     if (s1 > maxVel) s1 = maxVel;
@@ -434,7 +449,8 @@ hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, 
     if (A.n <= 0) return hipSuccess;
     const int64_t blocks = (4 * A.n + 255) / 256;
     static const bool generic_only = getenv("EMGPU_DEBUG_TERM_GENERIC") != nullptr;   // tests: the run-time-shape instance on the shipped shape
-    if (!generic_only && P.d_r[0] == 36 && P.d_r[1] == 7 && P.d_r[2] == 5) {
+    const bool shipped_order = P.d_ivar[0] == 3 && P.d_ivar[1] == 4 && P.d_ivar[2] == 5 && P.d_row[0] == 0 && P.d_row[1] == 1 && P.d_row[2] == 2;
+    if (!generic_only && shipped_order && P.d_r[0] == 36 && P.d_r[1] == 7 && P.d_r[2] == 5) {
         *name = "k_terminal_propagate<35,6,4>";
         hipLaunchKernelGGL((k_terminal_propagate<35, 6, 4>), dim3((unsigned)blocks), dim3(256), 0, s, P, A);
     } else {
