@@ -329,7 +329,8 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
         }
     int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
     uint32_t colk[3] = {0u, 0u, 0u};   // the step's CPT columns; the row addresses are formed at the draw (nine 64-bit pointers kept per lane cost 18 registers)
-    const bool has_c8[3] = {P.d_c8off[0] != 0u, P.d_c8off[1] != 0u, P.d_c8off[2] != 0u};   // wave-uniform
+    // (compile_plan builds the compact rows for exactly the rows of 9 to 48 thresholds: a compile-time fact in the shipped-shape instance)
+    const bool has_c8[3] = {rm1[0] > 8 && rm1[0] <= 48, rm1[1] > 8 && rm1[1] <= 48, rm1[2] > 8 && rm1[2] <= 48};   // wave-uniform
     double curr_hdg = 0;
     const bool dist8 = gDist.n <= 8;   // wave-uniform: the distance grid is compared squared
     int flushed = 0; // wave-uniform: rows [0, flushed) of every lane are in memory
@@ -357,14 +358,16 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 st[1] = (dist8 ? t_discretize8(d2_nm, s_cut8sq) : t_discretize(sqrt(d2_nm), s_bnd, gDist)) - 1;     // wave-uniform choices
                 st[2] = t_bearing_bin(xy0, xy1, s_bnd + gBear.off + 1, s_dir, gBear.n, gBear.lo, gBear.inv_step) - 1;
                 st[3] = t_discretize(heading_deg, s_bnd, gHead) - 1;
-                st[4] = (gAlt.n <= 8 ? t_discretize8(z_ft, s_cut8[3]) : t_discretize(z_ft, s_bnd, gAlt)) - 1;
-                st[5] = (gSpd.n <= 8 ? t_discretize8(speed, s_cut8[4]) : t_discretize(speed, s_bnd, gSpd)) - 1;      // norm(v_ft_s): the velocity has not changed since `speed`
+                st[4] = ((kShipped || gAlt.n <= 8) ? t_discretize8(z_ft, s_cut8[3]) : t_discretize(z_ft, s_bnd, gAlt)) - 1;   // (7 and 5 bins: at most 8 cut points, checked at launch)
+                st[5] = ((kShipped || gSpd.n <= 8) ? t_discretize8(speed, s_cut8[4]) : t_discretize(speed, s_bnd, gSpd)) - 1;    // norm(v_ft_s): the velocity has not changed since `speed`
                 // CPT column of each dynamic variable (asub2ind.m:13-14 as strides); topological position == variable id
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     uint32_t c = 0u;
 #pragma unroll
-                    for (int p = 0; p < 6; p++) c += cstr[k][p] * (uint32_t)st[p];   // st[0]: the intent, which never changes
+                    for (int p = 0; p < 6; p++)   // st[0]: the intent, which never changes
+                        c = kShipped ? __umul24(cstr[k][p], (uint32_t)st[p]) + c   // one v_mad_u32_u24 (launch_terminal_propagate checks the strides fit 24 bits)
+                                     : cstr[k][p] * (uint32_t)st[p] + c;
                     colk[k] = c;
                 }
             }
@@ -449,7 +452,14 @@ hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, 
     if (A.n <= 0) return hipSuccess;
     const int64_t blocks = (4 * A.n + 255) / 256;
     static const bool generic_only = getenv("EMGPU_DEBUG_TERM_GENERIC") != nullptr;   // tests: the run-time-shape instance on the shipped shape
-    const bool shipped_order = P.d_ivar[0] == 3 && P.d_ivar[1] == 4 && P.d_ivar[2] == 5 && P.d_row[0] == 0 && P.d_row[1] == 1 && P.d_row[2] == 2;
+    bool shipped_order = P.d_ivar[0] == 3 && P.d_ivar[1] == 4 && P.d_ivar[2] == 5 && P.d_row[0] == 0 && P.d_row[1] == 1 && P.d_row[2] == 2;
+    if ((int)P.i_nb[4] - 2 > 8 || (int)P.i_nb[5] - 2 > 8) shipped_order = false;   // altitude and speed grids compared against eight padded cut points
+    for (int k = 0; k < 3; k++)       // the folded strides of the instance's 24-bit multiply-adds
+        for (int p = 0; p < 6; p++) {
+            uint64_t sv = P.d_stride_static[k][p];
+            for (int q = 0; q < 3; q++) sv += ((int)P.d_ivar[q] == p) ? P.d_stride_cur[k][q] : 0u;
+            if (sv >= (1u << 24)) shipped_order = false;
+        }
     if (!generic_only && shipped_order && P.d_r[0] == 36 && P.d_r[1] == 7 && P.d_r[2] == 5) {
         *name = "k_terminal_propagate<35,6,4>";
         hipLaunchKernelGGL((k_terminal_propagate<35, 6, 4>), dim3((unsigned)blocks), dim3(256), 0, s, P, A);
