@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     // (compile_plan builds the compact rows for exactly the rows of 9 to 48 thresholds: a compile-time fact in the shipped-shape instance)
     const bool has_c8[3] = {rm1[0] > 8 && rm1[0] <= 48, rm1[1] > 8 && rm1[1] <= 48, rm1[2] > 8 && rm1[2] <= 48};   // wave-uniform
     double curr_hdg = 0;
-    const bool dist8 = gDist.n <= 8;   // wave-uniform: the distance grid is compared squared
+    const bool dist8 = kShipped || gDist.n <= 8;   // wave-uniform: the distance grid is compared squared (the shipped-shape instance is only launched on such a grid)
     int flushed = 0; // wave-uniform: rows [0, flushed) of every lane are in memory
     while (__ballot(!done) != 0ull) {
         if (!done && (att != 0 || rows - flushed < kRing)) do {
@@ -453,7 +453,7 @@ hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, 
     const int64_t blocks = (4 * A.n + 255) / 256;
     static const bool generic_only = getenv("EMGPU_DEBUG_TERM_GENERIC") != nullptr;   // tests: the run-time-shape instance on the shipped shape
     bool shipped_order = P.d_ivar[0] == 3 && P.d_ivar[1] == 4 && P.d_ivar[2] == 5 && P.d_row[0] == 0 && P.d_row[1] == 1 && P.d_row[2] == 2;
-    if ((int)P.i_nb[4] - 2 > 8 || (int)P.i_nb[5] - 2 > 8) shipped_order = false;   // altitude and speed grids compared against eight padded cut points
+    if ((int)P.i_nb[1] - 2 > 8 || (int)P.i_nb[4] - 2 > 8 || (int)P.i_nb[5] - 2 > 8) shipped_order = false;   // distance, altitude and speed grids compared against eight padded cut points
     for (int k = 0; k < 3; k++)       // the folded strides of the instance's 24-bit multiply-adds
         for (int p = 0; p < 6; p++) {
             uint64_t sv = P.d_stride_static[k][p];
