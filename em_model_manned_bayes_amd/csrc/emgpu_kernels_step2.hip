@@ -132,7 +132,8 @@ __device__ __attribute__((noinline)) uint32_t exact_hit(uint32_t c0, uint32_t c1
     return clamp32(hi | lo) < R ? 1u : 0u;                                                  // resample_events.m:24
 }
 
-// WMODE: 4 / 8 = every variable's columns are 4 / 8 words wide, 0 = decided per variable at run time.
+// WMODE: 4 / 8 = every variable's columns are 4 / 8 words wide, 0 = decided per variable at run time, 16 + m = variable k is 4 words wide
+// iff bit k of m is set (s2_w4).  A width left to run time is a wave-uniform branch per draw with both forms of the draw behind it.
 // REG ("regular"): exactly ND dynamic variables, all with a resample rate > 0.  The specialised
 // instances drop the wave-uniform tests and the code behind them (cor_v1: 25.2 -> 20.8 ms).
 // CUR / NEW: which dynamic variables are parents of which (t+1) node (bit 4k+q; step_parent_masks): an instance built for a
@@ -141,6 +142,11 @@ __device__ __attribute__((noinline)) uint32_t exact_hit(uint32_t c0, uint32_t c1
 // initial state (the column of a variable never changes along a trajectory).  For the fast-branch models k_uncor_fast does not
 // take (four dynamic variables: littoral_cor_v1); the per-second gathers then hit the same line every time.
 // EV: the event list as well (emgpu_events.h): what UncorEncounterModel.sample / dbn_hierarchical_sample return for these models.
+template <int WMODE>
+__device__ __forceinline__ bool s2_w4(const EmgpuPlan &P, int k) {
+    return WMODE == 4 || (WMODE >= 16 ? (((WMODE - 16) >> k) & 1) != 0 : (WMODE == 0 && P.d_pw[k] == 4));
+}
+
 template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW, bool FRZ = false, bool EV = false>
 __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
     static_assert(!FRZ || NEW == 0u, "a fast-branch model has no (t+1) parents");
@@ -300,7 +306,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
         };
         // the same column in the padded table of full thresholds (4 or 8 words per column)
         auto full_of = [&](int k, uint32_t colpk) {
-            const bool w4 = WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4);
+            const bool w4 = s2_w4<WMODE>(P, k);
             return (colpk - P.d_poffpk[k] * 4u) * (w4 ? 1u : 2u) + P.d_poff[k] * 4u;
         };
         if (8 * g8 + 7 < T) {
@@ -321,7 +327,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
 #pragma unroll
             for (int k = 0; k < ND; k++) {
                 zt[k] = make_uint4(0u, 0u, 0u, 0u);
-                if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) continue;   // (the plain form sees x_h = 0 against H = 0 as the tie it is)
+                if (s2_w4<WMODE>(P, k)) continue;   // (the plain form sees x_h = 0 against H = 0 as the tie it is)
                 uint32_t z[4];
 #pragma unroll
                 for (int p2 = 0; p2 < 4; p2++) asm("v_pk_sub_u16 %0, 1, %1 op_sel_hi:[0,1] clamp" : "=v"(z[p2]) : "v"(word_of(th[k], p2)));
@@ -356,7 +362,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
                         if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
                         const uint32_t wt = word_of(th[k], j >> 1), wz = word_of(zt[k], j >> 1);
                         const uint4 a = ca[k];
-                        if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) {   // the plain form: sel = 1 on a tie (the map offset goes straight to the lookup)
+                        if (s2_w4<WMODE>(P, k)) {   // the plain form: sel = 1 on a tie (the map offset goes straight to the lookup)
                             uint32_t tie;
                             const uint32_t off = (j & 1) ? plain_fired7<true>(wt, a.x, a.y, a.z, tie) : plain_fired7<false>(wt, a.x, a.y, a.z, tie);
                             nb1[k] = __builtin_amdgcn_ubfe(a.w, off, 4u);
@@ -375,7 +381,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
                             if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
                             if (__ballot((sel[k] & 1u) != 0u) == 0ull) continue;
                             const uint32_t cf = full_of(k, colv[k]);   // the full thresholds of the column, from the padded table
-                            if (WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4)) {
+                            if (s2_w4<WMODE>(P, k)) {
                                 const uint4 fa = load4(cf);
                                 const uint32_t b = exact_borrows(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, word_of(th[k], j >> 1), P.d_tvar[k], (uint32_t)g8, (uint32_t)j,
                                                                  fa.x, fa.y, fa.z, 0u, 0u, 0u);
@@ -442,7 +448,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
 #pragma unroll
                         for (int k = 0; k < ND; k++) {
                             if (kLev[k] != lev || (!REG && k >= P.nd)) continue;
-                            const bool w4 = WMODE == 4 || (WMODE == 0 && P.d_pw[k] == 4);
+                            const bool w4 = s2_w4<WMODE>(P, k);
                             const uint32_t col = full_of(k, column_of(k, nb1));   // the plain thresholds of the padded table
                             const uint4 a = load4(col);
                             uint4 b = make_uint4(0, 0, 0, 0);
@@ -572,6 +578,27 @@ static bool launch_masked(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args
     }
     EMGPU_S2_CASE(16, 4, 4, 0x8421u, 0x2100u, "[cor]")         // cor_v1: two independent aircraft, turn rate after vertical rate
     EMGPU_S2_CASE(16, 4, 8, 0x8421u, 0x2100u, "[cor]")
+    // the 3-variable families with the widths of the shipped files as compile-time facts (dense output only; WMODE 16 + mask of the
+    // 4-word variables): a width decided at run time is a wave-uniform branch per draw with both forms of the draw behind it
+    uint32_t wm = 0u;
+    for (int k = 0; k < P.nd; k++) wm |= (P.d_pw[k] == 4 ? 1u : 0u) << k;
+#define EMGPU_S2_CASE_W(NI_, ND_, WM_, C_, N_, TAG_)                                                               \
+    if (A.ev_count == nullptr && P.ni <= NI_ && P.nd == ND_ && wm == WM_ && cur == C_ && nw == N_) {               \
+        hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, 16 + WM_, true, C_, N_, false, false>), g, b, 0, s, P, A, F);    \
+        *tag = TAG_;                                                                                               \
+        return true;                                                                                               \
+    }
+    EMGPU_S2_CASE_W(7, 3, 4, 0x0421u, 0x0310u, "[chain,w884]")      // glider_v1
+    EMGPU_S2_CASE_W(7, 3, 0, 0x0421u, 0x0310u, "[chain,w888]")      // paraglider_v1
+    EMGPU_S2_CASE_W(7, 3, 7, 0x0421u, 0x0210u, "[2<-1,w444]")       // littoral_uncor_v1
+    EMGPU_S2_CASE_W(7, 3, 4, 0x0421u, 0x0210u, "[2<-1,w884]")       // paramotor_v1
+    EMGPU_S2_CASE_W(7, 3, 5, 0x0421u, 0x0210u, "[2<-1,w484]")       // skydiving_v1
+    EMGPU_S2_CASE_W(7, 3, 0, 0x0421u, 0x0110u, "[1<-0,2<-0,w888]")  // fai1_v1
+    EMGPU_S2_CASE_W(7, 3, 2, 0x0421u, 0x0110u, "[1<-0,2<-0,w848]")  // fai5_v1
+    EMGPU_S2_CASE_W(7, 3, 6, 0x0421u, 0x0300u, "[2<-0,1,w844]")     // uncor_1200code_v1
+    EMGPU_S2_CASE_W(7, 3, 5, 0x0577u, 0x0000u, "[per-step,w484]")   // uncor_1200code_v2p1 under EMGPU_TRANSITION_PER_STEP
+    EMGPU_S2_CASE_W(7, 3, 0, 0x0577u, 0x0000u, "[per-step,w888]")   // the v1.2 and allcode families under EMGPU_TRANSITION_PER_STEP
+#undef EMGPU_S2_CASE_W
     EMGPU_S2_CASE(7, 3, 0, 0x0421u, 0x0310u, "[chain]")        // glider_v1, paraglider_v1
     EMGPU_S2_CASE(7, 3, 0, 0x0421u, 0x0210u, "[2<-1]")         // littoral_uncor_v1, paramotor_v1, skydiving_v1
     EMGPU_S2_CASE(7, 3, 0, 0x0421u, 0x0110u, "[1<-0,2<-0]")    // fai1_v1, fai5_v1
