@@ -653,7 +653,8 @@ int emgpu_sample_dbn_blocks_device(emgpu_ctx *ctx, const emgpu_model *const *mod
         fill_run(ctx, u, h->m, &q, L.A);
         bind_outputs(L.A, h->m, &q, &o, col);
         // (event lists: k_uncor_fast_ev, one launch per block -- the shared launch writes the dense trace only)
-        L.shape = (emgpu::fast_uncor_eligible(u.cp.plan, L.A) && L.A.ev_count == nullptr) ? emgpu::uncor_fast_shape(u.cp.plan) : -1;
+        // (... and stores both dense outputs unconditionally)
+        L.shape = (emgpu::fast_uncor_eligible(u.cp.plan, L.A) && L.A.ev_count == nullptr && L.A.dyn_bin != nullptr && L.A.dyn_val != nullptr) ? emgpu::uncor_fast_shape(u.cp.plan) : -1;
         live.push_back(L);
     }
     ctx->last_launches = 0;

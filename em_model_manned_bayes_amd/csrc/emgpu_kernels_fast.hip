@@ -438,7 +438,7 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
         coop_dedisc<3, true, LB, IDX>(W, lane, gidx, rng, g8, need24, kind24, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
 #pragma unroll
         for (int k = 0; k < 3; k++)
-            coop_fill_store_msb<3, LB>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
+            coop_fill_store_msb<3, LB, !EV && !IDX>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],   // (the plain and the mixed kernel are only launched with both dense outputs)
                                    3u, h_slot[k], i0, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
         if constexpr (EV) ev_emit_block<3, LB>(W, lane, E, S, rng, P.bnd, g8, T, valid, hit24, kind24, prevw);
         wave_sync(); // results of this block are consumed before the next block's workers overwrite them
@@ -618,7 +618,7 @@ static hipError_t launch_idx_t(const EmgpuPlan &P, const EmgpuRun &A, const Fast
 hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
     if (A.n <= 0) return hipSuccess;
     const FastArgs F = fast_args_of(P);
-    if (A.indices != nullptr && A.ev_count == nullptr) {
+    if ((A.indices != nullptr || A.dyn_bin == nullptr || A.dyn_val == nullptr) && A.ev_count == nullptr) {   // an index list, or only one of the dense outputs
         switch (fast_shape_of(P)) {
         case 0: *name = "k_uncor_fast_idx<7,2,2,2>"; return launch_idx_t<7, 2, 2, 2>(P, A, F, s);
         case 1: *name = "k_uncor_fast_idx<7,2,4,2>"; return launch_idx_t<7, 2, 4, 2>(P, A, F, s);

@@ -150,6 +150,8 @@ __device__ __forceinline__ bool s2_w4(const EmgpuPlan &P, int k) {
 template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW, bool FRZ = false, bool EV = false>
 __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
     static_assert(!FRZ || NEW == 0u, "a fast-branch model has no (t+1) parents");
+    // the instances built for a model family's parent masks are only launched with both dense outputs (launch_masked): no null tests at the stores
+    constexpr bool kBoth = !EV && CUR != 0x0777u && CUR != 0xFFFFu;
     __shared__ CoopLds<ND, true> s_wave[4];
     __shared__ double s_bnd[ND][16];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -493,7 +495,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
 #pragma unroll
         for (int k = 0; k < ND; k++)
             if (k < P.nd)
-                coop_fill_store_msb<ND, true>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
+                coop_fill_store_msb<ND, true, kBoth>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
                                               (uint32_t)P.nd, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
         if constexpr (EV) {
             uint32_t hitp = 0u;
@@ -570,6 +572,7 @@ static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const Step2Arg
 // Instances built for the parent masks of the shipped model families (regular models only).  Returns false when none fits.
 static bool launch_masked(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args &F, hipStream_t s, int wmode, uint32_t cur, uint32_t nw, const char **tag) {
     const dim3 g((unsigned)((A.n + 255) / 256)), b(256);
+    if (A.ev_count == nullptr && (A.dyn_bin == nullptr || A.dyn_val == nullptr)) return false;   // these instances store both dense outputs unconditionally
 #define EMGPU_S2_CASE(NI_, ND_, W_, C_, N_, TAG_)                                                                  \
     if (P.ni <= NI_ && P.nd == ND_ && (W_ == 0 || wmode == W_) && cur == C_ && nw == N_) {                         \
         EMGPU_S2_LAUNCH(NI_, ND_, W_, true, C_, N_, false);                                                        \
@@ -645,7 +648,7 @@ static hipError_t launch_dbn_step2_inner(const EmgpuPlan &P, const EmgpuRun &A, 
         uint32_t cur, nw;
         step_parent_masks(P, &cur, &nw);
         if (nw != 0u) return hipErrorNotSupported;   // (cannot be: is_dynvar_depend would be set)
-        if (reg && wmode == 4 && P.ni <= 16 && cur == 0x8421u) {
+        if (reg && wmode == 4 && P.ni <= 16 && cur == 0x8421u && (A.ev_count != nullptr || (A.dyn_bin != nullptr && A.dyn_val != nullptr))) {
             *name = "k_dbn_step2<16,4,w4,reg>[frozen]";   // littoral_cor_v1: every variable's only dynamic parent is its own current bin
             EMGPU_S2_LAUNCH(16, 4, 4, true, 0x8421u, 0u, true);
         } else {

@@ -1412,3 +1412,35 @@ def test_start_log_weight_is_the_frequency_of_the_preset_values(gpu_ctx, model_d
     ob, _, _ = native.sample_bn_host(gpu_ctx, nm, n, 123)             # plain bn_sample on the unconstrained model
     hit = np.mean((ob[:, 0] == 1) & (ob[:, 1] == 4) & (ob[:, 2] == 2))
     assert abs(hit - p) < 5 * np.sqrt(p * (1 - p) / n), (hit, p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,both,one", [("uncor_1200code_v2p1", "k_uncor_fast<7,2,4,2>", "k_uncor_fast_idx<7,2,4,2>"),
+                                           ("cor_v1", "k_dbn_step2<16,4,w4,reg>[cor]", "k_dbn_step2<16,4,w4,reg>"),
+                                           ("glider_v1", "k_dbn_step2<7,3,reg>[chain,w884]", "k_dbn_step2<7,3,reg>"),
+                                           ("littoral_cor_v1", "k_dbn_step2<16,4,w4,reg>[frozen]", "k_dbn_step2<16,4>[frozen]")])
+def test_one_dense_output_alone_equals_both(name, both, one, model_dir):
+    """The benchmark instances store dyn_bin AND dyn_val without null tests (coop_fill_store_msb<BOTH>); a call that asks for only
+    one of the two runs on the instance that tests -- same numbers, and the mixed batch falls back to one launch per block."""
+    import torch
+    nm, pp, _ = load_pair(name, model_dir)
+    idx = uncor_indices(pp)
+    n, T, seed = 70_000, 101, 0x5EED0B07
+    dev = torch.device("cuda", 0)
+    ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    G4, nd = (T + 3) // 4, nm.n_dyn
+    p, _ = native.make_params(n, T, seed, first_index=123, **idx)
+
+    def run(want_bin, want_val):
+        db = torch.zeros((G4, nd, n), dtype=torch.int32, device=dev)
+        dv = torch.zeros((G4, nd, n, 4), dtype=torch.float32, device=dev)
+        native.sample_dbn_device(ctx, nm, p, dyn_bin=db.data_ptr() if want_bin else 0, dyn_val=dv.data_ptr() if want_val else 0)
+        ctx.sync()
+        return db, dv, ctx.last_kernel()
+    b0, v0, k0 = run(True, True)
+    assert k0 == both, k0
+    b1, v1, k1 = run(True, False)
+    b2, v2, k2 = run(False, True)
+    assert k1 == one and k2 == one, (k1, k2)
+    assert torch.equal(b1, b0) and torch.equal(v2, v0)
+    assert int(v1.abs().max()) == 0 and int(b2.abs().max()) == 0        # the output that was not asked for stays untouched
