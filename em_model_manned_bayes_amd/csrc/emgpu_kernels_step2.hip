@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
         uint32_t need = 0u, kind = 0u, fill8[ND];
 #pragma unroll
         for (int k = 0; k < ND; k++) {
-            const uint32_t n8 = (k < P.nd) ? ((hit8[k] | chg8[k]) & ~zer8[k] & 0xFFu) : 0u; // a dediscretize draw is due
+            const uint32_t n8 = (REG || k < P.nd) ? ((hit8[k] | chg8[k]) & ~zer8[k] & 0xFFu) : 0u; // a dediscretize draw is due (REG: P.nd == ND)
             fill8[k] = n8 | (chg8[k] & 0xFFu);                                              // ... or 0 on a change into the zero bin
             need |= n8 << (8 * k);
             kind |= (chg8[k] & 0xFFu) << (8 * k);
@@ -494,9 +494,9 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
         coop_dedisc<ND, true, true>(W, lane, gidx, rng, g8, need, kind, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
 #pragma unroll
         for (int k = 0; k < ND; k++)
-            if (k < P.nd)
+            if (REG || k < P.nd)
                 coop_fill_store_msb<ND, true, kBoth>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
-                                              (uint32_t)P.nd, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
+                                              REG ? (uint32_t)ND : (uint32_t)P.nd, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
         if constexpr (EV) {
             uint32_t hitp = 0u;
 #pragma unroll
