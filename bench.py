@@ -332,7 +332,7 @@ class DbnWorkload:
             assert int((self.dyn_bin[0, :, : self.n] & 0xFF).min()) >= 1
 
     def streaming_write(self, reps=20):
-        """What a kernel that does nothing but store reaches on THIS box: hipMemset (torch zero_) of the trace buffers the step just filled,
+        """What a kernel that does nothing but store reaches on THIS box: torch zero_() (its vectorised fill kernel) over the trace buffers the step just filled,
         median of `reps` after 3 untimed ones, HIP events.  The roofline's `peak` stays the guide's 8 TB/s; this is the ceiling a write
         stream meets in practice (tools/ubench/store_ubench.hip: a store-only twin of the sampler's own store pattern reaches the same)."""
         t = getattr(self.pl, "torch", None)
@@ -353,7 +353,7 @@ class DbnWorkload:
         ms.sort()
         med = ms[len(ms) // 2]
         return {"GB/s": nbytes / med / 1e6, "bytes": nbytes, "median_ms": med,
-                "how": "hipMemset (torch zero_) of the step's own dyn_bin + dyn_val buffers on this box, median of %d" % reps}
+                "how": "torch zero_() (a plain fill kernel) over the step's own dyn_bin + dyn_val buffers on this box, median of %d" % reps}
 
     def config(self):
         return {"workload": self.cfg["workload"] % dict(model=self.names[0], n=self.n, T=self.T),

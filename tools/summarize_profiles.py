@@ -33,7 +33,8 @@ for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
             w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-    top = rows[0]
+    ours = [r for r in rows if "emgpu::" in r["Name"]]   # (bench.py's write-ceiling calibration runs torch fill kernels after the timed region)
+    top = ours[0] if ours else rows[0]
     summary["kernel"] = top["Name"]
     summary["kernel_calls"] = int(top["Calls"])
     summary["kernel_avg_ms"] = float(top["AverageNs"]) / 1e6
