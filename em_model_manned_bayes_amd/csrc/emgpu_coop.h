@@ -276,7 +276,9 @@ __device__ __forceinline__ void coop_publish_bins(CoopLds<ND, true> &W, int lane
 
 // BOTH: dyn_bin and dyn_val are both there (the launch code checked): no null tests -- eight wave-uniform branches less per variable
 // and block, and the basic blocks they cut the fill of the variables into (k_dbn_step2 on cor_v1: 12.9 -> 11.7 ms)
-template <int ND, bool LB, bool BOTH = false>
+// SADDR (with BOTH): the stores take the row segment's address as a scalar base + the thread's 32-bit byte offset (no 64-bit vector add
+// per store): -1 % on k_uncor_fast; the four scalar pairs it keeps alive cost the 4-variable k_dbn_step2 6 %, which does not ask for it
+template <int ND, bool LB, bool BOTH = false, bool SADDR = false>
 __device__ __forceinline__ void coop_fill_store_msb(const CoopLds<ND, LB> &W, int lane, int k, int g8, int T, int G4, bool valid,
                                                     uint32_t fill8, float &cval, uint32_t pbA, uint32_t pbB,
                                                     uint32_t nd, uint32_t slot, int64_t i_wg, uint32_t tid, int64_t n,
@@ -298,7 +300,22 @@ __device__ __forceinline__ void coop_fill_store_msb(const CoopLds<ND, LB> &W, in
     if (valid) {
         // wave-uniform base (scalar registers) + the thread's 32-bit offset: no per-store 64-bit vector arithmetic
         const size_t o = ((size_t)(2 * g8) * nd + slot) * (size_t)n + (size_t)i_wg;
-      if constexpr (BOTH) {
+      if constexpr (BOTH && SADDR) {
+        typedef float v4f_t __attribute__((ext_vector_type(4)));
+        const uint32_t *bb = dyn_bin + o;
+        const float4 *vb = reinterpret_cast<const float4 *>(dyn_val) + o;
+        const uint32_t o4 = tid * 4u, o16 = tid * 16u;
+        const v4f_t a = {pv[0], pv[1], pv[2], pv[3]}, b = {pv[4], pv[5], pv[6], pv[7]};
+        asm volatile("global_store_dword %0, %1, %2" : : "v"(o4), "v"(pbA), "s"(bb) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(o16), "v"(a), "s"(vb) : "memory");
+        if (2 * g8 + 1 < G4) {
+            const size_t o2 = (size_t)nd * (size_t)n;
+            const uint32_t *bb2 = bb + o2;
+            const float4 *vb2 = vb + o2;
+            asm volatile("global_store_dword %0, %1, %2" : : "v"(o4), "v"(pbB), "s"(bb2) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(o16), "v"(b), "s"(vb2) : "memory");
+        }
+      } else if constexpr (BOTH) {
         uint32_t *__restrict__ bb = dyn_bin + o;
         float4 *__restrict__ vb = reinterpret_cast<float4 *>(dyn_val) + o;
         bb[tid] = pbA;

@@ -438,7 +438,7 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
         coop_dedisc<3, true, LB, IDX>(W, lane, gidx, rng, g8, need24, kind24, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
 #pragma unroll
         for (int k = 0; k < 3; k++)
-            coop_fill_store_msb<3, LB, !EV && !IDX>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],   // (the plain and the mixed kernel are only launched with both dense outputs)
+            coop_fill_store_msb<3, LB, !EV && !IDX, true>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],   // (the plain and the mixed kernel are only launched with both dense outputs)
                                    3u, h_slot[k], i0, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
         if constexpr (EV) ev_emit_block<3, LB>(W, lane, E, S, rng, P.bnd, g8, T, valid, hit24, kind24, prevw);
         wave_sync(); // results of this block are consumed before the next block's workers overwrite them
