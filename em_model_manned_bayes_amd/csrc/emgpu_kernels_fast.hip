@@ -436,6 +436,7 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
         coop_zero_results<3, LB>(W, lane);
         if constexpr (LB) coop_publish_bins<3>(W, lane, pbA, pbB);
         coop_dedisc<3, true, LB, IDX>(W, lane, gidx, rng, g8, need24, kind24, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
+        if (!EV || A.dyn_bin != nullptr || A.dyn_val != nullptr)   // (an event-list call without the dense trace: no forward fill at all)
 #pragma unroll
         for (int k = 0; k < 3; k++)
             coop_fill_store_msb<3, LB, !EV && !IDX, true>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],   // (the plain and the mixed kernel are only launched with both dense outputs)

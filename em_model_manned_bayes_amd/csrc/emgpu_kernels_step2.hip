@@ -492,6 +492,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
         coop_zero_results<ND, true>(W, lane);
         coop_publish_bins<ND>(W, lane, pbA, pbB);
         coop_dedisc<ND, true, true>(W, lane, gidx, rng, g8, need, kind, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
+        if (!EV || A.dyn_bin != nullptr || A.dyn_val != nullptr)   // (an event-list call without the dense trace: no forward fill at all)
 #pragma unroll
         for (int k = 0; k < ND; k++)
             if (REG || k < P.nd)
