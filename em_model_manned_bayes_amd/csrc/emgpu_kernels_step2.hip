@@ -18,8 +18,15 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     static const bool off = getenv("EMGPU_DEBUG_NO_STEP2") != nullptr;
     if (off) return false;
     if (P.nd < 1 || P.nd > 4) return false;
-    if (!(P.depend || A.per_step) && P.nd != 4) return false;   // a fast-branch model: only the four-variable ones (frozen columns, FRZ)
-    if ((A.ev_count != nullptr || A.events != nullptr) && !ev_plan_ok(P, A)) return false;
+    // (a fast-branch model -- frozen columns, FRZ -- that k_uncor_fast did not take: four dynamic variables, or one or two: balloon_v1)
+    if (A.ev_count != nullptr || A.events != nullptr) {
+        if (!ev_plan_ok(P, A)) return false;
+        // the event streams of a block are 8 - ND resample + ND transition streams of the INSTANCE that runs the model (ND = 4 for
+        // the frozen instances and the 16-variable shape, else 3), not of the model: a model with fewer dynamic variables than its
+        // instance may carry more rates than the instance has streams for
+        const bool inst4 = !(P.depend || A.per_step) || !(P.ni <= 9 && P.nd <= 3);
+        if (P.nact > (inst4 ? 4 : 5)) return false;
+    }
     if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
     for (int k = 0; k < P.nd; k++) {
         if (P.d_nb[k] == 0 || P.d_nb[k] > 16 || P.d_pw[k] == 0) return false;
@@ -97,7 +104,7 @@ static hipError_t launch_dbn_step2_inner(const EmgpuPlan &P, const EmgpuRun &A, 
         {"k_dbn_step2<16,4,w4,reg>", "k_dbn_step2<16,4,w8,reg>", "k_dbn_step2<16,4,reg>", "k_dbn_step2<16,4>"}};
     const int shape = (P.ni <= 7 && P.nd <= 3) ? 0 : ((P.ni <= 9 && P.nd <= 3) ? 1 : 2);
     const bool reg = all_res && P.nd == (shape == 2 ? 4 : 3);
-    if (frozen) {   // fast branch, four dynamic variables
+    if (frozen) {   // fast branch: four dynamic variables, or fewer than three
         const dim3 g((unsigned)((A.n + 255) / 256)), b(256);
         uint32_t cur, nw;
         step_parent_masks(P, &cur, &nw);

@@ -1444,3 +1444,28 @@ def test_one_dense_output_alone_equals_both(name, both, one, model_dir):
     assert k1 == one and k2 == one, (k1, k2)
     assert torch.equal(b1, b0) and torch.equal(v2, v0)
     assert int(v1.abs().max()) == 0 and int(b2.abs().max()) == 0        # the output that was not asked for stays untouched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dependent", [True, False])
+def test_event_lists_of_a_wide_model_with_five_rates(dependent, gpu_ctx, tmp_path):
+    """11 initial variables, 3 dynamic, FIVE variables with a resample rate: the model fits the event kernels' own limit (8 - n_dyn = 5
+    resample streams) but runs on the 16-variable shape's instances, which are built for four dynamic variables and have four: it must be
+    sent elsewhere (step2_eligible), not lose a stream.  Dependent and fast branch."""
+    from util import random_model
+    for seed in range(3):
+        rs = np.random.RandomState(9100 + seed)
+        parms = random_model(rs, nd=3, dependent=dependent, ni=11)
+        dyn = [i for i, lab in enumerate(parms["labels_transition"][:11]) if lab.endswith('(t)"')]
+        rates = np.zeros(11)
+        rates[dyn] = [0.11, 0.07, 0.05]
+        static = [v for v in range(11) if v not in dyn]
+        rates[static[0]], rates[static[3]] = 0.09, 0.13
+        parms["resample_rates"] = rates
+        path = str(tmp_path / ("wide%d.txt" % seed))
+        em_io.em_write(parms, path)
+        nm, pp = native.NativeModel.load_txt(path), O.parse_model_txt(path)
+        n, T = 900, 61
+        ref = O.uncor_sample(O.OracleModel(pp), n, T, 77 + seed)
+        got = native.sample_dbn_host(gpu_ctx, nm, n, T, 77 + seed, want_dense=True, want_events=True)
+        assert_uncor_parity(got, ref, T)

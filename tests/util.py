@@ -57,11 +57,11 @@ def assert_uncor_parity(got, ref, T, check_events=True, tol_rel=1e-6):
             assert np.array_equal(e["value"], r[:, 2].astype(np.float32)), "trajectory %d: values not bit-equal" % i
 
 
-def random_model(rs, dependent=None, nd=None):
+def random_model(rs, dependent=None, nd=None, ni=None):
     """A random small model in the em_read dict layout (for em_io.em_write): random DAGs, sparse count tables
     (zero entries, all-zero columns), categorical and continuous variables, zero-crossing boundaries,
     zero and non-zero resample rates.  rs: numpy RandomState."""
-    ni = int(rs.randint(3, 8))
+    ni = int(ni or rs.randint(3, 8))
     r = rs.randint(2, 9, ni)
     if rs.rand() < 0.3:
         r[rs.randint(ni)] = rs.randint(9, 13)
