@@ -1469,3 +1469,26 @@ def test_event_lists_of_a_wide_model_with_five_rates(dependent, gpu_ctx, tmp_pat
         ref = O.uncor_sample(O.OracleModel(pp), n, T, 77 + seed)
         got = native.sample_dbn_host(gpu_ctx, nm, n, T, 77 + seed, want_dense=True, want_events=True)
         assert_uncor_parity(got, ref, T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_wide_models_match_oracle(seed, gpu_ctx, tmp_path):
+    """The fuzzer of test_random_models_match_oracle on models of 8 to 14 initial variables (the 9- and 16-variable kernel shapes;
+    1 to 4 dynamic variables on instances built for 3 or 4): event lists, dense REFERENCE_AUTO, dense PER_STEP."""
+    from util import random_model
+    rs = np.random.RandomState(9300 + seed)
+    parms = random_model(rs, nd=(seed % 4) + 1, dependent=None if seed < 8 else bool(seed & 1), ni=int(rs.randint(8, 15)))
+    path = str(tmp_path / "w.txt")
+    em_io.em_write(parms, path)
+    nm, pp = native.NativeModel.load_txt(path), O.parse_model_txt(path)
+    om = O.OracleModel(pp)
+    n, T = 600 + 11 * seed, int(rs.choice([9, 40, 73]))
+    ref = O.uncor_sample(om, n, T, 90 + seed)
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, 90 + seed, want_dense=True, want_events=True)
+    assert_uncor_parity(got, ref, T)
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, 90 + seed, want_dense=True, want_events=False)
+    assert_uncor_parity(got, ref, T, check_events=False)
+    refp = O.uncor_sample(om, n, T, 90 + seed, per_step=True, want_events=False)
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, 90 + seed, want_dense=True, want_events=False, transition_mode=L.TRANSITION_PER_STEP)
+    assert_uncor_parity(got, refp, T, check_events=False)
