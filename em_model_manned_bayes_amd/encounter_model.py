@@ -344,7 +344,7 @@ class UncorEncounterModel(EncounterModel):
             # row r of sample i happens at absolute second at = cumsum(dt) and, if it names a variable, sets it
             # from then on; the state during [t, t+dt) before the row is what the row's control line reports.
             cnt = res["ev_count"].astype(np.int64)
-            flat = np.concatenate(res["events"]) if nn else np.zeros(0, dtype=native.EVENT_DTYPE)
+            flat = res["events_flat"]
             sid = np.repeat(np.arange(nn), cnt)
             dt = flat["dt"].astype(np.float64); var = flat["var"].astype(np.int64); val = flat["value"].astype(np.float64)
             ends = np.cumsum(cnt)

@@ -324,6 +324,7 @@ def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_even
     if want_events:
         out["events"] = [ev[i, : ec[i]] for i in range(n)]
         out["ev_count"] = ec
+        out["events_flat"] = ev[np.arange(ev.shape[1], dtype=np.uint32)[None, :] < ec[:, None]]   # all rows in order, one array (no per-sample concatenation)
     return out
 
 
