@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -82,6 +83,9 @@ struct emgpu_ctx {
     // a fresh hipMalloc + hipFree of several gigabytes per call cost tens of milliseconds, at random (measured: 29 vs 127 ms per call)
     struct Scratch { void *p = nullptr; size_t cap = 0; };
     std::vector<Scratch> scratch;
+    // getDynamicLimits.m as a table, per (model uid, model version, the track variables): building it walks N_initial{v} and
+    // N_initial{\dot h} over every (G, A, L range, v range) -- 4 ms on the host for uncor_1200code_v2p1, per call before it was kept
+    std::map<std::array<uint64_t, 3>, emgpu::UncorLimits> limits_cache;
     hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr, nullptr};
 };
@@ -1334,7 +1338,14 @@ static int track_uncor_rounds(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_
     if (p->n < 0 || p->sample_time < 1 || p->sample_time > 65535) throw Error(EMGPU_ERR_ARG, "n < 0 or sample_time outside 1..65535");
     if (p->max_track_attempts < 1 || p->max_attempts < 1 || p->record_stride < 1 || (10 * p->sample_time) % p->record_stride)
         throw Error(EMGPU_ERR_ARG, "max_track_attempts / max_attempts must be >= 1 and record_stride must divide 10 * sample_time");
-    const emgpu::UncorLimits L = emgpu::build_uncor_limits(m, track_vars(p));
+    const emgpu::UncorTrackVars tv = track_vars(p);
+    const std::array<uint64_t, 3> lkey = {m.uid, m.version,
+                                          (uint64_t)(uint8_t)tv.idxG | ((uint64_t)(uint8_t)tv.idxA << 8) | ((uint64_t)(uint8_t)tv.idxL << 16) | ((uint64_t)(uint8_t)tv.idxV << 24) |
+                                              ((uint64_t)(uint8_t)tv.idxDV << 32) | ((uint64_t)(uint8_t)tv.idxDH << 40) | ((uint64_t)(uint8_t)tv.idxDPsi << 48) | ((uint64_t)tv.is_rotorcraft << 56)};
+    if (ctx->limits_cache.size() > 32 && !ctx->limits_cache.count(lkey)) ctx->limits_cache.clear();
+    auto lit = ctx->limits_cache.find(lkey);
+    if (lit == ctx->limits_cache.end()) lit = ctx->limits_cache.emplace(lkey, emgpu::build_uncor_limits(m, tv)).first;
+    const emgpu::UncorLimits &L = lit->second;
     if (m.n_dyn() < 3) throw Error(EMGPU_ERR_ARG, "dynvar:empty: the model needs dynamic variables for acceleration, vertical rate and turn rate");
     auto row_of = [&](int idx) {   // row of the temporal map == row of the dense trace
         for (size_t k = 0; k < m.temporal_map.size(); k++) if (m.temporal_map[k][0] == idx) return (int)k;
