@@ -396,73 +396,75 @@ class DbnWorkload:
 
 
 class TerminalWorkload:
-    """configs[4]: geometry draw (k_bn, box + speed rejection) + PropagateTrajectory of both aircraft in both
-    directions (k_terminal_propagate) on synthetic trajectory tables, device-resident."""
+    """configs[4]: per step, fresh geometry draws (k_bn: the 15-variable network + box / speed rejection, @CorTerminalModel/sample.m:29-77),
+    the inputs of createEncounter (k_terminal_geo) and PropagateTrajectory of both aircraft in both directions (k_terminal_propagate) on
+    synthetic trajectory tables -- emgpu_sample_terminal_device, three launches, everything device-resident."""
 
     def __init__(self, args, cfg, pl, rank, world):
         import numpy as np
-        import ctypes as C
         import em_model_manned_bayes_amd as E
         from em_model_manned_bayes_amd import synthetic, _lib as L
-        self.np, self.C, self.L = np, C, L
-        self.pl, self.rank, self.world, self.cfg = pl, rank, world, cfg
+        self.np, self.L = np, L
+        self.pl, self.native, self.rank, self.world, self.cfg = pl, pl.native, rank, world, cfg
         self.n, self.seed = args.n or cfg["n"], cfg["seed"]
         self.dir = synthetic.write_terminal_directory(tempfile.mkdtemp(prefix="emgpu_bench_term_"))
         self.ctx = pl.context()
         self.t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=self.dir)
-        # the geometry samples the propagation starts from: drawn once on the GPU (k_bn), tiled to n encounters
-        m = 8192
-        _, samples = self.t.sample(m, seed=self.seed, ctx=self.ctx)
-        g, mo = self.t._geo_rows(samples)
-        reps = (self.n + m - 1) // m
-        self.geo_h, self.mo_h = g, mo
-        self.geo = pl.from_numpy(np.tile(g, (reps, 1))[: self.n].copy())
-        self.mof = pl.from_numpy(np.tile(mo, (reps, 1))[: self.n].reshape(-1).astype(np.int32))
         self.cap = 123
-        self.out = pl.empty((6, self.cap, 4 * self.n), "float32")
-        self.rows = pl.empty((4 * self.n,), "int32")
-        self.handles = (C.c_void_p * 10)(*[x.native._h for x in self.t._traj])
-        self.bytes_bound = 7335      # SURVEY.md 8d: 75 B geometry + 2 x 2 x <=121 steps x 3 variables x 5 B
+        n, ni = self.n, self.t.native.n_initial
+        self.ni = ni
+        self.geom_val = pl.empty((ni, n), "float32")
+        self.geo = pl.empty((n, 12), "float64")
+        self.mof = pl.empty((4 * n,), "int32")
+        self.traj = pl.empty((2 * n, 2 * self.native.terminal_t0_row(self.cap), 5), "float32")
+        self.rows = pl.empty((4 * n,), "int32")
+        self.att = pl.empty((n,), "int32")
+        self.bs = None if np.all(np.isinf(self.t.bounds_sample)) else self.t.bounds_sample
+        self.bytes_bound = 75 + 4 * 122 * 20      # geometry 5 B x 15 variables + 2 x 2 x <= 122 rows x 20 B
         self.bytes_data_dependent = True
-        self.bytes_per_unit = self.bytes_bound   # replaced in check() by 75 + 15 B x the track-seconds the run really produced
+        self.bytes_per_unit = self.bytes_bound   # replaced in check() by 75 + 20 B x the track-seconds the run really produced
         self.launches_per_step = 1
 
     def step(self, k):
         from em_model_manned_bayes_amd import sharding
-        C, L = self.C, self.L
-        p = L.TermParams()
-        p.seed, p.first_index, p.n, p.tmax_s = self.seed, sharding.step_first_index(k, self.rank, self.world, self.n), self.n, 120.0
-        p.max_resample, p.cap = 100000, self.cap
-        for i, v in enumerate(self.t._dyn_rows().reshape(-1)):
-            p.dyn_limits[i] = float(v)
-        L.check(L.lib().emgpu_propagate_terminal_device(self.ctx._h, self.handles, 10, C.byref(p), C.c_void_p(self.geo.data_ptr()),
-                                                        C.c_void_p(self.mof.data_ptr()), C.c_void_p(self.out.data_ptr()),
-                                                        C.c_void_p(self.rows.data_ptr())))
+        first = sharding.step_first_index(k, self.rank, self.world, self.n)
+        p, self._keep = self.native.terminal_sample_params(self.t.native, self.n, self.seed, self.t._dyn_rows(), first_index=first, tmax_s=120.0,
+                                                           cap=self.cap, bounds_sample=self.bs)
+        self.native.sample_terminal_device(self.ctx, self.t.native, [x.native for x in self.t._traj], p, self.geom_val.data_ptr(), self.geo.data_ptr(),
+                                           self.mof.data_ptr(), self.traj.data_ptr(), self.rows.data_ptr(), attempts=self.att.data_ptr())
 
     def sync(self):
         self.ctx.sync()
 
     def kernel_name(self):
-        return self.ctx.last_kernel()
+        return self.ctx.last_kernel().split(" + ")[-1]   # the dominant kernel of the step's three
 
     def check(self):
         # rows < 0: a track whose inner re-draw loop hit max_resample (the reference would spin on it, createEncounter.m:218-262)
         self.failed = int((self.rows < 0).sum())
         self.track_seconds = float(self.rows.clamp(min=0).sum().item()) / self.n
-        self.bytes_per_unit = 75.0 + 15.0 * self.track_seconds   # SURVEY.md 8d per-unit figure on the measured track lengths
+        # the joined track stores the t = 0 row of an aircraft once: rows written = track-seconds - 2 per encounter
+        self.bytes_per_unit = 75.0 + 20.0 * (self.track_seconds - 2.0)
+        self.geom_attempts = float(self.att.float().mean().item())
         assert int(self.rows.max()) <= self.cap and int(self.rows.max()) >= 2 and self.failed <= 0.01 * 4 * self.n, (int(self.rows.min()), self.failed)
 
     def config(self):
-        return {"workload": self.cfg["workload"] % dict(n=self.n), "output": "tracks f32 [6][%d][4n] + rows; algorithmic bytes = 75 + 15 B x track-seconds = %.0f B/encounter as measured (bound: %d)"
-                          % (self.cap, self.bytes_per_unit, self.bytes_bound),
-                "launches_per_step": 1, "sharding": "global encounter index, no collective",
+        return {"workload": self.cfg["workload"] % dict(n=self.n),
+                "output": "geometry sample f32 [15][n] + joined tracks f32 [2n][%d][5] (x y z heading speed per track-second; t_s = row number) + rows; "
+                          "algorithmic bytes = 75 + 20 B x rows written = %.0f B/encounter as measured (bound: %d)"
+                          % (2 * self.native.terminal_t0_row(self.cap), self.bytes_per_unit, self.bytes_bound),
+                "launches_per_step": 3, "kernels": self.ctx.last_kernel(),
+                "timed_region": "k_bn (fresh geometry draw with rejection) + k_terminal_geo + k_terminal_propagate, every step",
+                "sharding": "global encounter index, no collective",
                 "track_seconds_per_encounter": getattr(self, "track_seconds", None),
+                "geometry_attempts_per_encounter": getattr(self, "geom_attempts", None),
                 "tracks_over_the_redraw_cap": getattr(self, "failed", None)}
 
     def cpu_baseline(self, n_cpu):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import glob
         import oracle as O
+        np = self.np
         files = [glob.glob(os.path.join(self.dir, "*_" + s + ".txt"))[0] for s in
                  ["ownship_landing_model", "ownship_landing_model_reverse", "ownship_takeoff_model", "ownship_takeoff_model_reverse",
                   "intruder_landing_model", "intruder_landing_model_reverse", "intruder_takeoff_model", "intruder_landing_model_reverse",
@@ -472,12 +474,14 @@ class TerminalWorkload:
             pp = O.parse_model_txt(f)
             oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
         n_cpu = 2000
+        geo_h = self.geo[:n_cpu].cpu().numpy()
+        mo_h = self.mof[: 4 * n_cpu].cpu().numpy()
         t0 = time.perf_counter()
-        O.propagate(oms, self.mo_h[:n_cpu].reshape(-1), self.geo_h[:n_cpu], self.seed, self.t._dyn_rows())
+        O.propagate(oms, mo_h, geo_h, self.seed, self.t._dyn_rows())
         dt = time.perf_counter() - t0
         return {"value": n_cpu / dt, "unit": self.cfg["unit"], "cores": 1, "kind": "port",
-                "sample": "oracle/em_oracle.c em_propagate_batch (scalar port of createEncounter.m:93-329), %d encounters in %.1f s on 1 thread; "
-                          "MATLAB itself is not installed and cannot be timed" % (n_cpu, dt)}
+                "sample": "oracle/em_oracle.c em_propagate_batch (scalar port of createEncounter.m:93-329, one thread), propagation of %d encounters "
+                          "in %.1f s (the geometry draw, <1 %% of the work, is not in this figure); MATLAB itself is not installed and cannot be timed" % (n_cpu, dt)}
 
 
 def make_workload(args, pl, rank, world):
@@ -609,7 +613,7 @@ def recorded_traffic(kernel_name, algorithmic_bytes, lib_version, data_dependent
             continue
         line = s.get("bench_line", {})
         theirs = line.get("roofline", {}).get("algorithmic_bytes_per_launch")
-        # the same launch size: equal bytes -- or, where the bytes are a property of the sampled data (terminal: 75 + 15 B x the track-seconds
+        # the same launch size: equal bytes -- or, where the bytes are a property of the sampled data (terminal: 75 + 20 B x the track-seconds
         # the batch happened to produce, which moves in the fourth digit with the step's index range), within half a percent
         same_size = theirs == algorithmic_bytes or (data_dependent and isinstance(theirs, (int, float))
                                                     and abs(theirs - algorithmic_bytes) <= 0.005 * algorithmic_bytes)

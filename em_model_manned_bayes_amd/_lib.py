@@ -102,6 +102,12 @@ class TermParams(C.Structure):
                 ("max_resample", C.c_int32), ("cap", C.c_int32), ("dyn_limits", C.c_double * 10)]
 
 
+class TSampleParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("tmax_s", C.c_double),
+                ("max_resample", C.c_int32), ("cap", C.c_int32), ("dyn_limits", C.c_double * 10),
+                ("max_attempts", C.c_int32), ("flags", C.c_uint32), ("bounds_sample", C.c_void_p), ("idx", C.c_int32 * 12)]
+
+
 class BnParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("flags", C.c_uint32),
                 ("max_attempts", C.c_int32), ("bounds_sample", C.c_void_p),
@@ -118,12 +124,12 @@ SYMBOLS = [
     "emgpu_sample_dbn_device", "emgpu_sample_dbn_host", "emgpu_sample_bn_device", "emgpu_sample_bn_host",
     "emgpu_last_kernel_name", "emgpu_discretize_bayes", "emgpu_asub2ind",
     "emgpu_debug_column_thresholds", "emgpu_debug_bernoulli_threshold", "emgpu_debug_dynamic_column", "emgpu_debug_padded_column",
-    "emgpu_propagate_terminal_device", "emgpu_propagate_terminal_host",
+    "emgpu_propagate_terminal_device", "emgpu_propagate_terminal_host", "emgpu_sample_terminal_device",
     "emgpu_sample2track_device", "emgpu_sample2track_host",
     "emgpu_model_set_zero_bins", "emgpu_shard_range", "emgpu_device_count", "emgpu_mixed_blocks",
     "emgpu_sample_dbn_blocks_device", "emgpu_sample_dbn_multi_host", "emgpu_sample_dbn_multi_device",
     "emgpu_track_uncor_host", "emgpu_track_uncor_device", "emgpu_uncor_dynamic_limits", "emgpu_model_start_log_weight",
-    "emgpu_track_terminal_host", "emgpu_debug_parent_masks", "emgpu_last_launch_count", "emgpu_debug_pk_column",
+    "emgpu_track_terminal_host", "emgpu_debug_parent_masks", "emgpu_last_launch_count", "emgpu_debug_pk_column", "emgpu_debug_terminal_counters",
 ]
 
 _lib = None
@@ -226,6 +232,8 @@ def lib():
     L.emgpu_debug_parent_masks.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     for f in (L.emgpu_propagate_terminal_device, L.emgpu_propagate_terminal_host):
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(TermParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emgpu_debug_terminal_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.emgpu_sample_terminal_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(TSampleParams)] + [C.c_void_p] * 7
     for f in (L.emgpu_sample2track_device, L.emgpu_sample2track_host):
         f.argtypes = [C.c_void_p, C.POINTER(TrackParams)] + [C.c_void_p] * 6
     _lib = L

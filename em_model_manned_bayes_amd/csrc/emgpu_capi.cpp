@@ -67,6 +67,7 @@ struct emgpu_ctx {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     uint32_t *d_status = nullptr;
+    uint32_t *d_queue = nullptr;  // k_terminal_propagate: the launch's track queue (one word, zeroed by the launcher)
     uint32_t *h_status = nullptr; // pinned
     std::map<uint64_t, Uploaded> cache; // by Model::uid
     uint64_t use_clock = 0;
@@ -370,6 +371,7 @@ int emgpu_ctx_create(int32_t device, emgpu_ctx **out) {
     c->stream = c->own_stream;
     HIP_OK(hipMalloc((void **)&c->d_status, sizeof(uint32_t)));
     HIP_OK(hipMemset(c->d_status, 0, sizeof(uint32_t)));
+    HIP_OK(hipMalloc((void **)&c->d_queue, sizeof(uint32_t)));
     HIP_OK(hipHostMalloc((void **)&c->h_status, sizeof(uint32_t), hipHostMallocDefault));
     *c->h_status = 0;
     *out = c.release();
@@ -405,6 +407,7 @@ void emgpu_ctx_free(emgpu_ctx *ctx) {
     for (auto &kv : ctx->cache) kv.second.free_tables();
     for (auto &sc : ctx->scratch) (void)hipFree(sc.p);
     (void)hipFree(ctx->d_status);
+    (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_layers);
     (void)hipFree(ctx->d_thr_base);
     (void)hipHostFree(ctx->h_status);
@@ -916,6 +919,18 @@ int emgpu_sample_bn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_bn_pa
     EMGPU_CATCH
 }
 
+int emgpu_debug_terminal_counters(emgpu_ctx *ctx, uint64_t *out, int32_t n) {
+    EMGPU_TRY
+    if (!ctx || !out || n < 1) return fail(EMGPU_ERR_ARG, "null argument");
+    CTX_LOCK(ctx);
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    const int rc = emgpu::terminal_debug_counters((unsigned long long *)out, n);
+    if (rc < 0) return fail(EMGPU_ERR_HIP, "reading the counters failed");
+    return rc;
+    EMGPU_CATCH
+}
+
 int emgpu_debug_column_thresholds(const double *weights, int32_t r, uint32_t *out) {
     if (!weights || !out || r < 1 || r > EMGPU_MAX_R) return fail(EMGPU_ERR_ARG, "bad arguments");
     if (r > 1) emgpu::column_thresholds(weights, r, out);
@@ -1039,10 +1054,11 @@ static const Uploaded *terminal_tables(emgpu_ctx *ctx, const emgpu_model *const 
 
 int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
                                     const emgpu_term_params *p, const double *geo, const int32_t *model_of,
-                                    float *out, int32_t *rows) {
+                                    float *traj, int32_t *rows) {
     EMGPU_TRY
-    if (!ctx || !models || n_models < 1 || !p || !geo || !model_of || !out || !rows) return fail(EMGPU_ERR_ARG, "null argument");
+    if (!ctx || !models || n_models < 1 || !p || !geo || !model_of || !traj || !rows) return fail(EMGPU_ERR_ARG, "null argument");
     if (p->n < 0 || p->cap < 2 || p->max_resample < 1) return fail(EMGPU_ERR_ARG, "bad n / cap / max_resample");
+    if (p->n >= ((int64_t)1 << 29)) return fail(EMGPU_ERR_ARG, "more than 2^29 encounters in one call");
     CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     const Uploaded *first = terminal_tables(ctx, models, n_models);
@@ -1051,7 +1067,7 @@ int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *mo
     A.seed = p->seed; A.first_index = p->first_index; A.n = p->n; A.geo = geo; A.model_of = model_of; A.thr_base = ctx->d_thr_base;
     A.tmax_s = p->tmax_s; A.max_resample = p->max_resample; A.cap = p->cap;
     memcpy(A.dl, p->dyn_limits, sizeof A.dl);
-    A.out = out; A.rows = rows; A.status = ctx->d_status;
+    A.traj = traj; A.rows = rows; A.status = ctx->d_status; A.queue = ctx->d_queue;
     const char *name = "";
     hipError_t e = emgpu::launch_terminal_propagate(first->cp.plan, A, ctx->stream, &name);
     ctx->last_kernel = name;
@@ -1065,6 +1081,8 @@ int emgpu_propagate_terminal_host(emgpu_ctx *ctx, const emgpu_model *const *mode
                                   float *out, int32_t *rows) {
     EMGPU_TRY
     if (!ctx || !p || !geo || !model_of || !out || !rows) return fail(EMGPU_ERR_ARG, "null argument");
+    if (p->cap < 2) return fail(EMGPU_ERR_ARG, "bad cap");
+    const size_t out_bytes = (size_t)(p->n > 0 ? p->n : 0) * 2 * (size_t)EMGPU_TERMINAL_BLOCK_ROWS(p->cap) * 5 * sizeof(float);
     CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     const size_t n = (size_t)(p->n > 0 ? p->n : 0), nl = 4 * n;
@@ -1074,15 +1092,15 @@ int emgpu_propagate_terminal_host(emgpu_ctx *ctx, const emgpu_model *const *mode
         HIP_OK(hipMalloc((void **)&dg, n * 12 * sizeof(double) + 8));
         HIP_OK(hipMalloc((void **)&dm, nl * 4 + 4));
         HIP_OK(hipMalloc((void **)&dr, nl * 4 + 4));
-        HIP_OK(hipMalloc((void **)&dout, (size_t)6 * p->cap * nl * 4 + 4));
+        HIP_OK(hipMalloc((void **)&dout, out_bytes + 4));
         if (n) {
             HIP_OK(hipMemcpyAsync(dg, geo, n * 12 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
             HIP_OK(hipMemcpyAsync(dm, model_of, nl * 4, hipMemcpyHostToDevice, ctx->stream));
-            HIP_OK(hipMemsetAsync(dout, 0, (size_t)6 * p->cap * nl * 4, ctx->stream));
+            HIP_OK(hipMemsetAsync(dout, 0, out_bytes, ctx->stream));
         }
         rc = emgpu_propagate_terminal_device(ctx, models, n_models, p, dg, dm, dout, dr);
         if (rc == EMGPU_OK && n) {
-            HIP_OK(hipMemcpyAsync(out, dout, (size_t)6 * p->cap * nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_OK(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
             HIP_OK(hipMemcpyAsync(rows, dr, nl * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
         if (rc == EMGPU_OK) rc = emgpu_ctx_sync(ctx);
@@ -1094,6 +1112,60 @@ int emgpu_propagate_terminal_host(emgpu_ctx *ctx, const emgpu_model *const *mode
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(dg); (void)hipFree(dm); (void)hipFree(dr); (void)hipFree(dout);
     return rc;
+    EMGPU_CATCH
+}
+
+int emgpu_sample_terminal_device(emgpu_ctx *ctx, const emgpu_model *gm, const emgpu_model *const *traj_models, int32_t n_traj_models,
+                                 const emgpu_tsample_params *p, uint8_t *geom_bin, float *geom_val, double *geo, int32_t *model_of,
+                                 float *traj, int32_t *rows, int32_t *attempts) {
+    EMGPU_TRY
+    if (!ctx || !gm || !traj_models || !p || !geom_val || !geo || !model_of || !traj || !rows) return fail(EMGPU_ERR_ARG, "null argument");
+    if (p->n < 0 || p->cap < 2 || p->max_resample < 1 || p->max_attempts < 1) return fail(EMGPU_ERR_ARG, "bad n / cap / max_resample / max_attempts");
+    if (p->n >= ((int64_t)1 << 29)) return fail(EMGPU_ERR_ARG, "more than 2^29 encounters in one call");
+    if (n_traj_models != 10) return fail(EMGPU_ERR_ARG, "the terminal model has 10 trajectory models (CorTerminalModel.m:84-100)");
+    const Model &g = gm->m;
+    for (int k = 0; k < 12; k++) if (p->idx[k] < 1 || p->idx[k] > g.n_initial) return fail(EMGPU_ERR_ARG, "geometry variable index out of range");
+    CTX_LOCK(ctx);
+    HIP_OK(hipSetDevice(ctx->device));
+    if (p->n == 0) return EMGPU_OK;
+    std::set<uint64_t> pinned{gm->m.uid};   // the trajectory tables' pointers are published before the geometry model's upload
+    for (int i = 0; i < n_traj_models; i++) if (traj_models[i]) pinned.insert(traj_models[i]->m.uid);
+    const Uploaded *first = terminal_tables(ctx, traj_models, n_traj_models, &pinned);
+    Uploaded &ug = get_uploaded(ctx, gm, &pinned);
+    // geometry draw (sample.m:29-77)
+    emgpu_bn_params bp;
+    memset(&bp, 0, sizeof bp);
+    bp.seed = p->seed; bp.first_index = p->first_index; bp.n = p->n;
+    bp.max_attempts = p->max_attempts; bp.bounds_sample = p->bounds_sample;
+    bp.idx_own_speed = p->idx[3]; bp.idx_int_speed = p->idx[9];
+    bp.min_vel1 = p->dyn_limits[0][0]; bp.max_vel1 = p->dyn_limits[0][1]; bp.min_vel2 = p->dyn_limits[1][0]; bp.max_vel2 = p->dyn_limits[1][1];
+    EmgpuBnRun B;
+    fill_bn(ctx, ug, g, &bp, B);
+    B.out_bin = geom_bin; B.out_val = geom_val; B.attempts = attempts;
+    const char *name = "";
+    hipError_t e = emgpu::launch_bn(ug.cp.plan, B, ctx->stream, &name);
+    if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    std::string kernels = name;
+    // createEncounter.m:21-49
+    EmgpuTGeoRun G;
+    memset(&G, 0, sizeof G);
+    G.n = p->n; G.val = geom_val; G.geo = geo; G.model_of = model_of;
+    for (int k = 0; k < 12; k++) G.idx[k] = p->idx[k] - 1;
+    e = emgpu::launch_terminal_geo(G, ctx->stream);
+    if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    kernels += " + k_terminal_geo";
+    // PropagateTrajectory x 4 (createEncounter.m:52-72)
+    EmgpuTermRun A;
+    memset(&A, 0, sizeof A);
+    A.seed = p->seed; A.first_index = p->first_index; A.n = p->n; A.geo = geo; A.model_of = model_of; A.thr_base = ctx->d_thr_base;
+    A.tmax_s = p->tmax_s; A.max_resample = p->max_resample; A.cap = p->cap;
+    memcpy(A.dl, p->dyn_limits, sizeof A.dl);
+    A.traj = traj; A.rows = rows; A.status = ctx->d_status; A.queue = ctx->d_queue;
+    e = emgpu::launch_terminal_propagate(first->cp.plan, A, ctx->stream, &name);
+    if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    ctx->last_kernel = kernels + " + " + name;
+    ctx->last_launches = 3;
+    return EMGPU_OK;
     EMGPU_CATCH
 }
 
@@ -1121,7 +1193,7 @@ int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *gm, const emgpu
         float *d_val = (float *)dalloc(ni * n * 4);
         double *d_geo = (double *)dalloc(n * 12 * 8);
         int32_t *d_mo = (int32_t *)dalloc(4 * n * 4), *d_rows = (int32_t *)dalloc(4 * n * 4);
-        float *d_out = (float *)dalloc((size_t)6 * cap * 4 * n * 4);
+        float *d_out = (float *)dalloc((size_t)2 * n * (size_t)EMGPU_TERMINAL_BLOCK_ROWS(cap) * 5 * 4);
         uint8_t *d_acc = (uint8_t *)dalloc(n);
         uint64_t *d_gidx[2] = {(uint64_t *)dalloc(n * 8), (uint64_t *)dalloc(n * 8)};
         int64_t *d_slot[2] = {(int64_t *)dalloc(n * 8), (int64_t *)dalloc(n * 8)};
@@ -1168,14 +1240,14 @@ int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *gm, const emgpu
             A.seed = seed; A.first_index = p->first_index; A.n = (int64_t)count; A.geo = d_geo; A.model_of = d_mo; A.thr_base = ctx->d_thr_base;
             A.tmax_s = p->tmax_s; A.max_resample = p->max_resample; A.cap = cap;
             memcpy(A.dl, p->dyn_limits, sizeof A.dl);
-            A.out = d_out; A.rows = d_rows; A.status = ctx->d_status; A.indices = ind; A.quiet = 1;
+            A.traj = d_out; A.rows = d_rows; A.status = ctx->d_status; A.queue = ctx->d_queue; A.indices = ind; A.quiet = 1;
             e = emgpu::launch_terminal_propagate(first->cp.plan, A, ctx->stream, &name);
             if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
             kernels += std::string(" + ") + name;
             // the filters (track.m:62-145)
             EmgpuTFilterRun F;
             memset(&F, 0, sizeof F);
-            F.n = (int64_t)count; F.out = d_out; F.rows = d_rows; F.cap = cap; F.geo = d_geo; F.val = d_val; F.n_i = (int32_t)ni;
+            F.n = (int64_t)count; F.tracks = d_out; F.rows = d_rows; F.cap = cap; F.geo = d_geo; F.val = d_val; F.n_i = (int32_t)ni;
             memcpy(F.dl, p->dyn_limits, sizeof F.dl);
             for (int a = 0; a < 2; a++) { F.max_cum_turn[a] = p->max_cum_turn_deg[a]; F.pitch[a] = p->pitch_deg[a]; }
             F.min_enc_time_s = p->min_enc_time_s; F.thres_dist_ft = p->thres_dist_ft; F.thres_alt_low_ft = p->thres_alt_low_ft; F.thres_vertrate_ft_s = p->thres_vertrate_ft_s;

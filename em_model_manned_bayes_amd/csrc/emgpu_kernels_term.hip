@@ -6,22 +6,28 @@
 // "stay" prior (dbn_sample.m with t_max = 2 and every initial variable preset; a column's thresholds gathered
 // from the per-model table in one or two independent groups, r up to 36), validity re-draws, dediscretize.
 // Structure: ONE loop over attempts (a re-drawing lane does not hold its wave back), boundaries in LDS,
-// the recorded rows in a per-lane LDS ring that is flushed row by row with coalesced stores, the velocity's direction carried
+// persistent workgroups whose lanes take the next track from a queue when theirs ends (round 4), the recorded rows staged per lane in
+// LDS and written by the wave as contiguous pieces of a TRACK-MAJOR output (round 4), the velocity's direction carried
 // as an angle, sin/cos of the reduced angle as Horner sums, an instance for the terminal model's row shapes.
-// em-core's local_smooth (createEncounter.m:88-89) is not applied: un-vendored dependency.
+// em-core's local_smooth (createEncounter.m:88-89) is a separate, flagged pass (k_terminal_smooth): un-vendored dependency.
 // Round 3: ONE Philox call per attempt serves the transition draws of all three dynamic variables (slot map: block = the step,
 // word = the variable's row of the temporal map; the same for the dediscretize draws, made only when the lane has an event);
 // the bearing bin comes from an f32 guess of the angle walked to the exact bin with f64 cross products against the cut directions
 // (no atan2); distance is compared squared and the speed is carried (no square roots in the loop).
-// Bound: vector instruction issue at two waves per SIMD (256 registers of f64 state) + dependent gathers; output 24 B per second.
+// Bound: vector instruction issue + dependent gathers; output 20 B per track-second (x y z heading speed; t_s is the row number).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 #include "emgpu_device.h"
 #include "emgpu_launch.h"
 
 namespace emgpu {
+#ifdef EMGPU_TERM_COUNTERS
+__device__ unsigned long long g_term_dbg[32];
+#endif
 
 // A constant held in a SCALAR register pair at its use: the f64 constants of the step loop are loop invariants, and left to the compiler
 // they are materialised once and then occupy ~60 vector registers through the whole loop of a kernel that is short of them.
@@ -78,10 +84,6 @@ __device__ __forceinline__ double t_sign(double x) { return (double)((x > 0) - (
 // cut = boundaries(2:end-1).  The answer is guessed from the grid's first point and mean spacing (exact for the 10-degree bearing /
 // heading grids) and then walked to the true bin: any sorted grid gives the reference's answer, a uniform one in one or two LDS
 // reads instead of a scan.
-#ifndef EMGPU_TERM_RING
-#define EMGPU_TERM_RING 6
-#endif
-constexpr int kRing = EMGPU_TERM_RING;       // rows a lane may run ahead of the slowest lane of its wave
 constexpr int kBndStride = 68; // boundaries per variable in LDS (the host checks i_nb <= 66)
 struct CutGrid { int off, n; double lo, inv_step; };
 __device__ __forceinline__ int t_discretize(double x, const double *__restrict__ s_bnd, const CutGrid &gd) {
@@ -119,9 +121,41 @@ __device__ __forceinline__ int t_bearing_bin(double x, double y, const double *_
         return k + 1;
     }
     auto ge = [&](int q) { const double2 d = s_dir[q]; return d.x * y - d.y * x >= 0.0; };
+#ifdef EMGPU_TERM_COUNTERS
+    while (k > 0 && !ge(k - 1)) { k--; if (__builtin_ctzll(__ballot(true)) == (int)(threadIdx.x & 63)) atomicAdd(&g_term_dbg[13], 1ull); }
+    while (k < n && ge(k)) { k++; if (__builtin_ctzll(__ballot(true)) == (int)(threadIdx.x & 63)) atomicAdd(&g_term_dbg[14], 1ull); }
+    return k + 1;
+#endif
     while (k > 0 && !ge(k - 1)) k--;
     while (k < n && ge(k)) k++;
     return k + 1;
+}
+
+// The same bin from the bin of the second before.  The bearing of an aircraft moves by a fraction of a degree per second, so last step's
+// count k0 is almost always still right: two cross products confirm it.  The tests compare angles cyclically, so the walk stays inside the
+// angle's exact half -- [0, 180) holds the counts 0..kA (kA = cut points below 180), [180, 360) the counts kB..n (kB = cut points at or
+// below 180) -- where every cut point is within 180 degrees of the angle; when the half has changed the walk starts from the end of the
+// new half the position is next to (x >= 0: the 0 / 360 end).  atan2d(0, x < 0) = 180 belongs to the upper half-interval.
+__device__ __forceinline__ int t_bearing_walk(double x, double y, const double *__restrict__ cut, const double2 *__restrict__ s_dir, int n, int kA, int kB, int k0) {
+    if (x == 0.0 && y == 0.0) {                       // atan2d(0, 0) = 0: only cut points at or below 0 count
+        int k = 0;
+        while (k < n && 0.0 >= cut[k]) k++;
+        return k + 1;
+    }
+    const bool low = y > 0.0 || (y == 0.0 && x > 0.0);   // the angle is in [0, 180)
+    const int lo = low ? 0 : kB, hi = low ? kA : n;
+    int k = k0;
+    if (k < lo || k > hi) k = (x >= 0.0) == low ? lo : hi;
+    auto ge = [&](int q) { const double2 d = s_dir[q]; return d.x * y - d.y * x >= 0.0; };
+    while (k > lo && !ge(k - 1)) k--;
+    while (k < hi && ge(k)) k++;
+    return k + 1;
+}
+
+// dediscretize drew v from bin d (1-based) of a variable with nb boundaries: v lies in [bnd[d-1], bnd[d]), which discretize_bayes maps back to
+// d -- unless a rounding put it on the upper edge (the first bin has no lower cut point, the last no upper one)
+__device__ __forceinline__ bool t_in_bin(const double *__restrict__ bnd, int nb, int d, double v) {
+    return (d == 1 || v >= bnd[d - 1]) && (d == nb - 1 || v < bnd[d]);
 }
 
 // The same count on a grid of at most 8 cut points, held in LDS padded with +inf to 8: eight broadcast reads issued together and
@@ -190,6 +224,9 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
                 for (int q = 0; q < 6; q++) nf += (xp >= first[k][q]) ? 1 : 0;
                 out.bin[k] = (int)((nf < 4 ? first[k][6] >> (8 * nf) : first[k][7] >> (8 * (nf - 4))) & 0xFFu);
                 pivots = (first[k][7] >> 24) != 0u;            // a row with more than six distinct thresholds (none in sparse tables)
+#ifdef EMGPU_TERM_COUNTERS
+                { const unsigned long long bm = __ballot(pivots); if ((threadIdx.x & 63) == 0 && bm) { atomicAdd(&g_term_dbg[12], (unsigned long long)__popcll(bm)); atomicAdd(&g_term_dbg[20], 1ull); } }
+#endif
                 if (pivots) {
                     const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)piv[k], b = *(const uint4u_t __attribute__((address_space(1))) *)(piv[k] + 4);
                     first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
@@ -224,9 +261,37 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
 #ifndef EMGPU_TERM_WAVES
 #define EMGPU_TERM_WAVES 4
 #endif
+// -DEMGPU_TERM_COUNTERS: a measuring build (tools/term_counters.py) that counts, per launch, how many lanes take each path of the loop
+#ifdef EMGPU_TERM_COUNTERS
+#define TCNT(k, cond) dbg[k] += (unsigned)__popcll(__ballot(cond))
+#define TCNT1(k) dbg[k] += 1u
+#else
+#define TCNT(k, cond) ((void)0)
+#define TCNT1(k) ((void)0)
+#endif
+#ifndef EMGPU_TERM_ROWS
+#define EMGPU_TERM_ROWS 6
+#endif
+constexpr int kRows = EMGPU_TERM_ROWS;        // rows a lane collects in LDS before the wave writes them out as ONE contiguous piece of its track
+constexpr int kLaneStride = 5 * kRows + 1;    // dwords of a lane's staging area (odd: the lanes' rows fall on different banks)
+#ifndef EMGPU_TERM_REFILL
+#define EMGPU_TERM_REFILL 8
+#endif
+constexpr int kRefillMin = EMGPU_TERM_REFILL; // idle lanes a wave collects before it spends the (divergent) track set-up on them
+constexpr uint32_t kChunk = 128;              // tracks a wave takes from the launch's queue at a time (>= 64)
+
 // RM1_k: thresholds per row of dynamic variable k as a compile-time constant (0: read from the plan).  The instance built for the
 // terminal model's shape (36 headings, 7 altitude and 5 speed bins) folds every "is this index inside the row" test; left to run
 // time those wave-uniform masks are hoisted out of the loop, spill, and come back through v_readlane every iteration.
+//
+// Round 4: LANE REFILL + TRACK-MAJOR OUTPUT.  Tracks end anywhere between 2 and tmax_s + 2 rows, so a wave that owns 64 fixed tracks
+// idles a fifth of its lane-iterations behind its longest one.  Now the workgroups are persistent: a wave takes tracks from a queue (one
+// atomic per 128 tracks), and a lane whose track has ended starts the next one (set-up batched: kRefillMin idle lanes at a time).  The
+// lanes of a wave are then at unrelated rows of unrelated tracks, which rules out the row-synchronous planes of rounds 1-3
+// ([6][cap][4n]: a row of 64 neighbours = one store); the output is TRACK-MAJOR instead -- the joined, time-ordered track of an aircraft
+// (createEncounter.m:74-84: [fwd, bck(2:end)] sorted by t_s) is one contiguous [W][5] block, row C + t for second t (forward lanes write
+// upwards from C, backward lanes downwards; t_s itself is the row number and is not stored).  A lane stages kRows rows in LDS; the wave
+// then writes them as one contiguous 20 kRows-byte piece (lanes = consecutive dwords), so stores stay coalesced although tracks are not.
 template <int RM1_0, int RM1_1, int RM1_2>
 __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(const EmgpuPlan P, const EmgpuTermRun A) {
 #pragma clang fp contract(off)
@@ -235,9 +300,24 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     __shared__ double s_bnd[5 * kBndStride];
     __shared__ CutGrid s_grid[5];
     __shared__ double s_cut8[5][8];   // the cut points of a grid with at most 8 of them, padded with +inf
-    __shared__ float s_ring[4][kRing][5][64];   // per wave: the last kRing recorded rows of every lane (x y z heading speed; the time is the row number), field-major (conflict-free)
+    __shared__ float s_stage[4][64 * kLaneStride];   // per wave and lane: up to kRows recorded rows (x y z heading speed) waiting to be written
     __shared__ double2 s_dir[kBndStride];       // (cosd, sind) of the bearing variable's cut points
     __shared__ double s_cut8sq[8];              // squares of the distance variable's cut points (when it has at most 8)
+    // Wave-uniform values the loop needs now and then.  Held in scalar registers across the loop they do not fit (the kernel had 97 scalar
+    // spills, each reload a v_readlane in the loop: 95 per iteration); read from here where they are used (volatile: not hoisted back).
+    struct Uniforms {
+        double dl[2][5];                 // per aircraft: minVel maxVel maxTurnRate maxAltitude maxVertRate
+        double tmax_s, dist_hi2;         // CheckTrajectoryConditions (createEncounter.m:296-329)
+        double grid[2][2];               // bearing, heading: first cut point, 1 / spacing (the guess of the discretize walk)
+        int grid_n[2];
+        int alt_last[2], spd_first[2], spd_last[2];   // discreteValidAlt / discreteValidV as bin ranges (createEncounter.m:118-126), per aircraft
+        int cap, max_resample, quiet, pad;
+        int bear_kA, bear_kB;            // bearing cut points below 180 degrees / at or below 180
+        const double *geo; const int32_t *model_of; const uint32_t *const *thr_base; const uint64_t *indices; uint64_t first_index;
+        int32_t *rows; uint32_t *status; uint32_t *queue;
+    };
+    __shared__ Uniforms s_u;
+#define U(field) (*(const volatile std::remove_reference_t<decltype(s_u.field)> __attribute__((address_space(3))) *)&s_u.field)
     for (int q = threadIdx.x; q < (int)P.i_nb[2] - 2; q += 256) {
         double sd, cd;
         sincosd_small(P.bnd[P.i_boff[2] + 1 + q], sd, cd);
@@ -256,21 +336,39 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
             s_grid[v - 2] = CutGrid{(v - 2) * kBndStride, n, lo, (n > 1 && hi > lo) ? (double)(n - 1) / (hi - lo) : 0.0};
         }
     }
+    if (threadIdx.x < 10) s_u.dl[threadIdx.x / 5][threadIdx.x % 5] = A.dl[threadIdx.x / 5][threadIdx.x % 5];
+    if (threadIdx.x == 64) {
+        s_u.tmax_s = A.tmax_s; s_u.cap = A.cap; s_u.max_resample = A.max_resample; s_u.quiet = A.quiet;
+        s_u.geo = A.geo; s_u.model_of = A.model_of; s_u.thr_base = A.thr_base; s_u.indices = A.indices; s_u.first_index = A.first_index;
+        s_u.rows = A.rows; s_u.status = A.status; s_u.queue = A.queue;
+    }
     __syncthreads();
-    const int64_t L = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (L >= 4 * A.n) return;
-    const int64_t e = L >> 2;
-    const int role = (int)(L & 3), ac = role >> 1, lane = (int)(threadIdx.x & 63);
-    const double dt_s = (role & 1) ? -1.0 : 1.0;
-    const bool is_ownship = ac == 0;
-    const uint64_t gidx = A.indices ? A.indices[e] : A.first_index + (uint64_t)e;
-    Rng rng{(uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)role, (uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
-    const double *g = A.geo + e * 12 + ac * 6;
-    const int intent = (int)g[5];
-    const gptr_t thr = (gptr_t)A.thr_base[A.model_of[L]];
+    if (threadIdx.x < 2) {
+        // discreteValidAlt / discreteValidV as bin ranges (createEncounter.m:118-126)
+        const int a = threadIdx.x;
+        const double *bA = s_bnd + 3 * kBndStride, *bS = s_bnd + 4 * kBndStride;
+        int al = 0, sf = 0, sl = 0;
+        for (int q = 0; q < (int)P.i_nb[4]; q++) if (bA[q] <= A.dl[a][3]) al = q + 1;
+        for (int q = 0; q < (int)P.i_nb[5]; q++) { if (!(bS[q] >= A.dl[a][0])) sf = q + 1; if (bS[q] <= A.dl[a][1]) sl = q + 1; }
+        s_u.alt_last[a] = al; s_u.spd_first[a] = sf; s_u.spd_last[a] = sl;
+        const CutGrid gq = s_grid[1 + a];
+        s_u.grid[a][0] = gq.lo; s_u.grid[a][1] = gq.inv_step; s_u.grid_n[a] = gq.n;
+    }
+    if (threadIdx.x == 2) {
+        const double hi = s_bnd[P.i_nb[1] - 1];
+        s_u.dist_hi2 = hi * hi;
+        int ka = 0, kb = 0;
+        for (int q = 0; q < (int)P.i_nb[2] - 2; q++) { const double c = s_bnd[kBndStride + 1 + q]; ka += c < 180.0; kb += c <= 180.0; }
+        s_u.bear_kA = ka; s_u.bear_kB = kb;
+    }
+    __syncthreads();
+    const int lane = (int)(threadIdx.x & 63);
+    float *const stage = s_stage[threadIdx.x >> 6];
+    float *const mine = stage + lane * kLaneStride;
+    const uint32_t total = (uint32_t)(4 * A.n);
     // the aircraft's limits are picked from the kernel arguments where they are used (kept per lane they cost ten registers)
-#define T_LIM(q) (ac ? A.dl[1][q] : A.dl[0][q])
-    const double maxAlt = T_LIM(3);
+#define T_LIM(q) (*(const volatile double __attribute__((address_space(3))) *)&s_u.dl[ac][q])   // the limits an event needs (rare)
+#define T_LIMS(q) (ac ? A.dl[1][q] : A.dl[0][q])               // the two every step needs: from the kernel arguments (scalar)
     // the grids are wave-uniform: pinned in scalar registers (read back from LDS they would sit in 30 vector registers)
     auto sgrid = [&](int q) {
         const CutGrid gq = s_grid[q];
@@ -278,14 +376,10 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
         auto f64 = [&](double d) { const uint64_t b = (uint64_t)__double_as_longlong(d); return __longlong_as_double((long long)(((uint64_t)u32((uint32_t)(b >> 32)) << 32) | u32((uint32_t)b))); };
         return CutGrid{(int)u32((uint32_t)gq.off), (int)u32((uint32_t)gq.n), f64(gq.lo), f64(gq.inv_step)};
     };
-    const CutGrid gDist = sgrid(0), gBear = sgrid(1), gHead = sgrid(2), gAlt = sgrid(3), gSpd = sgrid(4);
-    int alt_last = 0, spd_first = 0, spd_last = 0;     // discreteValidAlt / discreteValidV as bin ranges (createEncounter.m:118-126)
-    {
-        const double *bA = s_bnd + 3 * kBndStride, *bS = s_bnd + 4 * kBndStride;
-        for (int q = 0; q < (int)P.i_nb[4]; q++) if (bA[q] <= maxAlt) alt_last = q + 1;
-        for (int q = 0; q < (int)P.i_nb[5]; q++) { if (!(bS[q] >= T_LIM(0))) spd_first = q + 1; if (bS[q] <= T_LIM(1)) spd_last = q + 1; }
-    }
-    const double bounds_dist_hi = s_bnd[P.i_nb[1] - 1];
+    const CutGrid gDist = sgrid(0);   // (only the run-time-shape instance reads it)
+    const int bear_n = __builtin_amdgcn_readfirstlane(s_grid[1].n);
+    const double dist_hi2 = U(dist_hi2);
+    const int bear_kA = __builtin_amdgcn_readfirstlane(U(bear_kA)), bear_kB = __builtin_amdgcn_readfirstlane(U(bear_kB));
     const int rm1[3] = {RM1_0 ? RM1_0 : (int)P.d_r[0] - 1, RM1_1 ? RM1_1 : (int)P.d_r[1] - 1, RM1_2 ? RM1_2 : (int)P.d_r[2] - 1};
     // which dynamic variable is heading / altitude / speed (the host checks that all three are there)
     // (the instance built for the shipped shape also knows the order: heading, altitude, speed with temporal-map rows 0, 1, 2 --
@@ -294,73 +388,155 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     const int kh = kShipped ? 0 : (P.d_ivar[0] == 3 ? 0 : (P.d_ivar[1] == 3 ? 1 : 2)), ka = kShipped ? 1 : (P.d_ivar[0] == 4 ? 0 : (P.d_ivar[1] == 4 ? 1 : 2)),
               ks = kShipped ? 2 : (P.d_ivar[0] == 5 ? 0 : (P.d_ivar[1] == 5 ? 1 : 2));
     const int drow[3] = {kShipped ? 0 : (int)P.d_row[0], kShipped ? 1 : (int)P.d_row[1], kShipped ? 2 : (int)P.d_row[2]};
-    // the part of a column index that never changes along a track: the intent (variable 1)
-
-    double xy0 = g[0], xy1 = g[1], z_ft = g[2], heading_deg = g[4], prev_z_rec = 0;
-    double sh, chh;
-    t_sincosd(heading_deg, sh, chh);
-    double v0 = chh * g[3], v1 = sh * g[3];
-    double speed = g[3];   // norm(v_ft_s), carried: the velocity is only ever speed * (cosd, sind) rotated (its norm to 1e-16)
-    // The direction of the velocity, carried as an angle: the velocity is only ever set to speed * (cosd, sind)(heading) and rotated
-    // by the step's turn, so atan2d(v) is this angle up to rounding (1e-14 degrees) -- the reference's per-step atan2d
-    // (createEncounter.m:163) costs a hundred instructions here.  (v = 0 would give atan2d = 0: speeds are clamped to minVel > 0.)
-    double vang = heading_deg;
-    int ii = 1, rows = 0;
-    const size_t nl = (size_t)4 * (size_t)A.n;
-    bool done = false, failed = false;
-    // ONE loop whose body is one attempt of the lane's current step: a lane whose draw produced an invalid event (createEncounter.m:
-    // 218-262 re-draws the step) comes round again with att + 1 while its neighbours start their next step, instead of the whole
-    // wave idling through an inner re-draw loop of the few.  The lanes of a wave therefore drift apart in their row numbers, and a
-    // row written straight to the [6][cap][4n] output would be 64 scattered 4-byte stores; each lane keeps its last kRing rows in
-    // LDS instead, and row r leaves for memory -- one 256-byte store per field for the wave -- once every running lane is past it.
-    // A lane more than kRing rows ahead of the slowest waits (the slowest lane sets the wave's run time either way).
     // asub2ind.m:13-14 over the step's start state: the strides of a transition node's current-bin parents (heading, altitude, speed
     // in the model's order) folded into the strides of the same variables as initial-state parents, once (wave-uniform, scalar) --
     // per step the column is then six multiply-adds per node instead of nine plus three 6-way selects
-    uint32_t cstr[3][6];
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-#pragma unroll
-        for (int p = 0; p < 6; p++) {
-            uint32_t sv = P.d_stride_static[k][p];
-#pragma unroll
-            for (int q = 0; q < 3; q++) sv += ((int)P.d_ivar[q] == p) ? P.d_stride_cur[k][q] : 0u;
-            cstr[k][p] = sv;
-        }
-    int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t colk[3] = {0u, 0u, 0u};   // the step's CPT columns; the row addresses are formed at the draw (nine 64-bit pointers kept per lane cost 18 registers)
+    // (18 wave-uniform strides: in LDS, read as five 16-byte loads next to the step's other LDS reads -- in scalar registers they and the
+    // Philox key schedule were what spilled)
+    __shared__ uint32_t s_cstr[20];
+    if (threadIdx.x < 18) {
+        const int k = threadIdx.x / 6, p = threadIdx.x % 6;
+        uint32_t sv = P.d_stride_static[k][p];
+        for (int q = 0; q < 3; q++) sv += ((int)P.d_ivar[q] == p) ? P.d_stride_cur[k][q] : 0u;
+        s_cstr[threadIdx.x] = sv;
+    }
+    __syncthreads();
     // (compile_plan builds the compact rows for exactly the rows of 9 to 48 thresholds: a compile-time fact in the shipped-shape instance)
     const bool has_c8[3] = {rm1[0] > 8 && rm1[0] <= 48, rm1[1] > 8 && rm1[1] <= 48, rm1[2] > 8 && rm1[2] <= 48};   // wave-uniform
-    double curr_hdg = 0;
     const bool dist8 = kShipped || gDist.n <= 8;   // wave-uniform: the distance grid is compared squared (the shipped-shape instance is only launched on such a grid)
-    int flushed = 0; // wave-uniform: rows [0, flushed) of every lane are in memory
-    while (__ballot(!done) != 0ull) {
-        if (!done && (att != 0 || rows - flushed < kRing)) do {
+    const int C = EMGPU_TERMINAL_T0_ROW(A.cap);    // row of t = 0 in an aircraft's block of W = 2 C rows
+    const size_t Wrows = (size_t)(2 * C);
+
+    // ---- the lane's track
+    bool active = false, failed = false;
+    uint32_t L = 0;                 // track = 4 * encounter + role, role = 2 * (aircraft - 1) + (backward)
+    int ac = 0, intent = 0;
+    double dt_s = 1.0;
+    Rng rng{0u, 0u, 0u, (uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
+    bool vdirty = false;            // the velocity's components are due from (speed, vang)
+    bool fresh = false;             // a new track: its bins come from the full discretize, once
+    // The bins of the three variables only an event changes (heading, altitude, speed: 0-based, one byte each), as the NEXT step will
+    // see them: an event writes the bin it drew -- the dediscretized value lies in it (checked; else the full discretize) -- instead of
+    // every step discretizing three values that have not changed since.  st[3..5] stay the step's own (createEncounter.m:187: `start`
+    // and heading_discrete are fixed while a step is re-drawn).
+    uint32_t pend = 0u;
+    gptr_t thr = nullptr;
+    double xy0 = 0, xy1 = 0, z_ft = 0, heading_deg = 0, prev_z_rec = 0, v0 = 0, v1 = 0, speed = 0, vang = 0, curr_hdg = 0;
+    double sh, chh;
+    int ii = 1, rows = 0, cnt = 0;  // rows: recorded so far; cnt: of them staged in LDS, not yet written
+    int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t colk[3] = {0u, 0u, 0u};   // the step's CPT columns; the row addresses are formed at the draw (nine 64-bit pointers kept per lane cost 18 registers)
+#ifdef EMGPU_TERM_COUNTERS
+    unsigned long long dbg[24];
+    for (int q = 0; q < 24; q++) dbg[q] = 0ull;
+#endif
+    // ---- the wave's share of the queue (wave-uniform)
+    uint32_t q_next = 0, q_end = 0;
+    bool exhausted = false;
+    for (;;) {
+        // ---- idle lanes take the next tracks
+        const uint64_t idle = __ballot(!active);
+        const int nidle = __popcll(idle);
+        if (!exhausted && nidle >= kRefillMin) {
+            const uint32_t avail = q_end - q_next;
+            uint32_t nb = 0;
+            const bool grab = avail < (uint32_t)nidle;
+            TCNT1(10);
+            if (grab) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(U(queue), kChunk);
+                nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            }
+            if (!active) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t t = rank < avail ? q_next + rank : nb + (rank - avail);
+                if (t < total) {
+                    // the track's start state (createEncounter.m:41-49, :96)
+                    // the queue hands out the tracks role by role (all forward ownship tracks, then the backward ones, ...): the lanes in
+                    // flight then gather from the tables of two or three trajectory models (one role, every intent) instead of all ten --
+                    // measured: table fetches from HBM 14 -> 4 GB per 2 M encounters, -6 % run time
+                    const uint32_t nn = (uint32_t)A.n;
+                    const int role = (int)(t >= nn) + (int)(t >= 2u * nn) + (int)(t >= 3u * nn);
+                    const uint32_t e = t - (uint32_t)role * nn;
+                    L = 4u * e + (uint32_t)role;
+                    ac = role >> 1;
+                    dt_s = (role & 1) ? -1.0 : 1.0;
+                    const uint64_t *ind = U(indices);
+                    const uint64_t gidx = ind ? ind[e] : U(first_index) + (uint64_t)e;
+                    rng.c0 = (uint32_t)gidx; rng.c1 = (uint32_t)(gidx >> 32);
+                    const double *g = U(geo) + (size_t)e * 12 + ac * 6;
+                    intent = (int)g[5];
+                    thr = (gptr_t)U(thr_base)[U(model_of)[L]];
+                    xy0 = g[0]; xy1 = g[1]; z_ft = g[2]; heading_deg = g[4]; prev_z_rec = 0;
+                    speed = g[3];   // norm(v_ft_s), carried: the velocity is only ever speed * (cosd, sind) of a direction (its norm to 1e-16)
+                    // The velocity is (speed, direction): it is only ever set to speed * (cosd, sind)(heading) (:96, :238-247) and rotated by the
+                    // step's turn (:262), so it IS speed * (cosd, sind)(vang) with vang = the heading it was last set to + the turns since, up to
+                    // rounding (1e-14 degrees) -- and atan2d(v) (createEncounter.m:176) is vang.  Its components are only read by the next step's
+                    // move: ONE place computes them (a new track, a speed event and a turn all mark them due) instead of a sincosd at each.
+                    // (v = 0 would give atan2d = 0: speeds are clamped to minVel > 0.)
+                    vang = heading_deg; vdirty = true; fresh = true;
+                    ii = 1; rows = 0; cnt = 0; att = 0; failed = false;
+                    active = true;
+                    TCNT(11, true);
+                }
+            }
+            if (grab) { q_next = nb + ((uint32_t)nidle - avail); q_end = nb + kChunk; }
+            else q_next += (uint32_t)nidle;
+            exhausted = q_next >= total;
+        }
+        if (__ballot(active) == 0ull) break;   // (the queue is exhausted: an all-idle wave always tries to refill)
+        TCNT1(0); TCNT(1, active); TCNT(2, active && att == 0); TCNT(7, active && att != 0);
+        // ---- ONE attempt of the lane's current step: a lane whose draw produced an invalid event (createEncounter.m:218-262 re-draws the
+        // step) comes round again with att + 1 while its neighbours start their next step
+        bool done = false;
+        const bool bck = dt_s < 0.0;
+        if (active) do {
             if (att == 0) {
                 // ---- the step begins: record the state, move, discretize (createEncounter.m:156-200)
                 if (rows >= A.cap) { failed = true; done = true; break; }
-                float *rec = &s_ring[threadIdx.x >> 6][rows % kRing][0][lane];
-                rec[0 * 64] = (float)xy0; rec[1 * 64] = (float)xy1; rec[4 * 64] = (float)speed;
+                if (vdirty) {
+                    t_sincosd(vang, sh, chh);
+                    v0 = chh * speed; v1 = sh * speed;
+                    vdirty = false;
+                }
+                // forward lanes fill their staging area upwards, backward lanes downwards: either way it holds ascending rows of the
+                // joined track; the backward track's row 0 is the forward track's (bck(1, 2:end), createEncounter.m:77) and is not kept
+                float *rec = mine + 5 * (bck ? kRows - 1 - cnt : cnt);
+                rec[0] = (float)xy0; rec[1] = (float)xy1; rec[4] = (float)speed;
                 xy0 += (v0 * dt_s) * t_k(1.0 / 6076.1154855643);
                 xy1 += (v1 * dt_s) * t_k(1.0 / 6076.1154855643);
                 curr_hdg = (speed > 0.0) ? t_mod360(vang) : 0.0;
                 double rec_z = z_ft;
                 if (ii > 1) {
                     const double alt_diff = z_ft - prev_z_rec;
-                    rec_z = prev_z_rec + t_sign(alt_diff) * fmin(T_LIM(4), fabs(alt_diff));
+                    rec_z = prev_z_rec + t_sign(alt_diff) * fmin(T_LIMS(4), fabs(alt_diff));
                 }
                 prev_z_rec = rec_z;
-                rec[2 * 64] = (float)rec_z; rec[3 * 64] = (float)curr_hdg;
+                rec[2] = (float)rec_z; rec[3] = (float)curr_hdg;
+                cnt += (bck && rows == 0) ? 0 : 1;
                 rows++;
                 // CreateStartDistribution (0-based bins), createEncounter.m:268-294
                 const double d2_nm = xy0 * xy0 + xy1 * xy1;
                 st[0] = intent - 1;
                 st[1] = (dist8 ? t_discretize8(d2_nm, s_cut8sq) : t_discretize(sqrt(d2_nm), s_bnd, gDist)) - 1;     // wave-uniform choices
-                st[2] = t_bearing_bin(xy0, xy1, s_bnd + gBear.off + 1, s_dir, gBear.n, gBear.lo, gBear.inv_step) - 1;
-                st[3] = t_discretize(heading_deg, s_bnd, gHead) - 1;
-                st[4] = ((kShipped || gAlt.n <= 8) ? t_discretize8(z_ft, s_cut8[3]) : t_discretize(z_ft, s_bnd, gAlt)) - 1;   // (7 and 5 bins: at most 8 cut points, checked at launch)
-                st[5] = ((kShipped || gSpd.n <= 8) ? t_discretize8(speed, s_cut8[4]) : t_discretize(speed, s_bnd, gSpd)) - 1;    // norm(v_ft_s): the velocity has not changed since `speed`
+                int kb0 = st[2];
+                if (fresh) {   // a track's first step: the full discretize (once); from then on events keep `pend` and the bearing is walked
+                    const CutGrid gB = s_grid[1];
+                    kb0 = t_bearing_bin(xy0, xy1, s_bnd + gB.off + 1, s_dir, gB.n, gB.lo, gB.inv_step) - 1;
+                    pend = (uint32_t)(t_discretize(heading_deg, s_bnd, s_grid[2]) - 1) | ((uint32_t)(t_discretize(z_ft, s_bnd, s_grid[3]) - 1) << 8) |
+                           ((uint32_t)(t_discretize(speed, s_bnd, s_grid[4]) - 1) << 16);
+                    fresh = false;
+                }
+                st[2] = t_bearing_walk(xy0, xy1, s_bnd + kBndStride + 1, s_dir, bear_n, bear_kA, bear_kB, kb0) - 1;
+                st[3] = (int)(pend & 0xFFu); st[4] = (int)((pend >> 8) & 0xFFu); st[5] = (int)(pend >> 16);   // (speed: norm(v_ft_s) is `speed`)
                 // CPT column of each dynamic variable (asub2ind.m:13-14 as strides); topological position == variable id
+                uint32_t cstr[3][6];
+                {
+                    int z = 0;
+                    asm volatile("" : "+v"(z));   // (keeps these loads inside the loop: hoisted they would be 18 registers for its whole length)
+#pragma unroll
+                    for (int q = 0; q < 18; q++) cstr[q / 6][q % 6] = s_cstr[z + q];
+                }
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     uint32_t c = 0u;
@@ -373,9 +549,11 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
             }
             // ---- one attempt at the step's transition draw (attempt number in the Philox key)
             if (att >= A.max_resample) { failed = true; done = true; break; }
-            rng.attempt = (uint32_t)role + 4u * (uint32_t)att;
+            rng.attempt = (L & 3u) + 4u * (uint32_t)att;
             uint32_t xw[3];
             {   // block = the step, word = the variable's row of the temporal map: one Philox call for the three draws
+                // (the round keys are scalar adds at the call, not 14 registers kept for the loop)
+                { uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32); asm volatile("" : "+s"(k0), "+s"(k1)); rng.k0 = k0; rng.k1 = k1; }
                 const uint4 tw = rng.block(11u /* TERM_TRANS */, 0u, (uint32_t)ii);
 #pragma unroll
                 for (int k = 0; k < 3; k++) xw[k] = word_of(tw, drow[k]);
@@ -387,70 +565,132 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 piv[k] = (rm1[k] > 8 && rm1[k] <= 48) ? thr + (P.d_pivoff[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;   // wave-uniform
                 c8[k] = has_c8[k] ? thr + (P.d_c8off[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;
             }
-            const Draw3 nb = t_draw3(row, piv, c8, has_c8, rm1, xw);
+            const Draw3 nb3 = t_draw3(row, piv, c8, has_c8, rm1, xw);
             // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude
             // or speed bin makes the step be drawn again -- the events applied before it stay applied, as in the reference's loop
             bool resample = false;
-            const int dH = kh == 0 ? nb.bin[0] : (kh == 1 ? nb.bin[1] : nb.bin[2]), dA = ka == 0 ? nb.bin[0] : (ka == 1 ? nb.bin[1] : nb.bin[2]),
-                      dS = ks == 0 ? nb.bin[0] : (ks == 1 ? nb.bin[1] : nb.bin[2]);
+            const int dH = kh == 0 ? nb3.bin[0] : (kh == 1 ? nb3.bin[1] : nb3.bin[2]), dA = ka == 0 ? nb3.bin[0] : (ka == 1 ? nb3.bin[1] : nb3.bin[2]),
+                      dS = ks == 0 ? nb3.bin[0] : (ks == 1 ? nb3.bin[1] : nb3.bin[2]);
             uint4 dw = make_uint4(0u, 0u, 0u, 0u);   // the step's dediscretize draws (one Philox call, made by the lanes that have an event)
+            TCNT(3, dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1); TCNT(4, dH != st[3] + 1); TCNT(5, dA != st[4] + 1); TCNT(6, dS != st[5] + 1);
+#ifdef EMGPU_TERM_COUNTERS
+            if (__ballot(dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1)) TCNT1(15);
+            if (__ballot(dS != st[5] + 1)) TCNT1(18);
+#endif
+            { uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32); asm volatile("" : "+s"(k0), "+s"(k1)); rng.k0 = k0; rng.k1 = k1; }
             if (dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1) dw = rng.block(12u /* TERM_DEDISC */, 0u, (uint32_t)ii);
-            if (dH != st[3] + 1) heading_deg = t_dedisc(s_bnd + 2 * kBndStride, dH, word_of(dw, kh == 0 ? drow[0] : (kh == 1 ? drow[1] : drow[2])));
+            if (dH != st[3] + 1) {
+                heading_deg = t_dedisc(s_bnd + 2 * kBndStride, dH, word_of(dw, kh == 0 ? drow[0] : (kh == 1 ? drow[1] : drow[2])));
+                const int b = t_in_bin(s_bnd + 2 * kBndStride, (int)P.i_nb[3], dH, heading_deg) ? dH : t_discretize(heading_deg, s_bnd, s_grid[2]);
+                pend = (pend & 0xFFFFFF00u) | (uint32_t)(b - 1);
+            }
             if (dA != st[4] + 1) {
                 // MATLAB: 1:[] is empty, so with no boundary at or below the limit no altitude event is valid
-                if (alt_last >= 1 && dA >= 1 && dA <= alt_last) z_ft = t_dedisc(s_bnd + 3 * kBndStride, dA, word_of(dw, ka == 0 ? drow[0] : (ka == 1 ? drow[1] : drow[2])));
-                else resample = true;
+                const int alt_last = U(alt_last[ac]);
+                if (alt_last >= 1 && dA >= 1 && dA <= alt_last) {
+                    z_ft = t_dedisc(s_bnd + 3 * kBndStride, dA, word_of(dw, ka == 0 ? drow[0] : (ka == 1 ? drow[1] : drow[2])));
+                    const int b = t_in_bin(s_bnd + 3 * kBndStride, (int)P.i_nb[4], dA, z_ft) ? dA : t_discretize(z_ft, s_bnd, s_grid[3]);
+                    pend = (pend & 0xFFFF00FFu) | ((uint32_t)(b - 1) << 8);
+                } else resample = true;
             }
             if (!resample && dS != st[5] + 1) {
+                const int spd_first = U(spd_first[ac]), spd_last = U(spd_last[ac]);
                 if (spd_first >= 1 && dS >= spd_first && dS <= spd_last) {
                     double s1 = t_dedisc(s_bnd + 4 * kBndStride, dS, word_of(dw, ks == 0 ? drow[0] : (ks == 1 ? drow[1] : drow[2])));
                     const double minVel = T_LIM(0), maxVel = T_LIM(1);
+                    const bool inside = !(s1 < minVel) && !(s1 > maxVel) && t_in_bin(s_bnd + 4 * kBndStride, (int)P.i_nb[5], dS, s1);
                     if (s1 < minVel) s1 = minVel;
                     if (s1 > maxVel) s1 = maxVel;
-                    t_sincosd(heading_deg, sh, chh);
-                    v0 = chh * s1; v1 = sh * s1;
-                    vang = heading_deg;
+                    const int b = inside ? dS : t_discretize(s1, s_bnd, s_grid[4]);   // (a clamped speed may have left its bin)
+                    pend = (pend & 0x0000FFFFu) | ((uint32_t)(b - 1) << 16);
+                    vang = heading_deg; vdirty = true;     // v = rotationmatrix(heading_deg) * [s1; 0]  (:246-247)
                     speed = s1;
                 } else resample = true;
             }
+#ifdef EMGPU_TERM_COUNTERS
+            if (__ballot(resample)) TCNT1(17);
+            TCNT(19, resample);
+#endif
             if (resample) { att++; break; }
             att = 0;
             // ---- the step ends: turn towards the new heading, advance the clock, stop conditions
             const double turn1 = round((heading_deg - curr_hdg) * t_k(100.0)) * t_k(0.01);
-            const double delta = fmin(fabs(turn1), T_LIM(2)) * t_sign(turn1);
-            if (delta != 0.0) {                                  // rotationmatrix(0) is the identity
-                t_sincosd(delta, sh, chh);
-                const double vx = chh * v0 - sh * v1, vy = sh * v0 + chh * v1;
-                v0 = vx; v1 = vy;
-                vang += delta;
-            }
+            const double delta = fmin(fabs(turn1), T_LIMS(2)) * t_sign(turn1);
+            TCNT(8, delta != 0.0);
+#ifdef EMGPU_TERM_COUNTERS
+            if (__ballot(delta != 0.0)) TCNT1(16);
+#endif
+            if (delta != 0.0) { vang += delta; vdirty = true; }  // v = rotationmatrix(delta) * v  (:262; rotationmatrix(0) is the identity)
             ii++;
             const double d2_nm = xy0 * xy0 + xy1 * xy1;   // (the position has not moved since the step began: recomputed, not carried)
-            done = ((double)(ii - 1) > A.tmax_s) || (d2_nm > bounds_dist_hi * bounds_dist_hi) || ((intent == 1 || intent == 2) && d2_nm <= 0.0625) || (is_ownship && xy1 > 0.25);
+            done = ((double)(ii - 1) > A.tmax_s) || (d2_nm > dist_hi2) || ((intent == 1 || intent == 2) && d2_nm <= 0.0625) || (ac == 0 && xy1 > 0.25);
         } while (false);
-        // ---- rows that every running lane has produced leave for memory
-        for (;;) {
-            if (__ballot(!done && rows <= flushed) != 0ull) break;   // a running lane has not produced this row yet
-            if (__ballot(rows > flushed) == 0ull) break;             // nobody holds it
-            if (rows > flushed) {
-                const float *rec = &s_ring[threadIdx.x >> 6][flushed % kRing][0][lane];
-                float *o = A.out + (size_t)flushed * nl + (size_t)L;
-                const size_t fs = (size_t)A.cap * nl;
-                o[0] = (float)(dt_s * (double)flushed);   // t_s = +-row: whole seconds, exact
-#pragma unroll
-                for (int f = 1; f < 6; f++) o[f * fs] = rec[(f - 1) * 64];
+        if (done) {
+            if (failed && !U(quiet)) atomicOr(U(status), 1u);
+            U(rows)[L] = failed ? -rows - 1 : rows;
+            active = false;
+        }
+        // ---- staged rows leave for memory: a lane whose staging area is full, or whose track has just ended, hands its rows to the wave,
+        // which writes them as one contiguous piece (lane j = dword j of the piece)
+        const bool fl = cnt == kRows || (done && cnt > 0);
+        uint64_t fm = __ballot(fl);
+        if (fm != 0ull) {
+            uint32_t dlo = 0u, dhi = 0u;   // the piece's address; bits 48-63: its source in the staging area (11 bits: dword) and its length (5 bits: dwords)
+            if (fl) {
+                // rows [rows - cnt, rows) of this direction: the piece starts at the joined track's row C + (rows - cnt) (forward) or
+                // C - (rows - 1) (backward)
+                const size_t r0 = (size_t)(bck ? C - (rows - 1) : C + (rows - cnt));
+                const uint64_t dst = (uint64_t)(A.traj + ((size_t)(L >> 1) * Wrows + r0) * 5);
+                dlo = (uint32_t)dst;
+                dhi = (uint32_t)(dst >> 32) | ((uint32_t)(lane * kLaneStride + (bck ? 5 * (kRows - cnt) : 0)) << 16) | ((uint32_t)(5 * cnt) << 27);
+                cnt = 0;
             }
-            flushed++;
+            __builtin_amdgcn_wave_barrier();
+            do {
+                TCNT1(9);
+                const int l = (int)__builtin_ctzll(fm);
+                fm &= fm - 1ull;
+                const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)dlo, l), shi = (uint32_t)__builtin_amdgcn_readlane((int)dhi, l);
+                const uint32_t sm = ((shi >> 16) & 0x7FFu) | ((shi >> 27) << 16);
+                float *d = (float *)(((uint64_t)(shi & 0xFFFFu) << 32) | slo);
+#if defined(EMGPU_TERM_NOSTORE)
+                if (lane < (int)(sm >> 16) && stage[(sm & 0xFFFFu) + lane] == 1.2345e-30f) d[lane] = 0.f;   // (measurement only: the loop without its stores)
+#elif defined(EMGPU_TERM_PLAIN_STORES)
+                if (lane < (int)(sm >> 16)) d[lane] = stage[(sm & 0xFFFFu) + lane];
+#else
+                // nontemporal: a piece is a part of a line that nobody reads back here; written through L2 as ordinary stores the 260 000
+                // half-written lines of the lanes in flight crowd the trajectory tables out of it (measured: table fetches 13 -> 30 GB per
+                // 2 M encounters, +3 % run time)
+                if (lane < (int)(sm >> 16)) __builtin_nontemporal_store(stage[(sm & 0xFFFFu) + lane], &d[lane]);
+#endif
+            } while (fm != 0ull);
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    if (failed && !A.quiet) atomicOr(A.status, 1u);
-    A.rows[L] = failed ? -rows - 1 : rows;
+#ifdef EMGPU_TERM_COUNTERS
+    if (lane == 0) for (int q = 0; q < 24; q++) atomicAdd(&g_term_dbg[q], dbg[q]);
+#endif
+}
+
+// measuring builds only: read (and clear) the path counters of the launches so far; returns 0 in a normal build
+int terminal_debug_counters(unsigned long long *out, int n) {
+#ifdef EMGPU_TERM_COUNTERS
+    unsigned long long h[32];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_term_dbg), sizeof h) != hipSuccess) return -1;
+    for (int q = 0; q < n && q < 32; q++) out[q] = h[q];
+    memset(h, 0, sizeof h);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_term_dbg), h, sizeof h) != hipSuccess) return -1;
+    return 1;
+#else
+    (void)out; (void)n;
+    return 0;
+#endif
 }
 
 hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, hipStream_t s, const char **name) {
     *name = "k_terminal_propagate";
     if (A.n <= 0) return hipSuccess;
-    const int64_t blocks = (4 * A.n + 255) / 256;
+    if (4 * A.n >= (int64_t)1 << 31) return hipErrorInvalidValue;   // the queue counts tracks in 32 bits
     static const bool generic_only = getenv("EMGPU_DEBUG_TERM_GENERIC") != nullptr;   // tests: the run-time-shape instance on the shipped shape
     bool shipped_order = P.d_ivar[0] == 3 && P.d_ivar[1] == 4 && P.d_ivar[2] == 5 && P.d_row[0] == 0 && P.d_row[1] == 1 && P.d_row[2] == 2;
     if ((int)P.i_nb[1] - 2 > 8 || (int)P.i_nb[4] - 2 > 8 || (int)P.i_nb[5] - 2 > 8) shipped_order = false;   // distance, altitude and speed grids compared against eight padded cut points
@@ -460,7 +700,21 @@ hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, 
             for (int q = 0; q < 3; q++) sv += ((int)P.d_ivar[q] == p) ? P.d_stride_cur[k][q] : 0u;
             if (sv >= (1u << 24)) shipped_order = false;
         }
-    if (!generic_only && shipped_order && P.d_r[0] == 36 && P.d_r[1] == 7 && P.d_r[2] == 5) {
+    const bool shipped = !generic_only && shipped_order && P.d_r[0] == 36 && P.d_r[1] == 7 && P.d_r[2] == 5;
+    // persistent workgroups: as many as the device holds at once (a wave takes its tracks from the queue), fewer for a small batch
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess)
+        e = shipped ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_terminal_propagate<35, 6, 4>, 256, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_terminal_propagate<0, 0, 0>, 256, 0);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t need = (4 * A.n + 255) / 256;
+    const int64_t blocks = need < (int64_t)cus * per_cu ? need : (int64_t)cus * per_cu;
+    e = hipMemsetAsync(A.queue, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    if (shipped) {
         *name = "k_terminal_propagate<35,6,4>";
         hipLaunchKernelGGL((k_terminal_propagate<35, 6, 4>), dim3((unsigned)blocks), dim3(256), 0, s, P, A);
     } else {

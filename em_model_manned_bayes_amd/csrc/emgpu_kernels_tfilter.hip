@@ -9,9 +9,10 @@
 // differences over the 1 s samples, the last value repeated, heading differences wrapped to (-pi, pi].  Reference defects
 // kept or decided: `isClimb` (track.m:122,134) is undefined there -- read as is_climb; the turn-rate test compares rad/s
 // with a deg/s limit (CorTerminalModel.m:296) and the runway distance uses 1.68781 as nm -> ft (:215): both kept.
-// Not a hot kernel: it reads the tracks once (24 B per track-second) behind a propagation that costs 100x more.
+// Not a hot kernel: it reads the tracks once (20 B per track-second) behind a propagation that costs 100x more.
 #include <hip/hip_runtime.h>
 
+#include "../../include/emgpu.h"
 #include "emgpu_launch.h"
 #include "emgpu_plan.h"
 
@@ -61,15 +62,14 @@ __global__ void __launch_bounds__(256) k_terminal_geo(const EmgpuTGeoRun A) {
     mo[0] = 2 * (intent[0] - 1); mo[1] = mo[0] + 1; mo[2] = 4 + 2 * (intent[1] - 1); mo[3] = mo[2] + 1;
 }
 
-// the merged, time-ordered track of one aircraft, read in place: element i is row rb-1-i of the backward track while i < rb-1
-// (its row 0 is t = 0, which the forward track carries: bck(1, 2:end), createEncounter.m:77), else row i-(rb-1) of the forward one
+// the joined, time-ordered track of one aircraft (createEncounter.m:74-84), read in place from k_terminal_propagate's track-major output:
+// element i is row lo + i of the aircraft's block, lo = C - (rb - 1) (the backward track's last second), its time lo + i - C
 struct Track {
-    const float *fwd, *bck;   // lane bases in `out`
-    size_t rs, fs;            // row stride, field stride
+    const float *base;        // row 0 of the aircraft's block [EMGPU_TERMINAL_BLOCK_ROWS(cap)][5]
+    int lo, C;
     int rf, rb, n;
     __device__ __forceinline__ double at(int field, int i) const {
-        const int nb = rb - 1;
-        return i < nb ? (double)bck[(size_t)field * fs + (size_t)(nb - i) * rs] : (double)fwd[(size_t)field * fs + (size_t)(i - nb) * rs];
+        return field == 0 ? (double)(lo + i - C) : (double)base[(size_t)(lo + i) * 5 + (size_t)(field - 1)];
     }
 };
 
@@ -129,16 +129,16 @@ __global__ void __launch_bounds__(256) k_terminal_filter(const EmgpuTFilterRun A
 #pragma clang fp contract(off)
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= A.n) return;
-    const size_t nl = (size_t)4 * (size_t)A.n;
     const int64_t slot = A.slot ? A.slot[e] : e;
     bool good = true;
     Track T[2];
     for (int a = 0; a < 2; a++) {
         const int rf = A.rows[4 * e + 2 * a], rb = A.rows[4 * e + 2 * a + 1];
         if (rf < 1 || rb < 1) good = false;                    // a track hit the re-draw cap: the attempt is void
-        T[a].fwd = A.out + (size_t)(4 * e + 2 * a); T[a].bck = A.out + (size_t)(4 * e + 2 * a + 1);
-        T[a].rs = nl; T[a].fs = (size_t)A.cap * nl;
+        T[a].base = A.tracks + (size_t)(2 * e + a) * (size_t)EMGPU_TERMINAL_BLOCK_ROWS(A.cap) * 5;
+        T[a].C = EMGPU_TERMINAL_T0_ROW(A.cap);
         T[a].rf = rf < 1 ? 1 : rf; T[a].rb = rb < 1 ? 1 : rb; T[a].n = T[a].rf + T[a].rb - 1;
+        T[a].lo = T[a].C - (T[a].rb - 1);
     }
     const int own_intent = (int)A.geo[e * 12 + 5], int_intent = (int)A.geo[e * 12 + 11];
     double tcpa = 0, hmd = INFINITY, vmd = 0;

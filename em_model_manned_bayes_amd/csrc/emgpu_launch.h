@@ -26,6 +26,7 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A);
 void step_parent_masks(const EmgpuPlan &P, uint32_t *cur_mask, uint32_t *new_mask);
 hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
 hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, hipStream_t s, const char **name);
+int terminal_debug_counters(unsigned long long *out, int n);   // -DEMGPU_TERM_COUNTERS builds: the loop's path counters (0: not such a build)
 hipError_t launch_terminal_geo(const EmgpuTGeoRun &A, hipStream_t s);
 hipError_t launch_terminal_filter(const EmgpuTFilterRun &A, hipStream_t s, const char **name);
 hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char **name);

@@ -170,9 +170,11 @@ struct EmgpuTermRun {
     double tmax_s;
     double dl[2][5];                 // minVel, maxVel, maxTurnRate, maxAltitude, maxVertRate per aircraft
     int32_t max_resample, cap;
-    float *out;                      // [6][cap][4n]: t_s x_nm y_nm z_ft heading_deg v_ft_s
-    int32_t *rows;                   // [4n] rows written; < 0: failed (cap / resample cap)
+    float *traj;                     // [2n][W][5]: the joined track of aircraft 2e + a (createEncounter.m:74-84), row C + t for second t (C = EMGPU_TERMINAL_T0_ROW(cap), W = 2 C):
+                                     // x_nm y_nm z_ft heading_deg v_ft_s (t_s is the row number; rows outside a track's span are not written)
+    int32_t *rows;                   // [4n] rows of track 4e + 2a + (backward), its t = 0 row included; < 0: failed (cap / resample cap)
     uint32_t *status;
+    uint32_t *queue;                 // device word, zeroed by the launcher: the next track nobody has taken
     const uint64_t *indices;         // optional: global index of encounter e (instead of first_index + e)
     int32_t quiet;                   // a failed track only marks rows < 0 (CorTerminalModel.track re-draws it) instead of raising the status bit
 };
@@ -187,7 +189,7 @@ struct EmgpuTGeoRun {
 };
 struct EmgpuTFilterRun {
     int64_t n;                       // encounters of this round
-    const float *out;                // [6][cap][4n] from k_terminal_propagate
+    const float *tracks;             // [2n][EMGPU_TERMINAL_BLOCK_ROWS(cap)][5] from k_terminal_propagate
     const int32_t *rows;             // [4n]
     int32_t cap;
     const double *geo;               // [n][12] (intents)

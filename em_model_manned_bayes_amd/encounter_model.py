@@ -593,18 +593,24 @@ class CorTerminalModel(EncounterModel):
         if first_index is not None:
             first = int(first_index)
         g, mo = self._geo_rows(samples)
-        out, rows = native.propagate_terminal_host(ctx or native.default_context(), [m.native for m in self._traj], g, mo, s,
-                                                   first_index=first, tmax_s=float(tmax_s), dyn_limits=self._dyn_rows())
+        cap = int(tmax_s) + 3
+        traj, rows = native.propagate_terminal_joined_host(ctx or native.default_context(), [m.native for m in self._traj], g, mo, s,
+                                                           first_index=first, tmax_s=float(tmax_s), dyn_limits=self._dyn_rows(), cap=cap)
         res = []
-        fields = ("t_s", "x_nm", "y_nm", "z_ft", "heading_deg", "v_ft_s")
+        fields = ("x_nm", "y_nm", "z_ft", "heading_deg", "v_ft_s")
         for e_ in range(len(samples)):
             pair = []
             for a in range(2):
-                fwd = out[4 * e_ + 2 * a, : rows[4 * e_ + 2 * a]].astype(np.float64)
-                bck = out[4 * e_ + 2 * a + 1, 1: rows[4 * e_ + 2 * a + 1]].astype(np.float64)   # bck(1, 2:end)  :77
-                both = np.concatenate([fwd, bck], axis=0)
-                both = both[np.argsort(both[:, 0], kind="stable")]                              # :81-84
-                pair.append({f: both[:, k].copy() for k, f in enumerate(fields)})
+                # the library hands back what :74-84 build: [fwd, bck(1, 2:end)] ordered in time, row c0 + t for second t
+                rf, rb = int(rows[4 * e_ + 2 * a]), int(rows[4 * e_ + 2 * a + 1])
+                if rf < 1 or rb < 1:
+                    raise RuntimeError("createEncounter: a track exceeded the re-draw cap (the reference would loop forever, createEncounter.m:192)")
+                c0 = native.terminal_t0_row(cap)
+                lo, hi = c0 - (rb - 1), c0 + (rf - 1)
+                both = traj[2 * e_ + a, lo: hi + 1].astype(np.float64)
+                d = {"t_s": np.arange(lo - c0, hi - c0 + 1, dtype=np.float64)}
+                d.update({f: both[:, k].copy() for k, f in enumerate(fields)})
+                pair.append(d)
             res.append(pair)
         return res[0] if single else res
 

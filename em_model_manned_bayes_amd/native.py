@@ -361,11 +361,17 @@ def sample_bn_host(ctx, model, n, seed, first_index=0, dediscretize=False, max_a
     return ob.T.copy(), ov.T.copy(), att
 
 
-def propagate_terminal_host(ctx, models, geo, model_of, seed, first_index=0, tmax_s=120.0, dyn_limits=None,
-                            max_resample=100000, cap=None):
-    """emgpu_propagate_terminal_host: PropagateTrajectory for 4 tracks per encounter (createEncounter.m:52-72).
-    models: list of NativeModel (stay prior already applied); geo [n, 12]; model_of [n, 4].
-    Returns (out [4n, rows<=cap, 6] f32 as t_s x_nm y_nm z_ft heading_deg v_ft_s, rows [4n])."""
+def terminal_t0_row(cap):
+    """EMGPU_TERMINAL_T0_ROW: the row of t = 0 in an aircraft's block of 2 * terminal_t0_row(cap) rows."""
+    return (int(cap) + 7) & ~7
+
+
+def propagate_terminal_joined_host(ctx, models, geo, model_of, seed, first_index=0, tmax_s=120.0, dyn_limits=None,
+                                   max_resample=100000, cap=None):
+    """emgpu_propagate_terminal_host: PropagateTrajectory for 4 tracks per encounter (createEncounter.m:52-72) in the library's
+    own layout.  models: list of NativeModel (stay prior already applied); geo [n, 12]; model_of [n, 4].
+    Returns (traj [2n, 2 C, 5] f32, C = terminal_t0_row(cap): the joined track of aircraft 2e + a, row C + t = second t, fields x_nm y_nm z_ft
+    heading_deg v_ft_s; rows [4n]: rows of track 4e + 2a + backward, < 0 = failed).  Rows outside a track's span are 0."""
     geo = np.ascontiguousarray(np.asarray(geo, dtype=np.float64).reshape(-1, 12))
     n = geo.shape[0]
     model_of = np.ascontiguousarray(np.asarray(model_of, dtype=np.int32).reshape(-1))
@@ -378,10 +384,36 @@ def propagate_terminal_host(ctx, models, geo, model_of, seed, first_index=0, tma
     for i in range(10):
         p.dyn_limits[i] = float(dl[i])
     handles = (C.c_void_p * len(models))(*[m._h for m in models])
-    out = np.zeros((6, cap, 4 * n), dtype=np.float32)
+    traj = np.zeros((2 * n, 2 * terminal_t0_row(cap), 5), dtype=np.float32)
     rows = np.zeros(4 * n, dtype=np.int32)
-    L.check(L.lib().emgpu_propagate_terminal_host(ctx._h, handles, len(models), C.byref(p), _p(geo), _p(model_of), _p(out), _p(rows)))
-    return np.ascontiguousarray(out.transpose(2, 1, 0)), rows
+    L.check(L.lib().emgpu_propagate_terminal_host(ctx._h, handles, len(models), C.byref(p), _p(geo), _p(model_of), _p(traj), _p(rows)))
+    return traj, rows
+
+
+def split_joined_tracks(traj, rows, cap):
+    """The four PropagateTrajectory results of every encounter, as the reference's function returns them one by one
+    (createEncounter.m:96, 162-167), cut out of the joined tracks: out [4n, cap, 6] f32 = t_s x_nm y_nm z_ft heading_deg v_ft_s of
+    track 4e + 2a + backward, row r = second +-r (rows beyond rows[l] are 0)."""
+    n4 = rows.size
+    out = np.zeros((n4, cap, 6), dtype=np.float32)
+    c0 = terminal_t0_row(cap)
+    r = np.arange(cap)
+    for d, sign in ((0, 1), (1, -1)):
+        src = traj[:, c0 + sign * r, :]                      # [2n, cap, 5]
+        lanes = np.arange(d, n4, 2)                            # lane 4e + 2a + d  <->  aircraft 2e + a
+        keep = r[None, :] < np.abs(np.where(rows[lanes] < 0, -rows[lanes] - 1, rows[lanes]))[:, None]
+        out[lanes, :, 1:] = np.where(keep[:, :, None], src, 0)
+        out[lanes, :, 0] = np.where(keep, sign * r[None, :], 0)
+    return out
+
+
+def propagate_terminal_host(ctx, models, geo, model_of, seed, first_index=0, tmax_s=120.0, dyn_limits=None,
+                            max_resample=100000, cap=None):
+    """propagate_terminal_joined_host, returned per PropagateTrajectory call like the reference does:
+    (out [4n, cap, 6] f32 as t_s x_nm y_nm z_ft heading_deg v_ft_s, rows [4n])."""
+    cap = int(cap or (int(tmax_s) + 3))
+    traj, rows = propagate_terminal_joined_host(ctx, models, geo, model_of, seed, first_index, tmax_s, dyn_limits, max_resample, cap)
+    return split_joined_tracks(traj, rows, cap), rows
 
 
 def utrack_params(model, n, sample_time, seed, first_index=0, is_quantize500=False, is_rotorcraft=False,
@@ -424,6 +456,35 @@ def uncor_dynamic_limits(model, initial, up_min, up_max, speed_min, speed_max, i
 
 
 TERMINAL_GEO_FIELDS = ("distance", "bearing", "alt", "speed", "heading", "intent")
+
+
+def terminal_sample_params(geom_model, n, seed, dyn_limits, first_index=0, tmax_s=120.0, cap=None, bounds_sample=None,
+                           max_attempts=100000, max_resample=100000):
+    """emgpu_tsample_params for emgpu_sample_terminal_device; returns (params, keep-alive) -- the variable ids are looked up by label like
+    @CorTerminalModel/sample.m:56-62 / createEncounter.m:45-49."""
+    labels = [s.strip('"') for s in geom_model.get_labels(L.F_LABELS_INITIAL)]
+    p = L.TSampleParams()
+    p.seed, p.first_index, p.n, p.tmax_s = int(seed) & (2**64 - 1), int(first_index), int(n), float(tmax_s)
+    p.max_resample, p.cap, p.max_attempts = int(max_resample), int(cap or (int(tmax_s) + 3)), int(max_attempts)
+    for i, v in enumerate(np.asarray(dyn_limits, dtype=np.float64).reshape(10)):
+        p.dyn_limits[i] = float(v)
+    bs = None
+    if bounds_sample is not None:
+        bs = np.ascontiguousarray(np.asarray(bounds_sample, dtype=np.float64).reshape(geom_model.n_initial, 2))
+        p.bounds_sample = _p(bs)
+    for a, pre in enumerate(("own", "int")):
+        for k, f in enumerate(TERMINAL_GEO_FIELDS):
+            p.idx[6 * a + k] = labels.index(pre + "_" + f) + 1
+    return p, bs
+
+
+def sample_terminal_device(ctx, geom_model, traj_models, p, geom_val, geo, model_of, traj, rows, geom_bin=0, attempts=0):
+    """emgpu_sample_terminal_device: geometry draw + createEncounter inputs + PropagateTrajectory x 4, device pointers (integers)."""
+    if len(traj_models) != 10:
+        raise ValueError("traj_models: the 10 trajectory models in CorTerminalModel.m:84-100 order")
+    handles = (C.c_void_p * 10)(*[m._h for m in traj_models])
+    L.check(L.lib().emgpu_sample_terminal_device(ctx._h, geom_model._h, handles, 10, C.byref(p), C.c_void_p(geom_bin), C.c_void_p(geom_val),
+                                                 C.c_void_p(geo), C.c_void_p(model_of), C.c_void_p(traj), C.c_void_p(rows), C.c_void_p(attempts)))
 
 
 def track_terminal_host(ctx, geom_model, traj_models, n, seed, dyn_limits, max_cum_turn_deg, pitch_deg, first_index=0, tmax_s=120.0,

@@ -279,24 +279,56 @@ int emgpu_sample_bn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_bn_pa
  * emgpu_model_set_transition_stay_prior.
  *   geo      [n][12] f64: x0_nm y0_nm z0_ft v0_ft_s heading0_deg intent for aircraft 1, then 2
  *            (createEncounter.m:41-49)
- *   model_of [4n] i32: index into models[] for lane 4e + role, role = 2*(aircraft-1) + (backward)
- *   out      [6][cap][4n] f32: t_s x_nm y_nm z_ft heading_deg v_ft_s per second (createEncounter.m:162-167)
- *   rows     [4n] i32: seconds written (<= tmax_s + 2); negative => cap / resample cap exceeded
+ *   model_of [4n] i32: index into models[] for track 4e + role, role = 2*(aircraft-1) + (backward)
+ *   traj     [2n][W][5] f32: TRACK-MAJOR -- the joined, time-ordered track of aircraft 2e + (aircraft-1), i.e. what
+ *            createEncounter.m:74-84 builds ([fwd, bck(1, 2:end)] sorted by t_s): row C+t holds second t (t < 0: the backward
+ *            track), fields x_nm y_nm z_ft heading_deg v_ft_s (createEncounter.m:162-167); t_s is the row number minus C and is
+ *            not stored.  C = EMGPU_TERMINAL_T0_ROW(cap) (cap rounded up to a multiple of 8: eight rows are 160 bytes, so the pieces
+ *            a wave writes start on 32-byte boundaries), W = EMGPU_TERMINAL_BLOCK_ROWS(cap) = 2 C.
+ *            Only rows C-(rows_bck-1) .. C+(rows_fwd-1) are written; the rest of the block is left untouched.
+ *            (Rounds 1-3 wrote six row-synchronous planes [6][cap][4n]; a lane now starts its next track the moment its own ends, so
+ *            the lanes of a wave are at unrelated rows and the output is by track.)
+ *   rows     [4n] i32: seconds of track 4e + role, its t = 0 row included (<= tmax_s + 2); negative => cap / resample cap exceeded
  * ---------------------------------------------------------------------------------------------- */
+#define EMGPU_TERMINAL_T0_ROW(cap) (((cap) + 7) & ~7)
+#define EMGPU_TERMINAL_BLOCK_ROWS(cap) (2 * EMGPU_TERMINAL_T0_ROW(cap))
 typedef struct {
     uint64_t seed, first_index;
-    int64_t n;
+    int64_t n;                   /* < 2^29 encounters per call                                      */
     double tmax_s;               /* 120 in @CorTerminalModel/track.m:33                            */
-    int32_t max_resample, cap;   /* inner re-draw cap (reference: unbounded); rows per track       */
+    int32_t max_resample, cap;   /* inner re-draw cap (reference: unbounded); rows per direction   */
     double dyn_limits[2][5];     /* per aircraft: minVel_ft_s maxVel_ft_s maxTurnRate_deg_s
                                     maxAltitude_ft maxVertRate_ft_s (getDynamicLimits.m:15-62)     */
 } emgpu_term_params;
 int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
                                     const emgpu_term_params *p, const double *geo, const int32_t *model_of,
-                                    float *out, int32_t *rows);
+                                    float *traj, int32_t *rows);
 int emgpu_propagate_terminal_host(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
                                   const emgpu_term_params *p, const double *geo, const int32_t *model_of,
-                                  float *out, int32_t *rows);
+                                  float *traj, int32_t *rows);
+
+/* CorTerminalModel.sample + createEncounter for n encounters in one call, everything device-resident (RUN_terminal.m:39-44 without the
+ * filters of track.m): the geometry draw of @CorTerminalModel/sample.m:29-77 (bn_sample + dediscretize + box / speed rejection), the
+ * inputs of createEncounter.m:21-49 (x0 y0 from distance and bearing, the trajectory model of each of the four tracks) and
+ * PropagateTrajectory x 4 (createEncounter.m:52-72), three launches on the ctx stream, asynchronous (emgpu_ctx_sync reports a geometry
+ * rejection cap or a re-draw cap).  geom_model: the 15-variable geometry network; traj_models[10] in CorTerminalModel.m:84-100 order with
+ * the stay prior set.  DEVICE pointers:
+ *   geom_bin [n_i][n] u8 (may be NULL), geom_val [n_i][n] f32: the accepted geometry sample;  attempts [n] i32 (may be NULL)
+ *   geo [n][12] f64, model_of [4n] i32: the inputs of createEncounter (outputs here);  traj, rows: as emgpu_propagate_terminal_device */
+typedef struct {
+    uint64_t seed, first_index;
+    int64_t n;
+    double tmax_s;
+    int32_t max_resample, cap;
+    double dyn_limits[2][5];
+    int32_t max_attempts;            /* cap of the geometry rejection loop (sample.m:32; unbounded in the reference) */
+    uint32_t flags;                  /* reserved, 0                                                          */
+    const double *bounds_sample;     /* HOST pointer: n_initial x 2 row-major or NULL (sample.m:45-53)       */
+    int32_t idx[12];                 /* 1-based geometry variable ids: own {distance bearing alt speed heading intent}, then int */
+} emgpu_tsample_params;
+int emgpu_sample_terminal_device(emgpu_ctx *ctx, const emgpu_model *geom_model, const emgpu_model *const *traj_models, int32_t n_traj_models,
+                                 const emgpu_tsample_params *p, uint8_t *geom_bin, float *geom_val, double *geo, int32_t *model_of,
+                                 float *traj, int32_t *rows, int32_t *attempts);
 
 /* sample2track.m:183-237 -- the 1 Hz dead-reckoning track `sample2track` builds from the em_sample
  * files, and its rejection tests, for n trajectories in one launch:
@@ -423,6 +455,10 @@ int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int3
  * half (0x10000: no such threshold); with a_t = H_t - x_h: a_t < 0 <=> threshold t fired, a_t == 0 <=> the low halfword decides; the
  * 1-based bin is (map >> 7 * fired) & 15. */
 int emgpu_debug_pk_column(const emgpu_model *m, int32_t k, int64_t col, uint32_t *words);
+
+/* Measuring builds of k_terminal_propagate (-DEMGPU_TERM_COUNTERS; tools/term_counters.py): the lanes that took each path of the loop
+ * since the last call (24 counters, cleared by the call).  Returns 1, or 0 in a normal build (out untouched). */
+int emgpu_debug_terminal_counters(emgpu_ctx *ctx, uint64_t *out, int32_t n);
 
 /* Which dynamic variables are parents of which (t+1) node, in plan order k = 0..n_dyn-1: bit 4k+q of cur_mask = the time-t
  * node of dynamic variable q is a parent of k's (t+1) node; of new_mask = its (t+1) node is (dbn_sample.m:65-93: the

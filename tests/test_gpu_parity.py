@@ -826,7 +826,9 @@ def test_terminal_ten_million_encounters_properties(terminal_dir):
     reps = (n + m - 1) // m
     geo = torch.tensor(np.tile(g, (reps, 1))[:n], device=dev)
     mof = torch.tensor(np.tile(mo, (reps, 1))[:n].reshape(-1), dtype=torch.int32, device=dev)
-    out = torch.empty((6, cap, 4 * n), dtype=torch.float32, device=dev)
+    c0 = native.terminal_t0_row(cap)
+    W = 2 * c0
+    out = torch.empty((2 * n, W, 5), dtype=torch.float32, device=dev)     # the joined track of aircraft 2e + a, row c0 + t
     rows = torch.empty(4 * n, dtype=torch.int32, device=dev)
     dl = t._dyn_rows()
     handles = (C.c_void_p * 10)(*[x.native._h for x in t._traj])
@@ -835,7 +837,9 @@ def test_terminal_ten_million_encounters_properties(terminal_dir):
         pp = O.parse_model_txt(f)
         oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
     total_seconds = 0
+    lim = torch.tensor(dl, dtype=torch.float32, device=dev)[torch.arange(2 * n, device=dev) & 1]   # [2n, 5] by aircraft
     for chunk in range(5):
+        out.fill_(float("nan"))                                             # a row outside a track's span must stay untouched
         p = L.TermParams()
         p.seed, p.first_index, p.n, p.tmax_s, p.max_resample, p.cap = seed, chunk * n, n, 120.0, 100000, cap
         for i, v in enumerate(dl.reshape(-1)):
@@ -845,16 +849,18 @@ def test_terminal_ten_million_encounters_properties(terminal_dir):
         ctx.sync()
         assert int(rows.min()) >= 1 and int(rows.max()) <= 122
         total_seconds += int(rows.sum())
-        valid = torch.arange(cap, device=dev)[:, None] < rows[None, :]                       # [cap, 4n]
-        sign = torch.where((torch.arange(4 * n, device=dev) & 1) == 1, -1.0, 1.0)
-        assert bool(((out[0] == torch.arange(cap, device=dev, dtype=torch.float32)[:, None] * sign[None, :]) | ~valid).all())   # t_s
-        lim = torch.tensor(dl, dtype=torch.float32, device=dev)[(torch.arange(4 * n, device=dev) >> 1) & 1]   # [4n, 5] by aircraft
-        v = out[5]
-        assert bool((((v >= lim[:, 0][None, :] - 1e-2) & (v <= lim[:, 1][None, :] + 1e-2)) | ~valid).all())
-        hdg = out[4]
+        rf, rb = rows[0::2], rows[1::2]                                     # [2n] forward / backward rows of every aircraft
+        r = torch.arange(W, device=dev)[None, :]
+        valid = (r >= (c0 - (rb - 1))[:, None]) & (r <= (c0 + (rf - 1))[:, None])        # [2n, W]: the joined track's span
+        written = ~torch.isnan(out[:, :, 0])
+        assert bool((written == valid).all())                               # every row of the span, and nothing else (t_s = row - c0)
+        v = out[:, :, 4]
+        assert bool((((v >= lim[:, 0][:, None] - 1e-2) & (v <= lim[:, 1][:, None] + 1e-2)) | ~valid).all())
+        hdg = out[:, :, 3]
         assert bool((((hdg > 0) & (hdg <= 360)) | ~valid).all())
-        dz = (out[3][1:] - out[3][:-1]).abs()
-        assert bool(((dz <= lim[:, 4][None, :] * 1.0001 + 1e-2) | ~valid[1:]).all())
+        dz = (out[:, 1:, 2] - out[:, :-1, 2]).abs()
+        assert bool(((dz <= lim[:, 4][:, None] * 1.0001 + 1e-2) | ~(valid[:, 1:] & valid[:, :-1])).all())
+        del valid, written, dz
         if chunk in (0, 3):                                                                   # slices against the oracle
             for lo_e in (0, n - 300):
                 sl = slice(lo_e, lo_e + 300)
@@ -862,7 +868,7 @@ def test_terminal_ten_million_encounters_properties(terminal_dir):
                                             first_index=chunk * n + lo_e, tmax_s=120.0)
                 got_rows = rows[4 * lo_e: 4 * lo_e + 1200].cpu().numpy()
                 assert np.array_equal(got_rows, ref_rows)
-                got = out[:, :, 4 * lo_e: 4 * lo_e + 1200].cpu().numpy().transpose(2, 1, 0)
+                got = native.split_joined_tracks(np.nan_to_num(out[2 * lo_e: 2 * lo_e + 600].cpu().numpy()), got_rows, cap)
                 for q in range(0, 1200, 7):
                     np.testing.assert_allclose(got[q, : got_rows[q]], ref[q, : got_rows[q]], rtol=1e-6, atol=1e-6)
     assert 300 < total_seconds / (5 * n) < 488        # mean track-seconds per encounter (4 tracks x <= 122)

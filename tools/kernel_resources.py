@@ -11,7 +11,7 @@ for l in out.splitlines():
     m = re.search(r"remark: (?:\S+ )?\s*Function Name: (\S+)", l)
     if m:
         cur = {"name": m.group(1)}; rows.append(cur); continue
-    m = re.search(r"remark:\s+(?:\S+ )?\s*([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", l)
+    m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", l)
     if m and cur is not None:
         cur[m.group(1).strip()] = int(m.group(2))
 for r in rows:
