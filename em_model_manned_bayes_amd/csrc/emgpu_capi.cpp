@@ -931,6 +931,54 @@ int emgpu_debug_terminal_counters(emgpu_ctx *ctx, uint64_t *out, int32_t n) {
     EMGPU_CATCH
 }
 
+// Test hook: k_uncor_track on caller-given initial values and control rows (no sampling, no limits): what the point-mass step does with
+// inputs a sampled batch seldom holds (a pitch command clamped to +-90 degrees that changes sign).
+int emgpu_debug_uncor_dynamics_host(emgpu_ctx *ctx, int64_t n, int32_t T, int32_t record_stride, int32_t literal, const double dyn[6],
+                                    const float *init, const float *controls, double *tracks) {
+    EMGPU_TRY
+    if (!ctx || !dyn || !init || !controls || !tracks || n < 1 || T < 1 || record_stride < 1 || (10 * T) % record_stride) return fail(EMGPU_ERR_ARG, "bad argument");
+    CTX_LOCK(ctx);
+    HIP_OK(hipSetDevice(ctx->device));
+    const size_t G4 = (size_t)(T + 3) / 4, S = (size_t)(10 * T / record_stride + 1);
+    std::vector<float> h_init(5 * (size_t)n), h_dyn(G4 * 3 * (size_t)n * 4, 0.f);
+    for (int64_t i = 0; i < n; i++) {
+        for (int k = 0; k < 5; k++) h_init[(size_t)k * n + i] = init[i * 5 + k];      // rows: L v \dot v \dot h \dot psi
+        for (int c = 0; c < T; c++)
+            for (int k = 0; k < 3; k++) h_dyn[((((size_t)c / 4) * 3 + k) * n + i) * 4 + c % 4] = controls[((size_t)i * T + c) * 3 + k];   // rows: \dot h, \dot psi, \dot v
+    }
+    float *d_init = nullptr, *d_dyn = nullptr; double *d_tr = nullptr, *d_lim = nullptr; uint8_t *d_acc = nullptr;
+    int rc = EMGPU_OK;
+    try {
+        HIP_OK(hipMalloc((void **)&d_init, h_init.size() * 4)); HIP_OK(hipMalloc((void **)&d_dyn, h_dyn.size() * 4));
+        HIP_OK(hipMalloc((void **)&d_tr, (size_t)n * S * 8 * 8)); HIP_OK(hipMalloc((void **)&d_lim, 3 * 8)); HIP_OK(hipMalloc((void **)&d_acc, (size_t)n));
+        const double lim[3] = {-1e300, 1e300, 1e300};
+        HIP_OK(hipMemcpyAsync(d_init, h_init.data(), h_init.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipMemcpyAsync(d_dyn, h_dyn.data(), h_dyn.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipMemcpyAsync(d_lim, lim, sizeof lim, hipMemcpyHostToDevice, ctx->stream));
+        EmgpuUTrackRun R;
+        memset(&R, 0, sizeof R);
+        R.n = n; R.ld = n; R.T = T; R.stride = record_stride;
+        R.iL = d_init; R.iV = d_init + n; R.iDV = d_init + 2 * n; R.iDH = d_init + 3 * n; R.iDPsi = d_init + 4 * n;
+        R.dyn_val = d_dyn; R.nd = 3; R.sDH = 0; R.sDPsi = 1; R.sDV = 2;
+        memcpy(R.dyn, dyn, sizeof R.dyn);
+        R.min_alt = -1e300; R.max_alt = 1e300; R.ordered = 0; R.lim = d_lim;
+        R.tracks = d_tr; R.S = (int64_t)S; R.accepted = d_acc;
+        const char *name = "";
+        hipError_t e = emgpu::launch_uncor_track(R, ctx->stream, &name, literal);
+        ctx->last_kernel = name;
+        if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+        HIP_OK(hipMemcpyAsync(tracks, d_tr, (size_t)n * S * 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    } catch (...) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_init); (void)hipFree(d_dyn); (void)hipFree(d_tr); (void)hipFree(d_lim); (void)hipFree(d_acc);
+        throw;
+    }
+    (void)hipFree(d_init); (void)hipFree(d_dyn); (void)hipFree(d_tr); (void)hipFree(d_lim); (void)hipFree(d_acc);
+    return rc;
+    EMGPU_CATCH
+}
+
 int emgpu_debug_column_thresholds(const double *weights, int32_t r, uint32_t *out) {
     if (!weights || !out || r < 1 || r > EMGPU_MAX_R) return fail(EMGPU_ERR_ARG, "bad arguments");
     if (r > 1) emgpu::column_thresholds(weights, r, out);

@@ -111,7 +111,8 @@ __device__ __forceinline__ int ut_discretize(double x, const double *cut, int n)
 //     within a second psidot is constant, so (cos psi, sin psi) are ROTATED by the second's (cos, sin)(psidot dt) instead of evaluated
 //   * the pitch either reaches its command, theta = asin(sn) with sn = hd / v -- then sin(theta) = sn and cos(theta) = sqrt(1 - sn^2) -- or
 //     turns towards it by q_max dt: a rotation of (cos theta, sin theta) by that fixed angle; which of the two, |asin(sn) - theta| <=
-//     q_max dt, is read off sin(asin(sn) - theta) = sn cos(theta) - sqrt(1 - sn^2) sin(theta): no asin
+//     q_max dt, is read off sin(asin(sn) - theta) = sn cos(theta) - sqrt(1 - sn^2) sin(theta) together with the sign of
+//     cos(asin(sn) - theta) (round 4: the sine alone is also small 180 degrees away): no asin
 //   * phi and theta themselves are only needed in the recorded rows (atan / asin once per recorded step).
 // One reciprocal, one square root and ~60 other f64 operations per 0.1 s step where the literal form takes three sin/cos pairs, an
 // atan and an asin; every quantity differs from the literal form's by rounding (1e-16 per step, accumulated 1e-13: the tracks are
@@ -158,9 +159,12 @@ __global__ void __launch_bounds__(256) k_uncor_track(const EmgpuUTrackRun A) {
                     double sn = hd * ut_rcp(v); sn = sn < -1 ? -1 : (sn > 1 ? 1 : sn);
                     const double cn = sqrt(fma(-sn, sn, 1.0));
                     const double dd = sn * ct - cn * st;                       // sin(asin(sn) - theta)
-                    if (fabs(dd) <= sdl) { st = sn; ct = cn; }                 // the pitch reaches its command
-                    else {                                                     // ... or turns towards it at q_max
-                        const double sg = dd < 0 ? -sdl : sdl, s2 = st * cdl + ct * sg, c2 = ct * cdl - st * sg;
+                    // |sin(x)| <= sin(q_max dt) says |x| <= q_max dt only while cos(x) > 0: a command clamped to +-90 degrees (|hdot| >= v:
+                    // a slow rotorcraft) that changes sign is up to 180 degrees away from the pitch, where sin(x) is small again
+                    if (fabs(dd) <= sdl && cn * ct + sn * st > 0.0) { st = sn; ct = cn; }   // the pitch reaches its command
+                    else {                                                     // ... or turns towards it at q_max (theta and asin(sn) are
+                        // both in [-90, 90] degrees, where sin is monotone: the command is above the pitch iff sn > sin(theta))
+                        const double sg = sn < st ? -sdl : sdl, s2 = st * cdl + ct * sg, c2 = ct * cdl - st * sg;
                         st = s2; ct = c2;
                     }
                     n = n + v * ct * cp * dt;
@@ -307,9 +311,9 @@ __global__ void __launch_bounds__(256) k_scatter_rejected(int64_t n, uint64_t fi
     slot_out[k] = slot_in ? slot_in[i] : i;
 }
 
-hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char **name) {
+hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char **name, int force_literal) {
     static const bool literal = getenv("EMGPU_DEBUG_UTRACK_LITERAL") != nullptr;   // tests: the literal step on the shipped limits
-    const bool fast = A.dyn[5] >= 32.0 && !literal;   // |atan - phi| / dt <= 10 pi: a bank-rate limit above that never binds
+    const bool fast = A.dyn[5] >= 32.0 && !literal && !force_literal;   // |atan - phi| / dt <= 10 pi: a bank-rate limit above that never binds
     *name = fast ? "k_uncor_track<fastbank>" : "k_uncor_track";
     if (A.n <= 0) return hipSuccess;
     if (fast) hipLaunchKernelGGL(k_uncor_track<true>, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, s, A);

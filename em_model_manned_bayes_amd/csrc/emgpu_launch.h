@@ -29,7 +29,7 @@ hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, 
 int terminal_debug_counters(unsigned long long *out, int n);   // -DEMGPU_TERM_COUNTERS builds: the loop's path counters (0: not such a build)
 hipError_t launch_terminal_geo(const EmgpuTGeoRun &A, hipStream_t s);
 hipError_t launch_terminal_filter(const EmgpuTFilterRun &A, hipStream_t s, const char **name);
-hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char **name);
+hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char **name, int force_literal = 0);
 // rejected lanes of a round -> the next round's index lists, in lane order; count: compact_scratch_words(n) words of device
 // scratch, count[0] receives the number of rejected lanes
 size_t compact_scratch_words(int64_t n);

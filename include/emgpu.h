@@ -456,6 +456,14 @@ int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int3
  * 1-based bin is (map >> 7 * fired) & 15. */
 int emgpu_debug_pk_column(const emgpu_model *m, int32_t k, int64_t col, uint32_t *words);
 
+/* Test hook: the point-mass dynamics kernel of emgpu_track_uncor_* (k_uncor_track) on caller-given inputs, without sampling or limits.
+ *   init [n][5] f32: L (ft), v (kt), \dot v (kt/s), \dot h (ft/min), \dot psi (deg/s) -- the sampled values of UncorEncounterModel.m:434-446
+ *   controls [n][T][3] f32: \dot h (ft/min), \dot psi (deg/s), \dot v (kt/s) active during each second (events2controls.m:16-27)
+ *   dyn[6]: v_low v_high dh_min dh_max q_max r_max (:414);  literal != 0: the literal step even where the reduced one applies
+ *   tracks [n][10 T / record_stride + 1][8] f64 as emgpu_track_uncor_host.  Host pointers. */
+int emgpu_debug_uncor_dynamics_host(emgpu_ctx *ctx, int64_t n, int32_t T, int32_t record_stride, int32_t literal, const double dyn[6],
+                                    const float *init, const float *controls, double *tracks);
+
 /* Measuring builds of k_terminal_propagate (-DEMGPU_TERM_COUNTERS; tools/term_counters.py): the lanes that took each path of the loop
  * since the last call (24 counters, cleared by the call).  Returns 1, or 0 in a normal build (out untouched). */
 int emgpu_debug_terminal_counters(emgpu_ctx *ctx, uint64_t *out, int32_t n);

@@ -1,4 +1,5 @@
 """-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
+import ctypes as C
 import os
 import sys
 
@@ -1378,6 +1379,48 @@ pickle.dump((got["tracks"], got["attempts"], got["limits"], got["kernel"]), open
     assert "fastbank" in res["fast"][3] and "fastbank" not in res["literal"][3]
     assert np.array_equal(res["fast"][1], res["literal"][1]) and np.array_equal(res["fast"][2], res["literal"][2])
     np.testing.assert_allclose(res["fast"][0], res["literal"][0], rtol=1e-10, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_uncor_track_pitch_command_clamped_to_vertical_then_reversed(gpu_ctx):
+    """A slow rotorcraft whose commanded vertical rate exceeds its speed: asin(clamp(hdot / v)) = +-90 degrees; when the command then changes
+    sign it is ~180 degrees away from the pitch, where sin(command - pitch) is as small as next to it.  The reduced step
+    (k_uncor_track<fastbank>) must slew at q_max like the literal one (round 3 jumped: ADVICE r3) -- both against the oracle's literal
+    em_point_mass_dynamics on the same f32 inputs, 1e-9."""
+    T, n = 70, 6
+    dyn = np.array([1.7, 250.0, -50.0, 50.0, np.deg2rad(3.0), 1e6])          # v_low v_high dh_min dh_max q_max r_max (:414)
+    init = np.zeros((n, 5), dtype=np.float32)
+    ctrl = np.zeros((n, T, 3), dtype=np.float32)
+    rng = np.random.RandomState(4)
+    for i in range(n):
+        v_kt = [2.0, 3.0, 5.0, 8.0, 4.0, 60.0][i]
+        up = 1500.0 if i % 2 == 0 else -1500.0                                   # ft/min: 25 ft/s against 3.4 .. 13.5 ft/s of speed (and 101 ft/s: never clamped)
+        init[i] = [3000.0, v_kt, 0.0, up * 0.1, 1.0]
+        ctrl[i, :, 0] = np.where(np.arange(T) < 35, up, -up)                     # climb (descend) for 35 s, then the opposite
+        ctrl[i, :, 1] = rng.uniform(-3, 3, T).round(1)
+        ctrl[i, :, 2] = 0.0
+    S = 10 * T + 1
+    got = {}
+    for literal in (0, 1):
+        tr = np.zeros((n, S, 8))
+        L.check(L.lib().emgpu_debug_uncor_dynamics_host(gpu_ctx._h, n, T, 1, literal, dyn.ctypes.data_as(C.c_void_p), init.ctypes.data_as(C.c_void_p),
+                                                         ctrl.ctypes.data_as(C.c_void_p), tr.ctypes.data_as(C.c_void_p)))
+        got[literal] = tr
+        assert ("fastbank" in gpu_ctx.last_kernel()) == (literal == 0)
+    for i in range(n):
+        v0 = float(init[i, 1]) * 1.68780972222222
+        dh0 = float(init[i, 3]) / 60.0
+        dpsi0 = float(init[i, 4]) * (np.pi / 180.0)
+        ic = [v0, 0, 0, float(init[i, 0]), 0, np.arcsin(dh0 / v0), np.arctan(v0 * dpsi0 / 32.2), 0.0]
+        c = np.stack([ctrl[i, :, 0].astype(np.float64) / 60.0, ctrl[i, :, 1].astype(np.float64) * (np.pi / 180.0),
+                      ctrl[i, :, 2].astype(np.float64) * 1.68780972222222], axis=1)
+        ref, _ = O.point_mass_dynamics(ic, c, dyn)
+        if i < 5:
+            assert np.abs(ref[:, 6]).max() > 1.5 and ref[:, 6].min() * ref[:, 6].max() < 0       # the case is the case: vertical, then through level
+            steps = np.abs(np.diff(ref[:, 6]))
+            assert steps.max() <= dyn[4] * 0.1 + 1e-12                                            # ... at q_max, never a jump
+        for literal in (0, 1):
+            np.testing.assert_allclose(got[literal][i], ref, rtol=1e-9, atol=1e-6, err_msg="trajectory %d, literal=%d" % (i, literal))
 
 
 @pytest.mark.gpu
