@@ -129,7 +129,7 @@ SYMBOLS = [
     "emgpu_model_set_zero_bins", "emgpu_shard_range", "emgpu_device_count", "emgpu_mixed_blocks",
     "emgpu_sample_dbn_blocks_device", "emgpu_sample_dbn_multi_host", "emgpu_sample_dbn_multi_device",
     "emgpu_track_uncor_host", "emgpu_track_uncor_device", "emgpu_uncor_dynamic_limits", "emgpu_model_start_log_weight",
-    "emgpu_track_terminal_host", "emgpu_debug_parent_masks", "emgpu_last_launch_count", "emgpu_debug_pk_column", "emgpu_debug_terminal_counters", "emgpu_debug_uncor_dynamics_host",
+    "emgpu_track_terminal_host", "emgpu_debug_parent_masks", "emgpu_last_launch_count", "emgpu_debug_pk_column", "emgpu_debug_terminal_counters", "emgpu_debug_uncor_dynamics_host", "emgpu_model_save_bin", "emgpu_model_load_bin",
 ]
 
 _lib = None
@@ -232,6 +232,8 @@ def lib():
     L.emgpu_debug_parent_masks.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     for f in (L.emgpu_propagate_terminal_device, L.emgpu_propagate_terminal_host):
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(TermParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emgpu_model_save_bin.argtypes = [C.c_void_p, C.c_char_p]
+    L.emgpu_model_load_bin.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     L.emgpu_debug_uncor_dynamics_host.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.emgpu_debug_terminal_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.emgpu_sample_terminal_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(TSampleParams)] + [C.c_void_p] * 7

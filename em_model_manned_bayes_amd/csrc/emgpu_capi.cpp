@@ -120,6 +120,24 @@ int emgpu_model_load_txt(const char *path, const int32_t *idx_zero_boundaries, i
     EMGPU_CATCH
 }
 
+/* em_read.m:47-107 once, then the binary cache */
+int emgpu_model_save_bin(const emgpu_model *m, const char *path) {
+    EMGPU_TRY
+    if (!m || !path) return fail(EMGPU_ERR_ARG, "null argument");
+    emgpu::save_bin(m->m, path, EMGPU_SRC_HASH);
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+int emgpu_model_load_bin(const char *path, emgpu_model **out) {
+    EMGPU_TRY
+    if (!path || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    std::unique_ptr<Model> m(emgpu::load_bin(path, EMGPU_SRC_HASH));
+    emgpu_model *h = new emgpu_model{std::move(*m)};
+    *out = h;
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
 static std::vector<std::string> split_nl(const char *s) {
     std::vector<std::string> out;
     if (!s) return out;
@@ -447,7 +465,7 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h, const std::s
     u.last_use = ++ctx->use_clock;
     if (u.version == h->m.version && u.d_thr) return u;
     // (re)compile: tables depend on N, alpha, start, boundaries, rates
-    CompiledPlan cp = emgpu::compile_plan(h->m);
+    CompiledPlan cp = *emgpu::plan_of(h->m);   // (the model keeps its plan: a second ctx, or a model read from the binary cache, does not search the thresholds again)
     HIP_OK(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read the old tables
     u.free_tables();
     // 64 words of slack: k_terminal_propagate reads a row's thresholds in fixed groups (8, or every 6th up to index 41) and masks
@@ -991,7 +1009,7 @@ int emgpu_debug_dynamic_column(const emgpu_model *m, int32_t k, int64_t col, int
                                uint32_t *thr, int32_t *meff, uint32_t *cthr, uint32_t *map) {
     EMGPU_TRY
     if (!m || !tvar || !r || !q || !thr || !meff || !cthr || !map) return fail(EMGPU_ERR_ARG, "null argument");
-    const emgpu::CompiledPlan cp = emgpu::compile_plan(m->m);
+    const std::shared_ptr<const emgpu::CompiledPlan> cp_keep = emgpu::plan_of(m->m); const emgpu::CompiledPlan &cp = *cp_keep;
     const EmgpuPlan &P = cp.plan;
     if (k < 0 || k >= P.nd) return fail(EMGPU_ERR_ARG, "no such dynamic variable");
     *tvar = (int32_t)P.d_tvar[k] + 1;
@@ -1014,7 +1032,7 @@ int emgpu_debug_dynamic_column(const emgpu_model *m, int32_t k, int64_t col, int
 int emgpu_debug_parent_masks(const emgpu_model *m, uint32_t *cur_mask, uint32_t *new_mask) {
     EMGPU_TRY
     if (!m || !cur_mask || !new_mask) return fail(EMGPU_ERR_ARG, "null argument");
-    const emgpu::CompiledPlan cp = emgpu::compile_plan(m->m);
+    const std::shared_ptr<const emgpu::CompiledPlan> cp_keep = emgpu::plan_of(m->m); const emgpu::CompiledPlan &cp = *cp_keep;
     emgpu::step_parent_masks(cp.plan, cur_mask, new_mask);
     return EMGPU_OK;
     EMGPU_CATCH
@@ -1023,7 +1041,7 @@ int emgpu_debug_parent_masks(const emgpu_model *m, uint32_t *cur_mask, uint32_t 
 int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int32_t *width, uint32_t *words) {
     EMGPU_TRY
     if (!m || !width || !words) return fail(EMGPU_ERR_ARG, "null argument");
-    const emgpu::CompiledPlan cp = emgpu::compile_plan(m->m);
+    const std::shared_ptr<const emgpu::CompiledPlan> cp_keep = emgpu::plan_of(m->m); const emgpu::CompiledPlan &cp = *cp_keep;
     const EmgpuPlan &P = cp.plan;
     if (k < 0 || k >= P.nd) return fail(EMGPU_ERR_ARG, "no such dynamic variable");
     if (col < 0 || col >= m->m.q_transition[P.d_tvar[k]]) return fail(EMGPU_ERR_ARG, "no such column");
@@ -1036,7 +1054,7 @@ int emgpu_debug_padded_column(const emgpu_model *m, int32_t k, int64_t col, int3
 int emgpu_debug_pk_column(const emgpu_model *m, int32_t k, int64_t col, uint32_t *words) {
     EMGPU_TRY
     if (!m || !words) return fail(EMGPU_ERR_ARG, "null argument");
-    const emgpu::CompiledPlan cp = emgpu::compile_plan(m->m);
+    const std::shared_ptr<const emgpu::CompiledPlan> cp_keep = emgpu::plan_of(m->m); const emgpu::CompiledPlan &cp = *cp_keep;
     const EmgpuPlan &P = cp.plan;
     if (k < 0 || k >= P.nd || P.d_pw[k] == 0) return fail(EMGPU_ERR_ARG, "no such padded dynamic variable");
     if (col < 0 || col >= m->m.q_transition[P.d_tvar[k]]) return fail(EMGPU_ERR_ARG, "no such column");

@@ -3,6 +3,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -16,6 +17,7 @@ struct Error : std::runtime_error {
     Error(int c, const std::string &what) : std::runtime_error(what), code(c) {}
 };
 
+struct CompiledPlan;
 struct Model {
     // em_read.m:47-107 fields
     std::vector<std::string> labels_initial, labels_transition;
@@ -35,6 +37,10 @@ struct Model {
     std::vector<int> start; // 0 = unset
     uint64_t version = 1;   // bumped by every setter: invalidates uploaded plans
     uint64_t uid = 0;       // process-unique id (a freed model's address can be reused: never key a cache by pointer)
+    // the plan compiled for `plan_version` of this model, when somebody has it already (load_bin restores it from the cache file:
+    // the threshold search of compile_plan is most of what loading a model costs)
+    mutable std::shared_ptr<const CompiledPlan> plan_cache;
+    mutable uint64_t plan_version = 0;
 
     int n_dyn() const { return (int)temporal_map.size(); }
     bool is_dynvar_depend() const;
@@ -48,6 +54,13 @@ struct Model {
 };
 
 Model *load_txt(const char *path, const int32_t *idx_zero, int n_idx, bool overwrite);
+// Binary model cache (em_read.m:47-107 is what it saves re-doing): the parsed model -- every field em_read returns, the
+// priors and `start` -- plus its compiled plan, in one file tagged with the library's source hash.  load_bin refuses (EMGPU_ERR_PARSE) a
+// file written by other sources: the caller then reads the .txt again.
+void save_bin(const Model &m, const char *path, const char *src_hash);
+Model *load_bin(const char *path, const char *src_hash);
+// the model's plan: the cached one when it is current, else compiled now (and kept)
+std::shared_ptr<const CompiledPlan> plan_of(const Model &m);
 std::vector<int> bn_sort(const std::vector<uint8_t> &G, int n);
 std::vector<int> extract_zero_bins(const std::vector<std::vector<double>> &b);
 

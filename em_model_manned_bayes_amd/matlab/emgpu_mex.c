@@ -15,6 +15,7 @@
  *         emgpu_mex('set_prior', h, prior)         numeric or 'dbe'                                EncounterModel.m:194-203
  *         emgpu_mex('set_alpha', h, dirichlet_initial, dirichlet_transition)   cell arrays as passed to dbn_sample.m:1
  *         emgpu_mex('set_start', h, start)         double vector, 0 / NaN = unset                  bn_sample.m:44-50
+ *         emgpu_mex('save_bin', h, filename);  h = emgpu_mex('load_bin', filename)   the binary model cache (parsed model + compiled plan)
  *         emgpu_mex('free', h)
  *   devices
  *     n = emgpu_mex('device_count');   emgpu_mex('use_devices', [0 1 ...])   later sample_uncor calls are split over them
@@ -264,6 +265,19 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         mxSetField(s, 0, "resample_rates", rates);
         emgpu_model_free(m);
         plhs[0] = s;
+    } else if (!strcmp(cmd, "save_bin")) {
+        need(nrhs, 3, "emgpu_mex('save_bin', h, filename)");
+        char path[4096];
+        get_string(prhs[2], path, sizeof path);
+        check(emgpu_model_save_bin((const emgpu_model *)(uintptr_t)(*(uint64_t *)mxGetData(prhs[1])), path));
+    } else if (!strcmp(cmd, "load_bin")) {
+        need(nrhs, 2, "h = emgpu_mex('load_bin', filename)");
+        char path[4096];
+        get_string(prhs[1], path, sizeof path);
+        emgpu_model *m = NULL;
+        check(emgpu_model_load_bin(path, &m));
+        plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
+        *(uint64_t *)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)m;
     } else if (!strcmp(cmd, "from_struct")) {
         need(nrhs, 2, "h = emgpu_mex('from_struct', parms)");
         const mxArray *P = prhs[1];
@@ -458,13 +472,22 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         const size_t nl = 4 * (size_t)p.n, cap = (size_t)p.cap;
         int32_t *mo = (int32_t *)mxMalloc(sizeof(int32_t) * (nl + 1)), *rows = (int32_t *)mxMalloc(sizeof(int32_t) * (nl + 1));
         for (size_t i = 0; i < nl; i++) mo[i] = (int32_t)mxGetPr(prhs[3])[i];
-        float *out = (float *)mxMalloc(sizeof(float) * (6 * cap * nl + 1));
+        /* the library's layout: the joined track of aircraft 2e + a, [2n][W][5], row C + t = second t (include/emgpu.h) */
+        const size_t C0 = (size_t)EMGPU_TERMINAL_T0_ROW(p.cap), W = (size_t)EMGPU_TERMINAL_BLOCK_ROWS(p.cap);
+        float *out = (float *)mxCalloc((nl / 2) * W * 5 + 1, sizeof(float));
         check(emgpu_propagate_terminal_host(ctx0(), models, nm, &p, mxGetPr(prhs[2]), mo, out, rows));
         mwSize dims[3];
         dims[0] = (mwSize)nl; dims[1] = (mwSize)cap; dims[2] = 6;                                     /* out(lane, second, field) */
         plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
-        for (size_t f = 0; f < 6; f++) for (size_t t = 0; t < cap; t++) for (size_t l = 0; l < nl; l++)
-            mxGetPr(plhs[0])[(f * cap + t) * nl + l] = out[(f * cap + t) * nl + l];                  /* same order: [6][cap][4n] */
+        for (size_t l = 0; l < nl; l++) {                          /* lane 4e + 2a + backward: row r of it is row C +- r of aircraft l / 2 */
+            const size_t r_l = (size_t)(rows[l] < 0 ? -rows[l] - 1 : rows[l]);
+            const int back = (int)(l & 1);
+            for (size_t t = 0; t < cap && t < r_l; t++) {
+                const float *q = out + ((l >> 1) * W + (back ? C0 - t : C0 + t)) * 5;
+                mxGetPr(plhs[0])[(0 * cap + t) * nl + l] = back ? -(double)t : (double)t;            /* t_s */
+                for (size_t f = 1; f < 6; f++) mxGetPr(plhs[0])[(f * cap + t) * nl + l] = q[f - 1];
+            }
+        }
         if (nlhs > 1) { plhs[1] = mxCreateDoubleMatrix((mwSize)nl, 1, mxREAL); for (size_t l = 0; l < nl; l++) mxGetPr(plhs[1])[l] = rows[l]; }
         mxFree(mo); mxFree(rows); mxFree(out);
     } else if (!strcmp(cmd, "track_uncor")) {

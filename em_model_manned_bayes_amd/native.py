@@ -35,6 +35,37 @@ class NativeModel:
         L.check(L.lib().emgpu_model_load_txt(str(path).encode(), _p(idx), len(idx), int(bool(is_overwrite_zero_boundaries)), C.byref(h)))
         return cls(h.value)
 
+    def save_bin(self, path):
+        """emgpu_model_save_bin: the parsed model + its compiled plan as one binary file."""
+        L.check(L.lib().emgpu_model_save_bin(self._h, str(path).encode()))
+
+    @classmethod
+    def load_bin(cls, path):
+        """emgpu_model_load_bin; raises EmgpuError(ERR_PARSE) for a file written by another build of the library."""
+        h = C.c_void_p()
+        L.check(L.lib().emgpu_model_load_bin(str(path).encode(), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def load_cached(cls, path, idx_zero_boundaries=(1, 2, 3), is_overwrite_zero_boundaries=False, cache_dir=None):
+        """load_txt through the binary cache: `<name>.z<idx>.o<flag>.emgpubin` next to the .txt (or in cache_dir) is read when it is at
+        least as new as the .txt and was written by this build of the library; otherwise the .txt is parsed and the cache (re)written."""
+        import os
+        tag = ".z%s.o%d.emgpubin" % ("".join(str(int(i)) for i in idx_zero_boundaries), int(bool(is_overwrite_zero_boundaries)))
+        base = os.path.join(cache_dir, os.path.basename(str(path))) if cache_dir else str(path)
+        binp = base + tag
+        try:
+            if os.path.getmtime(binp) >= os.path.getmtime(str(path)):
+                return cls.load_bin(binp)
+        except (OSError, L.EmgpuError):
+            pass
+        m = cls.load_txt(path, idx_zero_boundaries, is_overwrite_zero_boundaries)
+        try:
+            m.save_bin(binp)
+        except L.EmgpuError:
+            pass   # a read-only directory: the cache is an optimisation
+        return m
+
     @classmethod
     def from_arrays(cls, G_initial, r_initial, N_initial, G_transition=None, r_transition=None, N_transition=None,
                     temporal_map=None, boundaries=None, zero_bins=None, resample_rates=None,

@@ -55,6 +55,14 @@ const char *emgpu_version(void);
 int emgpu_model_load_txt(const char *path, const int32_t *idx_zero_boundaries, int32_t n_idx,
                          int32_t is_overwrite_zero_boundaries, emgpu_model **out);
 
+/* Binary model cache: em_read parses 0.5-3 MB of text and the plan compiler then searches a quantile threshold for
+ * every count -- emgpu_model_save_bin writes the parsed model (every field of em_read.m:47-107, the priors, `start`) AND its compiled plan
+ * to one file; emgpu_model_load_bin reads it back (no parse, no search).  The file carries the hash of the library's sources
+ * (emgpu_version()): a file written by other sources is refused with EMGPU_ERR_PARSE and the caller reads the .txt again.  A loaded model
+ * is an ordinary model: setters invalidate its plan like anybody's. */
+int emgpu_model_save_bin(const emgpu_model *m, const char *path);
+int emgpu_model_load_bin(const char *path, emgpu_model **out);
+
 /* Build a model from caller arrays (the MATLAB struct contract of dbn_sample.m:25-33), so that
  * MATLAB-side edits of N_initial / N_transition / boundaries propagate.
  *   G_*: n x n row-major uint8, [parent][child] (em_read.m:204, bn_sample.m:42).

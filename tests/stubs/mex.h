@@ -38,6 +38,7 @@ int mxIsCell(const mxArray *a);
 int mxIsStruct(const mxArray *a);
 int mexAtExit(void (*fn)(void));
 void *mxMalloc(size_t n);
+void *mxCalloc(size_t n, size_t size);
 void mxFree(void *p);
 void mexErrMsgIdAndTxt(const char *id, const char *fmt, ...);
 #endif

@@ -151,6 +151,125 @@ def test_from_arrays_equals_load_txt(model_dir):
     assert np.array_equal(m.get_f64(L.F_N_TRANSITION, 6), p["native"].get_f64(L.F_N_TRANSITION, 6))
 
 
+def _model_fields(m):
+    """Everything the C ABI hands out about a model, as comparable Python values."""
+    info = (m.n_initial, m.n_transition, m.n_dyn, m.is_dynvar_depend)
+    ints = {f: m.get_i32(f).tolist() for f in (L.F_R_INITIAL, L.F_R_TRANSITION, L.F_ORDER_INITIAL, L.F_ORDER_TRANSITION, L.F_TEMPORAL_MAP, L.F_ZERO_BINS,
+                                               L.F_START, L.F_G_INITIAL, L.F_G_TRANSITION)}
+    tabs = {}
+    for v in range(1, m.n_initial + 1):
+        tabs[("Ni", v)] = m.get_f64(L.F_N_INITIAL, v).tobytes()
+        tabs[("Ai", v)] = m.get_f64(L.F_ALPHA_INITIAL, v).tobytes()
+        tabs[("b", v)] = m.get_f64(L.F_BOUNDARIES, v).tobytes()
+    for v in range(m.n_initial + 1, m.n_transition + 1):
+        tabs[("Nt", v)] = m.get_f64(L.F_N_TRANSITION, v).tobytes()
+        tabs[("At", v)] = m.get_f64(L.F_ALPHA_TRANSITION, v).tobytes()
+    rates = m.get_f64(L.F_RESAMPLE_RATES).tobytes()
+    return info, ints, tabs, rates, m.get_labels(L.F_LABELS_INITIAL), m.get_labels(L.F_LABELS_TRANSITION)
+
+
+def _plan_columns(m, cols=(0, 1, 7)):
+    """The compiled plan as the kernels read it, through the debug hooks (a model without dynamic variables: nothing)."""
+    out = []
+    for k in range(m.n_dyn):
+        for col in cols:
+            tvar, r, q, meff, mp = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32(), C.c_uint32()
+            thr = np.zeros(64, dtype=np.uint32); cthr = np.zeros(7, dtype=np.uint32)
+            rc = L.lib().emgpu_debug_dynamic_column(m._h, k, col, C.byref(tvar), C.byref(r), C.byref(q), thr.ctypes.data, C.byref(meff), cthr.ctypes.data, C.byref(mp))
+            out.append((rc, tvar.value, r.value, q.value, meff.value, mp.value, thr.tobytes(), cthr.tobytes()))
+    return out
+
+
+@pytest.mark.parametrize("name", ["uncor_1200code_v2p1", "cor_v1", "glider_v1", "haa_v1", "terminal_v3_radar_encounter_model", "balloon_v1"])
+def test_binary_cache_equals_the_txt_load(name, model_dir, tmp_path):
+    """emgpu_model_save_bin / emgpu_model_load_bin -- the parsed model (em_read.m:47-107) and its compiled plan from
+    one file.  A model read from the cache equals the model parsed from the .txt in every field the ABI exposes and in the plan's columns;
+    priors and `start` set before saving survive; a file from other sources, a truncated file and a foreign file are refused."""
+    import time
+    path = em_io.materialize_model(name, model_dir)
+    t0 = time.perf_counter()
+    a = native.NativeModel.load_txt(path)
+    cols_a = _plan_columns(a)                       # (forces the plan: what a first upload pays)
+    t1 = time.perf_counter()
+    binp = str(tmp_path / (name + ".emgpubin"))
+    a.save_bin(binp)
+    t2 = time.perf_counter()
+    b = native.NativeModel.load_bin(binp)
+    cols_b = _plan_columns(b)
+    t3 = time.perf_counter()
+    assert _model_fields(a) == _model_fields(b)
+    assert cols_a == cols_b
+    print("\n%s: .txt parse + plan %.1f ms, cache read + plan %.1f ms (file %.1f MB)" % (name, (t1 - t0) * 1e3, (t3 - t2) * 1e3, os.path.getsize(binp) / 1e6))
+    # a model with a prior and a preset keeps both
+    a.set_prior(0.5)
+    st = np.zeros(a.n_initial, dtype=np.int32); st[0] = 1
+    a.set_start(st)
+    a.save_bin(binp)
+    c = native.NativeModel.load_bin(binp)
+    assert _model_fields(a) == _model_fields(c) and c.get_i32(L.F_START)[0] == 1
+    c.set_prior(0.0)                                # a loaded model is an ordinary model: setters work and invalidate its plan
+    c.set_start(np.zeros(a.n_initial, dtype=np.int32))
+    assert _model_fields(c) == _model_fields(b) and _plan_columns(c) == cols_b
+    # refused files
+    raw = open(binp, "rb").read()
+    bad = str(tmp_path / "bad.emgpubin")
+    for blob in (raw[:12] + b"0123456789ab" + raw[24:], raw[: len(raw) // 2], b"not a model", raw + b"x"):
+        open(bad, "wb").write(blob)
+        with pytest.raises(L.EmgpuError) as e:
+            native.NativeModel.load_bin(bad)
+        assert e.value.code == L.ERR_PARSE
+    with pytest.raises(L.EmgpuError) as e:
+        native.NativeModel.load_bin(str(tmp_path / "missing.emgpubin"))
+    assert e.value.code == L.ERR_IO
+
+
+def test_load_cached_writes_reads_and_refreshes(model_dir, tmp_path):
+    import shutil
+    src = em_io.materialize_model("uncor_1200code_v1", model_dir)
+    path = str(tmp_path / "m.txt")
+    shutil.copy(src, path)
+    a = native.NativeModel.load_cached(path)
+    binp = path + ".z123.o0.emgpubin"
+    assert os.path.exists(binp)
+    b = native.NativeModel.load_cached(path)                      # from the cache
+    assert _model_fields(a) == _model_fields(b)
+    c = native.NativeModel.load_cached(path, is_overwrite_zero_boundaries=True)   # other options, another cache file
+    v = next(k for k in (1, 2, 3) if a.get_f64(L.F_BOUNDARIES, k).size > 0)
+    assert os.path.exists(path + ".z123.o1.emgpubin") and c.get_f64(L.F_BOUNDARIES, v).size == 0
+    open(binp, "wb").write(b"garbage")                             # a broken cache is ignored and rewritten
+    os.utime(binp, None)
+    d = native.NativeModel.load_cached(path)
+    assert _model_fields(a) == _model_fields(d) and os.path.getsize(binp) > 1000
+
+
+def test_number_scanner_equals_strtod(tmp_path):
+    """load_txt's own number scanner (digits -> one exact multiply or divide, strtod for the rest) returns the doubles Python's float()
+    does -- on the forms the model files use and on the ones that must take the fallback."""
+    toks = ["0", "-0", "7", "459966244", "1558178395", "0.0127706", ".5", "-.25", "5.", "1e-3", "1E+3", "-2.5e-7", "3.141592653589793", "0.1", "0.3",
+            "123456789012345678", "1234567890123456789012", "9007199254740993", "1e22", "1e23", "1.7976931348623157e308", "4.9e-324", "2.2250738585072014e-308",
+            "0.000001", "1e-22", "1e-23", "100000000000000000000", "6076.1154855643", "1.68780972222222", "0.592484", "-1500", "+12", "00012", "1.0e0",
+            "8.5e-3", "99999999999999999999e-20", "0.30000000000000004", "5e-1", "72057594037927936", "72057594037927937"]
+    rng = np.random.RandomState(3)
+    toks += ["%.17g" % v for v in rng.standard_normal(200) * 10.0 ** rng.randint(-12, 12, 200)]
+    toks += ["%d" % v for v in rng.randint(0, 2**31 - 1, 200)]
+    toks += ["%.7f" % v for v in rng.uniform(-1000, 1000, 200)]
+    want = sorted(set(float(t) for t in toks))
+    # strictly increasing boundaries of ONE variable: the values themselves, sorted (duplicates removed)
+    ordered = sorted(set(toks), key=float)
+    vals = []
+    for t in ordered:
+        if not vals or float(t) > float(vals[-1]):
+            vals.append(t)
+    r = len(vals) - 1
+    txt = "# labels_initial\n\"x\"\n# G_initial\n0\n# r_initial\n%d\n# N_initial\n%s\n# boundaries\n%s\n# resample_rates\n0\n" % (
+        r, " ".join(["1"] * r), "  ".join(vals) + " ")
+    path = str(tmp_path / "scan.txt")
+    open(path, "w").write(txt)
+    m = native.NativeModel.load_txt(path, is_overwrite_zero_boundaries=False)
+    got = m.get_f64(L.F_BOUNDARIES, 1)
+    assert got.tolist() == [float(t) for t in vals] and len(vals) > 500 and set(got.tolist()) <= set(want)
+
+
 def _oracle_bin(w, u):
     w = np.ascontiguousarray(np.asarray(w, dtype=np.float64))
     return O.lib().em_select_random_r(w.ctypes.data_as(C.c_void_p), len(w), C.c_double(u))
@@ -442,7 +561,7 @@ def test_mex_gateway_compiles():
     src = open(os.path.join(ROOT, "em_model_manned_bayes_amd", "matlab", "emgpu_mex.c")).read()
     have = set(re.findall(r'!strcmp\(cmd, "([a-z_0-9]+)"\)', src))
     assert {"load_txt", "em_read", "from_struct", "set_prior", "set_alpha", "set_start", "bn_sample", "sample_uncor", "geom_sample",
-            "propagate_terminal", "track_uncor", "sample2track", "device_count", "use_devices", "free"} <= have
+            "propagate_terminal", "track_uncor", "sample2track", "device_count", "use_devices", "free", "save_bin", "load_bin"} <= have
     used = set()
     mdir = os.path.join(ROOT, "em_model_manned_bayes_amd", "matlab")
     for base, _, files in os.walk(mdir):
