@@ -81,6 +81,7 @@ def parse_args(argv=None):
                     help="DIAGNOSTIC (tools/power_probe.sh): idle this long after every launch; the line then says so and is no benchmark line")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each entry of `configs` (2 warm-up steps before)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="minimum units timed on the CPU oracle (scaled up to ~10 s)")
+    ap.add_argument("--local-smooth", action="store_true", help="terminal: add the smoothing pass of createEncounter.m:88-89 (k_terminal_smooth: the flagged stand-in for em-core's local_smooth; a second pass over the tracks)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: allow more ranks than GPUs (ranks share devices, gloo barrier); the line says so")
     return ap.parse_args(argv)
@@ -420,6 +421,7 @@ class TerminalWorkload:
         self.rows = pl.empty((4 * n,), "int32")
         self.att = pl.empty((n,), "int32")
         self.bs = None if np.all(np.isinf(self.t.bounds_sample)) else self.t.bounds_sample
+        self.local_smooth = bool(getattr(args, "local_smooth", False))
         self.bytes_bound = 75 + 4 * 122 * 20      # geometry 5 B x 15 variables + 2 x 2 x <= 122 rows x 20 B
         self.bytes_data_dependent = True
         self.bytes_per_unit = self.bytes_bound   # replaced in check() by 75 + 20 B x the track-seconds the run really produced
@@ -429,7 +431,7 @@ class TerminalWorkload:
         from em_model_manned_bayes_amd import sharding
         first = sharding.step_first_index(k, self.rank, self.world, self.n)
         p, self._keep = self.native.terminal_sample_params(self.t.native, self.n, self.seed, self.t._dyn_rows(), first_index=first, tmax_s=120.0,
-                                                           cap=self.cap, bounds_sample=self.bs)
+                                                           cap=self.cap, bounds_sample=self.bs, local_smooth=self.local_smooth)
         self.native.sample_terminal_device(self.ctx, self.t.native, [x.native for x in self.t._traj], p, self.geom_val.data_ptr(), self.geo.data_ptr(),
                                            self.mof.data_ptr(), self.traj.data_ptr(), self.rows.data_ptr(), attempts=self.att.data_ptr())
 
@@ -437,7 +439,7 @@ class TerminalWorkload:
         self.ctx.sync()
 
     def kernel_name(self):
-        return self.ctx.last_kernel().split(" + ")[-1]   # the dominant kernel of the step's three
+        return self.ctx.last_kernel().split(" + ")[-1]   # the dominant kernel of the step's launches
 
     def check(self):
         # rows < 0: a track whose inner re-draw loop hit max_resample (the reference would spin on it, createEncounter.m:218-262)
@@ -453,8 +455,9 @@ class TerminalWorkload:
                 "output": "geometry sample f32 [15][n] + joined tracks f32 [2n][%d][5] (x y z heading speed per track-second; t_s = row number) + rows; "
                           "algorithmic bytes = 75 + 20 B x rows written = %.0f B/encounter as measured (bound: %d)"
                           % (2 * self.native.terminal_t0_row(self.cap), self.bytes_per_unit, self.bytes_bound),
-                "launches_per_step": 3, "kernels": self.ctx.last_kernel(),
-                "timed_region": "k_bn (fresh geometry draw with rejection) + k_terminal_geo + k_terminal_propagate, every step",
+                "launches_per_step": 4 if self.local_smooth else 3, "kernels": self.ctx.last_kernel(),
+                "timed_region": "k_bn (fresh geometry draw with rejection) + k_terminal_geo + k_terminal_propagate%s, every step"
+                                % (" + k_terminal_smooth (createEncounter.m:88-89 through the documented stand-in for em-core's local_smooth)" if self.local_smooth else ""),
                 "sharding": "global encounter index, no collective",
                 "track_seconds_per_encounter": getattr(self, "track_seconds", None),
                 "geometry_attempts_per_encounter": getattr(self, "geom_attempts", None),

@@ -23,7 +23,7 @@ F_N_INITIAL, F_N_TRANSITION, F_ALPHA_INITIAL, F_ALPHA_TRANSITION, F_BOUNDARIES, 
 F_LABELS_INITIAL, F_LABELS_TRANSITION = 64, 65
 
 TRANSITION_REFERENCE_AUTO, TRANSITION_PER_STEP = 0, 1
-FLAG_QUANTIZE500, FLAG_NO_RESAMPLE, FLAG_NO_DEDISC, FLAG_NO_TERMINATOR = 1, 2, 4, 8
+FLAG_QUANTIZE500, FLAG_NO_RESAMPLE, FLAG_NO_DEDISC, FLAG_NO_TERMINATOR, FLAG_LOCAL_SMOOTH = 1, 2, 4, 8, 16
 
 # MATLAB error identifiers the reference raises for the same condition
 _MATLAB_IDS = {
@@ -81,7 +81,7 @@ class UTrackParams(C.Structure):  # emgpu_utrack_params
 
 class TTrackParams(C.Structure):  # emgpu_ttrack_params
     _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("tmax_s", C.c_double),
-                ("max_resample", C.c_int32), ("max_track_attempts", C.c_int32), ("max_attempts", C.c_int32), ("_pad", C.c_int32),
+                ("max_resample", C.c_int32), ("max_track_attempts", C.c_int32), ("max_attempts", C.c_int32), ("flags", C.c_uint32),
                 ("dyn_limits", C.c_double * 10), ("max_cum_turn_deg", C.c_double * 2), ("pitch_deg", C.c_double * 2),
                 ("min_enc_time_s", C.c_double), ("thres_dist_ft", C.c_double), ("thres_alt_low_ft", C.c_double), ("thres_vertrate_ft_s", C.c_double),
                 ("bounds_sample", C.c_void_p), ("idx", C.c_int32 * 12)]
@@ -99,7 +99,7 @@ class TrackParams(C.Structure):   # emgpu_track_params
 
 class TermParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("tmax_s", C.c_double),
-                ("max_resample", C.c_int32), ("cap", C.c_int32), ("dyn_limits", C.c_double * 10)]
+                ("max_resample", C.c_int32), ("cap", C.c_int32), ("dyn_limits", C.c_double * 10), ("flags", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class TSampleParams(C.Structure):

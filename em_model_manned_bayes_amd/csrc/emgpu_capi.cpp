@@ -1135,8 +1135,13 @@ int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *mo
     memcpy(A.dl, p->dyn_limits, sizeof A.dl);
     A.traj = traj; A.rows = rows; A.status = ctx->d_status; A.queue = ctx->d_queue;
     const char *name = "";
+    if ((p->flags & EMGPU_FLAG_LOCAL_SMOOTH) && EMGPU_TERMINAL_BLOCK_ROWS(p->cap) > 256) return fail(EMGPU_ERR_UNSUPPORTED, "EMGPU_FLAG_LOCAL_SMOOTH: cap above 128");
     hipError_t e = emgpu::launch_terminal_propagate(first->cp.plan, A, ctx->stream, &name);
     ctx->last_kernel = name;
+    if (e == hipSuccess && (p->flags & EMGPU_FLAG_LOCAL_SMOOTH)) {
+        e = emgpu::launch_terminal_smooth(traj, rows, 2 * p->n, p->cap, ctx->stream);
+        ctx->last_kernel += " + k_terminal_smooth";
+    }
     if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return EMGPU_OK;
     EMGPU_CATCH
@@ -1231,6 +1236,12 @@ int emgpu_sample_terminal_device(emgpu_ctx *ctx, const emgpu_model *gm, const em
     if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     ctx->last_kernel = kernels + " + " + name;
     ctx->last_launches = 3;
+    if (p->flags & EMGPU_FLAG_LOCAL_SMOOTH) {
+        e = emgpu::launch_terminal_smooth(traj, rows, 2 * p->n, p->cap, ctx->stream);
+        if (e != hipSuccess) return fail(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+        ctx->last_kernel = kernels + " + k_terminal_smooth + " + name;   // (the dominant kernel stays last in the list)
+        ctx->last_launches = 4;
+    }
     return EMGPU_OK;
     EMGPU_CATCH
 }
@@ -1310,6 +1321,11 @@ int emgpu_track_terminal_host(emgpu_ctx *ctx, const emgpu_model *gm, const emgpu
             e = emgpu::launch_terminal_propagate(first->cp.plan, A, ctx->stream, &name);
             if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
             kernels += std::string(" + ") + name;
+            if (p->flags & EMGPU_FLAG_LOCAL_SMOOTH) {   // createEncounter.m:88-89 (stand-in): the filters read the smoothed speed and altitude
+                e = emgpu::launch_terminal_smooth(d_out, d_rows, 2 * (int64_t)count, cap, ctx->stream);
+                if (e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+                kernels += " + k_terminal_smooth";
+            }
             // the filters (track.m:62-145)
             EmgpuTFilterRun F;
             memset(&F, 0, sizeof F);

@@ -212,6 +212,54 @@ __global__ void __launch_bounds__(256) k_terminal_filter(const EmgpuTFilterRun A
     }
 }
 
+// createEncounter.m:88-89, the stand-in for em-core's local_smooth (EMGPU_FLAG_LOCAL_SMOOTH in include/emgpu.h; oracle: em_local_smooth): one
+// wave per joined track, its speed and altitude columns in LDS, row i = the mean of rows i-k..i+k summed in ascending order in f64.
+__global__ void __launch_bounds__(256) k_terminal_smooth(float *traj, const int32_t *rows, int64_t n2, int32_t cap) {
+#pragma clang fp contract(off)
+    // the track's rows as they lie in memory (contiguous: read and written back as whole lines; a pass that touched only the two columns
+    // would still move every 32-byte sector of the block both ways)
+    __shared__ float s_rows[4][256 * 5];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t a = (int64_t)blockIdx.x * 4 + w;           // aircraft 2e + a
+    if (a >= n2) return;
+    const int rf = rows[2 * a], rb = rows[2 * a + 1];
+    if (rf < 1 || rb < 1) return;                             // a void attempt: nobody reads it
+    const int C0 = EMGPU_TERMINAL_T0_ROW(cap), W = 2 * C0;
+    const int lo = C0 - (rb - 1), n = rf + rb - 1;
+    float *base = traj + ((size_t)a * (size_t)W + (size_t)lo) * 5;
+    float *sr = s_rows[w];
+    for (int j = lane; j < 5 * n; j += 64) sr[j] = base[j];
+    __builtin_amdgcn_wave_barrier();
+    float out[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int i = lane + 64 * it;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            int k = c ? 7 : 2;                                // (w - 1) / 2 of w = 15 (altitude), 5 (speed)
+            k = i < k ? i : k; k = n - 1 - i < k ? n - 1 - i : k;
+            double sum = 0.0;
+            if (i < n) for (int q = i - k; q <= i + k; q++) sum += (double)sr[q * 5 + (c ? 2 : 4)];
+            out[it][c] = (float)(sum / (double)(2 * k + 1));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int i = lane + 64 * it;
+        if (i < n) { sr[i * 5 + 4] = out[it][0]; sr[i * 5 + 2] = out[it][1]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < 5 * n; j += 64) __builtin_nontemporal_store(sr[j], &base[j]);
+}
+
+hipError_t launch_terminal_smooth(float *traj, const int32_t *rows, int64_t n2, int32_t cap, hipStream_t s) {
+    if (n2 <= 0) return hipSuccess;
+    if (EMGPU_TERMINAL_BLOCK_ROWS(cap) > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_terminal_smooth, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, s, traj, rows, n2, cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_terminal_geo(const EmgpuTGeoRun &A, hipStream_t s) {
     if (A.n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_terminal_geo, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, s, A);

@@ -27,6 +27,8 @@ void step_parent_masks(const EmgpuPlan &P, uint32_t *cur_mask, uint32_t *new_mas
 hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
 hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, hipStream_t s, const char **name);
 int terminal_debug_counters(unsigned long long *out, int n);   // -DEMGPU_TERM_COUNTERS builds: the loop's path counters (0: not such a build)
+// createEncounter.m:88-89 through the stand-in of EMGPU_FLAG_LOCAL_SMOOTH: v_ft_s (5 s) and z_ft (15 s) of n2 joined tracks, in place
+hipError_t launch_terminal_smooth(float *traj, const int32_t *rows, int64_t n2, int32_t cap, hipStream_t s);
 hipError_t launch_terminal_geo(const EmgpuTGeoRun &A, hipStream_t s);
 hipError_t launch_terminal_filter(const EmgpuTFilterRun &A, hipStream_t s, const char **name);
 hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char **name, int force_literal = 0);

@@ -579,11 +579,12 @@ class CorTerminalModel(EncounterModel):
         keys = ("minVel_ft_s", "maxVel_ft_s", "maxTurnRate_deg_s", "maxAltitude_ft", "maxVertRate_ft_s")
         return np.array([[self.dynLimits1[k] for k in keys], [self.dynLimits2[k] for k in keys]], dtype=np.float64)
 
-    def createEncounter(self, sample_geo, tmax_s=120, seed=None, first_index=None, ctx=None):
+    def createEncounter(self, sample_geo, tmax_s=120, seed=None, first_index=None, ctx=None, local_smooth=True):
         """traj = createEncounter(self, sample_geo, tmax_s)  (createEncounter.m:1): a list of two dicts with
         t_s, x_nm, y_nm, z_ft, heading_deg, v_ft_s sorted in time.  sample_geo may be one dict or a list of
-        dicts (then a list of pairs is returned).  em-core's local_smooth of speed and altitude (:88-89) is
-        not applied."""
+        dicts (then a list of pairs is returned).  local_smooth: speed and altitude smoothed over 5 / 15 s like :88-89 -- em-core's
+        local_smooth is not vendored by the reference, so this is the library's stand-in (EMGPU_FLAG_LOCAL_SMOOTH in include/emgpu.h: a centred
+        moving average whose window shrinks at a track's ends), UNPINNED; False returns the propagated values as they are."""
         if self._traj is None:
             raise NotImplementedError("the terminal trajectory-model files are not in parameters_directory (they are absent from the "
                                       "reference mount); synthetic.write_terminal_directory builds stand-ins")
@@ -595,7 +596,8 @@ class CorTerminalModel(EncounterModel):
         g, mo = self._geo_rows(samples)
         cap = int(tmax_s) + 3
         traj, rows = native.propagate_terminal_joined_host(ctx or native.default_context(), [m.native for m in self._traj], g, mo, s,
-                                                           first_index=first, tmax_s=float(tmax_s), dyn_limits=self._dyn_rows(), cap=cap)
+                                                           first_index=first, tmax_s=float(tmax_s), dyn_limits=self._dyn_rows(), cap=cap,
+                                                           local_smooth=local_smooth)
         res = []
         fields = ("x_nm", "y_nm", "z_ft", "heading_deg", "v_ft_s")
         for e_ in range(len(samples)):
@@ -615,7 +617,7 @@ class CorTerminalModel(EncounterModel):
         return res[0] if single else res
 
     def track(self, nSamples, initialSeed=None, firstID=1, minEncTime_s=30, thresDist_ft=2.5 * 6076, thresAltLow_ft=750,
-              thresVertRate_ft_s=300 / 60, max_track_attempts=500, first_index=None, ctx=None, return_info=False):
+              thresVertRate_ft_s=300 / 60, max_track_attempts=500, first_index=None, ctx=None, return_info=False, local_smooth=True):
         """[out_results, gen_time_s] = track(self, nSamples, 'initialSeed', s, 'firstID', 1, 'minEncTime_s', 30, ...)
         (@CorTerminalModel/track.m).  out_results[i] = {"sample": dict of the geometry sample + id, tcpa, hmd_ft, vmd_ft, nmac, ...,
         "traj": [ownship, intruder]} with each trajectory cut to the common time span and re-based like reformatTrajFiles
@@ -623,7 +625,8 @@ class CorTerminalModel(EncounterModel):
 
         Runs on the GPU in rounds (geometry draw -> createEncounter inputs -> propagation -> filters, attempt j under the key
         initialSeed + j).  Unpinned pieces: em-core's computeVerticalRate / computeHeadingRate are forward differences here,
-        `isClimb` (track.m:122,134, undefined in the reference) is read as is_climb, local_smooth is not applied; the
+        `isClimb` (track.m:122,134, undefined in the reference) is read as is_climb, local_smooth (createEncounter.m:88-89) is the library's
+        stand-in (see createEncounter; local_smooth=False: the filters read the unsmoothed tracks); the
         trajectory-model files must be in parameters_directory (synthetic.write_terminal_directory builds stand-ins)."""
         if self._traj is None:
             raise NotImplementedError("the terminal trajectory-model files are not in parameters_directory (they are absent from the "
@@ -638,7 +641,8 @@ class CorTerminalModel(EncounterModel):
         res = native.track_terminal_host(ctx or native.default_context(), self.native, [m.native for m in self._traj], int(nSamples), s,
                                          self._dyn_rows(), [x["maxCumTurn_deg"] for x in d], [x["pitch_deg"] for x in d], first_index=first,
                                          min_enc_time_s=minEncTime_s, thres_dist_ft=thresDist_ft, thres_alt_low_ft=thresAltLow_ft,
-                                         thres_vertrate_ft_s=thresVertRate_ft_s, bounds_sample=bs, max_track_attempts=max_track_attempts)
+                                         thres_vertrate_ft_s=thresVertRate_ft_s, bounds_sample=bs, max_track_attempts=max_track_attempts,
+                                         local_smooth=local_smooth)
         names = [lab.replace('"', "") for lab in self.labels_initial]
         out = []
         for i in range(int(nSamples)):

@@ -398,7 +398,7 @@ def terminal_t0_row(cap):
 
 
 def propagate_terminal_joined_host(ctx, models, geo, model_of, seed, first_index=0, tmax_s=120.0, dyn_limits=None,
-                                   max_resample=100000, cap=None):
+                                   max_resample=100000, cap=None, local_smooth=False):
     """emgpu_propagate_terminal_host: PropagateTrajectory for 4 tracks per encounter (createEncounter.m:52-72) in the library's
     own layout.  models: list of NativeModel (stay prior already applied); geo [n, 12]; model_of [n, 4].
     Returns (traj [2n, 2 C, 5] f32, C = terminal_t0_row(cap): the joined track of aircraft 2e + a, row C + t = second t, fields x_nm y_nm z_ft
@@ -411,6 +411,7 @@ def propagate_terminal_joined_host(ctx, models, geo, model_of, seed, first_index
     p = L.TermParams()
     p.seed, p.first_index, p.n, p.tmax_s = int(seed) & (2**64 - 1), int(first_index), n, float(tmax_s)
     p.max_resample, p.cap = int(max_resample), cap
+    p.flags = L.FLAG_LOCAL_SMOOTH if local_smooth else 0
     dl = np.asarray(dyn_limits, dtype=np.float64).reshape(10)
     for i in range(10):
         p.dyn_limits[i] = float(dl[i])
@@ -439,11 +440,11 @@ def split_joined_tracks(traj, rows, cap):
 
 
 def propagate_terminal_host(ctx, models, geo, model_of, seed, first_index=0, tmax_s=120.0, dyn_limits=None,
-                            max_resample=100000, cap=None):
+                            max_resample=100000, cap=None, local_smooth=False):
     """propagate_terminal_joined_host, returned per PropagateTrajectory call like the reference does:
     (out [4n, cap, 6] f32 as t_s x_nm y_nm z_ft heading_deg v_ft_s, rows [4n])."""
     cap = int(cap or (int(tmax_s) + 3))
-    traj, rows = propagate_terminal_joined_host(ctx, models, geo, model_of, seed, first_index, tmax_s, dyn_limits, max_resample, cap)
+    traj, rows = propagate_terminal_joined_host(ctx, models, geo, model_of, seed, first_index, tmax_s, dyn_limits, max_resample, cap, local_smooth)
     return split_joined_tracks(traj, rows, cap), rows
 
 
@@ -490,13 +491,14 @@ TERMINAL_GEO_FIELDS = ("distance", "bearing", "alt", "speed", "heading", "intent
 
 
 def terminal_sample_params(geom_model, n, seed, dyn_limits, first_index=0, tmax_s=120.0, cap=None, bounds_sample=None,
-                           max_attempts=100000, max_resample=100000):
+                           max_attempts=100000, max_resample=100000, local_smooth=False):
     """emgpu_tsample_params for emgpu_sample_terminal_device; returns (params, keep-alive) -- the variable ids are looked up by label like
     @CorTerminalModel/sample.m:56-62 / createEncounter.m:45-49."""
     labels = [s.strip('"') for s in geom_model.get_labels(L.F_LABELS_INITIAL)]
     p = L.TSampleParams()
     p.seed, p.first_index, p.n, p.tmax_s = int(seed) & (2**64 - 1), int(first_index), int(n), float(tmax_s)
     p.max_resample, p.cap, p.max_attempts = int(max_resample), int(cap or (int(tmax_s) + 3)), int(max_attempts)
+    p.flags = L.FLAG_LOCAL_SMOOTH if local_smooth else 0
     for i, v in enumerate(np.asarray(dyn_limits, dtype=np.float64).reshape(10)):
         p.dyn_limits[i] = float(v)
     bs = None
@@ -520,13 +522,14 @@ def sample_terminal_device(ctx, geom_model, traj_models, p, geom_val, geo, model
 
 def track_terminal_host(ctx, geom_model, traj_models, n, seed, dyn_limits, max_cum_turn_deg, pitch_deg, first_index=0, tmax_s=120.0,
                         min_enc_time_s=30.0, thres_dist_ft=2.5 * 6076, thres_alt_low_ft=750.0, thres_vertrate_ft_s=300.0 / 60.0,
-                        bounds_sample=None, max_track_attempts=500, max_attempts=100000, max_resample=100000, allow_cap=False):
+                        bounds_sample=None, max_track_attempts=500, max_attempts=100000, max_resample=100000, allow_cap=False, local_smooth=False):
     """emgpu_track_terminal_host: CorTerminalModel.track (track.m:45-150) on the GPU.  Returns dict: sample [n, n_i], traj [n, 2, cap2, 6]
     (t_s x_nm y_nm z_ft heading_deg v_ft_s, time-ordered), len [n, 2], meta [n, 4] (tcpa_s hmd_ft vmd_ft enc_time_s), attempts [n]."""
     labels = [s.strip('"') for s in geom_model.get_labels(L.F_LABELS_INITIAL)]
     p = L.TTrackParams()
     p.seed, p.first_index, p.n, p.tmax_s = int(seed) & (2**64 - 1), int(first_index), int(n), float(tmax_s)
     p.max_resample, p.max_track_attempts, p.max_attempts = int(max_resample), int(max_track_attempts), int(max_attempts)
+    p.flags = L.FLAG_LOCAL_SMOOTH if local_smooth else 0
     for i, v in enumerate(np.asarray(dyn_limits, dtype=np.float64).reshape(10)):
         p.dyn_limits[i] = float(v)
     for a in range(2):

@@ -157,6 +157,9 @@ enum { EMGPU_TRANSITION_REFERENCE_AUTO = 0, EMGPU_TRANSITION_PER_STEP = 1 };
 #define EMGPU_FLAG_NO_RESAMPLE 2u /* skip resample_events (plain dbn_sample.m semantics)           */
 #define EMGPU_FLAG_NO_DEDISC 4u   /* skip dediscretize: values are the bin indices                 */
 #define EMGPU_FLAG_NO_TERMINATOR 8u /* event lists end without the [T-sum(dt) 0 0] row            */
+#define EMGPU_FLAG_LOCAL_SMOOTH 16u /* terminal tracks: smooth speed (5 s) and altitude (15 s) like createEncounter.m:88-89.  local_smooth is
+                                       em-core's (not vendored: UNPINNED); the stand-in is a centred moving average whose window shrinks
+                                       symmetrically at a track's ends (row i = mean of rows i-k..i+k, k = min((w-1)/2, i, n-1-i)) */
 
 typedef struct {
     uint64_t seed;        /* Philox key.  'seed' of .sample (UncorEncounterModel.m:201)            */
@@ -280,8 +283,8 @@ int emgpu_sample_bn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_bn_pa
 
 /* ------------------------------------------------------------------------------------------------
  * Terminal trajectory propagation: replaces PropagateTrajectory (@CorTerminalModel/createEncounter.m:
- * 93-265) for both aircraft and both directions of n encounters (createEncounter.m:52-72), without
- * em-core's local_smooth (:88-89).  models[]: trajectory models with the 6 initial variables
+ * 93-265) for both aircraft and both directions of n encounters (createEncounter.m:52-72); em-core's
+ * local_smooth (:88-89) only as the stand-in of EMGPU_FLAG_LOCAL_SMOOTH.  models[]: trajectory models with the 6 initial variables
  * {intent, distance, bearing, heading, altitude, speed} and 3 dynamic ones, all of the same shapes and
  * boundaries; the caller has applied setTransitionPriors(...,1) (createEncounter.m:129) through
  * emgpu_model_set_transition_stay_prior.
@@ -307,6 +310,7 @@ typedef struct {
     int32_t max_resample, cap;   /* inner re-draw cap (reference: unbounded); rows per direction   */
     double dyn_limits[2][5];     /* per aircraft: minVel_ft_s maxVel_ft_s maxTurnRate_deg_s
                                     maxAltitude_ft maxVertRate_ft_s (getDynamicLimits.m:15-62)     */
+    uint32_t flags, _pad;        /* EMGPU_FLAG_LOCAL_SMOOTH: the joined tracks' v_ft_s and z_ft are smoothed in place (:88-89)  */
 } emgpu_term_params;
 int emgpu_propagate_terminal_device(emgpu_ctx *ctx, const emgpu_model *const *models, int32_t n_models,
                                     const emgpu_term_params *p, const double *geo, const int32_t *model_of,
@@ -330,7 +334,7 @@ typedef struct {
     int32_t max_resample, cap;
     double dyn_limits[2][5];
     int32_t max_attempts;            /* cap of the geometry rejection loop (sample.m:32; unbounded in the reference) */
-    uint32_t flags;                  /* reserved, 0                                                          */
+    uint32_t flags;                  /* EMGPU_FLAG_LOCAL_SMOOTH                                              */
     const double *bounds_sample;     /* HOST pointer: n_initial x 2 row-major or NULL (sample.m:45-53)       */
     int32_t idx[12];                 /* 1-based geometry variable ids: own {distance bearing alt speed heading intent}, then int */
 } emgpu_tsample_params;
@@ -406,7 +410,8 @@ int emgpu_uncor_dynamic_limits(const emgpu_model *m, const emgpu_utrack_params *
  * emgpu_track_uncor_*: attempt j of every encounter uses the Philox key seed + j (the reference continues one MT19937 stream,
  * track.m:36-58) and the encounter's global index; a track that hits the re-draw cap voids its attempt.
  * em-core's computeVerticalRate / computeHeadingRate (not vendored) are forward differences of the 1 s samples; `isClimb`
- * (track.m:122,134, undefined in the reference) is read as is_climb; local_smooth (createEncounter.m:88-89) is not applied.
+ * (track.m:122,134, undefined in the reference) is read as is_climb; local_smooth (createEncounter.m:88-89) is the flagged stand-in of
+ * EMGPU_FLAG_LOCAL_SMOOTH (off: the filters read the unsmoothed tracks).
  *   geom_model   the 15-variable geometry network; traj_models[10] in CorTerminalModel.m:84-100 order with the stay prior set
  *   sample   [n][n_initial(geom)] f64   the accepted geometry sample (out_results(ii).sample, track.m:158)
  *   traj     [n][2][cap2][6] f64        ownship / intruder, time-ordered: t_s x_nm y_nm z_ft heading_deg v_ft_s (createEncounter.m:74-84)
@@ -420,7 +425,7 @@ typedef struct {
     int32_t max_resample;            /* re-draw cap inside PropagateTrajectory                             */
     int32_t max_track_attempts;      /* cap of the while of track.m:55 (unbounded in the reference)        */
     int32_t max_attempts;            /* cap of the geometry rejection loop (sample.m:32)                   */
-    int32_t _pad;
+    uint32_t flags;                  /* EMGPU_FLAG_LOCAL_SMOOTH: the filters read the smoothed tracks, like the reference's (:88-89) */
     double dyn_limits[2][5];         /* per aircraft: minVel maxVel maxTurnRate_deg_s maxAltitude maxVertRate (getDynamicLimits.m:15-62) */
     double max_cum_turn_deg[2], pitch_deg[2];
     double min_enc_time_s, thres_dist_ft, thres_alt_low_ft, thres_vertrate_ft_s;  /* track.m:14-17 */

@@ -1307,6 +1307,7 @@ typedef struct {
     int32_t idx[12];            /* 1-based variable ids: own {distance bearing alt speed heading intent}, then int */
     double min_enc_time_s, thres_dist_ft, thres_alt_low_ft, thres_vertrate_ft_s;   /* track.m:14-17 */
     double max_cum_turn_deg[2], pitch_deg[2];                                       /* getDynamicLimits.m */
+    int32_t local_smooth, pad;  /* createEncounter.m:88-89 through the stand-in below */
 } em_ttrack_opts_t;
 
 typedef struct { int n; double t[260], x[260], y[260], z[260], hdg[260], v[260]; } em_traj_t;
@@ -1465,6 +1466,20 @@ int em_terminal_filters(const em_traj_t *tr, int own_intent, int int_intent, con
     return is_long && prox1 && prox2 && own_ok && int_ok && dyn1 && dyn2;                    /* :144 */
 }
 
+/* createEncounter.m:88-89: traj.v_ft_s = local_smooth(t_s, v_ft_s, 5); traj.z_ft = local_smooth(t_s, z_ft, 15).  local_smooth lives in  */
+/* em-core, which the reference does not vendor: UNPINNED.  The stand-in (the same in csrc/emgpu_kernels_tfilter.hip): a centred moving  */
+/* average over w samples of the 1 s track, the window shrunk symmetrically at the ends -- row i becomes the mean of rows i-k .. i+k,    */
+/* k = min((w-1)/2, i, n-1-i) (MATLAB smooth()'s rule for a moving average) --, summed in ascending row order in f64.                    */
+void em_local_smooth(const double *x, int n, int w, double *out) {
+    const int h = (w - 1) / 2;
+    for (int i = 0; i < n; i++) {
+        int k = h; if (i < k) k = i; if (n - 1 - i < k) k = n - 1 - i;
+        double s = 0;
+        for (int q = i - k; q <= i + k; q++) s += x[q];
+        out[i] = s / (double)(2 * k + 1);
+    }
+}
+
 /* forward + backward tracks of one aircraft, as the device stores them (f32), merged and ordered in time (createEncounter.m:74-84) */
 static void em_merge_tracks(const double *fwd, int rf, const double *bck, int rb, int f32, em_traj_t *out) {
     int n = 0;
@@ -1519,6 +1534,14 @@ int64_t em_terminal_track_batch(const em_model_t *const *models, uint64_t seed, 
             if (prc != 0) { em_margin_ptr = NULL; continue; }
             em_traj_t tr[2];
             for (int a = 0; a < 2; a++) em_merge_tracks(out4 + (size_t)(2 * a) * cap * 6, rows[2 * a], out4 + (size_t)(2 * a + 1) * cap * 6, rows[2 * a + 1], f32, &tr[a]);
+            if (o->local_smooth)
+                for (int a = 0; a < 2; a++) {
+                    double tmp[260];
+                    em_local_smooth(tr[a].v, tr[a].n, 5, tmp);
+                    for (int r = 0; r < tr[a].n; r++) tr[a].v[r] = f32 ? (double)(float)tmp[r] : tmp[r];
+                    em_local_smooth(tr[a].z, tr[a].n, 15, tmp);
+                    for (int r = 0; r < tr[a].n; r++) tr[a].z[r] = f32 ? (double)(float)tmp[r] : tmp[r];
+                }
             double mt[4];
             const int good = em_terminal_filters(tr, oi, ii_, dl, o, mt);
             em_margin_ptr = NULL;

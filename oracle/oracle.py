@@ -637,7 +637,16 @@ def uncor_track(om, n, T, seed, mode=RNG_PHILOX, first_index=0, is_quantize500=F
 
 class _TTrackOpts(C.Structure):
     _fields_ = [("idx", C.c_int32 * 12), ("min_enc_time_s", C.c_double), ("thres_dist_ft", C.c_double), ("thres_alt_low_ft", C.c_double),
-                ("thres_vertrate_ft_s", C.c_double), ("max_cum_turn_deg", C.c_double * 2), ("pitch_deg", C.c_double * 2)]
+                ("thres_vertrate_ft_s", C.c_double), ("max_cum_turn_deg", C.c_double * 2), ("pitch_deg", C.c_double * 2),
+                ("local_smooth", C.c_int32), ("pad", C.c_int32)]
+
+
+def local_smooth(x, w):
+    """The stand-in for em-core's local_smooth (createEncounter.m:88-89; UNPINNED): em_local_smooth of em_oracle.c."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros_like(x)
+    lib().em_local_smooth(_ptr(x), C.c_int(x.size), C.c_int(int(w)), _ptr(out))
+    return out
 
 
 def check_cum_turn(heading_deg, limit):
@@ -648,7 +657,7 @@ def check_cum_turn(heading_deg, limit):
 
 def terminal_track(gom, oms, n, seed, dyn_limits, max_cum_turn_deg, pitch_deg, first_index=0, tmax_s=120.0, min_enc_time_s=30.0,
                    thres_dist_ft=2.5 * 6076, thres_alt_low_ft=750.0, thres_vertrate_ft_s=5.0, bounds_sample=None, max_track_attempts=500,
-                   max_attempts=100000, max_resample=100000, f32=True, margin_cap=None):
+                   max_attempts=100000, max_resample=100000, f32=True, margin_cap=None, local_smooth=False):
     """CorTerminalModel.track restated (track.m:45-150), Philox mode.  gom: geometry OracleModel; oms: the 10 trajectory OracleModels with the
     stay prior.  Returns dict like native.track_terminal_host."""
     L = lib()
@@ -661,6 +670,7 @@ def terminal_track(gom, oms, n, seed, dyn_limits, max_cum_turn_deg, pitch_deg, f
     o.min_enc_time_s, o.thres_dist_ft, o.thres_alt_low_ft, o.thres_vertrate_ft_s = min_enc_time_s, thres_dist_ft, thres_alt_low_ft, thres_vertrate_ft_s
     for a in range(2):
         o.max_cum_turn_deg[a], o.pitch_deg[a] = float(max_cum_turn_deg[a]), float(pitch_deg[a])
+    o.local_smooth = int(bool(local_smooth))
     go = _GeomOpts()
     bs = None
     if bounds_sample is not None:

@@ -802,13 +802,20 @@ def test_terminal_propagation_matches_oracle(actypes, terminal_dir, gpu_ctx):
         r = rows[L_]
         np.testing.assert_allclose(got[L_, :r], ref[L_, :r], rtol=1e-6, atol=1e-6)
     # the class method: forward + backward combined and ordered in time (createEncounter.m:74-84)
-    traj = t.createEncounter(samples[:5], 120, seed=seed, ctx=gpu_ctx)
+    traj = t.createEncounter(samples[:5], 120, seed=seed, ctx=gpu_ctx, local_smooth=False)
+    smooth = t.createEncounter(samples[:5], 120, seed=seed, ctx=gpu_ctx)        # the default: createEncounter.m:88-89 through the stand-in
     for e_, pair in enumerate(traj):
         for a in range(2):
             tt = pair[a]["t_s"]
             assert np.all(np.diff(tt) == 1) and tt[0] <= 0 <= tt[-1]
             k0 = int(np.nonzero(tt == 0)[0][0])
             assert abs(pair[a]["v_ft_s"][k0] - samples[e_][("own", "int")[a] + "_speed"]) < 1e-3
+            sm = smooth[e_][a]
+            for f in ("t_s", "x_nm", "y_nm", "heading_deg"):
+                assert np.array_equal(sm[f], pair[a][f])
+            np.testing.assert_allclose(sm["v_ft_s"], O.local_smooth(pair[a]["v_ft_s"], 5), rtol=1e-6)
+            np.testing.assert_allclose(sm["z_ft"], O.local_smooth(pair[a]["z_ft"], 15), rtol=1e-6)
+
 
 
 def test_terminal_ten_million_encounters_properties(terminal_dir):
@@ -875,9 +882,10 @@ def test_terminal_ten_million_encounters_properties(terminal_dir):
     assert 300 < total_seconds / (5 * n) < 488        # mean track-seconds per encounter (4 tracks x <= 122)
 
 
-@pytest.mark.parametrize("actypes,n,cap,cum_override", [(("GENERIC", "GENERIC"), 2000, 150, None), (("GENERIC", "RTCA228_A1"), 120, 600, None),
-                                                        (("RTCA228_A3", "RTCA228_A2"), 120, 600, None), (("GENERIC", "GENERIC"), 600, 150, (40.0, 40.0))])
-def test_terminal_track_matches_oracle(actypes, n, cap, cum_override, terminal_dir, gpu_ctx):
+@pytest.mark.parametrize("actypes,n,cap,cum_override,smooth", [(("GENERIC", "GENERIC"), 2000, 150, None, False), (("GENERIC", "RTCA228_A1"), 120, 600, None, False),
+                                                               (("RTCA228_A3", "RTCA228_A2"), 120, 600, None, False), (("GENERIC", "GENERIC"), 600, 150, (40.0, 40.0), False),
+                                                               (("GENERIC", "GENERIC"), 1000, 150, None, True), (("GENERIC", "RTCA228_A1"), 120, 600, None, True)])
+def test_terminal_track_matches_oracle(actypes, n, cap, cum_override, smooth, terminal_dir, gpu_ctx):
     """CorTerminalModel.track (track.m:45-150) on the GPU -- rounds of geometry draw -> createEncounter inputs -> propagation ->
     the filters of CorTerminalModel.m:117-316 -- against the oracle's per-encounter loop on the same Philox keys (attempt j:
     seed + j).  EVERY encounter must accept the same attempt (or stay rejected through the cap on both sides), except where the
@@ -900,9 +908,12 @@ def test_terminal_track_matches_oracle(actypes, n, cap, cum_override, terminal_d
     if cum_override:
         cum = list(cum_override)
     seed = 0xF2
-    ref = O.terminal_track(gom, oms, n, seed, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap)
+    # smooth: EMGPU_FLAG_LOCAL_SMOOTH on both sides -- createEncounter.m:88-89 through the documented stand-in (em-core's local_smooth is not
+    # vendored: UNPINNED); the filters then read the smoothed speed and altitude, like the reference's
+    ref = O.terminal_track(gom, oms, n, seed, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap, local_smooth=smooth)
     got = native.track_terminal_host(gpu_ctx, t.native, [m.native for m in t._traj], n, seed, t._dyn_rows(), cum, pitch, first_index=5,
-                                     max_track_attempts=cap, allow_cap=True)   # encounters still rejected after `cap` attempts: -1 on both sides
+                                     max_track_attempts=cap, allow_cap=True, local_smooth=smooth)   # encounters still rejected after `cap` attempts: -1 on both sides
+    assert ("k_terminal_smooth" in got["kernel"]) == smooth
     if (ref["attempts"] < 0).any() and n <= 200:
         with pytest.raises(L.EmgpuError) as ei:
             native.track_terminal_host(gpu_ctx, t.native, [m.native for m in t._traj], n, seed, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap)
@@ -914,7 +925,7 @@ def test_terminal_track_matches_oracle(actypes, n, cap, cum_override, terminal_d
     if actypes == ("GENERIC", "GENERIC"):   # (the RTCA limits -- pitch 15 deg, cumulative turn 180 deg, narrow speed bands -- reject most synthetic tracks:
         assert ok.sum() >= n // 5 and (ref["attempts"][ok] > 1).any()   #  there the test is that both sides reject the same attempts)
     if cum_override:   # CheckCumTurn decides: without the limit the same encounters accept an earlier attempt
-        free = O.terminal_track(gom, oms, n, seed, t._dyn_rows(), [np.inf, np.inf], pitch, first_index=5, max_track_attempts=cap)
+        free = O.terminal_track(gom, oms, n, seed, t._dyn_rows(), [np.inf, np.inf], pitch, first_index=5, max_track_attempts=cap, local_smooth=smooth)
         decided = (free["attempts"] > 0) & (free["attempts"] != ref["attempts"])
         assert decided.sum() >= n // 20, decided.sum()
     assert np.array_equal(got["sample"][ok], ref["sample"][ok]) and np.array_equal(got["len"][ok], ref["len"][ok])

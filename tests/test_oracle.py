@@ -347,3 +347,11 @@ def test_golden_sample2track():
     assert np.array_equal(xyz, g["xyz"]) and np.array_equal(flags, g["flags"]) and np.array_equal(vmm, g["speed_minmax"])
     assert flags[0] == 0 and np.all(np.diff(g["xyz"][0, :, 0]) > 0) and np.all(g["xyz"][0, :, 1] == 0)   # straight and level
     assert flags[2] & 1                                                                                # dives into the ground
+
+
+def test_local_smooth_stand_in_known_answers():
+    """The stand-in for em-core's local_smooth (UNPINNED): centred moving average, the window shrinking symmetrically at the ends."""
+    x = np.array([1.0, 2.0, 4.0, 8.0, 16.0, 32.0, 64.0])
+    assert O.local_smooth(x, 5).tolist() == [1.0, 7.0 / 3.0, 31.0 / 5.0, 62.0 / 5.0, 124.0 / 5.0, 112.0 / 3.0, 64.0]
+    assert O.local_smooth(x, 15).tolist() == [1.0, 7.0 / 3.0, 31.0 / 5.0, 127.0 / 7.0, 124.0 / 5.0, 112.0 / 3.0, 64.0]
+    assert O.local_smooth(x[:1], 5).tolist() == [1.0] and O.local_smooth(x, 1).tolist() == x.tolist()
