@@ -63,13 +63,13 @@ class SampleParams(C.Structure):
                 ("sample_time", C.c_int32), ("transition_mode", C.c_int32), ("flags", C.c_uint32),
                 ("max_attempts", C.c_int32), ("idx_L", C.c_int32), ("idx_v", C.c_int32), ("idx_dh", C.c_int32),
                 ("n_layers", C.c_int32), ("layers", C.c_void_p), ("event_cap", C.c_int32), ("_pad", C.c_int32),
-                ("indices", C.c_void_p)]
+                ("indices", C.c_void_p), ("start", C.c_void_p)]
 
 
 class SampleOut(C.Structure):
     _fields_ = [("init_bin", C.c_void_p), ("init_val", C.c_void_p), ("dyn_bin", C.c_void_p), ("dyn_val", C.c_void_p),
                 ("ev_count", C.c_void_p), ("events", C.c_void_p), ("attempts", C.c_void_p),
-                ("ld", C.c_int64), ("col_offset", C.c_int64)]
+                ("ld", C.c_int64), ("col_offset", C.c_int64), ("log_weight", C.c_void_p)]
 
 
 class UTrackParams(C.Structure):  # emgpu_utrack_params
@@ -112,7 +112,8 @@ class BnParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("flags", C.c_uint32),
                 ("max_attempts", C.c_int32), ("bounds_sample", C.c_void_p),
                 ("idx_own_speed", C.c_int32), ("idx_int_speed", C.c_int32),
-                ("min_vel1", C.c_double), ("max_vel1", C.c_double), ("min_vel2", C.c_double), ("max_vel2", C.c_double)]
+                ("min_vel1", C.c_double), ("max_vel1", C.c_double), ("min_vel2", C.c_double), ("max_vel2", C.c_double),
+                ("start", C.c_void_p), ("log_weight", C.c_void_p)]
 
 
 # every symbol include/emgpu.h declares (tests check the list against the header)

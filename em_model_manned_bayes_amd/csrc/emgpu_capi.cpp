@@ -54,9 +54,11 @@ struct Uploaded {
     uint32_t *d_pthr = nullptr;
     double *d_bnd = nullptr;
     void *d_planf = nullptr; // the plan itself (+ k_uncor_fast's resample thresholds) for launches that serve several models
+    double *d_logp = nullptr; // log P of the initial network (emgpu::initial_log_prob), uploaded when a call first asks for log-weights
+    uint32_t lp_off[EMGPU_MAX_NI] = {0};
     void free_tables() {
-        (void)hipFree(d_thr); (void)hipFree(d_cthr); (void)hipFree(d_pthr); (void)hipFree(d_bnd); (void)hipFree(d_planf);
-        d_thr = d_cthr = d_pthr = nullptr; d_bnd = nullptr; d_planf = nullptr;
+        (void)hipFree(d_thr); (void)hipFree(d_cthr); (void)hipFree(d_pthr); (void)hipFree(d_bnd); (void)hipFree(d_planf); (void)hipFree(d_logp);
+        d_thr = d_cthr = d_pthr = nullptr; d_bnd = nullptr; d_planf = nullptr; d_logp = nullptr;
     }
 };
 } // namespace
@@ -414,6 +416,7 @@ int emgpu_ctx_sync(emgpu_ctx *ctx) {
     HIP_OK(hipStreamSynchronize(ctx->stream));
     const uint32_t st = *ctx->h_status;
     if (st & 1u) return fail(EMGPU_ERR_REJECT_CAP, "rejection loop reached max_attempts for at least one trajectory");
+    if (st & 4u) return fail(EMGPU_ERR_PRESET, "Attempt to preset a dependent variable (a row of the start grid presets a node without its parents, or a bin outside 1..r)");
     if (st & 2u) return fail(EMGPU_ERR_EVENT_CAP, "an event list did not fit event_cap rows");
     return EMGPU_OK;
     EMGPU_CATCH
@@ -495,6 +498,16 @@ static Uploaded &get_uploaded(emgpu_ctx *ctx, const emgpu_model *h, const std::s
     return u;
 }
 
+// the log-probability table behind per-sample log-weights, uploaded on first use (with the model version it was built for: get_uploaded
+// frees every table when the model changes)
+static void ensure_logp(emgpu_ctx *ctx, Uploaded &u, const Model &m) {
+    if (u.d_logp) return;
+    const std::vector<double> lp = emgpu::initial_log_prob(m, u.lp_off);
+    HIP_OK(hipMalloc((void **)&u.d_logp, (lp.size() + 1) * sizeof(double)));
+    HIP_OK(hipMemcpyAsync(u.d_logp, lp.data(), lp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+}
+
 // slot-th scratch buffer of the ctx, at least `bytes` long (contents undefined; valid until the next request for the same slot)
 static void *ctx_scratch(emgpu_ctx *ctx, size_t slot, size_t bytes) {
     if (ctx->scratch.size() <= slot) ctx->scratch.resize(slot + 1);
@@ -543,6 +556,7 @@ static void fill_run(emgpu_ctx *ctx, const Uploaded &u, const Model &m, const em
     A.status = ctx->d_status;
     A.ld = p->n;
     A.indices = p->indices;
+    A.start = p->start;
 }
 
 // Point the run at the caller's buffers: column col_offset of arrays whose trajectory dimension is ld.
@@ -561,6 +575,7 @@ static void bind_outputs(EmgpuRun &A, const Model &m, const emgpu_sample_params 
     A.ev_count = out->ev_count ? out->ev_count + o : nullptr;
     A.events = out->events ? reinterpret_cast<uint64_t *>(out->events) + o * (size_t)p->event_cap : nullptr;
     A.attempts = out->attempts ? out->attempts + o : nullptr;
+    A.log_weight = out->log_weight;
     (void)m;
 }
 
@@ -607,6 +622,7 @@ int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sa
     EmgpuRun A;
     fill_run(ctx, u, h->m, p, A);
     bind_outputs(A, h->m, p, out);
+    if (A.log_weight) { ensure_logp(ctx, u, h->m); A.logp = u.d_logp; memcpy(A.lp_off, u.lp_off, sizeof A.lp_off); }
     ctx->last_launches = 0;
     launch_dbn(ctx, u, A);
     return EMGPU_OK;
@@ -646,6 +662,7 @@ int emgpu_sample_dbn_blocks_device(emgpu_ctx *ctx, const emgpu_model *const *mod
                                    const emgpu_sample_out *out) {
     EMGPU_TRY
     if (!ctx || !models || n_models < 1 || !p || (!blocks && n_blocks > 0) || n_blocks < 0 || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    if (p->start || out->log_weight) return fail(EMGPU_ERR_UNSUPPORTED, "a start grid / log-weights in a mixed-model batch: sample the models one by one");
     CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     std::set<uint64_t> pinned;
@@ -770,6 +787,7 @@ int emgpu_sample_dbn_multi_device(emgpu_ctx *const *ctxs, int32_t n_ctx, const e
         emgpu_sample_params q = *p;
         q.first_index = p->first_index + (uint64_t)lo; q.n = hi - lo;
         if (p->indices) q.indices = p->indices + lo;   // shard d draws entries [lo, hi) of the list (device pointer valid on every device: managed / peer memory is the caller's business)
+        if (p->start) q.start = p->start + (size_t)lo * (size_t)h->m.n_initial;   // (the same for the start grid; outs[d].log_weight is the shard's own)
         return emgpu_sample_dbn_device(ctxs[d], h, &q, &outs[d]);
     });
     EMGPU_CATCH
@@ -787,9 +805,11 @@ int emgpu_sample_dbn_multi_host(emgpu_ctx *const *ctxs, int32_t n_ctx, const emg
         emgpu_sample_params q = *p;
         q.first_index = p->first_index + (uint64_t)lo; q.n = hi - lo;
         if (p->indices) q.indices = p->indices + lo;   // host list: shard d uploads and draws its own entries [lo, hi)
+        if (p->start) q.start = p->start + (size_t)lo * (size_t)h->m.n_initial;   // ... and its own rows of the start grid
         emgpu_sample_out o = *out;
         o.ld = out->ld ? out->ld : p->n;
         o.col_offset = out->col_offset + lo;
+        if (out->log_weight) o.log_weight = out->log_weight + lo;
         return emgpu_sample_dbn_host(ctxs[d], h, &q, &o);
     });
     EMGPU_CATCH
@@ -821,6 +841,13 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_samp
         if (out->events) d.events = (emgpu_event *)dalloc(b_ev);
         if (out->attempts) d.attempts = (int32_t *)dalloc(b_at);
         emgpu_sample_params pd = *p;
+        if (out->log_weight) d.log_weight = (double *)dalloc(n * sizeof(double));
+        if (p->start && n) {     // the start grid is caller (host) memory here
+            int32_t *ds = (int32_t *)dalloc(n * ni * sizeof(int32_t));
+            HIP_OK(hipMemcpyAsync(ds, p->start, n * ni * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            HIP_OK(hipStreamSynchronize(ctx->stream));
+            pd.start = ds;
+        }
         if (p->indices && n) {   // the index list is caller (host) memory here
             uint64_t *di = (uint64_t *)dalloc(n * sizeof(uint64_t));
             HIP_OK(hipMemcpyAsync(di, p->indices, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
@@ -840,6 +867,7 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_samp
             back(out->dyn_bin, d.dyn_bin, G4 * nd, 4); back(out->dyn_val, d.dyn_val, G4 * nd, 16);
             back(out->ev_count, d.ev_count, 1, 4);
             back(out->attempts, d.attempts, 1, 4);
+            if (out->log_weight && n) HIP_OK(hipMemcpyAsync(out->log_weight, d.log_weight, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             rc = emgpu_ctx_sync(ctx);
             uint32_t *h_ec = out->ev_count ? out->ev_count + off : nullptr;
             emgpu_event *h_ev = out->events ? out->events + off * (size_t)p->event_cap : nullptr;
@@ -888,6 +916,7 @@ static void fill_bn(emgpu_ctx *ctx, const Uploaded &u, const Model &m, const emg
     }
     A.min1 = p->min_vel1; A.max1 = p->max_vel1; A.min2 = p->min_vel2; A.max2 = p->max_vel2;
     A.status = ctx->d_status;
+    A.start = p->start; A.log_weight = p->log_weight;
 }
 
 int emgpu_sample_bn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_bn_params *p, uint8_t *out_bin, float *out_val, int32_t *attempts) {
@@ -899,6 +928,7 @@ int emgpu_sample_bn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_bn_
     EmgpuBnRun A;
     fill_bn(ctx, u, h->m, p, A);
     A.out_bin = out_bin; A.out_val = out_val; A.attempts = attempts;
+    if (A.log_weight) { ensure_logp(ctx, u, h->m); A.logp = u.d_logp; memcpy(A.lp_off, u.lp_off, sizeof A.lp_off); }
     const char *name = "";
     hipError_t e = emgpu::launch_bn(u.cp.plan, A, ctx->stream, &name);
     ctx->last_kernel = name;
@@ -913,14 +943,23 @@ int emgpu_sample_bn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_bn_pa
     CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
     const size_t n = (size_t)(p->n > 0 ? p->n : 0), ni = h->m.n_initial;
-    uint8_t *db = nullptr; float *dv = nullptr; int32_t *da = nullptr;
+    uint8_t *db = nullptr; float *dv = nullptr; int32_t *da = nullptr, *ds = nullptr; double *dw = nullptr;
     int rc;
     try {
         if (out_bin) HIP_OK(hipMalloc((void **)&db, ni * n + 1));
         if (out_val) HIP_OK(hipMalloc((void **)&dv, ni * n * 4 + 4));
         if (attempts) HIP_OK(hipMalloc((void **)&da, n * 4 + 4));
-        rc = emgpu_sample_bn_device(ctx, h, p, db, dv, da);
+        emgpu_bn_params pd = *p;
+        if (p->start && n) {
+            HIP_OK(hipMalloc((void **)&ds, n * ni * 4));
+            HIP_OK(hipMemcpyAsync(ds, p->start, n * ni * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIP_OK(hipStreamSynchronize(ctx->stream));
+            pd.start = ds;
+        }
+        if (p->log_weight) { HIP_OK(hipMalloc((void **)&dw, n * 8 + 8)); pd.log_weight = dw; }
+        rc = emgpu_sample_bn_device(ctx, h, &pd, db, dv, da);
         if (rc == EMGPU_OK) {
+            if (p->log_weight && n) HIP_OK(hipMemcpyAsync(p->log_weight, dw, n * 8, hipMemcpyDeviceToHost, ctx->stream));
             if (out_bin && n) HIP_OK(hipMemcpyAsync(out_bin, db, ni * n, hipMemcpyDeviceToHost, ctx->stream));
             if (out_val && n) HIP_OK(hipMemcpyAsync(out_val, dv, ni * n * 4, hipMemcpyDeviceToHost, ctx->stream));
             if (attempts && n) HIP_OK(hipMemcpyAsync(attempts, da, n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -928,11 +967,11 @@ int emgpu_sample_bn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_bn_pa
         }
     } catch (...) {
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(db); (void)hipFree(dv); (void)hipFree(da);
+        (void)hipFree(db); (void)hipFree(dv); (void)hipFree(da); (void)hipFree(ds); (void)hipFree(dw);
         throw;
     }
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(db); (void)hipFree(dv); (void)hipFree(da);
+    (void)hipFree(db); (void)hipFree(dv); (void)hipFree(da); (void)hipFree(ds); (void)hipFree(dw);
     return rc;
     EMGPU_CATCH
 }

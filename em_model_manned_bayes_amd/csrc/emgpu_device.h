@@ -150,22 +150,65 @@ __device__ __forceinline__ double round500(double num) { // UncorEncounterModel.
     return 500.0 * (floor(num / 500.0) + ((fmod(num, 500.0) > 250.0) ? 1.0 : 0.0));
 }
 
+// The presets of one lane (bn_sample.m:44-50): sp[p] = the preset bin (1-based) of the node at position p or 0; a lane's own row of the
+// start grid (entry of variable id, 0 = unset) wins over the model's start.  A preset node needs all its parents preset ('Attempt to
+// preset a dependent variable', :47) and a bin inside 1..r: otherwise bit 2 of *status is raised (EMGPU_ERR_PRESET) and the preset is
+// dropped.  Returns the lane's log-weight: the sum over its preset nodes of log P(preset | parents) read from `logp` (0 without a table).
+template <int NI>
+__device__ __forceinline__ double lane_presets(const EmgpuPlan &P, const int32_t *start_row, const double *logp, const uint32_t *lp_off, uint32_t *status, int (&sp)[NI]) {
+    uint32_t mask = 0u;
+    double lw = 0.0;
+    uint32_t colbin[NI];
+#pragma unroll
+    for (int p = 0; p < NI; p++) {
+        sp[p] = 0; colbin[p] = 0u;
+        if (p >= P.ni) continue;
+        int s = start_row ? start_row[P.i_var[p]] : 0;
+        if (s == 0) s = (int)P.i_start[p];
+        if (s == 0) continue;
+        bool ok = s >= 1 && s <= (int)P.i_r[p];
+        uint32_t col = 0u;
+#pragma unroll
+        for (int q = 0; q < p; q++) {
+            if (P.i_stride[p][q] == 0u) continue;
+            if (!((mask >> q) & 1u)) ok = false;
+            col += P.i_stride[p][q] * colbin[q];
+        }
+        if (!ok) { atomicOr(status, 4u); continue; }
+        sp[p] = s; colbin[p] = (uint32_t)(s - 1); mask |= 1u << p;
+        if (logp) lw += logp[lp_off[p] + (size_t)col * (uint32_t)P.i_r[p] + (uint32_t)(s - 1)];
+    }
+    return lw;
+}
+
 // Initial network + dediscretize + rejection loop, shared by every DBN kernel.
 // bn_sample.m:39-57, dbn_hierarchical_sample.m:25-31, UncorEncounterModel.m:248-281.
 // bin[]: 0-based bins by topological position; val[]: dediscretised f64.  Returns the number of
 // attempts used (>= 1) or -1 when max_attempts was reached; leaves rng.attempt at the accepted attempt.
-template <int NI>
-__device__ __forceinline__ int32_t init_network(const EmgpuPlan &P, const EmgpuRun &A, Rng &rng, int (&bin)[NI], double (&val)[NI]) {
+// PS: the lane's presets may come from a start grid (A.start, row `lane`) and its log-weight is wanted (A.log_weight): k_dbn_generic.
+template <int NI, bool PS = false>
+__device__ __forceinline__ int32_t init_network(const EmgpuPlan &P, const EmgpuRun &A, Rng &rng, int (&bin)[NI], double (&val)[NI], int64_t lane = 0) {
     int32_t attempts_used = -1;
     const bool no_dedisc = (A.flags & EMGPU_FLAG_NO_DEDISC) != 0;
+    int sp[NI];
+    if constexpr (PS) {
+        if (A.start || A.log_weight) {
+            const double lw = lane_presets<NI>(P, A.start ? A.start + (size_t)lane * (size_t)P.ni : nullptr, A.log_weight ? A.logp : nullptr, A.lp_off, A.status, sp);
+            if (A.log_weight) A.log_weight[lane] = lw;
+        } else {
+#pragma unroll
+            for (int p = 0; p < NI; p++) sp[p] = p < P.ni ? (int)P.i_start[p] : 0;
+        }
+    }
     for (uint32_t attempt = 0; attempt < (uint32_t)A.max_attempts; attempt++) {
         rng.attempt = attempt;
         uint4 wc = make_uint4(0, 0, 0, 0);
         int wblk = -1;
 #pragma unroll
         for (int p = 0; p < NI; p++) {
-            if (p < P.ni && P.i_start[p] != 0) { // bn_sample.m:44-50
-                bin[p] = (int)P.i_start[p] - 1;
+            const int preset = PS ? sp[p] : (p < P.ni ? (int)P.i_start[p] : 0);
+            if (p < P.ni && preset != 0) { // bn_sample.m:44-50
+                bin[p] = preset - 1;
             } else if (p < P.ni) {
                 uint32_t col = 0; // asub2ind.m:13-14 as strides
 #pragma unroll

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const Em
 #pragma unroll
     for (int p = 0; p < NI; p++) { bin[p] = 0; val[p] = 0.0; }
 
-    const int32_t attempts_used = init_network<NI>(P, A, rng, bin, val);
+    const int32_t attempts_used = init_network<NI, true>(P, A, rng, bin, val, i);   // (the one DBN kernel that takes a start grid)
     if (attempts_used < 0) atomicOr(A.status, 1u);
     if (A.attempts) A.attempts[i] = attempts_used;
 #pragma unroll
@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const Em
 // ---------------------------------------------------------------------------------------------
 // bn_sample.m:39-57 + @CorTerminalModel/sample.m:32-72
 // ---------------------------------------------------------------------------------------------
-template <int NI>
+// PS: per-sample presets and / or log-weights (a start grid in one launch, InitStartTerminal.m:57-90)
+template <int NI, bool PS>
 __global__ void __launch_bounds__(256) k_bn(const EmgpuPlan P, const EmgpuBnRun A) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= A.n) return;
@@ -220,6 +221,11 @@ __global__ void __launch_bounds__(256) k_bn(const EmgpuPlan P, const EmgpuBnRun 
 #pragma unroll
     for (int p = 0; p < NI; p++) { bin[p] = 0; val[p] = 0.0; }
     int32_t attempts_used = -1;
+    int sp[NI];
+    if constexpr (PS) {
+        const double lw = lane_presets<NI>(P, A.start ? A.start + (size_t)i * (size_t)P.ni : nullptr, A.log_weight ? A.logp : nullptr, A.lp_off, A.status, sp);
+        if (A.log_weight) A.log_weight[i] = lw;
+    }
     for (uint32_t attempt = 0; attempt < (uint32_t)A.max_attempts; attempt++) {
         rng.attempt = attempt;
         uint4 wc = make_uint4(0, 0, 0, 0);
@@ -227,8 +233,9 @@ __global__ void __launch_bounds__(256) k_bn(const EmgpuPlan P, const EmgpuBnRun 
 #pragma unroll
         for (int p = 0; p < NI; p++) {
             if (p >= P.ni) continue;
-            if (P.i_start[p] != 0) {
-                bin[p] = (int)P.i_start[p] - 1;
+            const int preset = PS ? sp[p] : (int)P.i_start[p];
+            if (preset != 0) {
+                bin[p] = preset - 1;
             } else {
                 uint32_t col = 0;
 #pragma unroll
@@ -292,8 +299,16 @@ hipError_t launch_dbn_generic(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t
 hipError_t launch_bn(const EmgpuPlan &P, const EmgpuBnRun &A, hipStream_t s, const char **name) {
     if (A.n <= 0) return hipSuccess;
     const int64_t blocks = (A.n + 255) / 256;
-    if (P.ni <= 8) { *name = "k_bn<8>"; hipLaunchKernelGGL((k_bn<8>), dim3((unsigned)blocks), dim3(256), 0, s, P, A); }
-    else { *name = "k_bn<16>"; hipLaunchKernelGGL((k_bn<16>), dim3((unsigned)blocks), dim3(256), 0, s, P, A); }
+    const bool ps = A.start != nullptr || A.log_weight != nullptr;
+    if (P.ni <= 8) {
+        *name = ps ? "k_bn<8>+start" : "k_bn<8>";
+        if (ps) hipLaunchKernelGGL((k_bn<8, true>), dim3((unsigned)blocks), dim3(256), 0, s, P, A);
+        else hipLaunchKernelGGL((k_bn<8, false>), dim3((unsigned)blocks), dim3(256), 0, s, P, A);
+    } else {
+        *name = ps ? "k_bn<16>+start" : "k_bn<16>";
+        if (ps) hipLaunchKernelGGL((k_bn<16, true>), dim3((unsigned)blocks), dim3(256), 0, s, P, A);
+        else hipLaunchKernelGGL((k_bn<16, false>), dim3((unsigned)blocks), dim3(256), 0, s, P, A);
+    }
     return hipGetLastError();
 }
 

@@ -203,6 +203,25 @@ double Model::start_log_weight() const {
     return lw;
 }
 
+std::vector<double> initial_log_prob(const Model &m, uint32_t off[EMGPU_MAX_NI]) {
+    std::vector<double> lp;
+    for (int p = 0; p < m.n_initial && p < EMGPU_MAX_NI; p++) {
+        const int v = m.order_initial[(size_t)p] - 1, r = m.r_initial[(size_t)v];
+        off[p] = (uint32_t)lp.size();
+        const std::vector<double> &N = m.N_initial[(size_t)v], &A = m.A_initial[(size_t)v];
+        const int64_t q = m.q_initial[(size_t)v];
+        for (int64_t c = 0; c < q; c++) {
+            double tot = 0.0;
+            for (int k = 0; k < r; k++) tot += N[(size_t)(c * r + k)] + A[(size_t)(c * r + k)];
+            for (int k = 0; k < r; k++) {
+                const double w = N[(size_t)(c * r + k)] + A[(size_t)(c * r + k)];
+                lp.push_back(tot > 0 ? std::log(w / tot) : (k == 0 ? 0.0 : -INFINITY));
+            }
+        }
+    }
+    return lp;
+}
+
 void Model::set_transition_stay_prior(double prior) {
     // setTransitionPriors.m:12-33
     for (auto &tm : temporal_map) {

@@ -94,6 +94,12 @@ struct UncorLimits {
 };
 UncorLimits build_uncor_limits(const Model &m, const UncorTrackVars &tv);
 
+// log P(bin | column) of the initial network as the kernels index it: node after node BY TOPOLOGICAL POSITION, column after column (the
+// column number of asub2ind.m:13-14, i.e. the plan's strides), r entries each; off[p] = the first entry of position p.  P is the
+// column-normalised N + alpha; an all-zero column draws bin 1 with certainty (select_random.m:17-20: sthres = 0).  The table behind the
+// per-sample log-weights of a start grid (InitStartTerminal.m:57-90).
+std::vector<double> initial_log_prob(const Model &m, uint32_t off[EMGPU_MAX_NI]);
+
 // Quantile thresholds of one CPT column (r weights): out[r-1].
 void column_thresholds(const double *w, int r, uint32_t *out);
 uint32_t bernoulli_threshold(double rate);

@@ -143,6 +143,11 @@ struct EmgpuRun {
     int32_t *attempts;
     uint32_t *status; // device word: bit0 = rejection cap hit, bit1 = event cap hit
     const uint64_t *indices; // optional: global index of lane i (instead of first_index + i); every DBN kernel but the round-1 k_dbn_step
+    // per-sample presets (a start GRID in one launch: InitStartTerminal.m:57-90, UncorEncounterModel.m:204) -- k_dbn_generic only
+    const int32_t *start;    // [n][ni] by variable id, 0 = unset (then the model's own start applies); null: the model's start for every lane
+    double *log_weight;      // [n] sum over the lane's preset nodes of log P(preset | parents); null: not wanted
+    const double *logp;      // log of the column-normalised (N + alpha) of the initial network, node after node (by position), column after column
+    uint32_t lp_off[EMGPU_MAX_NI];
 };
 
 struct EmgpuBnRun {
@@ -159,6 +164,10 @@ struct EmgpuBnRun {
     int32_t *attempts;
     uint32_t *status;
     const uint64_t *indices; // optional: global index of lane i (instead of first_index + i)
+    const int32_t *start;    // per-sample presets, log-weights and the table they read: as in EmgpuRun
+    double *log_weight;
+    const double *logp;
+    uint32_t lp_off[EMGPU_MAX_NI];
 };
 
 struct EmgpuTermRun {

@@ -504,8 +504,16 @@ class CorTerminalModel(EncounterModel):
     def dynLimits2(self):
         return self.getDynamicLimits(2)
 
-    def sample(self, nSamples, seed=None, max_attempts=100000, first_index=None, ctx=None):
-        """[outInits, outSamples] = sample(self, nSamples, 'seed', s)  (@CorTerminalModel/sample.m:1-82)."""
+    def sample(self, nSamples, seed=None, max_attempts=100000, first_index=None, ctx=None, start_grid=None, return_log_weight=False):
+        """[outInits, outSamples] = sample(self, nSamples, 'seed', s)  (@CorTerminalModel/sample.m:1-82).
+        start_grid: the rows InitStartTerminal returns (or any list of `start` values, one per sample: None / 0 = unset) -- the whole grid
+        is drawn in ONE launch, sample i with the presets of row i (RUN_terminal.m:33-50 sets self.start and calls sample once per row);
+        nSamples must then equal its length.  return_log_weight: also return log P(presets of the row) per sample (importance weights)."""
+        grid = None
+        if start_grid is not None:
+            grid = np.array([[0 if (v is None or (isinstance(v, float) and np.isnan(v))) else int(v) for v in row] for row in start_grid], dtype=np.int32)
+            if grid.shape != (int(nSamples), self.n_initial):
+                raise ValueError("start_grid must have nSamples rows of n_initial entries")
         s, first = _take(seed, nSamples)
         if first_index is not None:
             first = int(first_index)
@@ -513,13 +521,16 @@ class CorTerminalModel(EncounterModel):
         io, ii = labs.index('"own_speed"') + 1, labs.index('"int_speed"') + 1
         d1, d2 = self.dynLimits1, self.dynLimits2
         bs = None if np.all(np.isinf(self.bounds_sample)) else self.bounds_sample
-        _, ov, _ = native.sample_bn_host(ctx or native.default_context(), self.native, int(nSamples), s, first_index=first,
-                                         dediscretize=True, max_attempts=max_attempts, bounds_sample=bs,
-                                         idx_own_speed=io, idx_int_speed=ii,
-                                         lim1=(d1["minVel_ft_s"], d1["maxVel_ft_s"]), lim2=(d2["minVel_ft_s"], d2["maxVel_ft_s"]))
-        outInits = ov.astype(np.float64)
+        res = native.sample_bn_host(ctx or native.default_context(), self.native, int(nSamples), s, first_index=first,
+                                    dediscretize=True, max_attempts=max_attempts, bounds_sample=bs,
+                                    idx_own_speed=io, idx_int_speed=ii,
+                                    lim1=(d1["minVel_ft_s"], d1["maxVel_ft_s"]), lim2=(d2["minVel_ft_s"], d2["maxVel_ft_s"]),
+                                    start=grid, want_log_weight=return_log_weight)
+        outInits = res[1].astype(np.float64)
         names = [lab.replace('"', "") for lab in labs]
         outSamples = [dict(zip(names, row)) for row in outInits]
+        if return_log_weight:
+            return outInits, outSamples, res[3]
         return outInits, outSamples
 
     def InitStartTerminal(self, nSamples=1000000, airspace_class=(False, True, True, True), own_intent=(True, True),

@@ -24,7 +24,8 @@
  *     [initial, ev_count, events] = emgpu_mex('sample_uncor', h, n, T, seed, first_index, flags, idxL, idxV, idxDH, layers, event_cap)
  *         flags: EMGPU_FLAG_* ; idxV = idxDH = 0 => dbn_hierarchical_sample.m:1 ; with NO_RESAMPLE|NO_DEDISC|NO_TERMINATOR => dbn_sample.m:1
  *         initial n x n_initial double; ev_count n x 1; events event_cap x 3 x n rows [dt var value]
- *     [outInits, attempts] = emgpu_mex('geom_sample', h, n, seed, first_index, bounds_sample, idxOwnSpeed, idxIntSpeed, lim1, lim2)
+ *     [outInits, attempts, logWeight] = emgpu_mex('geom_sample', h, n, seed, first_index, bounds_sample, idxOwnSpeed, idxIntSpeed, lim1, lim2, startGrid)
+ *         startGrid (optional): n x n_initial presets, one row per sample (InitStartTerminal.m:57-90), drawn in ONE launch; logWeight n x 1
  *                                                                                                  @CorTerminalModel/sample.m:29-77
  *     [out, rows] = emgpu_mex('propagate_terminal', handles, geo, model_of, seed, first_index, tmax_s, dyn_limits)
  *         handles 1 x 10 uint64 (stay prior applied); geo 12 x n; model_of 4 x n (0-based); dyn_limits 5 x 2
@@ -447,14 +448,26 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
             p.min_vel1 = mxGetPr(prhs[8])[0]; p.max_vel1 = mxGetPr(prhs[8])[1]; p.min_vel2 = mxGetPr(prhs[9])[0]; p.max_vel2 = mxGetPr(prhs[9])[1];
         }
         const size_t n = (size_t)(p.n > 0 ? p.n : 0);
+        /* a start GRID (InitStartTerminal.m:57-90: one row of presets per sample, n x n_initial, 0 / NaN = unset): one launch for the lot */
+        int32_t *grid = NULL;
+        double *lw = NULL;
+        if (nrhs > 10 && !mxIsEmpty(prhs[10])) {
+            if (mxGetM(prhs[10]) != n || mxGetN(prhs[10]) != ni) mexErrMsgIdAndTxt("emgpu:usage", "start_grid must be n x n_initial");
+            grid = (int32_t *)mxMalloc(sizeof(int32_t) * (n * ni + 1));
+            for (size_t i = 0; i < n; i++) for (size_t v = 0; v < ni; v++) { const double x = mxGetPr(prhs[10])[v * n + i]; grid[i * ni + v] = (x != x) ? 0 : (int32_t)x; }
+            p.start = grid;
+        }
+        if (nlhs > 2) { lw = (double *)mxMalloc(sizeof(double) * (n + 1)); p.log_weight = lw; }
         float *ov = (float *)mxMalloc(sizeof(float) * (ni * n + 1));
         int32_t *att = (int32_t *)mxMalloc(sizeof(int32_t) * (n + 1));
         check(emgpu_sample_bn_host(ctx0(), m, &p, NULL, ov, att));
         plhs[0] = mxCreateDoubleMatrix((mwSize)n, (mwSize)ni, mxREAL);
         for (size_t v = 0; v < ni; v++) for (size_t i = 0; i < n; i++) mxGetPr(plhs[0])[v * n + i] = ov[v * n + i];
         if (nlhs > 1) { plhs[1] = mxCreateDoubleMatrix((mwSize)n, 1, mxREAL); for (size_t i = 0; i < n; i++) mxGetPr(plhs[1])[i] = att[i]; }
+        if (nlhs > 2) { plhs[2] = mxCreateDoubleMatrix((mwSize)n, 1, mxREAL); for (size_t i = 0; i < n; i++) mxGetPr(plhs[2])[i] = lw[i]; mxFree(lw); }
         mxFree(ov); mxFree(att);
         if (bs) mxFree(bs);
+        if (grid) mxFree(grid);
     } else if (!strcmp(cmd, "propagate_terminal")) {
         need(nrhs, 8, "[out, rows] = emgpu_mex('propagate_terminal', handles, geo, model_of, seed, first_index, tmax_s, dyn_limits)");
         const int nm = (int)mxGetNumberOfElements(prhs[1]);

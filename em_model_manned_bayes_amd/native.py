@@ -234,9 +234,10 @@ def all_device_contexts():
 
 
 def make_params(n, sample_time, seed, first_index=0, transition_mode=L.TRANSITION_REFERENCE_AUTO, flags=0,
-                max_attempts=1000, idx_L=0, idx_v=0, idx_dh=0, layers=None, event_cap=0, indices=None):
+                max_attempts=1000, idx_L=0, idx_v=0, idx_dh=0, layers=None, event_cap=0, indices=None, start=None):
     """emgpu_sample_params.  indices: a numpy uint64 array (host calls) or a raw device pointer (device calls) of n
-    global indices replacing first_index + i."""
+    global indices replacing first_index + i.  start: a start grid [n, n_initial] of preset bins (0 = unset), numpy (host calls) or a raw
+    device pointer."""
     p = L.SampleParams()
     p.seed, p.first_index, p.n, p.sample_time = int(seed) & (2**64 - 1), int(first_index), int(n), int(sample_time)
     p.transition_mode, p.flags, p.max_attempts = int(transition_mode), int(flags), int(max_attempts)
@@ -254,6 +255,14 @@ def make_params(n, sample_time, seed, first_index=0, transition_mode=L.TRANSITIO
             assert idx.size == int(n)
             p.indices = idx.ctypes.data
             keep = (keep, idx)
+    if start is not None:
+        if isinstance(start, int):
+            p.start = start
+        else:
+            st = np.ascontiguousarray(start, dtype=np.int32)
+            assert st.ndim == 2 and st.shape[0] == int(n)
+            p.start = st.ctypes.data
+            keep = (keep, st)
     return p, keep
 
 
@@ -317,7 +326,7 @@ def sample_dbn_multi_device(ctxs, model, params, outs):
     L.check(L.lib().emgpu_sample_dbn_multi_device(hs, len(ctxs), model._h, C.byref(params), arr))
 
 
-def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_events=False, event_cap=None, **kw):
+def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_events=False, event_cap=None, want_log_weight=False, **kw):
     """Synchronous host-buffer call.  Returns a dict of numpy arrays in user-facing shapes:
     init_bin [n, n_i] u8, init_val [n, n_i] f32, dyn_bin [n, T, n_d] u8, dyn_val [n, T, n_d] f32,
     events: list of structured arrays (EVENT_DTYPE), attempts [n].
@@ -342,6 +351,9 @@ def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_even
         ec = np.zeros(n, dtype=np.uint32)
         ev = np.zeros((n, event_cap), dtype=EVENT_DTYPE)
         o.ev_count, o.events = _p(ec), _p(ev)
+    if want_log_weight:
+        lw = np.zeros(n, dtype=np.float64)
+        o.log_weight = _p(lw)
     if isinstance(ctx, (list, tuple)):
         hs = (C.c_void_p * len(ctx))(*[c._h for c in ctx])
         L.check(L.lib().emgpu_sample_dbn_multi_host(hs, len(ctx), model._h, C.byref(p), C.byref(o)))
@@ -349,6 +361,8 @@ def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_even
     else:
         L.check(L.lib().emgpu_sample_dbn_host(ctx._h, model._h, C.byref(p), C.byref(o)))
     out = {"init_bin": ib.T.copy(), "init_val": iv.T.copy(), "attempts": att, "kernel": ctx.last_kernel()}
+    if want_log_weight:
+        out["log_weight"] = lw
     if want_dense and nd > 0:
         out["dyn_bin"] = unpack_dyn_bin(db, T)
         out["dyn_val"] = unpack_dyn_val(dv, T)
@@ -373,8 +387,9 @@ def unpack_dyn_val(dv, T):
 
 
 def sample_bn_host(ctx, model, n, seed, first_index=0, dediscretize=False, max_attempts=100000, bounds_sample=None,
-                   idx_own_speed=0, idx_int_speed=0, lim1=(0.0, np.inf), lim2=(0.0, np.inf)):
-    """bn_sample.m (dediscretize=False) or the CorTerminalModel geometry draw (sample.m:29-77)."""
+                   idx_own_speed=0, idx_int_speed=0, lim1=(0.0, np.inf), lim2=(0.0, np.inf), start=None, want_log_weight=False):
+    """bn_sample.m (dediscretize=False) or the CorTerminalModel geometry draw (sample.m:29-77).  start: a start grid [n, n_initial]
+    (0 = unset) -- one row of presets per sample, ONE launch; want_log_weight: also return the per-sample log-weights (4th value)."""
     p = L.BnParams()
     p.seed, p.first_index, p.n = int(seed) & (2**64 - 1), int(first_index), int(n)
     p.flags = 0 if dediscretize else L.FLAG_NO_DEDISC
@@ -388,7 +403,17 @@ def sample_bn_host(ctx, model, n, seed, first_index=0, dediscretize=False, max_a
     ob = np.zeros((model.n_initial, n), dtype=np.uint8)
     ov = np.zeros((model.n_initial, n), dtype=np.float32)
     att = np.zeros(n, dtype=np.int32)
+    st = lw = None
+    if start is not None:
+        st = np.ascontiguousarray(start, dtype=np.int32)
+        assert st.shape == (n, model.n_initial)
+        p.start = _p(st)
+    if want_log_weight:
+        lw = np.zeros(n, dtype=np.float64)
+        p.log_weight = _p(lw)
     L.check(L.lib().emgpu_sample_bn_host(ctx._h, model._h, C.byref(p), _p(ob), _p(ov), _p(att)))
+    if want_log_weight:
+        return ob.T.copy(), ov.T.copy(), att, lw
     return ob.T.copy(), ov.T.copy(), att
 
 

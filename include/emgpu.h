@@ -126,7 +126,9 @@ int emgpu_model_set_start(emgpu_model *m, const int32_t *start, int32_t n);
 /* Importance-sampling hook next to `start` and `layers` (UncorEncounterModel.m:204,259-272; InitStartTerminal.m:1-92):
  * log of the model probability of the preset values, sum over preset nodes of log P(x_i = start_i | parents) with
  * P = (N + alpha) column-normalised.  Preset nodes have only preset parents (bn_sample.m:45-47), so this is ONE number per
- * call -- the log-weight of every sample drawn with this `start` (0 when nothing is preset, -inf for an impossible preset). */
+ * call -- the log-weight of every sample drawn with this `start` (0 when nothing is preset, -inf for an impossible preset).
+ * A start GRID (one row of presets per sample) with per-sample weights: emgpu_sample_params.start / emgpu_sample_out.log_weight and
+ * emgpu_bn_params.start / .log_weight. */
 int emgpu_model_start_log_weight(const emgpu_model *m, double *out);
 /* EncounterModel.zero_bins (EncounterModel.m:40; derived once by em_read.m:110-114,143-156 and, like in
  * the reference, NOT re-derived when boundaries are replaced): n_initial entries, 0 = none. */
@@ -178,6 +180,12 @@ typedef struct {
     const uint64_t *indices; /* optional: n global indices replacing first_index + i (a device pointer for
                                 *_device calls, a host pointer for *_host): arbitrary subsets of a batch, e.g.
                                 the trajectories .track re-draws; NULL = the contiguous range               */
+    const int32_t *start;    /* optional: a start GRID -- n rows of n_initial preset bins by variable id (row-major; 0 = unset: the
+                                model's own `start` then applies), one row per trajectory: what a loop over EncounterModel.start values
+                                (UncorEncounterModel.m:204, bn_sample.m:44-50) does in as many calls, in ONE.  A device pointer for
+                                *_device calls, a host pointer for *_host.  A row that presets a node without presetting its parents,
+                                or a bin outside 1..r, is reported as EMGPU_ERR_PRESET (by emgpu_ctx_sync for *_device calls).
+                                Calls with a start grid or log-weights run on the general kernel.                                   */
 } emgpu_sample_params;
 
 /* Event row (8 bytes): what one row [dt var value] of out_events{i} carries. */
@@ -209,6 +217,9 @@ typedef struct {
     int32_t *attempts;   /* [n] attempts used by the rejection loop; <0 => cap hit                */
     int64_t ld;          /* trajectory dimension of every buffer above; 0 => params.n             */
     int64_t col_offset;  /* column of trajectory 0 of this call; col_offset + n <= ld             */
+    double *log_weight;  /* [n] (NOT offset by col_offset) per-trajectory importance weight of its presets: the sum over the trajectory's
+                            preset nodes of log P(preset | parents), P = (N + alpha) column-normalised -- emgpu_model_start_log_weight
+                            per row of the start grid; NULL: not wanted                            */
 } emgpu_sample_out;
 
 /* Asynchronous: enqueue on the ctx stream with DEVICE pointers in `out`; returns after launch.
@@ -275,6 +286,10 @@ typedef struct {
     const double *bounds_sample; /* n_initial x 2 row-major or NULL (sample.m:45-53)              */
     int32_t idx_own_speed, idx_int_speed; /* 1-based; 0 = no speed test (sample.m:64-70)          */
     double min_vel1, max_vel1, min_vel2, max_vel2;
+    const int32_t *start;    /* optional start grid [n][n_initial] and per-sample log-weights [n]: as in emgpu_sample_params /
+                                emgpu_sample_out -- InitStartTerminal.m:57-90 builds such a grid and RUN_terminal.m:33-50 loops over its 18
+                                rows with one .sample call each; here the grid is ONE launch (device pointers for _device, host for _host) */
+    double *log_weight;
 } emgpu_bn_params;
 int emgpu_sample_bn_device(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_bn_params *p,
                            uint8_t *out_bin, float *out_val, int32_t *attempts);

@@ -1434,6 +1434,81 @@ def test_uncor_track_pitch_command_clamped_to_vertical_then_reversed(gpu_ctx):
             np.testing.assert_allclose(got[literal][i], ref, rtol=1e-9, atol=1e-6, err_msg="trajectory %d, literal=%d" % (i, literal))
 
 
+def test_start_grid_in_one_launch_terminal(terminal_dir, gpu_ctx):
+    """SURVEY.md 8 f4 / InitStartTerminal.m:57-90 + RUN_terminal.m:33-50: the 18-row start grid (airspace class x ownship intent x intruder
+    intent preset in turn) drawn in ONE launch, sample i with the presets of row i -- against the oracle run ROW BY ROW with the model's
+    `start` set (sample.m:34 -> bn_sample.m:44-50), and against the library's own per-row calls; the per-sample log-weights equal
+    emgpu_model_start_log_weight of the row."""
+    t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=terminal_dir)
+    per, seed, first = 40, 0x5EED0005, 1000
+    grid = t.InitStartTerminal(nSamples=18 * per)
+    n = len(grid)
+    assert n == 18 * per and len({tuple(r[:3]) for r in grid}) == 18
+    inits, samples, lw = t.sample(n, seed=seed, first_index=first, ctx=gpu_ctx, start_grid=grid, return_log_weight=True)
+    assert gpu_ctx.last_kernel() == "k_bn<16>+start"
+    pp = O.parse_model_txt(t.parameters_filename)
+    labs = t.labels_initial
+    io, ii = labs.index('"own_speed"') + 1, labs.index('"int_speed"') + 1
+    d1, d2 = t.dynLimits1, t.dynLimits2
+    bs = None if np.all(np.isinf(t.bounds_sample)) else t.bounds_sample
+    for k in range(18):
+        row = grid[k * per]
+        sl = slice(k * per, (k + 1) * per)
+        assert np.all(inits[sl, :3] == np.array(row[:3], dtype=float))
+        # the oracle, this row only: the same global indices
+        om = O.OracleModel(pp, start=[v or 0 for v in row])
+        _, ov, _ = O.geom_sample(om, per, seed, first_index=first + k * per, bounds_sample=bs, idx_own_speed=io, idx_int_speed=ii,
+                                 lim1=(d1["minVel_ft_s"], d1["maxVel_ft_s"]), lim2=(d2["minVel_ft_s"], d2["maxVel_ft_s"]))
+        assert np.array_equal(inits[sl].astype(np.float32), ov.astype(np.float32)), "row %d of the grid" % k
+        # the library, this row only (the model's own start, like RUN_terminal.m:36-39)
+        t.start = row
+        one, _ = t.sample(per, seed=seed, first_index=first + k * per, ctx=gpu_ctx)
+        assert gpu_ctx.last_kernel() == "k_bn<16>"
+        assert np.array_equal(one, inits[sl])
+        assert np.all(lw[sl] == lw[k * per]) and abs(lw[k * per] - t.start_log_weight) < 1e-12 and np.isfinite(lw[k * per]) and lw[k * per] < 0
+    t.start = [None] * t.n_initial
+    # a row that presets a node without its parent: 'Attempt to preset a dependent variable' (bn_sample.m:47)
+    G = np.array(t.G_initial)
+    child = next(c for c in range(t.n_initial) if G[:, c].any())
+    bad = [[None] * t.n_initial for _ in range(8)]
+    bad[5][child] = 1
+    with pytest.raises(L.EmgpuError) as ei:
+        t.sample(8, seed=1, ctx=gpu_ctx, start_grid=bad)
+    assert ei.value.code == L.ERR_PRESET
+    bad[5][child] = None
+    bad[2][0] = 99                                           # a bin outside 1..r
+    with pytest.raises(L.EmgpuError) as ei:
+        t.sample(8, seed=1, ctx=gpu_ctx, start_grid=bad)
+    assert ei.value.code == L.ERR_PRESET
+
+
+def test_start_grid_in_one_launch_dbn(gpu_ctx, model_dir):
+    """The same for the DBN sampler (UncorEncounterModel.m:204 `start`, RUN_uncor.m:43-48): a grid of presets, one row per trajectory, in
+    one call -- dense trace, event lists and log-weights equal to per-row calls with the model's start set, and to the oracle's."""
+    nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
+    idx = uncor_indices(pp)
+    rows = [[1, 4, 2, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0], [3, 0, 0, 0, 0, 0, 0], [2, 2, 0, 0, 0, 0, 0]]   # RUN_uncor.m:43-45 is the first
+    per, T, seed, first = 60, 50, 0xA5, 300
+    grid = np.repeat(np.array(rows, dtype=np.int32), per, axis=0)
+    n = grid.shape[0]
+    got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, first_index=first, want_dense=True, want_events=True, want_log_weight=True, start=grid, **idx)
+    assert got["kernel"].startswith("k_dbn_generic")
+    for k, row in enumerate(rows):
+        sl = slice(k * per, (k + 1) * per)
+        nm.set_start([v or None for v in row])
+        one = native.sample_dbn_host(gpu_ctx, nm, per, T, seed, first_index=first + k * per, want_dense=True, want_events=True, **idx)
+        lw_row = nm.start_log_weight()
+        nm.set_start([None] * 7)
+        for f in ("init_bin", "init_val", "dyn_bin", "dyn_val", "attempts", "ev_count"):
+            assert np.array_equal(one[f], got[f][sl]), (k, f)
+        assert all(np.array_equal(a, b) for a, b in zip(one["events"], got["events"][sl]))
+        assert np.all(got["log_weight"][sl] == got["log_weight"][k * per]) and abs(got["log_weight"][k * per] - lw_row) < 1e-12
+        ref = O.uncor_sample(O.OracleModel(pp, start=row), per, T, seed, mode=O.RNG_PHILOX, first_index=first + k * per)
+        sub = {f: (v[sl] if isinstance(v, (np.ndarray, list)) else v) for f, v in got.items()}
+        assert_uncor_parity(sub, ref, T)
+    assert got["log_weight"][per] == 0.0 and got["log_weight"][0] < 0 and got["log_weight"][2 * per] < 0 and got["log_weight"][3 * per] < 0
+
+
 @pytest.mark.gpu
 def test_uncor_class_track_and_index_lists(gpu_ctx, model_dir):
     """The class method (timetable columns, initialSeed semantics, the cap) and emgpu_sample_params.indices on its own:
