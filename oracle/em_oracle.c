@@ -1466,6 +1466,23 @@ int em_terminal_filters(const em_traj_t *tr, int own_intent, int int_intent, con
     return is_long && prox1 && prox2 && own_ok && int_ok && dyn1 && dyn2;                    /* :144 */
 }
 
+/* test hook: the filters on two tracks given as rows [t_s x_nm y_nm z_ft heading_deg v_ft_s] (tests/test_oracle.py pins them against pyref.py) */
+int em_terminal_filters_rows(const double *own, int n_own, const double *intr, int n_int, int own_intent, int int_intent,
+                             const em_dynlims_t *dl, const em_ttrack_opts_t *o, double meta[4]) {
+    em_traj_t tr[2];
+    const double *src[2] = {own, intr};
+    const int n[2] = {n_own, n_int};
+    for (int a = 0; a < 2; a++) {
+        if (n[a] < 1 || n[a] > 260) return -1;
+        tr[a].n = n[a];
+        for (int r = 0; r < n[a]; r++) {
+            const double *q = src[a] + (size_t)r * 6;
+            tr[a].t[r] = q[0]; tr[a].x[r] = q[1]; tr[a].y[r] = q[2]; tr[a].z[r] = q[3]; tr[a].hdg[r] = q[4]; tr[a].v[r] = q[5];
+        }
+    }
+    return em_terminal_filters(tr, own_intent, int_intent, dl, o, meta);
+}
+
 /* createEncounter.m:88-89: traj.v_ft_s = local_smooth(t_s, v_ft_s, 5); traj.z_ft = local_smooth(t_s, z_ft, 15).  local_smooth lives in  */
 /* em-core, which the reference does not vendor: UNPINNED.  The stand-in (the same in csrc/emgpu_kernels_tfilter.hip): a centred moving  */
 /* average over w samples of the 1 s track, the window shrunk symmetrically at the ends -- row i becomes the mean of rows i-k .. i+k,    */

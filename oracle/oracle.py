@@ -655,6 +655,29 @@ def check_cum_turn(heading_deg, limit):
     return bool(lib().em_check_cum_turn(_ptr(h), C.c_int(h.size), C.c_double(limit)))
 
 
+def terminal_filters(own, intr, own_intent, int_intent, dyn_limits, max_cum_turn_deg, pitch_deg, min_enc_time_s=30.0, thres_dist_ft=2.5 * 6076,
+                     thres_alt_low_ft=750.0, thres_vertrate_ft_s=5.0):
+    """The filters of track.m:79-145 on two time-ordered tracks given as rows [t_s x_nm y_nm z_ft heading_deg v_ft_s]:
+    (is_good, meta = tcpa_s hmd_ft vmd_ft enc_time_s)."""
+    L = lib()
+    o = _TTrackOpts()
+    o.min_enc_time_s, o.thres_dist_ft, o.thres_alt_low_ft, o.thres_vertrate_ft_s = min_enc_time_s, thres_dist_ft, thres_alt_low_ft, thres_vertrate_ft_s
+    for a in range(2):
+        o.max_cum_turn_deg[a], o.pitch_deg[a] = float(max_cum_turn_deg[a]), float(pitch_deg[a])
+    d = np.asarray(dyn_limits, dtype=np.float64).reshape(2, 5)
+    dl = (_DynLims * 2)()
+    for a in range(2):
+        dl[a].minVel_ft_s, dl[a].maxVel_ft_s, dl[a].maxTurnRate_deg_s, dl[a].maxAltitude_ft, dl[a].maxVertRate_ft_s = [float(x) for x in d[a]]
+    own = np.ascontiguousarray(own, dtype=np.float64).reshape(-1, 6)
+    intr = np.ascontiguousarray(intr, dtype=np.float64).reshape(-1, 6)
+    meta = np.zeros(4)
+    rc = L.em_terminal_filters_rows(_ptr(own), C.c_int(own.shape[0]), _ptr(intr), C.c_int(intr.shape[0]), C.c_int(int(own_intent)), C.c_int(int(int_intent)),
+                                    dl, C.byref(o), _ptr(meta))
+    if rc < 0:
+        raise RuntimeError("em_terminal_filters_rows failed rc=%d" % rc)
+    return bool(rc), meta
+
+
 def terminal_track(gom, oms, n, seed, dyn_limits, max_cum_turn_deg, pitch_deg, first_index=0, tmax_s=120.0, min_enc_time_s=30.0,
                    thres_dist_ft=2.5 * 6076, thres_alt_low_ft=750.0, thres_vertrate_ft_s=5.0, bounds_sample=None, max_track_attempts=500,
                    max_attempts=100000, max_resample=100000, f32=True, margin_cap=None, local_smooth=False):

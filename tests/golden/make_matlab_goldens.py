@@ -13,6 +13,9 @@ Everything is written as plain CSV with %.17g so MATLAB's readmatrix / dlmread r
                                              and cor_v1 through em_read (16 variables, non-identity order_initial)
   bn_sort_orders.csv                         topological orders of every non-upper-triangular graph shipped
   trig_table.csv                             sind / cosd / wrapTo360 / atan2d as restated for createEncounter.m
+  geom_<srcData>_inits.csv                   CorTerminalModel('srcData', s).sample(500, 'seed', 1) (RUN_terminal.m:39 without a start) and the
+  geom_<srcData>_start_inits.csv             same with mdl.start = {2, 1, 3, [], ...} (a row of InitStartTerminal): the 15-variable geometry
+                                             network, dediscretize and the GENERIC speed rejection (@CorTerminalModel/sample.m:29-77)
 
 The oracle is cross-checked draw-for-draw against the second restatement (oracle/pyref.py) before
 anything is written.
@@ -76,6 +79,17 @@ def main():
         save("hier_%s_inits.csv" % name, r["init_val"], "initial of %d successive dbn_hierarchical_sample(parms, a_i, a_t, %d, ...) calls after rng(%d,'twister'): %d x %d"
              % (n, T, seed, n, pp["n_initial"]))
         save("hier_%s_events.csv" % name, events_table(r["events"]), "events stacked: [call dt var value]")
+    # ---- the terminal geometry network (@CorTerminalModel/sample.m:29-77): acType GENERIC / GENERIC, bounds_sample = +-inf (CorTerminalModel.m:81,108)
+    for src, stem in (("terminalradar", "terminal_v3_radar_encounter_model"), ("opensky", "terminal_v3_opensky_encounter_model")):
+        pp = O.parse_model_txt(em_io.materialize_model(stem, tmp))
+        labs = [x.strip('"') for x in pp["labels_initial"]]
+        io, ii = labs.index("own_speed") + 1, labs.index("int_speed") + 1
+        for tag, start in (("", [0] * 15), ("_start", [2, 1, 3] + [0] * 12)):
+            _, ov, _ = O.geom_sample(O.OracleModel(pp, start=start), 500, 1, mode=O.RNG_MT19937, idx_own_speed=io, idx_int_speed=ii, lim1=(50, 506), lim2=(50, 506))
+            ref, _ = P.geom_sample(pp, 500, 1, lim1=(50, 506), lim2=(50, 506), start=[v or None for v in start])
+            assert np.array_equal(ov, ref), (src, tag)
+            save("geom_%s%s_inits.csv" % (src, tag), ov, "outInits of CorTerminalModel('srcData','%s')%s.sample(500, 'seed', 1): 500 x 15 (acType GENERIC / GENERIC)"
+                 % (src, "" if not tag else " with start = {2, 1, 3, [], ...}"))
     # ---- bn_sort: every shipped graph whose order is not the identity
     rows = []
     names = sorted(os.path.splitext(f)[0] for f in os.listdir(os.path.join(ROOT, "models")) if f.endswith(".npz"))

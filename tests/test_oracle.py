@@ -355,3 +355,109 @@ def test_local_smooth_stand_in_known_answers():
     assert O.local_smooth(x, 5).tolist() == [1.0, 7.0 / 3.0, 31.0 / 5.0, 62.0 / 5.0, 124.0 / 5.0, 112.0 / 3.0, 64.0]
     assert O.local_smooth(x, 15).tolist() == [1.0, 7.0 / 3.0, 31.0 / 5.0, 127.0 / 7.0, 124.0 / 5.0, 112.0 / 3.0, 64.0]
     assert O.local_smooth(x[:1], 5).tolist() == [1.0] and O.local_smooth(x, 1).tolist() == x.tolist()
+
+
+_TERM_ORDER = ["ownship_landing_model", "ownship_landing_model_reverse", "ownship_takeoff_model", "ownship_takeoff_model_reverse",
+               "intruder_landing_model", "intruder_landing_model_reverse", "intruder_takeoff_model", "intruder_landing_model_reverse",
+               "intruder_transit_model", "intruder_landing_model_reverse"]        # CorTerminalModel.m:84-100 (its copy-paste of the reverse files kept)
+_DL = {"GENERIC": dict(minVel_ft_s=50, maxVel_ft_s=506, maxTurnRate_deg_s=12, maxAltitude_ft=5000, maxVertRate_ft_s=6000 / 60, maxCumTurn_deg=np.inf, pitch_deg=np.inf),
+       "RTCA228_A2": dict(minVel_ft_s=68, maxVel_ft_s=338, maxTurnRate_deg_s=3, maxAltitude_ft=5000, maxVertRate_ft_s=1500 / 60, maxCumTurn_deg=180, pitch_deg=15),
+       "TEST": dict(minVel_ft_s=68, maxVel_ft_s=186, maxTurnRate_deg_s=7, maxAltitude_ft=1200, maxVertRate_ft_s=500 / 60, maxCumTurn_deg=180, pitch_deg=15)}
+
+
+def _dl_rows(a, b):
+    k = ("minVel_ft_s", "maxVel_ft_s", "maxTurnRate_deg_s", "maxAltitude_ft", "maxVertRate_ft_s")
+    return np.array([[_DL[a][q] for q in k], [_DL[b][q] for q in k]], dtype=float)
+
+
+@pytest.mark.parametrize("src", ["terminal_v3_radar_encounter_model", "terminal_v3_opensky_encounter_model"])
+def test_geometry_restatements_agree_draw_for_draw(src, model_dir):
+    """@CorTerminalModel/sample.m:29-77 twice: oracle/em_oracle.c (em_geom_sample_batch, MT19937 mode) and oracle/pyref.py, with the box
+    and speed rejection exercised and with presets (InitStartTerminal's first three variables)."""
+    pp = O.parse_model_txt(em_io.materialize_model(src, model_dir))
+    labs = [x.strip('"') for x in pp["labels_initial"]]
+    io, ii = labs.index("own_speed") + 1, labs.index("int_speed") + 1
+    bs = np.tile([-np.inf, np.inf], (pp["n_initial"], 1))
+    bs[labs.index("own_distance")] = [0.0, 4.0]                      # a box that rejects a good part of the draws
+    for start, lim1, lim2, seed in (([0] * 15, (50, 506), (50, 506), 1), ([2, 1, 3] + [0] * 12, (169, 491), (68, 338), 7)):
+        om = O.OracleModel(pp, start=start)
+        n = 30
+        ob, ov, att = O.geom_sample(om, n, seed, mode=O.RNG_MT19937, bounds_sample=bs, idx_own_speed=io, idx_int_speed=ii, lim1=lim1, lim2=lim2)
+        ref, R = P.geom_sample(pp, n, seed, bounds_sample=bs, lim1=lim1, lim2=lim2, start=[v or None for v in start])
+        assert np.array_equal(ov, ref)
+        assert att.sum() > n                                         # the rejection loop ran
+        if start[0]:
+            assert np.all(ov[:, :3] == np.array(start[:3], dtype=float))
+
+
+def test_terminal_restatements_agree_draw_for_draw(tmp_path, model_dir):
+    """createEncounter.m:52-329 (PropagateTrajectory, CreateStartDistribution, CheckTrajectoryConditions), the static checks of
+    CorTerminalModel.m:117-316 and the filters of track.m:79-145, twice: the C oracle (MT19937 mode: one stream through the encounters,
+    aircraft 1 forward, backward, aircraft 2 forward, backward) and pyref.py -- every recorded row equal to the last bit, the same filter
+    decisions and CPA metadata."""
+    import glob
+    from em_model_manned_bayes_amd import synthetic
+    d = synthetic.write_terminal_directory(str(tmp_path))
+    pps = [O.parse_model_txt(glob.glob(os.path.join(d, "*_" + s + ".txt"))[0]) for s in _TERM_ORDER]
+    oms = [O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)) for pp in pps]
+    gp = O.parse_model_txt(em_io.materialize_model("terminal_v3_radar_encounter_model", model_dir))
+    labs = [x.strip('"') for x in gp["labels_initial"]]
+    decided = {True: 0, False: 0}
+    for (a1, a2), seed, n in ((("GENERIC", "GENERIC"), 3, 14), (("RTCA228_A2", "TEST"), 11, 6)):
+        dl = _dl_rows(a1, a2)
+        geom, _ = P.geom_sample(gp, n, seed + 100, lim1=tuple(dl[0, :2]), lim2=tuple(dl[1, :2]))
+        samples = [dict(zip(labs, row)) for row in geom]
+        geo = np.zeros((n, 12)); mo = np.zeros((n, 4), dtype=np.int32)
+        for e, sg in enumerate(samples):
+            for a, pre in enumerate(("own", "int")):
+                sn, cs = P.sincosd(sg[pre + "_bearing"])
+                geo[e, 6 * a: 6 * a + 6] = [sg[pre + "_distance"] * cs, sg[pre + "_distance"] * sn, sg[pre + "_alt"], sg[pre + "_speed"], sg[pre + "_heading"], sg[pre + "_intent"]]
+            oi, ii_ = int(sg["own_intent"]), int(sg["int_intent"])
+            mo[e] = [2 * (oi - 1), 2 * (oi - 1) + 1, 4 + 2 * (ii_ - 1), 4 + 2 * (ii_ - 1) + 1]
+        out, rows = O.propagate(oms, mo, geo, seed, dl, mode=O.RNG_MT19937, tmax_s=120.0)
+        R = P.Rand(seed)
+        dlp = [_DL[a1], _DL[a2]]
+        for e, sg in enumerate(samples):
+            traj = P.create_encounter(pps, mo[e], sg, 120.0, dlp, R)
+            rows_c = []
+            for a in range(2):
+                fwd = out[4 * e + 2 * a, : rows[4 * e + 2 * a]]
+                bck = out[4 * e + 2 * a + 1, 1: rows[4 * e + 2 * a + 1]]
+                both = np.concatenate([fwd, bck], axis=0)
+                both = both[np.argsort(both[:, 0], kind="stable")]
+                mine = np.stack([traj[a][k] for k in ("t_s", "x_nm", "y_nm", "z_ft", "heading_deg", "v_ft_s")], axis=1)
+                assert np.array_equal(both, mine), "encounter %d aircraft %d" % (e, a)
+                rows_c.append(both)
+            good_c, meta_c = O.terminal_filters(rows_c[0], rows_c[1], sg["own_intent"], sg["int_intent"], dl, [dlp[0]["maxCumTurn_deg"], dlp[1]["maxCumTurn_deg"]],
+                                                [dlp[0]["pitch_deg"], dlp[1]["pitch_deg"]])
+            good_p, meta_p = P.terminal_filters(traj, int(sg["own_intent"]), int(sg["int_intent"]), dlp, [dlp[0]["maxCumTurn_deg"], dlp[1]["maxCumTurn_deg"]],
+                                                [dlp[0]["pitch_deg"], dlp[1]["pitch_deg"]])
+            assert good_c == good_p and np.array_equal(meta_c, np.array(meta_p)), (e, good_c, good_p, meta_c, meta_p)
+            decided[good_c] += 1
+            for a in range(2):                                      # CheckCumTurn on its own, with a limit that decides
+                for lim in (20.0, 60.0, 180.0):
+                    assert O.check_cum_turn(traj[a]["heading_deg"], lim) == P.check_cum_turn(traj[a]["heading_deg"], lim)
+            sm = P.create_encounter(pps, mo[e], sg, 120.0, dlp, P.Rand(seed + 999), smooth=True) if e == 0 else None
+            if sm is not None:
+                raw = P.create_encounter(pps, mo[e], sg, 120.0, dlp, P.Rand(seed + 999))
+                assert np.array_equal(sm[0]["v_ft_s"], O.local_smooth(raw[0]["v_ft_s"], 5)) and np.array_equal(sm[1]["z_ft"], O.local_smooth(raw[1]["z_ft"], 15))
+    assert decided[False] > 0                                        # (the synthetic tables pass the filters about once in 150 attempts)
+
+
+def test_sample2track_restatements_agree():
+    """sample2track.m:183-243 twice (em_sample2track_batch and pyref.sample2track): positions to the last bit, the same CFIT / speed flags."""
+    rs = np.random.RandomState(8)
+    n, T = 25, 40
+    alt0 = rs.uniform(50, 3000, n); speed0 = rs.uniform(30, 200, n)
+    alt0[:8] = rs.uniform(5, 120, 8)                                 # low starts: some tracks reach the ground (CFIT, :234-237)
+    upd = np.stack([rs.uniform(-1500, 1500, (n, T)), rs.uniform(-2, 2, (n, T)), rs.uniform(-6, 6, (n, T))], axis=2)
+    ur_speed, ur_vr, ur_h = 6076.1154855643 / 3600.0, 1.0 / 60.0, 1.0
+    xyz, flags, vmm = O.sample2track(alt0, speed0, upd, ur_speed, ur_vr, ur_h, 40.0, 180.0)
+    seen = set()
+    for i in range(n):
+        x, y, z, cfit, rej = P.sample2track(alt0[i], speed0[i], upd[i], ur_speed, ur_vr, ur_h, 40.0, 180.0)
+        assert np.array_equal(xyz[i, :, 0], x) and np.array_equal(xyz[i, :, 1], y) and np.array_equal(xyz[i, :, 2], z)
+        assert bool(flags[i] & 1) == cfit and bool(flags[i] & 2) == rej
+        seen.add((cfit, rej))
+    assert len(seen) >= 3
+

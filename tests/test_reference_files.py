@@ -69,3 +69,10 @@ def test_matlab_goldens_are_current(tmp_path):
         assert np.array_equal(np.loadtxt(os.path.join(gold, "matlab", "hier_%s_inits.csv" % name), delimiter=",", comments="%"), r["init_val"])
         ev = np.loadtxt(os.path.join(gold, "matlab", "hier_%s_events.csv" % name), delimiter=",", comments="%")
         assert np.array_equal(ev[:, 1:4], np.concatenate(r["events"])[:, :3])
+    for src, stem in (("terminalradar", "terminal_v3_radar_encounter_model"), ("opensky", "terminal_v3_opensky_encounter_model")):
+        pp = O.parse_model_txt(em_io.materialize_model(stem, str(tmp_path)))
+        labs = [x.strip('"') for x in pp["labels_initial"]]
+        for tag, start in (("", [0] * 15), ("_start", [2, 1, 3] + [0] * 12)):
+            _, ov, _ = O.geom_sample(O.OracleModel(pp, start=start), 500, 1, mode=O.RNG_MT19937, idx_own_speed=labs.index("own_speed") + 1,
+                                     idx_int_speed=labs.index("int_speed") + 1, lim1=(50, 506), lim2=(50, 506))
+            assert np.array_equal(np.loadtxt(os.path.join(gold, "matlab", "geom_%s%s_inits.csv" % (src, tag)), delimiter=",", comments="%"), ov)

@@ -22,10 +22,12 @@ function ok = emgpu_check_parity(repo_dir)
 %        (16 initial / 4 dynamic variables; order_initial is not the identity; r_transition from the file).
 %     4. bn_sort (toposort 'stable', bn_sort.m:17-20) on every shipped graph that is not upper-triangular.
 %     5. sind / cosd as restated for createEncounter.m (report only: max difference in ulps).
+%     6. the terminal geometry network: CorTerminalModel('srcData', s).sample(500, 'seed', 1) for s = terminalradar, opensky, without a
+%        start and with mdl.start = {2, 1, 3, [], ...} (@CorTerminalModel/sample.m:29-77, RUN_terminal.m:36-39; acType GENERIC / GENERIC).
 %   Discrete fields (dt, var, bins) must be equal; dediscretised doubles must be bit-equal (same IEEE
 %   operations in the same order: a + (b - a) * rand), reported as max relative difference otherwise.
 %
-%   Returns true when checks 1-4 pass.  Please attach the printed output to an issue either way.
+%   Returns true when checks 1-4 and 6 pass.  Please attach the printed output to an issue either way.
 
     if nargin < 1, repo_dir = fileparts(fileparts(fileparts(mfilename('fullpath')))); end
     gold = fullfile(repo_dir, 'tests', 'golden', 'matlab');
@@ -80,6 +82,28 @@ function ok = emgpu_check_parity(repo_dir)
         ds = abs(sind(tt(:, 1)) - tt(:, 2)) ./ eps(max(abs(tt(:, 2)), realmin));
         dc = abs(cosd(tt(:, 1)) - tt(:, 3)) ./ eps(max(abs(tt(:, 3)), realmin));
         fprintf('5 sind/cosd restatement: max difference %.1f / %.1f ulp over %d angles (0 = bit-equal)\n', max(ds), max(dc), size(tt, 1));
+    end
+    %% 6. terminal geometry network ---------------------------------------------------------------------------
+    srcs = {'terminalradar', 'opensky'};
+    for c = 1:numel(srcs)
+        for withStart = [false true]
+            mdl = CorTerminalModel('srcData', srcs{c});
+            tag = '';
+            if withStart
+                st = cell(1, mdl.n_initial); st(1:3) = {2, 1, 3};
+                mdl.start = st; tag = '_start';
+            end
+            outInits = mdl.sample(500, 'seed', 1);
+            g = readmatrix(fullfile(gold, ['geom_' srcs{c} tag '_inits.csv']), 'CommentStyle', '%');
+            good = isequal(size(outInits), size(g)) && isequal(outInits, g);
+            msg = '';
+            if ~good && isequal(size(outInits), size(g))
+                [r, cc] = find(outInits ~= g, 1);
+                msg = sprintf('outInits(%d,%d): MATLAB %.17g, emgpu %.17g; max rel diff %.3g', r, cc, outInits(r, cc), g(r, cc), ...
+                              max(abs(outInits(:) - g(:)) ./ max(abs(g(:)), realmin)));
+            end
+            report(sprintf('6 CorTerminalModel(''srcData'',''%s'')%s.sample(500,''seed'',1)', srcs{c}, tag), good, msg); ok = ok && good;
+        end
     end
     if ok, fprintf('ALL PASS: the emgpu oracle reproduces this MATLAB bit for bit on the checked paths.\n');
     else, fprintf('FAILURES above: please report them with this output.\n'); end
