@@ -82,6 +82,8 @@ def parse_args(argv=None):
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each entry of `configs` (2 warm-up steps before)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="minimum units timed on the CPU oracle (scaled up to ~10 s)")
     ap.add_argument("--local-smooth", action="store_true", help="terminal: add the smoothing pass of createEncounter.m:88-89 (k_terminal_smooth: the flagged stand-in for em-core's local_smooth; a second pass over the tracks)")
+    ap.add_argument("--telemetry-s", type=float, default=2.5,
+                    help="seconds of untimed back-to-back steps after the timed region during which the shader clock and socket power are read (0: skip)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: allow more ranks than GPUs (ranks share devices, gloo barrier); the line says so")
     return ap.parse_args(argv)
@@ -91,30 +93,29 @@ def parse_args(argv=None):
 # launcher: --gpus N without a launcher's environment
 # ------------------------------------------------------------------------------------------------
 def visible_gpu_count():
-    """GPUs this process tree may use, counted WITHOUT loading a GPU runtime into this process: the KFD topology in sysfs
-    (a node with simd_count > 0 is a GPU), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES;
-    when sysfs is not readable, a child process asks the library (emgpu_device_count) and exits."""
+    """GPUs this process tree may use, counted WITHOUT loading a GPU runtime into THIS process: a child process asks the library
+    (emgpu_device_count: what the ranks themselves will see -- the runtime applies HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES and only
+    counts devices whose files the container may open) and exits.  Only when that child cannot run (no library yet) the KFD topology in
+    sysfs is counted instead (a node with simd_count > 0 is a GPU; sysfs ignores cgroup / device-file restrictions, so this can
+    over-count inside a container that was granted some of the host's GPUs), narrowed by the *_VISIBLE_DEVICES lists."""
     import glob
     import re
-    total = None
-    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
-    if nodes:
-        total = 0
-        for f in nodes:
-            try:
-                m = re.search(r"^simd_count\s+(\d+)", open(f).read(), re.M)
-            except OSError:
-                total = None
-                break
-            total += 1 if (m and int(m.group(1)) > 0) else 0
-    if total is None:
-        code = ("import ctypes,sys; sys.path.insert(0, %r); from em_model_manned_bayes_amd import _lib as L; c = ctypes.c_int32(0); "
-                "L.lib().emgpu_device_count(ctypes.byref(c)); print(c.value)" % ROOT)
+    code = ("import ctypes,sys; sys.path.insert(0, %r); from em_model_manned_bayes_amd import _lib as L; c = ctypes.c_int32(0); "
+            "L.lib().emgpu_device_count(ctypes.byref(c)); print('emgpu_device_count', c.value)" % ROOT)
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300).stdout.decode()
+        m = re.search(r"emgpu_device_count (\d+)", out)
+        if m:
+            return int(m.group(1))
+    except Exception:
+        pass
+    total = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
         try:
-            total = int(subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300).stdout.decode().strip() or 0)
-        except Exception:
-            total = 0
-        return total   # the runtime already applied the *_VISIBLE_DEVICES masks
+            m = re.search(r"^simd_count\s+(\d+)", open(f).read(), re.M)
+        except OSError:
+            continue
+        total += 1 if (m and int(m.group(1)) > 0) else 0
     for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
@@ -366,9 +367,9 @@ class DbnWorkload:
                 "trace_ld": self.ld, "models": self.names, "launches_per_step": self.launches_per_step, "model_blocks_per_step": getattr(self, "blocks_per_step", 1),
                 "sharding": "global sample index, no collective"}
 
-    def cpu_baseline(self, n_cpu):
+    def cpu_baseline(self, n_cpu, seconds=10.0):
         """The CPU oracle (a faithful scalar port of the reference algorithm) on the same workload,
-        bounded sample, one thread and all threads.  Reported baseline, not the target."""
+        bounded sample (about `seconds` of work per leg), one thread and all threads.  Reported baseline, not the target."""
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as O
         om = O.OracleModel(O.parse_model_txt(self.paths[0]))
@@ -376,7 +377,7 @@ class DbnWorkload:
         t0 = time.perf_counter()
         O.uncor_sample(om, 2000, T, seed, mode=O.RNG_PHILOX, want_events=False, want_dense=True)  # warm + calibrate
         rate = 2000 / (time.perf_counter() - t0)
-        n_cpu = int(min(max(n_cpu, rate * 10.0), 2_000_000))  # about 10 s of CPU work per leg
+        n_cpu = int(min(max(n_cpu if seconds >= 10.0 else 1000, rate * seconds), 2_000_000))  # about `seconds` of CPU work per leg
         t0 = time.perf_counter()
         O.uncor_sample(om, n_cpu, T, seed, mode=O.RNG_PHILOX, per_step=self.per_step, want_events=False, want_dense=True)
         dt1 = time.perf_counter() - t0
@@ -385,7 +386,7 @@ class DbnWorkload:
         n_cal = max(cores * 512, 4096)   # calibrate first: the sample is sized from the rate the threads really reach
         t0 = time.perf_counter()
         O.uncor_sample_throughput_mt(om, n_cal, T, seed, cores, per_step=self.per_step)
-        n_mt = int(min(max(n_cal, n_cal / (time.perf_counter() - t0) * 10.0), 20_000_000))
+        n_mt = int(min(max(n_cal, n_cal / (time.perf_counter() - t0) * seconds), 20_000_000))
         t0 = time.perf_counter()
         O.uncor_sample_throughput_mt(om, n_mt, T, seed, cores, per_step=self.per_step)
         dtm = time.perf_counter() - t0
@@ -463,7 +464,7 @@ class TerminalWorkload:
                 "geometry_attempts_per_encounter": getattr(self, "geom_attempts", None),
                 "tracks_over_the_redraw_cap": getattr(self, "failed", None)}
 
-    def cpu_baseline(self, n_cpu):
+    def cpu_baseline(self, n_cpu, seconds=10.0):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import glob
         import oracle as O
@@ -476,7 +477,7 @@ class TerminalWorkload:
         for f in files:
             pp = O.parse_model_txt(f)
             oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
-        n_cpu = 2000
+        n_cpu = 2000 if seconds >= 10.0 else 600
         geo_h = self.geo[:n_cpu].cpu().numpy()
         mo_h = self.mof[: 4 * n_cpu].cpu().numpy()
         t0 = time.perf_counter()
@@ -492,6 +493,77 @@ def make_workload(args, pl, rank, world):
     return (TerminalWorkload if args.config == "terminal" else DbnWorkload)(args, cfg, pl, rank, world)
 
 
+class GpuTelemetry:
+    """Shader clock and socket power of this rank's GPU DURING the timed region, read from amdgpu's hwmon files in sysfs (freq1_input =
+    sclk in Hz, power1_input = package power in microwatts: 0.03 ms per read, no profiler, no privileges) by a thread that samples every
+    2 ms.  The benchmark kernel runs at the board's power limit; how far a box lets the clock drop there differs from box to box by up to
+    20 %: with the clock in the line a reader can tell a slow box from a regression."""
+
+    def __init__(self, local_index=0):
+        import glob
+        cards = []
+        for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"):
+            try:
+                if open(os.path.join(os.path.dirname(f), "freq1_label")).read().strip() == "sclk":
+                    cards.append((int(f.split("/card")[1].split("/")[0]), os.path.dirname(f)))
+            except (OSError, ValueError):
+                pass
+        cards.sort()
+        self.dir = cards[local_index][1] if local_index < len(cards) else None
+        self.samples, self._stop, self._th = [], None, None
+
+    def _read(self):
+        try:
+            mhz = int(open(os.path.join(self.dir, "freq1_input")).read()) / 1e6
+        except (OSError, ValueError):
+            return None
+        try:
+            watts = int(open(os.path.join(self.dir, "power1_input")).read()) / 1e6
+        except (OSError, ValueError):
+            watts = None
+        return mhz, watts
+
+    def start(self):
+        if not self.dir:
+            return
+        import threading
+        self.samples, self._stop = [], threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                v = self._read()
+                if v:
+                    self.samples.append(v)
+                self._stop.wait(0.002)
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if self._th:
+            self._stop.set()
+            self._th.join()
+            self._th = None
+
+    def summary(self, tail=1.0):
+        """Statistics of the last `tail` fraction of the samples."""
+        if not self.samples:
+            return None
+
+        def stat(v):
+            v = sorted(v)
+            return {"median": v[len(v) // 2], "min": v[0], "max": v[-1]}
+        keep = self.samples[int(len(self.samples) * (1.0 - tail)):]
+        out = {"sclk_mhz": stat([a for a, _ in keep]), "samples": len(keep)}
+        pw = [b for _, b in keep if b is not None]
+        if pw:
+            out["socket_power_w"] = stat(pw)
+        try:
+            out["power_cap_w"] = int(open(os.path.join(self.dir, "power1_cap")).read()) / 1e6
+        except (OSError, ValueError):
+            pass
+        return out
+
+
 # ------------------------------------------------------------------------------------------------
 def measure(w, pl, args, warmup, steps):
     """warmup untimed steps, then `steps` timed ones bracketed by barrier + device synchronisation on both sides; the launch
@@ -501,6 +573,9 @@ def measure(w, pl, args, warmup, steps):
     w.sync()
     pl.barrier()
     ev = [(pl.event(), pl.event()) for _ in range(steps)]
+    tel = GpuTelemetry(getattr(getattr(pl, "dev", None), "index", 0) or 0) if hasattr(pl, "torch") else None
+    if tel:
+        tel.start()
     t0 = time.perf_counter()
     for k in range(steps):
         pl.record(ev[k][0])
@@ -511,10 +586,31 @@ def measure(w, pl, args, warmup, steps):
             time.sleep(args.step_gap_ms * 1e-3)
     pl.barrier()
     t1 = time.perf_counter()
+    in_region = None
+    if tel:
+        tel.stop()
+        in_region = tel.summary()
     w.sync()
     elapsed = pl.max_over_ranks(t1 - t0)
     step_ms = [pl.elapsed_ms(a, b) for a, b in ev]
     w.check()
+    if tel and tel.dir and getattr(args, "telemetry_s", 0.0) > 0.0:
+        # The SMU's clock / power readings are moving averages that trail the load by more than a second (tools/power_probe.sh: 2 s from
+        # idle to the sustained values), the timed region lasts tens of milliseconds: what the box does under THIS step is read in an
+        # untimed run of the same back-to-back launches, from its last 40 %.
+        tel.start()
+        t_end, k = time.perf_counter() + args.telemetry_s, warmup + steps
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                w.step(k)
+                k += 1
+            w.sync()
+        tel.stop()
+        w.telemetry = tel.summary(tail=0.4)
+        if w.telemetry:
+            w.telemetry["how"] = ("amdgpu hwmon in sysfs (freq1_input, power1_input), every 2 ms during %.1f s of the same step launched back to back after the timed "
+                                  "region; statistics of the last 40 %% (the readings trail the load by over a second)" % args.telemetry_s)
+            w.telemetry["inside_the_timed_region"] = in_region
     return elapsed, step_ms
 
 
@@ -530,6 +626,9 @@ def roofline_of(w, step_ms, lib_version):
          "avg_launch_ms": avg_step_s * 1e3 / w.launches_per_step, "launches_per_step": w.launches_per_step,
          "avg_step_ms": avg_step_s * 1e3, "step_ms": [round(x, 3) for x in step_ms], "algorithmic_bytes_per_launch": per_launch,
          "algorithmic_bytes_per_unit": w.bytes_per_unit}
+    if getattr(w, "telemetry", None):   # the box, while it ran the timed region
+        r["sclk_mhz"] = w.telemetry["sclk_mhz"]["median"]
+        r["gpu_telemetry"] = w.telemetry
     if w.launches_per_step > 1:   # blocks of different kernel instances: they run on the ctx stream and three side streams
         r["launches_overlap"] = "avg_launch_ms is avg_step_ms / launches_per_step; single launches in a kernel trace overlap"
     r.update(recorded_traffic(kernel, per_launch, lib_version, data_dependent=getattr(w, "bytes_data_dependent", False)))
@@ -558,6 +657,8 @@ def other_configs(args, pl, lib_version):
             res[name] = {"metric": cfg["metric"], "value": w.n * args.other_steps / elapsed, "unit": cfg["unit"],
                          "ms_per_step": elapsed / args.other_steps * 1e3, "steps": args.other_steps, "warmup": 2,
                          "kernel": w.kernel_name(), "config": w.config(), "roofline": roofline_of(w, step_ms, lib_version)}
+            if not args.no_cpu_baseline:   # the same oracle beside every config, on a smaller sample (about 3 s per leg)
+                res[name]["cpu_baseline"] = w.cpu_baseline(args.cpu_sample, seconds=3.0)
         except Exception as e:   # an entry that cannot run says so; the headline line is still printed
             res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         w = None

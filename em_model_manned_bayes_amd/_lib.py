@@ -130,7 +130,7 @@ SYMBOLS = [
     "emgpu_model_set_zero_bins", "emgpu_shard_range", "emgpu_device_count", "emgpu_mixed_blocks",
     "emgpu_sample_dbn_blocks_device", "emgpu_sample_dbn_multi_host", "emgpu_sample_dbn_multi_device",
     "emgpu_track_uncor_host", "emgpu_track_uncor_device", "emgpu_uncor_dynamic_limits", "emgpu_model_start_log_weight",
-    "emgpu_track_terminal_host", "emgpu_debug_parent_masks", "emgpu_last_launch_count", "emgpu_debug_pk_column", "emgpu_debug_terminal_counters", "emgpu_debug_uncor_dynamics_host", "emgpu_model_save_bin", "emgpu_model_load_bin",
+    "emgpu_track_terminal_host", "emgpu_debug_parent_masks", "emgpu_last_launch_count", "emgpu_debug_pk_column", "emgpu_debug_terminal_counters", "emgpu_debug_uncor_dynamics_host", "emgpu_model_save_bin", "emgpu_model_load_bin", "emgpu_philox_rounds", "emgpu_ctx_trim",
 ]
 
 _lib = None
@@ -157,10 +157,47 @@ def _share_hip_runtime():
         return
     path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
     if os.path.exists(path):
+        # only when the wheel's copy answers to the soname libemgpu.so asks for: a wheel of another ROCm major (libamdhip64.so.6 beside a
+        # system .7) would be loaded IN ADDITION to the system copy the NEEDED entry still resolves to -- the two runtimes this function
+        # exists to prevent
+        want, have = _needed_hip_soname(LIB_PATH), _soname_of(path)
+        if want and have and want != have:
+            import warnings
+            warnings.warn("emgpu: the installed torch wheel bundles %s but libemgpu.so was linked against %s: not preloading it "
+                          "(importing torch in this process as well would map two HIP runtimes)" % (have, want))
+            return
         try:
             _hip_runtime = C.CDLL(path, mode=C.RTLD_GLOBAL)
         except OSError:
             _hip_runtime = None
+
+
+def _soname_of(path):
+    """The soname a libamdhip64 build carries (its DT_SONAME string, "libamdhip64.so.<major>", read from the file's string table)."""
+    return _needed_hip_soname(path)
+
+
+def _needed_hip_soname(lib_path):
+    import mmap
+    import re
+    try:
+        with open(lib_path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as data:
+            m = re.search(rb"libamdhip64\.so\.\d+", data)
+            return m.group(0).decode() if m else None
+    except (OSError, ValueError):
+        return None
+
+
+def mapped_hip_runtimes():
+    """The distinct libamdhip64 files mapped into this process (/proc/self/maps): more than one is the failure _share_hip_runtime prevents."""
+    seen = set()
+    try:
+        for ln in open("/proc/self/maps"):
+            if "libamdhip64" in ln:
+                seen.add(os.path.realpath(ln.split()[-1]))
+    except OSError:
+        pass
+    return sorted(seen)
 
 
 def lib():
@@ -173,6 +210,10 @@ def lib():
                           "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
     _share_hip_runtime()
     L = C.CDLL(LIB_PATH)
+    two = mapped_hip_runtimes()
+    if len(two) > 1:
+        raise ImportError("two HIP runtimes are mapped into this process (%s): libemgpu.so and torch would each talk to the GPU through its own; "
+                          "import em_model_manned_bayes_amd before torch, or set EMGPU_HIP_RUNTIME=system in a process that never imports torch" % ", ".join(two))
     for s in SYMBOLS:
         getattr(L, s)  # AttributeError if the ABI is incomplete
     L.emgpu_last_error.restype = C.c_char_p
@@ -233,6 +274,8 @@ def lib():
     L.emgpu_debug_parent_masks.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     for f in (L.emgpu_propagate_terminal_device, L.emgpu_propagate_terminal_host):
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(TermParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emgpu_philox_rounds.restype = C.c_int32
+    L.emgpu_ctx_trim.argtypes = [C.c_void_p]
     L.emgpu_model_save_bin.argtypes = [C.c_void_p, C.c_char_p]
     L.emgpu_model_load_bin.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     L.emgpu_debug_uncor_dynamics_host.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -110,7 +110,10 @@ const char *emgpu_last_error(void) { return g_err.c_str(); }
 #ifndef EMGPU_SRC_HASH
 #define EMGPU_SRC_HASH "unhashed"
 #endif
-const char *emgpu_version(void) { return "emgpu 0.2 (gfx950) src:" EMGPU_SRC_HASH; }
+#define EMGPU_STR2(x) #x
+#define EMGPU_STR(x) EMGPU_STR2(x)
+const char *emgpu_version(void) { return "emgpu 0.3 (gfx950) philox4x32-" EMGPU_STR(EMGPU_PHILOX_ROUNDS) " src:" EMGPU_SRC_HASH; }
+int32_t emgpu_philox_rounds(void) { return EMGPU_PHILOX_ROUNDS; }
 
 int emgpu_model_load_txt(const char *path, const int32_t *idx_zero_boundaries, int32_t n_idx,
                          int32_t is_overwrite_zero_boundaries, emgpu_model **out) {
@@ -418,6 +421,17 @@ int emgpu_ctx_sync(emgpu_ctx *ctx) {
     if (st & 1u) return fail(EMGPU_ERR_REJECT_CAP, "rejection loop reached max_attempts for at least one trajectory");
     if (st & 4u) return fail(EMGPU_ERR_PRESET, "Attempt to preset a dependent variable (a row of the start grid presets a node without its parents, or a bin outside 1..r)");
     if (st & 2u) return fail(EMGPU_ERR_EVENT_CAP, "an event list did not fit event_cap rows");
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_ctx_trim(emgpu_ctx *ctx) {
+    EMGPU_TRY
+    if (!ctx) return fail(EMGPU_ERR_ARG, "null ctx");
+    CTX_LOCK(ctx);
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    for (auto &sc : ctx->scratch) { if (sc.p) HIP_OK(hipFree(sc.p)); sc.p = nullptr; sc.cap = 0; }
     return EMGPU_OK;
     EMGPU_CATCH
 }

@@ -203,6 +203,10 @@ class Context:
     def sync(self):
         L.check(L.lib().emgpu_ctx_sync(self._h))
 
+    def trim(self):
+        """emgpu_ctx_trim: release the device scratch the host-pointer / .track entry points keep between calls (the tables stay)."""
+        L.check(L.lib().emgpu_ctx_trim(self._h))
+
     def last_kernel(self):
         return L.lib().emgpu_last_kernel_name(self._h).decode()
 

@@ -44,7 +44,11 @@ typedef struct emgpu_model emgpu_model; /* parsed model + priors + start (Encoun
 typedef struct emgpu_ctx emgpu_ctx;     /* one device + one stream + uploaded tables               */
 
 const char *emgpu_last_error(void);
-const char *emgpu_version(void);
+const char *emgpu_version(void);   /* "emgpu <version> (gfx950) philox4x32-<rounds> src:<hash of the sources it was built from>" */
+/* Rounds of the Philox4x32 generator this build draws with (7; builds before round 3 and -DEMGPU_PHILOX_ROUNDS=10 builds: 10).  The
+ * round count is part of the sampler's identity: the same (seed, global index) gives other samples under another count, so data and
+ * goldens of one count are not comparable with, or resumable by, a build of the other -- check it where that matters. */
+int32_t emgpu_philox_rounds(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Model: replaces em_read.m:1-206 and the data half of @EncounterModel/EncounterModel.m
@@ -147,6 +151,9 @@ int emgpu_ctx_set_stream(emgpu_ctx *ctx, void *hip_stream);
 /* Wait for the ctx stream and report deferred per-trajectory errors of *_device calls
  * (EMGPU_ERR_REJECT_CAP / EMGPU_ERR_EVENT_CAP). */
 int emgpu_ctx_sync(emgpu_ctx *ctx);
+/* Give the device scratch of the host-pointer and .track entry points back (it is kept between calls and only ever grows: one
+ * 1 M x 240 s dense host call leaves 3-4 GB with the ctx); the uploaded model tables stay.  Synchronises the ctx stream. */
+int emgpu_ctx_trim(emgpu_ctx *ctx);
 void emgpu_ctx_free(emgpu_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------------------

@@ -771,6 +771,23 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert line["config"]["launches_per_step"] == 1 and line["config"]["model_blocks_per_step"] == 6
     rf = line["roofline"]   # every timed launch listed; the write ceiling of this box measured on the step's own buffers
     assert len(rf["step_ms"]) == 2 and rf["streaming_write"]["GB/s"] > 1000 and 0 < rf["frac_of_streaming_write"] < 1.5
+    assert rf["sclk_mhz"] > 50 and rf["gpu_telemetry"]["samples"] >= 1          # the box's shader clock during the timed region is in the line
+
+
+def test_bench_launcher_with_eight_ranks(tmp_path):
+    """The node layout of SCALE runs, executed on hardware before a driver ever needs it: `python bench.py --gpus 8` as its own launcher --
+    eight rank processes (spawned, watched, rank 0's line relayed), here sharing the box's one GPU behind a gloo barrier (--oversubscribe,
+    a test-only flag the line reports).  Tiny n: what is tested is the launcher and the rank logic, not a rate."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--n", "20000", "--no-cpu-baseline", "--oversubscribe"]
+    r = subprocess.run(cmd, env=env, capture_output=True, timeout=1200)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["oversubscribed"] is True and line["scaling"] == "weak"
+    assert line["value"] > 0 and abs(line["value"] - 8 * 20000 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]   # the whole job's units / the slowest rank's time
+    assert "configs" not in line and "cpu_baseline" not in line
 
 
 @pytest.fixture(scope="module")

@@ -28,6 +28,13 @@ def test_library_exports_every_symbol_the_header_declares():
     assert lib.emgpu_version().decode().startswith("emgpu")
 
 
+def test_version_names_the_generator_and_the_sources():
+    v = L.lib().emgpu_version().decode()
+    r = int(L.lib().emgpu_philox_rounds())
+    assert r in (7, 10) and ("philox4x32-%d" % r) in v and "src:" in v
+    assert r == O.philox_rounds()        # (tests/conftest.py refuses to start a session otherwise)
+
+
 def test_no_cpu_fallback_without_a_device():
     import torch
     if torch.cuda.is_available():
