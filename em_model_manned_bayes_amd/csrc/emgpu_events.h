@@ -218,4 +218,139 @@ __device__ __forceinline__ void ev_tail(const EvPlan &E, EvState &S, const Rng &
     }
 }
 
+
+// ---- WIDE lists (round 4): more variables with a resample rate than the 8 - ND streams above hold (haa_v1: 7 of its 9 variables).
+// The rule of resample_events.m:16-37 is unchanged -- per second the resample rows of EVERY rated variable in ascending id, then the
+// transition rows -- only the block's flag matrix grows to 16 streams per second: stream b < 16 - ND = the b-th rated variable (ascending
+// id, static or dynamic alike), the last ND = the transitions.  Two 8 x 8 transposes, byte-interleaved per second, give a 128-bit mask
+// whose leading bit is the lane's next row; what a stream is (variable, zero bin, boundaries, threshold) sits in LDS (EvStream, filled
+// once per workgroup) instead of packed registers.
+struct EvStream { uint8_t var1, kdyn, zero, nb; uint16_t boff, pad; uint32_t R, RR1; };
+template <int ND>
+__device__ __forceinline__ void ev_wide_plan(const EmgpuPlan &P, EvStream *s_ev /* [16] in LDS; call from every thread, then barrier */) {
+    constexpr int NRES = 16 - ND;
+    const int b = threadIdx.x;
+    if (b < 16) {
+        EvStream E{0, 0xFF, 0, 0, 0, 0, 0u, 0x00010001u};
+        if (b < NRES) {
+            if (b < P.nact) {
+                const uint32_t pos = P.a_pos[b];
+                E.var1 = (uint8_t)(P.a_var[b] + 1u); E.kdyn = (uint8_t)P.a_dyn[b]; E.zero = P.i_zero[pos]; E.nb = P.i_nb[pos]; E.boff = P.i_boff[pos];
+                E.R = P.a_R[b]; E.RR1 = ((P.a_R[b] >> 16) + 1u) * 0x00010001u;
+            }
+        } else if (b - NRES < P.nd) {
+            const uint32_t k = P.d_emit[b - NRES];
+            E.var1 = (uint8_t)(P.d_ivar[k] + 1u); E.kdyn = (uint8_t)k; E.zero = P.d_zero[k]; E.nb = P.d_nb[k];
+        }
+        s_ev[b] = E;
+    }
+}
+struct EvStateW {
+    EvState S;
+    uint64_t sb_lo, sb_hi;   // byte b: 1-based bin of rated variable b when it is static
+};
+template <int NI, int ND>
+__device__ __forceinline__ EvStateW ev_state_w_of(const EmgpuPlan &P, const EmgpuRun &A, const int (&bin)[NI], bool valid, int64_t i) {
+    EvStateW W{};
+    W.S.ev = A.events + (size_t)(valid ? i : 0) * (size_t)A.event_cap;
+    W.S.cap = valid ? (uint32_t)A.event_cap : 0u;
+#pragma unroll
+    for (int b = 0; b < 16 - ND; b++)
+        if (b < P.nact && P.a_dyn[b] < 0) {
+            const uint64_t v = (uint64_t)(uint32_t)(pick<NI>(bin, P.a_pos[b]) + 1);
+            if (b < 8) W.sb_lo |= v << (8 * b); else W.sb_hi |= v << (8 * (b - 8));
+        }
+    return W;
+}
+// bytes a3 a2 a1 a0 and c3 c2 c1 c0 -> a3 c3 a2 c2 a1 c1 a0 c0
+__device__ __forceinline__ uint64_t ev_interleave_bytes(uint32_t a, uint32_t c) {
+    const uint32_t hi = __builtin_amdgcn_perm(a, c, 0x07030602u), lo = __builtin_amdgcn_perm(a, c, 0x05010400u);
+    return ((uint64_t)hi << 32) | lo;
+}
+inline bool ev_plan_wide_ok(const EmgpuPlan &P, const EmgpuRun &A) {
+    if (P.nact > 16 - P.nd || A.event_cap < 1) return false;
+    for (int a = 0; a < P.nact; a++)
+        if (P.a_R[a] >= 0xFFFF0000u) return false;
+    return true;
+}
+template <int ND, bool LB>
+__device__ __forceinline__ void ev_emit_block_wide(const CoopLds<ND, LB> &W, int lane, const EvStream *s_ev, int nact, EvStateW &SW, const Rng &rng, const double *bnd,
+                                                   int g8, int T, bool valid, uint32_t hitp, uint32_t chgp, uint32_t prevp) {
+    constexpr int NRES = 16 - ND;
+    const uint32_t live8 = (g8 == 0 ? 0x7Fu : 0xFFu) & (8 * g8 + 7 < T ? 0xFFu : (0xFF00u >> (T - 8 * g8)) & 0xFFu);   // seconds 1 <= c < T
+    uint64_t in1 = 0ull, in2 = 0ull;   // streams 0-7 / 8-15: byte 7 - (b & 7) = stream b, bit 7 - j = second j
+    for (int b = 0; b < nact; b++) {                           // wave-uniform trip count
+        const uint32_t kd = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ev[b].kdyn);
+        uint32_t st;
+        if (kd != 0xFFu) st = (hitp >> (8u * kd)) & 0xFFu;
+        else {
+            const uint32_t var0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ev[b].var1) - 1u;
+            const uint32_t Rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ev[b].R), RR1b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ev[b].RR1);
+            st = static_hits8(rng, var0, g8, Rb, RR1b) & live8;
+        }
+        if (b < 8) in1 |= (uint64_t)st << (8 * (7 - b)); else in2 |= (uint64_t)st << (8 * (15 - b));
+    }
+#pragma unroll
+    for (int e = 0; e < ND; e++) {
+        const uint32_t kd = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ev[NRES + e].kdyn);
+        if (kd != 0xFFu) in2 |= (uint64_t)((chgp >> (8u * kd)) & 0xFFu) << (8 * (15 - (NRES + e)));
+    }
+    const uint64_t t1 = valid ? transpose8x8(in1) : 0ull, t2 = valid ? transpose8x8(in2) : 0ull;   // byte 7 - j = second j, bit 7 - (b & 7) = stream b
+    uint64_t pend_hi = ev_interleave_bytes((uint32_t)(t1 >> 32), (uint32_t)(t2 >> 32));            // seconds 0-3: bit 63 - (16 j + b)
+    uint64_t pend_lo = ev_interleave_bytes((uint32_t)t1, (uint32_t)t2);                            // seconds 4-7
+    const uint8_t *bins8 = reinterpret_cast<const uint8_t *>(&W.res[lane * CoopLds<ND, LB>::kStride + CoopLds<ND, LB>::kBins]);
+    const float *res32 = &W.res[lane * CoopLds<ND, LB>::kStride];
+    while (__ballot((pend_hi | pend_lo) != 0ull) != 0ull) {
+        if ((pend_hi | pend_lo) != 0ull) {
+            uint32_t pos;
+            if (pend_hi != 0ull) { pos = (uint32_t)__clzll((long long)pend_hi); pend_hi &= ~(0x8000000000000000ull >> pos); }
+            else { pos = (uint32_t)__clzll((long long)pend_lo); pend_lo &= ~(0x8000000000000000ull >> pos); pos += 64u; }
+            const uint32_t j = pos >> 4, b = pos & 15u;
+            const EvStream E = s_ev[b];
+            const uint32_t var1 = E.var1, kd = E.kdyn, zb = E.zero;
+            const uint32_t c = 8u * (uint32_t)g8 + j;
+            uint32_t bin1;
+            float v = 0.f;
+            bool draw = false;
+            if (b >= (uint32_t)NRES) {                          // a transition row: the new bin and its value
+                bin1 = bins8[8u * kd + j];
+                if (bin1 != zb) v = res32[8u * kd + j];
+            } else if (kd != 0xFFu) {                           // a resample row of a dynamic variable: the bin BEFORE this second's transition
+                bin1 = j ? bins8[8u * kd + j - 1u] : ((prevp >> (8u * kd)) & 0xFFu);
+                const bool hidden = ((chgp >> (8u * kd + 7u - j)) & 1u) != 0u;
+                if (bin1 != zb) { if (hidden) draw = true; else v = res32[8u * kd + j]; }
+            } else {                                            // a resample row of a static variable
+                bin1 = (uint32_t)((b < 8u ? SW.sb_lo >> (8u * b) : SW.sb_hi >> (8u * (b - 8u))) & 0xFFull);
+                if (E.nb == 0u) v = (float)bin1; else if (bin1 != zb) draw = true;
+            }
+            if (draw) v = ev_draw(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, bnd, var1 - 1u, c, bin1 - 1u, E.boff);
+            SW.S.emit(c, var1, bin1, v);
+        }
+    }
+}
+template <int ND>
+__device__ __forceinline__ void ev_tail_wide(const EvStream *s_ev, int nact, EvStateW &SW, const Rng &rng, const double *bnd, int T, uint32_t curp, const EmgpuRun &A, bool valid, int64_t i) {
+    const uint32_t Tu = (uint32_t)T;
+    for (int b = 0; b < nact; b++) {
+        const EvStream E = s_ev[b];
+        const uint32_t var0 = (uint32_t)E.var1 - 1u, kd = E.kdyn;
+        const uint4 rh = rng.block(EMGPU_SEC_RES, var0, Tu >> 3), rl = rng.block(EMGPU_SEC_RES_LO, var0, Tu >> 3);
+        uint32_t x = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) x = ((Tu & 7u) == (uint32_t)j) ? split_draw(rh, rl, j) : x;
+        if (clamp32(x) < E.R) {
+            const uint32_t bin1 = kd != 0xFFu ? ((curp >> (8u * kd)) & 0xFFu) : (uint32_t)((b < 8 ? SW.sb_lo >> (8 * b) : SW.sb_hi >> (8 * (b - 8))) & 0xFFull);
+            float v = 0.f;
+            if (E.nb == 0u) v = (float)bin1;
+            else if (bin1 != (uint32_t)E.zero) v = ev_draw(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, bnd, var0, Tu, bin1 - 1u, E.boff);
+            SW.S.emit(Tu, var0 + 1u, bin1, v);
+        }
+    }
+    if (!(A.flags & EMGPU_FLAG_NO_TERMINATOR)) SW.S.emit(Tu, 0u, 0u, 0.f);
+    if (valid) {
+        A.ev_count[i] = SW.S.count;
+        if (SW.S.count > (uint32_t)A.event_cap) atomicOr(A.status, 2u);
+    }
+}
+
 } // namespace emgpu

@@ -319,7 +319,8 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
 // EV: the event list of dbn_hierarchical_sample.m:33-60 is written as well (uncor_fast_events below).
 // IDX: an index list may be in use (emgpu_sample_params.indices): the workers read the owner's global index from LDS instead of
 // deriving it from their own (kept out of the plain instance: the benchmark kernel pays 1 % for the possibility).
-template <int NI, int M0, int M1, int M2, bool MIXED = false, bool EV = false, bool IDX = false>
+// EVW: the event list of a model with more rated variables than the eight streams of EV hold (haa_v1): emgpu_events.h "WIDE lists"
+template <int NI, int M0, int M1, int M2, bool MIXED = false, bool EV = false, bool IDX = false, bool EVW = false>
 __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs &F, const int64_t i0 /* trajectory of lane 0: wave-uniform, may be < 0 */) {
     // workers look the bin of a request up in LDS (the owner does not encode it into the request): -1.8 % on the
     // <7,4,6,6> instance too since the packed compare pass freed its registers
@@ -408,9 +409,16 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
     const uint32_t *col_slot = reinterpret_cast<const uint32_t *>(&W.res[lane * CoopLds<3, LB>::kStride + CoopLds<3, LB>::kSpare]);
     EvPlan E{};
     EvState S{};
-    if constexpr (EV) {
+    EvStateW SW{};
+    __shared__ EvStream s_evw[EVW ? 16 : 1];
+    if constexpr (EV && !EVW) {
         E = ev_plan_of<NI, 3>(P);
         S = ev_state_of<NI, 3>(P, A, bin, valid, i);
+    }
+    if constexpr (EVW) {
+        ev_wide_plan<3>(P, s_evw);
+        SW = ev_state_w_of<NI, 3>(P, A, bin, valid, i);
+        __syncthreads();
     }
     const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
     for (int g8 = 0; g8 < G8; g8++) {
@@ -441,12 +449,14 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
         for (int k = 0; k < 3; k++)
             coop_fill_store_msb<3, LB, !EV && !IDX, true>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],   // (the plain and the mixed kernel are only launched with both dense outputs)
                                    3u, h_slot[k], i0, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
-        if constexpr (EV) ev_emit_block<3, LB>(W, lane, E, S, rng, P.bnd, g8, T, valid, hit24, kind24, prevw);
+        if constexpr (EV && !EVW) ev_emit_block<3, LB>(W, lane, E, S, rng, P.bnd, g8, T, valid, hit24, kind24, prevw);
+        if constexpr (EVW) ev_emit_block_wide<3, LB>(W, lane, s_evw, P.nact, SW, rng, P.bnd, g8, T, valid, hit24, kind24, prevw);
         wave_sync(); // results of this block are consumed before the next block's workers overwrite them
     }
     if constexpr (EV) {
         const uint32_t curp = (cur1[0] & 0x7Fu) | ((cur1[1] & 0x7Fu) << 8) | ((cur1[2] & 0x7Fu) << 16);
-        ev_tail<3>(E, S, rng, P.bnd, T, curp, A, valid, i);
+        if constexpr (EVW) ev_tail_wide<3>(s_evw, P.nact, SW, rng, P.bnd, T, curp, A, valid, i);
+        else ev_tail<3>(E, S, rng, P.bnd, T, curp, A, valid, i);
     }
 }
 
@@ -462,6 +472,11 @@ __global__ void __launch_bounds__(256, EMGPU_FAST_WAVES) k_uncor_fast(const Emgp
 template <int NI, int M0, int M1, int M2>
 __global__ void __launch_bounds__(256, 3) k_uncor_fast_ev(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
     uncor_fast_body<NI, M0, M1, M2, false, true, true>(P, A, F, (int64_t)blockIdx.x * 256 - (A.col0 & 255));
+}
+// ... and for a model with up to 13 rated variables (haa_v1 has 7: it ran on k_dbn_generic)
+template <int NI, int M0, int M1, int M2>
+__global__ void __launch_bounds__(256, 3) k_uncor_fast_evw(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
+    uncor_fast_body<NI, M0, M1, M2, false, true, true, true>(P, A, F, (int64_t)blockIdx.x * 256 - (A.col0 & 255));
 }
 // the dense kernel for an index list (the later rounds of UncorEncounterModel.track: the trajectories still rejected)
 template <int NI, int M0, int M1, int M2>
@@ -528,7 +543,7 @@ static int fast_shape_of(const EmgpuPlan &P) {
 bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     if (P.nd != 3 || P.depend || A.per_step) return false;
     if (A.start != nullptr || A.log_weight != nullptr) return false;   // a start grid / per-sample weights: the generic kernel
-    if ((A.ev_count != nullptr || A.events != nullptr) && !ev_plan_ok(P, A)) return false;
+    if ((A.ev_count != nullptr || A.events != nullptr) && !ev_plan_ok(P, A) && !(ev_plan_wide_ok(P, A) && P.ni <= 9)) return false;
     if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
     for (int k = 0; k < 3; k++) {
         if (P.d_nb[k] == 0 || P.d_nb[k] > 16 || P.d_meff[k] == 0) return false;
@@ -632,6 +647,12 @@ hipError_t launch_uncor_fast(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t 
         case 7: *name = "k_uncor_fast_idx<9,6,6,6>"; return launch_idx_t<9, 6, 6, 6>(P, A, F, s);
         default: *name = "none"; return hipErrorNotSupported;
         }
+    }
+    if (A.ev_count != nullptr && !ev_plan_ok(P, A)) {   // more rated variables than eight streams hold: the wide list, on the widest instance
+        const int64_t blocks = (A.n + (A.col0 & 255) + 255) / 256;
+        *name = "k_uncor_fast_evw<9,6,6,6>";
+        hipLaunchKernelGGL((k_uncor_fast_evw<9, 6, 6, 6>), dim3((unsigned)blocks), dim3(256), 0, s, P, A, F);
+        return hipGetLastError();
     }
     if (A.ev_count != nullptr) {
         switch (fast_shape_of(P)) {

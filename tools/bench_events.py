@@ -11,7 +11,17 @@ def bench(name):
     nm = native.NativeModel.load_txt(em_io.materialize_model(name, tempfile.mkdtemp()))
     labs = nm.get_labels(L.F_LABELS_INITIAL)
     idx = {k: (labs.index('"%s"' % v) + 1 if '"%s"' % v in labs else 0) for k, v in (("idx_L", "L"), ("idx_v", "v"), ("idx_dh", "\\dot h"))}
-    n, T, cap = 1_000_000, 240, 512
+    n, T = 1_000_000, 240
+    for cap in (512, 2048):                  # (haa_v1: seven rated variables, lists of up to ~700 rows)
+        try:
+            return bench_cap(name, nm, idx, n, T, cap)
+        except L.EmgpuError as e:
+            if e.code != L.ERR_EVENT_CAP or cap == 2048:
+                raise
+            ctx.trim()
+
+
+def bench_cap(name, nm, idx, n, T, cap):
     ni = nm.n_initial
     ib = torch.empty((ni, n), dtype=torch.uint8, device=dev); iv = torch.empty((ni, n), dtype=torch.float32, device=dev)
     evc = torch.empty(n, dtype=torch.int32, device=dev); ev = torch.empty((n, cap, 2), dtype=torch.float32, device=dev)
