@@ -573,7 +573,7 @@ def measure(w, pl, args, warmup, steps):
     w.sync()
     pl.barrier()
     ev = [(pl.event(), pl.event()) for _ in range(steps)]
-    tel = GpuTelemetry(getattr(getattr(pl, "dev", None), "index", 0) or 0) if hasattr(pl, "torch") else None
+    tel = GpuTelemetry(getattr(getattr(pl, "dev", None), "index", 0) or 0) if (hasattr(pl, "torch") and getattr(args, "telemetry_s", 0.0) > 0.0) else None
     if tel:
         tel.start()
     t0 = time.perf_counter()

@@ -70,6 +70,7 @@ struct emgpu_ctx {
     hipStream_t own_stream = nullptr;
     uint32_t *d_status = nullptr;
     uint32_t *d_queue = nullptr;  // k_terminal_propagate: the launch's track queue (one word, zeroed by the launcher)
+    EmgpuPresets *d_presets = nullptr;   // the start grid / log-weight block of the last DBN call that had one
     uint32_t *h_status = nullptr; // pinned
     std::map<uint64_t, Uploaded> cache; // by Model::uid
     uint64_t use_clock = 0;
@@ -443,6 +444,7 @@ void emgpu_ctx_free(emgpu_ctx *ctx) {
     for (auto &sc : ctx->scratch) (void)hipFree(sc.p);
     (void)hipFree(ctx->d_status);
     (void)hipFree(ctx->d_queue);
+    (void)hipFree(ctx->d_presets);
     (void)hipFree(ctx->d_layers);
     (void)hipFree(ctx->d_thr_base);
     (void)hipHostFree(ctx->h_status);
@@ -570,7 +572,6 @@ static void fill_run(emgpu_ctx *ctx, const Uploaded &u, const Model &m, const em
     A.status = ctx->d_status;
     A.ld = p->n;
     A.indices = p->indices;
-    A.start = p->start;
 }
 
 // Point the run at the caller's buffers: column col_offset of arrays whose trajectory dimension is ld.
@@ -589,7 +590,6 @@ static void bind_outputs(EmgpuRun &A, const Model &m, const emgpu_sample_params 
     A.ev_count = out->ev_count ? out->ev_count + o : nullptr;
     A.events = out->events ? reinterpret_cast<uint64_t *>(out->events) + o * (size_t)p->event_cap : nullptr;
     A.attempts = out->attempts ? out->attempts + o : nullptr;
-    A.log_weight = out->log_weight;
     (void)m;
 }
 
@@ -636,7 +636,17 @@ int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sa
     EmgpuRun A;
     fill_run(ctx, u, h->m, p, A);
     bind_outputs(A, h->m, p, out);
-    if (A.log_weight) { ensure_logp(ctx, u, h->m); A.logp = u.d_logp; memcpy(A.lp_off, u.lp_off, sizeof A.lp_off); }
+    if (p->start || out->log_weight) {   // a start grid / per-sample log-weights: a small block of device memory the kernel reads them through
+        EmgpuPresets Q;
+        memset(&Q, 0, sizeof Q);
+        Q.start = p->start; Q.log_weight = out->log_weight;
+        if (Q.log_weight) { ensure_logp(ctx, u, h->m); Q.logp = u.d_logp; memcpy(Q.lp_off, u.lp_off, sizeof Q.lp_off); }
+        if (!ctx->d_presets) HIP_OK(hipMalloc((void **)&ctx->d_presets, sizeof(EmgpuPresets)));
+        HIP_OK(hipStreamSynchronize(ctx->stream));   // (an earlier launch may still read the block)
+        HIP_OK(hipMemcpyAsync(ctx->d_presets, &Q, sizeof Q, hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));   // Q is a local
+        A.presets = ctx->d_presets;
+    }
     ctx->last_launches = 0;
     launch_dbn(ctx, u, A);
     return EMGPU_OK;

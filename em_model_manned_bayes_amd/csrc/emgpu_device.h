@@ -192,9 +192,10 @@ __device__ __forceinline__ int32_t init_network(const EmgpuPlan &P, const EmgpuR
     const bool no_dedisc = (A.flags & EMGPU_FLAG_NO_DEDISC) != 0;
     int sp[NI];
     if constexpr (PS) {
-        if (A.start || A.log_weight) {
-            const double lw = lane_presets<NI>(P, A.start ? A.start + (size_t)lane * (size_t)P.ni : nullptr, A.log_weight ? A.logp : nullptr, A.lp_off, A.status, sp);
-            if (A.log_weight) A.log_weight[lane] = lw;
+        if (A.presets) {
+            const EmgpuPresets &Q = *A.presets;
+            const double lw = lane_presets<NI>(P, Q.start ? Q.start + (size_t)lane * (size_t)P.ni : nullptr, Q.log_weight ? Q.logp : nullptr, Q.lp_off, A.status, sp);
+            if (Q.log_weight) Q.log_weight[lane] = lw;
         } else {
 #pragma unroll
             for (int p = 0; p < NI; p++) sp[p] = p < P.ni ? (int)P.i_start[p] : 0;

@@ -542,7 +542,7 @@ static int fast_shape_of(const EmgpuPlan &P) {
 
 bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     if (P.nd != 3 || P.depend || A.per_step) return false;
-    if (A.start != nullptr || A.log_weight != nullptr) return false;   // a start grid / per-sample weights: the generic kernel
+    if (A.presets != nullptr) return false;   // a start grid / per-sample weights: the generic kernel
     if ((A.ev_count != nullptr || A.events != nullptr) && !ev_plan_ok(P, A) && !(ev_plan_wide_ok(P, A) && P.ni <= 9)) return false;
     if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
     for (int k = 0; k < 3; k++) {
