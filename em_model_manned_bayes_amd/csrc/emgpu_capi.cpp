@@ -593,11 +593,12 @@ static void bind_outputs(EmgpuRun &A, const Model &m, const emgpu_sample_params 
     (void)m;
 }
 
-static void launch_dbn(emgpu_ctx *ctx, const Uploaded &u, const EmgpuRun &A, hipStream_t stream = nullptr) {
+static void launch_dbn(emgpu_ctx *ctx, const Uploaded &u, const EmgpuRun &A, hipStream_t stream = nullptr, const EmgpuPresets *presets = nullptr) {
     const char *name = "";
     hipError_t e;
     if (!stream) stream = ctx->stream;
-    if (emgpu::fast_uncor_eligible(u.cp.plan, A)) e = emgpu::launch_uncor_fast(u.cp.plan, A, stream, &name);
+    if (presets) e = emgpu::launch_dbn_generic(u.cp.plan, A, stream, &name, presets);   // a start grid / per-sample log-weights: the general kernel
+    else if (emgpu::fast_uncor_eligible(u.cp.plan, A)) e = emgpu::launch_uncor_fast(u.cp.plan, A, stream, &name);
     else if (emgpu::step2_eligible(u.cp.plan, A)) e = emgpu::launch_dbn_step2(u.cp.plan, A, stream, &name);
     else if (emgpu::step_eligible(u.cp.plan, A)) e = emgpu::launch_dbn_step(u.cp.plan, A, stream, &name);
     else e = emgpu::launch_dbn_generic(u.cp.plan, A, stream, &name);
@@ -636,6 +637,7 @@ int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sa
     EmgpuRun A;
     fill_run(ctx, u, h->m, p, A);
     bind_outputs(A, h->m, p, out);
+    const EmgpuPresets *presets = nullptr;
     if (p->start || out->log_weight) {   // a start grid / per-sample log-weights: a small block of device memory the kernel reads them through
         EmgpuPresets Q;
         memset(&Q, 0, sizeof Q);
@@ -645,10 +647,10 @@ int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sa
         HIP_OK(hipStreamSynchronize(ctx->stream));   // (an earlier launch may still read the block)
         HIP_OK(hipMemcpyAsync(ctx->d_presets, &Q, sizeof Q, hipMemcpyHostToDevice, ctx->stream));
         HIP_OK(hipStreamSynchronize(ctx->stream));   // Q is a local
-        A.presets = ctx->d_presets;
+        presets = ctx->d_presets;
     }
     ctx->last_launches = 0;
-    launch_dbn(ctx, u, A);
+    launch_dbn(ctx, u, A, nullptr, presets);
     return EMGPU_OK;
     EMGPU_CATCH
 }

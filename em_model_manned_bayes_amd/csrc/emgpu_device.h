@@ -185,15 +185,81 @@ __device__ __forceinline__ double lane_presets(const EmgpuPlan &P, const int32_t
 // bn_sample.m:39-57, dbn_hierarchical_sample.m:25-31, UncorEncounterModel.m:248-281.
 // bin[]: 0-based bins by topological position; val[]: dediscretised f64.  Returns the number of
 // attempts used (>= 1) or -1 when max_attempts was reached; leaves rng.attempt at the accepted attempt.
-// PS: the lane's presets may come from a start grid (A.start, row `lane`) and its log-weight is wanted (A.log_weight): k_dbn_generic.
-template <int NI, bool PS = false>
-__device__ __forceinline__ int32_t init_network(const EmgpuPlan &P, const EmgpuRun &A, Rng &rng, int (&bin)[NI], double (&val)[NI], int64_t lane = 0) {
+template <int NI>
+__device__ __forceinline__ int32_t init_network(const EmgpuPlan &P, const EmgpuRun &A, Rng &rng, int (&bin)[NI], double (&val)[NI]) {
+    int32_t attempts_used = -1;
+    const bool no_dedisc = (A.flags & EMGPU_FLAG_NO_DEDISC) != 0;
+    for (uint32_t attempt = 0; attempt < (uint32_t)A.max_attempts; attempt++) {
+        rng.attempt = attempt;
+        uint4 wc = make_uint4(0, 0, 0, 0);
+        int wblk = -1;
+#pragma unroll
+        for (int p = 0; p < NI; p++) {
+            if (p < P.ni && P.i_start[p] != 0) { // bn_sample.m:44-50
+                bin[p] = (int)P.i_start[p] - 1;
+            } else if (p < P.ni) {
+                uint32_t col = 0; // asub2ind.m:13-14 as strides
+#pragma unroll
+                for (int q = 0; q < p; q++) col += P.i_stride[p][q] * (uint32_t)bin[q];
+                const int r = P.i_r[p];
+                const int var = P.i_var[p];
+                if ((var >> 2) != wblk) { wblk = var >> 2; wc = rng.block(EMGPU_SEC_INIT, 0u, (uint32_t)wblk); }
+                bin[p] = draw_bin(P.thr + P.i_off[p] + (size_t)col * (uint32_t)(r - 1), r, word_of(wc, var & 3)); // bn_sample.m:55
+            }
+        }
+        // dbn_hierarchical_sample.m:25-31
+        wblk = -1;
+#pragma unroll
+        for (int p = 0; p < NI; p++) {
+            double v = (double)(bin[p] + 1);
+            if (p < P.ni && !no_dedisc && P.i_nb[p] != 0 && !P.i_skip[p]) {
+                const int var = P.i_var[p];
+                if ((var >> 2) != wblk) { wblk = var >> 2; wc = rng.block(EMGPU_SEC_DEDISC_INIT, 0u, (uint32_t)wblk); }
+                v = (P.i_zero[p] == bin[p] + 1) ? 0.0 : dedisc_f64(P.bnd, P.i_boff[p], bin[p], word_of(wc, var & 3));
+            }
+            val[p] = v;
+        }
+        // UncorEncounterModel.m:259-272
+        if (A.pos_L >= 0 && (A.layers != nullptr || (A.flags & EMGPU_FLAG_QUANTIZE500))) {
+            double h_ft = pick<NI>(val, A.pos_L);
+            if (A.layers != nullptr) {
+                int b = (int)h_ft;
+                b = b < 1 ? 1 : (b > A.n_layers ? A.n_layers : b);
+                const double lo = A.layers[2 * (b - 1)], hi = A.layers[2 * (b - 1) + 1];
+                const uint4 wl = rng.block(EMGPU_SEC_LAYER, 0u, 0u);
+                {
+#pragma clang fp contract(off)
+                    const double d = hi - lo;
+                    const double m = uniform32(wl.x) * d;
+                    h_ft = lo + m;
+                }
+            }
+            if ((A.flags & EMGPU_FLAG_QUANTIZE500) && A.pos_dh >= 0 && pick<NI>(val, A.pos_dh) == 0.0) h_ft = round500(h_ft);
+            put<NI>(val, A.pos_L, h_ft);
+        }
+        bool good = true;
+        if (A.pos_v >= 0 && A.pos_dh >= 0) { // :275
+#pragma clang fp contract(off)
+            const double lhs = pick<NI>(val, A.pos_v) * 1.68781;
+            const double rhs = fabs(pick<NI>(val, A.pos_dh)) / 60.0;
+            good = lhs > rhs;
+        }
+        if (good) { attempts_used = (int32_t)attempt + 1; break; }
+    }
+    return attempts_used;
+}
+
+// The same with the lane's presets possibly coming from a start grid (Q->start, row `lane`) and its log-weight wanted (Q->log_weight):
+// k_dbn_generic (Q null: the model's own start, like init_network).
+template <int NI>
+__device__ __forceinline__ int32_t init_network_ps(const EmgpuPlan &P, const EmgpuRun &A, const EmgpuPresets *Qp, Rng &rng, int (&bin)[NI], double (&val)[NI], int64_t lane) {
+    constexpr bool PS = true;
     int32_t attempts_used = -1;
     const bool no_dedisc = (A.flags & EMGPU_FLAG_NO_DEDISC) != 0;
     int sp[NI];
     if constexpr (PS) {
-        if (A.presets) {
-            const EmgpuPresets &Q = *A.presets;
+        if (Qp) {
+            const EmgpuPresets &Q = *Qp;
             const double lw = lane_presets<NI>(P, Q.start ? Q.start + (size_t)lane * (size_t)P.ni : nullptr, Q.log_weight ? Q.logp : nullptr, Q.lp_off, A.status, sp);
             if (Q.log_weight) Q.log_weight[lane] = lw;
         } else {

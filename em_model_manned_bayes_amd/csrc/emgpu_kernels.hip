@@ -18,7 +18,7 @@
 namespace emgpu {
 
 template <int NI, int ND, int NA>
-__global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const EmgpuRun A) {
+__global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const EmgpuRun A, const EmgpuPresets *Q /* a start grid / log-weights, or null */) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= A.n) return;
     const uint64_t gidx = A.indices ? A.indices[i] : A.first_index + (uint64_t)i;
@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) k_dbn_generic(const EmgpuPlan P, const Em
 #pragma unroll
     for (int p = 0; p < NI; p++) { bin[p] = 0; val[p] = 0.0; }
 
-    const int32_t attempts_used = init_network<NI, true>(P, A, rng, bin, val, i);   // (the one DBN kernel that takes a start grid)
+    const int32_t attempts_used = init_network_ps<NI>(P, A, Q, rng, bin, val, i);   // (the one DBN kernel that takes a start grid)
     if (attempts_used < 0) atomicOr(A.status, 1u);
     if (A.attempts) A.attempts[i] = attempts_used;
 #pragma unroll
@@ -280,20 +280,20 @@ __global__ void __launch_bounds__(256) k_bn(const EmgpuPlan P, const EmgpuBnRun 
 // launchers
 // ---------------------------------------------------------------------------------------------
 template <int NI, int ND, int NA>
-static hipError_t launch_generic_t(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s) {
+static hipError_t launch_generic_t(const EmgpuPlan &P, const EmgpuRun &A, const EmgpuPresets *Q, hipStream_t s) {
     const int64_t blocks = (A.n + 255) / 256;
-    hipLaunchKernelGGL((k_dbn_generic<NI, ND, NA>), dim3((unsigned)blocks), dim3(256), 0, s, P, A);
+    hipLaunchKernelGGL((k_dbn_generic<NI, ND, NA>), dim3((unsigned)blocks), dim3(256), 0, s, P, A, Q);
     return hipGetLastError();
 }
 
-hipError_t launch_dbn_generic(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
+hipError_t launch_dbn_generic(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name, const EmgpuPresets *Q) {
     if (A.n <= 0) return hipSuccess;
-    if (P.ni <= 7 && P.nd <= 3 && P.nact <= 4) { *name = "k_dbn_generic<7,3,4>"; return launch_generic_t<7, 3, 4>(P, A, s); }
-    if (P.ni <= 7 && P.nd <= 3 && P.nact <= 7) { *name = "k_dbn_generic<7,3,7>"; return launch_generic_t<7, 3, 7>(P, A, s); }
-    if (P.ni <= 9 && P.nd <= 3 && P.nact <= 9) { *name = "k_dbn_generic<9,3,9>"; return launch_generic_t<9, 3, 9>(P, A, s); }
-    if (P.nact <= 4) { *name = "k_dbn_generic<16,4,4>"; return launch_generic_t<16, 4, 4>(P, A, s); }
+    if (P.ni <= 7 && P.nd <= 3 && P.nact <= 4) { *name = "k_dbn_generic<7,3,4>"; return launch_generic_t<7, 3, 4>(P, A, Q, s); }
+    if (P.ni <= 7 && P.nd <= 3 && P.nact <= 7) { *name = "k_dbn_generic<7,3,7>"; return launch_generic_t<7, 3, 7>(P, A, Q, s); }
+    if (P.ni <= 9 && P.nd <= 3 && P.nact <= 9) { *name = "k_dbn_generic<9,3,9>"; return launch_generic_t<9, 3, 9>(P, A, Q, s); }
+    if (P.nact <= 4) { *name = "k_dbn_generic<16,4,4>"; return launch_generic_t<16, 4, 4>(P, A, Q, s); }
     *name = "k_dbn_generic<16,4,16>";
-    return launch_generic_t<16, 4, 16>(P, A, s);
+    return launch_generic_t<16, 4, 16>(P, A, Q, s);
 }
 
 hipError_t launch_bn(const EmgpuPlan &P, const EmgpuBnRun &A, hipStream_t s, const char **name) {

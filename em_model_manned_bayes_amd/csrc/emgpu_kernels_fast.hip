@@ -319,6 +319,12 @@ __device__ __forceinline__ void eight_seconds(const Rng &rng, uint32_t tvar, uin
 // EV: the event list of dbn_hierarchical_sample.m:33-60 is written as well (uncor_fast_events below).
 // IDX: an index list may be in use (emgpu_sample_params.indices): the workers read the owner's global index from LDS instead of
 // deriving it from their own (kept out of the plain instance: the benchmark kernel pays 1 % for the possibility).
+// the stream table of a wide event list lives in LDS of the instances that write one, and nowhere else
+template <bool EVW>
+__device__ __forceinline__ EvStream *evw_lds() {
+    if constexpr (EVW) { __shared__ EvStream s[16]; return s; }
+    else return nullptr;
+}
 // EVW: the event list of a model with more rated variables than the eight streams of EV hold (haa_v1): emgpu_events.h "WIDE lists"
 template <int NI, int M0, int M1, int M2, bool MIXED = false, bool EV = false, bool IDX = false, bool EVW = false>
 __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs &F, const int64_t i0 /* trajectory of lane 0: wave-uniform, may be < 0 */) {
@@ -410,7 +416,7 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
     EvPlan E{};
     EvState S{};
     EvStateW SW{};
-    __shared__ EvStream s_evw[EVW ? 16 : 1];
+    EvStream *s_evw = evw_lds<EVW>();
     if constexpr (EV && !EVW) {
         E = ev_plan_of<NI, 3>(P);
         S = ev_state_of<NI, 3>(P, A, bin, valid, i);
@@ -542,7 +548,6 @@ static int fast_shape_of(const EmgpuPlan &P) {
 
 bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     if (P.nd != 3 || P.depend || A.per_step) return false;
-    if (A.presets != nullptr) return false;   // a start grid / per-sample weights: the generic kernel
     if ((A.ev_count != nullptr || A.events != nullptr) && !ev_plan_ok(P, A) && !(ev_plan_wide_ok(P, A) && P.ni <= 9)) return false;
     if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
     for (int k = 0; k < 3; k++) {

@@ -163,7 +163,6 @@ __global__ void __launch_bounds__(256, 2) k_dbn_step(const EmgpuPlan P, const Em
 }
 
 bool step_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
-    if (A.presets != nullptr) return false;   // a start grid / per-sample weights: the generic kernel
     if (A.indices != nullptr) return false; // an index list goes through the generic kernel
     if (P.nd < 1 || P.nd > 4) return false;
     if (!(P.depend || A.per_step)) return false;

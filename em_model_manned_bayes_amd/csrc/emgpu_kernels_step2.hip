@@ -14,7 +14,6 @@ void step_parent_masks(const EmgpuPlan &P, uint32_t *cur_mask, uint32_t *new_mas
 }
 
 bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
-    if (A.presets != nullptr) return false;   // a start grid / per-sample weights: the generic kernel
     if (A.indices != nullptr) return false; // an index list: k_uncor_fast_idx / _ev for the fast-branch models, else the generic kernel
     static const bool off = getenv("EMGPU_DEBUG_NO_STEP2") != nullptr;
     if (off) return false;

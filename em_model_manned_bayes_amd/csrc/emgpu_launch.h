@@ -5,7 +5,7 @@
 #include "emgpu_plan.h"
 
 namespace emgpu {
-hipError_t launch_dbn_generic(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
+hipError_t launch_dbn_generic(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name, const EmgpuPresets *presets = nullptr);
 hipError_t launch_bn(const EmgpuPlan &P, const EmgpuBnRun &A, hipStream_t s, const char **name);
 // Returns false when the (plan, run) pair is outside what the specialised kernel covers.
 bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A);

@@ -143,11 +143,10 @@ struct EmgpuRun {
     int32_t *attempts;
     uint32_t *status; // device word: bit0 = rejection cap hit, bit1 = event cap hit
     const uint64_t *indices; // optional: global index of lane i (instead of first_index + i); every DBN kernel but the round-1 k_dbn_step
-    // per-sample presets (a start GRID in one launch: InitStartTerminal.m:57-90, UncorEncounterModel.m:204) -- k_dbn_generic only.  A
-    // POINTER to device memory, null in every call without them: the four fields by value made the kernel arguments of the benchmark
-    // kernel 88 bytes longer and the kernel 2 % slower (more scalar registers to spill) for a feature it never uses.
-    const struct EmgpuPresets *presets;
 };
+// per-sample presets (a start GRID in one launch: InitStartTerminal.m:57-90, UncorEncounterModel.m:204): a block of device memory handed to
+// k_dbn_generic as an argument of its own.  NOT part of EmgpuRun: the benchmark kernel sits at the edge of its scalar registers, and a
+// pointer it never reads cost it 45 more spill reloads in its loops (+3.7 % vector instructions, measured).
 struct EmgpuPresets {
     const int32_t *start;    // [n][ni] by variable id, 0 = unset (then the model's own start applies); null: the model's start for every lane
     double *log_weight;      // [n] sum over the lane's preset nodes of log P(preset | parents); null: not wanted

@@ -4,7 +4,7 @@
 # uncor_1200code_v1 / PER_STEP / littoral_cor_v1 (frozen columns), the event-list kernels, the sample2track consumer, the
 # UncorEncounterModel.track pipeline and terminal propagation.  tools/summarize_others.py condenses the stats.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/others_$TAG
 rm -rf $OUT; mkdir -p $OUT

@@ -62,6 +62,10 @@ for d in ("pmc_write", "pmc_fetch", "pmc_sq1", "pmc_sq2"):
             if r["Kernel_Name"] == summary.get("kernel"):
                 pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary["pmc_per_launch"] = {k: sum(v) / len(v) for k, v in pmc.items()}
+pl = summary["pmc_per_launch"]
+if "SQ_THREAD_CYCLES_VALU" in pl and pl.get("SQ_ACTIVE_INST_VALU"):
+    # lanes active per cycle in which the vector unit executes (thread-cycles / (64 x busy cycles)): 1.0 = no divergence, no idle lanes
+    summary["valu_lanes_active"] = pl["SQ_THREAD_CYCLES_VALU"] / (64.0 * pl["SQ_ACTIVE_INST_VALU"])
 if "WRITE_SIZE" in pmc:
     # MI355X_MICROARCH.md "HBM": WRITE_SIZE (KiB) is exact for 16-B-per-lane streaming stores;
     # FETCH_SIZE (KiB) reports 1/2 of the bytes of wide coalesced reads on gfx950 -> doubled.
