@@ -499,17 +499,27 @@ class GpuTelemetry:
     2 ms.  The benchmark kernel runs at the board's power limit; how far a box lets the clock drop there differs from box to box by up to
     20 %: with the clock in the line a reader can tell a slow box from a regression."""
 
-    def __init__(self, local_index=0):
+    def __init__(self, local_index=0, pci=None):
+        """`pci` = "dddd:bb:dd.f" of the device this rank computes on: a box may list more cards in sysfs than the process can see
+        (a 1-GPU slice of an 8-GPU node), so the visible device's index says nothing about the card number; without it the
+        `local_index`-th card with an sclk sensor is read."""
         import glob
         cards = []
         for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"):
             try:
                 if open(os.path.join(os.path.dirname(f), "freq1_label")).read().strip() == "sclk":
-                    cards.append((int(f.split("/card")[1].split("/")[0]), os.path.dirname(f)))
+                    dev = os.path.realpath(f.split("/hwmon/")[0])
+                    cards.append((int(f.split("/card")[1].split("/")[0]), os.path.dirname(f), os.path.basename(dev).lower()))
             except (OSError, ValueError):
                 pass
         cards.sort()
-        self.dir = cards[local_index][1] if local_index < len(cards) else None
+        self.dir, self.card = None, None
+        if pci:
+            for n, d, addr in cards:
+                if addr == pci.lower():
+                    self.dir, self.card = d, "card%d %s" % (n, addr)
+        if self.dir is None and pci is None and local_index < len(cards):
+            self.dir, self.card = cards[local_index][1], "card%d %s (by index)" % (cards[local_index][0], cards[local_index][2])
         self.samples, self._stop, self._th = [], None, None
 
     def _read(self):
@@ -573,7 +583,15 @@ def measure(w, pl, args, warmup, steps):
     w.sync()
     pl.barrier()
     ev = [(pl.event(), pl.event()) for _ in range(steps)]
-    tel = GpuTelemetry(getattr(getattr(pl, "dev", None), "index", 0) or 0) if (hasattr(pl, "torch") and getattr(args, "telemetry_s", 0.0) > 0.0) else None
+    tel = None
+    if hasattr(pl, "torch") and getattr(args, "telemetry_s", 0.0) > 0.0:
+        idx = getattr(getattr(pl, "dev", None), "index", 0) or 0
+        try:
+            pr = pl.torch.cuda.get_device_properties(idx)
+            pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except (AttributeError, RuntimeError):
+            pci = None
+        tel = GpuTelemetry(idx, pci)
     if tel:
         tel.start()
     t0 = time.perf_counter()
@@ -611,6 +629,7 @@ def measure(w, pl, args, warmup, steps):
             w.telemetry["how"] = ("amdgpu hwmon in sysfs (freq1_input, power1_input), every 2 ms during %.1f s of the same step launched back to back after the timed "
                                   "region; statistics of the last 40 %% (the readings trail the load by over a second)" % args.telemetry_s)
             w.telemetry["inside_the_timed_region"] = in_region
+            w.telemetry["sensor"] = tel.card
     return elapsed, step_ms
 
 
