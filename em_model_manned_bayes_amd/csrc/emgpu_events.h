@@ -240,7 +240,7 @@ __device__ __forceinline__ void ev_wide_plan(const EmgpuPlan &P, EvStream *s_ev 
             }
         } else if (b - NRES < P.nd) {
             const uint32_t k = P.d_emit[b - NRES];
-            E.var1 = (uint8_t)(P.d_ivar[k] + 1u); E.kdyn = (uint8_t)k; E.zero = P.d_zero[k]; E.nb = P.d_nb[k];
+            E.var1 = (uint8_t)(P.d_ivar[k] + 1u); E.kdyn = (uint8_t)k; E.zero = P.d_zero[k]; E.nb = P.d_nb[k]; E.boff = P.d_boff[k];
         }
         s_ev[b] = E;
     }
@@ -273,9 +273,10 @@ inline bool ev_plan_wide_ok(const EmgpuPlan &P, const EmgpuRun &A) {
         if (P.a_R[a] >= 0xFFFF0000u) return false;
     return true;
 }
-template <int ND, bool LB>
-__device__ __forceinline__ void ev_emit_block_wide(const CoopLds<ND, LB> &W, int lane, const EvStream *s_ev, int nact, EvStateW &SW, const Rng &rng, const double *bnd,
-                                                   int g8, int T, bool valid, uint32_t hitp, uint32_t chgp, uint32_t prevp) {
+// the rows of one block as a 128-bit mask in list order: bit 63 - (16 j + b) of `hi` = (second j < 4, stream b), `lo` the same for seconds 4-7
+template <int ND>
+__device__ __forceinline__ void ev_wide_mask(const EvStream *s_ev, int nact, const Rng &rng, int g8, int T, bool valid, uint32_t hitp, uint32_t chgp,
+                                             uint64_t &pend_hi, uint64_t &pend_lo) {
     constexpr int NRES = 16 - ND;
     const uint32_t live8 = (g8 == 0 ? 0x7Fu : 0xFFu) & (8 * g8 + 7 < T ? 0xFFu : (0xFF00u >> (T - 8 * g8)) & 0xFFu);   // seconds 1 <= c < T
     uint64_t in1 = 0ull, in2 = 0ull;   // streams 0-7 / 8-15: byte 7 - (b & 7) = stream b, bit 7 - j = second j
@@ -296,8 +297,15 @@ __device__ __forceinline__ void ev_emit_block_wide(const CoopLds<ND, LB> &W, int
         if (kd != 0xFFu) in2 |= (uint64_t)((chgp >> (8u * kd)) & 0xFFu) << (8 * (15 - (NRES + e)));
     }
     const uint64_t t1 = valid ? transpose8x8(in1) : 0ull, t2 = valid ? transpose8x8(in2) : 0ull;   // byte 7 - j = second j, bit 7 - (b & 7) = stream b
-    uint64_t pend_hi = ev_interleave_bytes((uint32_t)(t1 >> 32), (uint32_t)(t2 >> 32));            // seconds 0-3: bit 63 - (16 j + b)
-    uint64_t pend_lo = ev_interleave_bytes((uint32_t)t1, (uint32_t)t2);                            // seconds 4-7
+    pend_hi = ev_interleave_bytes((uint32_t)(t1 >> 32), (uint32_t)(t2 >> 32));                     // seconds 0-3: bit 63 - (16 j + b)
+    pend_lo = ev_interleave_bytes((uint32_t)t1, (uint32_t)t2);                                     // seconds 4-7
+}
+template <int ND, bool LB>
+__device__ __forceinline__ void ev_emit_block_wide(const CoopLds<ND, LB> &W, int lane, const EvStream *s_ev, int nact, EvStateW &SW, const Rng &rng, const double *bnd,
+                                                   int g8, int T, bool valid, uint32_t hitp, uint32_t chgp, uint32_t prevp) {
+    constexpr int NRES = 16 - ND;
+    uint64_t pend_hi, pend_lo;
+    ev_wide_mask<ND>(s_ev, nact, rng, g8, T, valid, hitp, chgp, pend_hi, pend_lo);
     const uint8_t *bins8 = reinterpret_cast<const uint8_t *>(&W.res[lane * CoopLds<ND, LB>::kStride + CoopLds<ND, LB>::kBins]);
     const float *res32 = &W.res[lane * CoopLds<ND, LB>::kStride];
     while (__ballot((pend_hi | pend_lo) != 0ull) != 0ull) {
@@ -327,6 +335,115 @@ __device__ __forceinline__ void ev_emit_block_wide(const CoopLds<ND, LB> &W, int
             SW.S.emit(c, var1, bin1, v);
         }
     }
+}
+// ---- ROWS BY THE WAVE (round 4): an events-only call of a wide model.  ev_emit_block_wide walks each lane's mask row by row: the wave runs
+// at the pace of its longest list (haa_v1: 14 rows per lane and block on average, 22+ at most), every row that needs a draw of its own
+// (a static variable, a hidden resample row) is a Philox call for the few lanes that have one, and the dynamic variables' values took a
+// cooperative pass of their own before.  Here a row IS the unit of work: the set bits of all 64 masks are queued (positions from one prefix
+// sum, like coop_dedisc; a lane's requests in list order), and a worker lane builds one row from the owner's published block state -- its
+// place in the list from its distance to the owner's first request, dt from the request before it, the bin by the stream's kind, ONE dediscretize draw in the row's own
+// slot (DEDISC_TRANS for a transition row, DEDISC_RES for every resample row: no row shares a result slot, so nothing is "hidden") -- and
+// stores it.  No result slots, no per-lane loop; 64 rows per pass whatever the lists' lengths.
+// Published per lane (the result slots are free in this mode), words of the lane's CoopLds row:
+// 4 rows so far, 5 time of the last row, 6 the bins the block began with, 7 the queue position of the lane's first request, 8-11 the static
+// variables' bins (ev_rows_publish_static); the mask itself stays with its lane.
+constexpr int kEvRowsQueue = 1024;   // requests per compaction round (uint16_t each; entry 0 of the array = the last request of the round before)
+template <int ND>
+__device__ __forceinline__ void ev_rows_publish_static(CoopLds<ND, true> &W, int lane, const EvStateW &SW) {
+    uint32_t *row = reinterpret_cast<uint32_t *>(&W.res[lane * CoopLds<ND, true>::kStride]);
+    row[8] = (uint32_t)SW.sb_lo; row[9] = (uint32_t)(SW.sb_lo >> 32); row[10] = (uint32_t)SW.sb_hi; row[11] = (uint32_t)(SW.sb_hi >> 32);
+}
+// One pass: worker lane l builds the row of request q0 + l.  A lane's requests sit in the queue in list order, one after the other, from
+// position row[7] on: the row's rank in its block is its distance from there, and the row before it is the request before it.
+template <int ND>
+__device__ __forceinline__ void ev_rows_worker(const CoopLds<ND, true> &W, const uint16_t *queue /* entry k + 1 = request rb + k */, int lane, uint32_t rb, uint32_t q0,
+                                               uint32_t cnt, const EvStream *s_ev, const Rng &rng, const double *bnd, int g8, const EmgpuRun &A, int64_t i) {
+    using L = CoopLds<ND, true>;
+    constexpr uint32_t NRES = 16 - ND;
+    const uint32_t q = q0 + (uint32_t)lane;
+    if (q < cnt) {
+        const uint32_t d = queue[q + 1u];
+        const uint32_t owner = d & 63u, pos = d >> 6;
+        const uint32_t *orow = reinterpret_cast<const uint32_t *>(&W.res[owner * L::kStride]);
+        const uint32_t rank = rb + q - orow[7];
+        const uint32_t j = pos >> 4, b = pos & 15u;
+        const uint32_t c = 8u * (uint32_t)g8 + j;
+        const uint32_t dt = rank ? j - ((uint32_t)queue[q] >> 10) : c - orow[5];
+        const uint32_t nrow = orow[4] + rank;
+        const EvStream E = s_ev[b];
+        const uint32_t var1 = E.var1, kd = E.kdyn, zb = E.zero;
+        const uint8_t *bins8 = reinterpret_cast<const uint8_t *>(orow + L::kBins);
+        uint32_t bin1, sec = EMGPU_SEC_DEDISC_RES;
+        if (b >= NRES) { bin1 = bins8[8u * kd + j]; sec = EMGPU_SEC_DEDISC_TRANS; }                           // a transition row: the new bin
+        else if (kd != 0xFFu) bin1 = j ? bins8[8u * kd + j - 1u] : ((orow[6] >> (8u * kd)) & 0xFFu);           // a resample row: the bin before this second's transition
+        else bin1 = (orow[8u + (b >> 2)] >> (8u * (b & 3u))) & 0xFFu;                                          // ... of a static variable
+        float v = 0.f;
+        if (b < NRES && kd == 0xFFu && E.nb == 0u) v = (float)bin1;
+        else if (bin1 != zb) {
+            const uint64_t go = *reinterpret_cast<const uint64_t *>(orow + L::kGidx);
+            const uint4 r4 = philox4x32((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner], (sec << 28) | ((var1 - 1u) << 20) | (c >> 2), rng.k0, rng.k1);
+            const uint32_t w = c & 3u;
+            v = (float)dedisc_f64(bnd, (int)E.boff, (int)bin1 - 1, w == 0 ? r4.x : (w == 1 ? r4.y : (w == 2 ? r4.z : r4.w)));
+        }
+        if (nrow < (uint32_t)A.event_cap)
+            A.events[(size_t)(i - lane + (int64_t)owner) * (size_t)A.event_cap + nrow] =
+                (uint64_t)(dt & 0xFFFFu) | ((uint64_t)var1 << 16) | ((uint64_t)bin1 << 24) | ((uint64_t)__float_as_uint(v) << 32);
+    }
+}
+template <int ND>
+__device__ __forceinline__ void ev_rows_block_wide(CoopLds<ND, true> &W, uint16_t *queue, int lane, const EvStream *s_ev, int nact, EvStateW &SW, const Rng &rng,
+                                                   const double *bnd, int g8, int T, bool valid, uint32_t hitp, uint32_t chgp, uint32_t prevp, const EmgpuRun &A, int64_t i) {
+    using L = CoopLds<ND, true>;
+    uint64_t hi, lo;
+    ev_wide_mask<ND>(s_ev, nact, rng, g8, T, valid, hitp, chgp, hi, lo);
+    const uint32_t c = (uint32_t)__popcll(hi) + (uint32_t)__popcll(lo);
+    const uint32_t inc = wave_inclusive_add(c);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    if (total == 0u) return;
+    uint32_t *row = reinterpret_cast<uint32_t *>(&W.res[lane * L::kStride]);
+    uint32_t a = inc - c;
+    row[4] = SW.S.count; row[5] = SW.S.last_t; row[6] = prevp; row[7] = a;
+    if (total <= (uint32_t)kEvRowsQueue) {
+        // the usual case, one round: the four words of the mask one after the other, leading bit first (a lane's requests stay in list order)
+        uint16_t *qp = queue + 1 + a;
+        const uint32_t w4[4] = {(uint32_t)(hi >> 32), (uint32_t)hi, (uint32_t)(lo >> 32), (uint32_t)lo};
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t m = w4[w];
+            while (__ballot(m != 0u) != 0ull) {
+                if (m != 0u) {
+                    const uint32_t p = (uint32_t)__clz((int)m);
+                    m &= ~(0x80000000u >> p);
+                    *qp++ = (uint16_t)((uint32_t)lane | ((p + 32u * (uint32_t)w) << 6));
+                }
+            }
+        }
+        wave_sync();
+        for (uint32_t q0 = 0u; q0 < total; q0 += 64u) ev_rows_worker<ND>(W, queue, lane, 0u, q0, total, s_ev, rng, bnd, g8, A, i);
+        wave_sync();
+    } else {
+        const uint32_t aend = inc;
+        uint64_t mh = hi, ml = lo;
+        for (uint32_t rb = 0u; rb < total; rb += (uint32_t)kEvRowsQueue) {
+            if (rb != 0u) { if (lane == 0) queue[0] = queue[kEvRowsQueue]; wave_sync(); }   // the request before this round's first
+            const uint32_t lim = min(aend, rb + (uint32_t)kEvRowsQueue);   // a lane is active while a < lim
+            while (__ballot(a < lim) != 0ull) {
+                if (a < lim) {
+                    uint32_t pos;
+                    if (mh != 0ull) { pos = (uint32_t)__clzll((long long)mh); mh &= ~(0x8000000000000000ull >> pos); }
+                    else { pos = (uint32_t)__clzll((long long)ml); ml &= ~(0x8000000000000000ull >> pos); pos += 64u; }
+                    queue[1u + a - rb] = (uint16_t)((uint32_t)lane | (pos << 6));
+                    a++;
+                }
+            }
+            wave_sync();
+            const uint32_t cnt = min(total - rb, (uint32_t)kEvRowsQueue);
+            for (uint32_t q0 = 0u; q0 < cnt; q0 += 64u) ev_rows_worker<ND>(W, queue, lane, rb, q0, cnt, s_ev, rng, bnd, g8, A, i);
+            wave_sync();
+        }
+    }
+    SW.S.count += c;
+    if (c != 0u) SW.S.last_t = 8u * (uint32_t)g8 + ((lo != 0ull ? 127u - (uint32_t)__builtin_ctzll(lo) : 63u - (uint32_t)__builtin_ctzll(hi)) >> 4);
 }
 template <int ND>
 __device__ __forceinline__ void ev_tail_wide(const EvStream *s_ev, int nact, EvStateW &SW, const Rng &rng, const double *bnd, int T, uint32_t curp, const EmgpuRun &A, bool valid, int64_t i) {

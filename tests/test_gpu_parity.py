@@ -53,6 +53,8 @@ def test_event_lists_from_the_fast_kernel_match_oracle(name, T, n, cap, gpu_ctx,
         return
     got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, first_index=first, want_dense=False, want_events=True, event_cap=cap, **idx)
     assert got["kernel"].startswith("k_uncor_fast_ev") or got["kernel"].endswith("+events"), got["kernel"]
+    if name in FAST_MODELS:   # the list alone: the rows of a block are built 64 at a time by the wave (haa_v1's seven rated variables included)
+        assert got["kernel"].startswith("k_uncor_fast_evu"), got["kernel"]
     assert np.array_equal(got["ev_count"], ref_cnt)
     for i in range(n):
         g, r = got["events"][i], ref["events"][i]
@@ -1196,6 +1198,48 @@ print("fallback ok")
     env = dict(os.environ, EMGPU_DEBUG_NO_STEP2="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("rows", ["lane", "wide"])
+def test_every_fast_model_through_the_per_lane_event_kernels(rows, model_dir):
+    """A list asked for alone comes from k_uncor_fast_evu (rows built by the wave: the tests above); k_uncor_fast_ev / k_uncor_fast_evw
+    (result slots + a row loop per lane) serve the calls that want the dense trace as well.  A child process with
+    EMGPU_DEBUG_EVENT_ROWS sends every fast-branch model's lists through them too ("lane": ev, evw for haa_v1; "wide": evw, whose
+    instance takes any fast-branch shape): row for row against the oracle, lengths on and off the block boundary, an overrun capacity."""
+    import subprocess, sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle as O
+from em_model_manned_bayes_amd import native, _lib as L
+from util import load_pair, uncor_indices
+ctx = native.Context(0)
+rows = %r
+for name in %r:
+    want = "k_uncor_fast_evw" if rows == "wide" or name == "haa_v1" else "k_uncor_fast_ev<"
+    nm, pp, _ = load_pair(name, %r)
+    idx = uncor_indices(pp)
+    for T, n, cap in [(240, 1500, 1024), (8, 300, 64), (13, 500, 64), (1, 100, 8), (33, 700, 4096)]:
+        seed, first = 0xE7E8, 2**35 + 7
+        ref = O.uncor_sample(O.OracleModel(pp), n, T, seed, mode=O.RNG_PHILOX, first_index=first)
+        got = native.sample_dbn_host(ctx, nm, n, T, seed, first_index=first, want_dense=False, want_events=True, event_cap=cap, **idx)
+        assert got["kernel"].startswith(want), got["kernel"]
+        assert np.array_equal(got["ev_count"], np.array([len(e) for e in ref["events"]]))
+        for i in range(n):
+            g, r = got["events"][i], ref["events"][i]
+            assert np.array_equal(g["dt"], r[:, 0]) and np.array_equal(g["var"], r[:, 1]) and np.array_equal(g["bin"], r[:, 3]), (name, T, i)
+            assert np.array_equal(g["value"], r[:, 2].astype(np.float32)), (name, T, i)
+    # a capacity that some lists overrun: the error, and the counts still exact
+    try:
+        native.sample_dbn_host(ctx, nm, 400, 240, 5, want_dense=False, want_events=True, event_cap=6, **idx)
+        raise SystemExit("no overrun reported")
+    except L.EmgpuError as e:
+        assert e.code == L.ERR_EVENT_CAP
+print("wide ok")
+''' % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"), os.path.join(ROOT_DIR, "oracle"), rows, FAST_MODELS, str(model_dir))
+    env = dict(os.environ, EMGPU_DEBUG_EVENT_ROWS=rows)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "wide ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_terminal_propagation_on_the_run_time_shape_instance(terminal_dir):
