@@ -135,7 +135,8 @@ __device__ __attribute__((noinline)) float ev_draw(uint32_t c0, uint32_t c1, uin
 // prevp: byte k = the bin variable k had when the block began.
 template <int ND, bool LB>
 __device__ __forceinline__ void ev_emit_block(const CoopLds<ND, LB> &W, int lane, const EvPlan &E, EvState &S, const Rng &rng, const double *bnd,
-                                              int g8, int T, bool valid, uint32_t hitp, uint32_t chgp, uint32_t prevp) {
+                                              int g8, int T, bool valid, uint32_t hitp, uint32_t chgp, uint32_t prevp,
+                                              bool values_are_bins = false /* EMGPU_FLAG_NO_DEDISC (plain dbn_sample.m) */) {
     constexpr int NRES = 8 - ND;
     // streams: byte 7 - b of `in` = stream b, bit 7 - j = second j; after the transpose bit 63 - (8 j + b) is event (j, b)
     const uint32_t live8 = (g8 == 0 ? 0x7Fu : 0xFFu) & (8 * g8 + 7 < T ? 0xFFu : (0xFF00u >> (T - 8 * g8)) & 0xFFu);   // seconds 1 <= c < T
@@ -179,6 +180,7 @@ __device__ __forceinline__ void ev_emit_block(const CoopLds<ND, LB> &W, int lane
                 const uint32_t nb = (uint32_t)(E.nb >> sh) & 0xFFu;
                 if (nb == 0u) v = (float)bin1; else if (bin1 != zb) draw = true;
             }
+            if (values_are_bins) { draw = false; v = (float)bin1; }
             if (draw) {
                 const uint32_t boff = b < 4u ? (uint32_t)(E.boff >> (16u * b)) & 0xFFFFu : E.boff4;
                 v = ev_draw(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, bnd, var1 - 1u, c, bin1 - 1u, boff);
@@ -275,8 +277,8 @@ inline bool ev_plan_wide_ok(const EmgpuPlan &P, const EmgpuRun &A) {
 }
 // the rows of one block as a 128-bit mask in list order: bit 63 - (16 j + b) of `hi` = (second j < 4, stream b), `lo` the same for seconds 4-7
 template <int ND>
-__device__ __forceinline__ void ev_wide_mask(const EvStream *s_ev, int nact, const Rng &rng, int g8, int T, bool valid, uint32_t hitp, uint32_t chgp,
-                                             uint64_t &pend_hi, uint64_t &pend_lo) {
+__device__ __forceinline__ void ev_wide_mask(const EvStream *s_ev, int nact /* 0: no resample rows (plain dbn_sample.m) */, const Rng &rng, int g8, int T, bool valid,
+                                             uint32_t hitp, uint32_t chgp, uint64_t &pend_hi, uint64_t &pend_lo) {
     constexpr int NRES = 16 - ND;
     const uint32_t live8 = (g8 == 0 ? 0x7Fu : 0xFFu) & (8 * g8 + 7 < T ? 0xFFu : (0xFF00u >> (T - 8 * g8)) & 0xFFu);   // seconds 1 <= c < T
     uint64_t in1 = 0ull, in2 = 0ull;   // streams 0-7 / 8-15: byte 7 - (b & 7) = stream b, bit 7 - j = second j
@@ -378,7 +380,7 @@ __device__ __forceinline__ void ev_rows_worker(const CoopLds<ND, true> &W, const
         else if (kd != 0xFFu) bin1 = j ? bins8[8u * kd + j - 1u] : ((orow[6] >> (8u * kd)) & 0xFFu);           // a resample row: the bin before this second's transition
         else bin1 = (orow[8u + (b >> 2)] >> (8u * (b & 3u))) & 0xFFu;                                          // ... of a static variable
         float v = 0.f;
-        if (b < NRES && kd == 0xFFu && E.nb == 0u) v = (float)bin1;
+        if ((b < NRES && kd == 0xFFu && E.nb == 0u) || (A.flags & EMGPU_FLAG_NO_DEDISC)) v = (float)bin1;   // (plain dbn_sample.m: the value of a row is its bin)
         else if (bin1 != zb) {
             const uint64_t go = *reinterpret_cast<const uint64_t *>(orow + L::kGidx);
             const uint4 r4 = philox4x32((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner], (sec << 28) | ((var1 - 1u) << 20) | (c >> 2), rng.k0, rng.k1);
@@ -395,7 +397,7 @@ __device__ __forceinline__ void ev_rows_block_wide(CoopLds<ND, true> &W, uint16_
                                                    const double *bnd, int g8, int T, bool valid, uint32_t hitp, uint32_t chgp, uint32_t prevp, const EmgpuRun &A, int64_t i) {
     using L = CoopLds<ND, true>;
     uint64_t hi, lo;
-    ev_wide_mask<ND>(s_ev, nact, rng, g8, T, valid, hitp, chgp, hi, lo);
+    ev_wide_mask<ND>(s_ev, (A.flags & EMGPU_FLAG_NO_RESAMPLE) ? 0 : nact, rng, g8, T, valid, hitp, chgp, hi, lo);
     const uint32_t c = (uint32_t)__popcll(hi) + (uint32_t)__popcll(lo);
     const uint32_t inc = wave_inclusive_add(c);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -448,6 +450,7 @@ __device__ __forceinline__ void ev_rows_block_wide(CoopLds<ND, true> &W, uint16_
 template <int ND>
 __device__ __forceinline__ void ev_tail_wide(const EvStream *s_ev, int nact, EvStateW &SW, const Rng &rng, const double *bnd, int T, uint32_t curp, const EmgpuRun &A, bool valid, int64_t i) {
     const uint32_t Tu = (uint32_t)T;
+    if (A.flags & EMGPU_FLAG_NO_RESAMPLE) nact = 0;
     for (int b = 0; b < nact; b++) {
         const EvStream E = s_ev[b];
         const uint32_t var0 = (uint32_t)E.var1 - 1u, kd = E.kdyn;
@@ -458,7 +461,7 @@ __device__ __forceinline__ void ev_tail_wide(const EvStream *s_ev, int nact, EvS
         if (clamp32(x) < E.R) {
             const uint32_t bin1 = kd != 0xFFu ? ((curp >> (8u * kd)) & 0xFFu) : (uint32_t)((b < 8 ? SW.sb_lo >> (8 * b) : SW.sb_hi >> (8 * (b - 8))) & 0xFFull);
             float v = 0.f;
-            if (E.nb == 0u) v = (float)bin1;
+            if (E.nb == 0u || (A.flags & EMGPU_FLAG_NO_DEDISC)) v = (float)bin1;
             else if (bin1 != (uint32_t)E.zero) v = ev_draw(rng.c0, rng.c1, rng.attempt, rng.k0, rng.k1, bnd, var0, Tu, bin1 - 1u, E.boff);
             SW.S.emit(Tu, var0 + 1u, bin1, v);
         }

@@ -9,7 +9,9 @@ hipError_t launch_uncor_fast_events(const EmgpuPlan &P, const EmgpuRun &A, const
 bool fast_uncor_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     if (P.nd != 3 || P.depend || A.per_step) return false;
     if ((A.ev_count != nullptr || A.events != nullptr) && !ev_plan_ok(P, A) && !(ev_plan_wide_ok(P, A) && P.ni <= 9)) return false;
-    if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
+    // plain dbn_sample.m (no resample rows, values = bins) returns a list and nothing else: k_uncor_fast_evu serves exactly that
+    if ((A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) && !(A.ev_count != nullptr && A.dyn_bin == nullptr && A.dyn_val == nullptr && ev_plan_wide_ok(P, A)))
+        return false;
     for (int k = 0; k < 3; k++) {
         if (P.d_nb[k] == 0 || P.d_nb[k] > 16 || P.d_meff[k] == 0) return false;
         for (int a = 0; a < P.nact; a++)

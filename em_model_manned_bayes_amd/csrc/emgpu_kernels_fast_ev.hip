@@ -27,7 +27,8 @@ hipError_t launch_uncor_fast_events(const EmgpuPlan &P, const EmgpuRun &A, const
     static const char *rows_env = getenv("EMGPU_DEBUG_EVENT_ROWS");
     const bool force_lane = rows_env != nullptr && rows_env[0] == 'l', force_wide = rows_env != nullptr && rows_env[0] == 'w' && rows_env[1] == 'i';
     const bool list_alone = A.dyn_bin == nullptr && A.dyn_val == nullptr;
-    if (list_alone && !force_lane && !force_wide && ev_plan_wide_ok(P, A)) {
+    const bool plain = (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) != 0;   // (only eligible as a list alone: fast_uncor_eligible)
+    if (list_alone && ((!force_lane && !force_wide) || plain) && ev_plan_wide_ok(P, A)) {
         switch (fast_shape_of(P)) {
         case 0: *name = "k_uncor_fast_evu<7,2,2,2>"; return launch_evu_t<7, 2, 2, 2>(P, A, F, s);
         case 1: *name = "k_uncor_fast_evu<7,2,4,2>"; return launch_evu_t<7, 2, 4, 2>(P, A, F, s);

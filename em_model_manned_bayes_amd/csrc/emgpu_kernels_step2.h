@@ -490,6 +490,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
             kind |= (chg8[k] & 0xFFu) << (8 * k);
         }
         if (!valid) need = 0u;
+        if constexpr (EV) { if (A.flags & EMGPU_FLAG_NO_DEDISC) need = 0u; }   // (plain dbn_sample.m: no draw is due)
         EMGPU_COUNT(5, lane, 1);
         coop_zero_results<ND, true>(W, lane);
         coop_publish_bins<ND>(W, lane, pbA, pbB);
@@ -504,7 +505,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
             uint32_t hitp = 0u;
 #pragma unroll
             for (int k = 0; k < ND; k++) hitp |= (hit8[k] & 0xFFu) << (8 * k);
-            ev_emit_block<ND, true>(W, lane, E, S, rng, P.bnd, g8, T, valid, hitp, kind, prevp);
+            ev_emit_block<ND, true>(W, lane, E, S, rng, P.bnd, g8, T, valid, hitp, kind, prevp, (A.flags & EMGPU_FLAG_NO_DEDISC) != 0);
         }
         wave_sync();
     }

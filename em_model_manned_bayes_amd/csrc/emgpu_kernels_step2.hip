@@ -19,6 +19,17 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
     if (off) return false;
     if (P.nd < 1 || P.nd > 4) return false;
     // (a fast-branch model -- frozen columns, FRZ -- that k_uncor_fast did not take: four dynamic variables, or one or two: balloon_v1)
+    // plain dbn_sample.m (no resample rows, the value of a row is its bin) returns a list and nothing else: the event instances serve it
+    // with the resample streams switched off (launch_dbn_step2) and the rows' values taken from their bins
+    const bool plain = (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) != 0;
+    if (plain && !(A.ev_count != nullptr && A.dyn_bin == nullptr && A.dyn_val == nullptr)) return false;
+    if (A.flags & EMGPU_FLAG_NO_RESAMPLE) {
+        EmgpuPlan Q = P;
+        Q.nact = 0;
+        EmgpuRun B = A;
+        B.flags &= ~EMGPU_FLAG_NO_RESAMPLE;
+        return step2_eligible(Q, B);
+    }
     if (A.ev_count != nullptr || A.events != nullptr) {
         if (!ev_plan_ok(P, A)) return false;
         // the event streams of a block are 8 - ND resample + ND transition streams of the INSTANCE that runs the model (ND = 4 for
@@ -27,7 +38,6 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
         const bool inst4 = !(P.depend || A.per_step) || !(P.ni <= 9 && P.nd <= 3);
         if (P.nact > (inst4 ? 4 : 5)) return false;
     }
-    if (A.flags & (EMGPU_FLAG_NO_RESAMPLE | EMGPU_FLAG_NO_DEDISC)) return false;
     for (int k = 0; k < P.nd; k++) {
         if (P.d_nb[k] == 0 || P.d_nb[k] > 16 || P.d_pw[k] == 0) return false;
         for (int q = 0; q < P.nd; q++)
@@ -73,7 +83,9 @@ static bool launch_masked(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args
 }
 
 static hipError_t launch_dbn_step2_inner(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name);
-hipError_t launch_dbn_step2(const EmgpuPlan &P, const EmgpuRun &A, hipStream_t s, const char **name) {
+hipError_t launch_dbn_step2(const EmgpuPlan &P0, const EmgpuRun &A, hipStream_t s, const char **name) {
+    EmgpuPlan P = P0;
+    if (A.flags & EMGPU_FLAG_NO_RESAMPLE) P.nact = 0;   // no variable has a rate: no resample stream, no resample pass (the instances without "reg")
     const hipError_t e = launch_dbn_step2_inner(P, A, s, name);
     if (A.ev_count != nullptr) {   // the same kernel with the event list written as well
         static thread_local char evname[96];

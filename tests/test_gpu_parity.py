@@ -172,6 +172,27 @@ def test_start_presets_prior_layers_quantize(gpu_ctx, model_dir):
     nm.set_start([0] * 7)
 
 
+@pytest.mark.parametrize("name", FAST_MODELS + DEP_MODELS + ["cor_v1", "littoral_cor_v1", "balloon_v1"])
+def test_plain_dbn_sample_from_the_fast_kernel(name, gpu_ctx, model_dir):
+    """dbn_sample.m:1 itself -- no resample rows, no dediscretize, no terminator: [initial bins, rows (dt, variable, new bin)] -- comes
+    from k_uncor_fast_evu on a fast-branch model and from k_dbn_step2<...>+events (resample streams off, values = bins) on the others
+    (rounds 1-3: k_dbn_generic), row for row the oracle's; lengths on and off the block."""
+    path = em_io.materialize_model(name, model_dir)
+    p = E.em_read(path)
+    om = O.OracleModel(O.parse_model_txt(path))
+    di = E.bn_dirichlet_prior(p["N_initial"], 0)
+    dt = E.bn_dirichlet_prior(p["N_transition"], 0)
+    for T, n, seed in [(240, 700, 5), (8, 300, 6), (29, 500, 7), (1, 100, 8)]:
+        inits, evs = E.dbn_sample(p, di, dt, T, seed=seed, num_samples=n, ctx=gpu_ctx)
+        k = gpu_ctx.last_kernel()
+        assert k.startswith("k_uncor_fast_evu") if name in FAST_MODELS else (k.startswith("k_dbn_step2") and k.endswith("+events")), k
+        rb, rev = O.dbn_sample(om, n, T, seed)
+        assert np.array_equal(inits, rb)
+        assert sum(len(b) for b in rev) > 0 or T == 1
+        for a, b in zip(evs, rev):
+            assert np.array_equal(a, b), (name, T)
+
+
 def test_dbn_sample_and_hierarchical_functions(gpu_ctx, model_dir):
     path = em_io.materialize_model("uncor_1200code_v1", model_dir)
     p = E.em_read(path)
