@@ -56,10 +56,10 @@ CONFIGS = {
                   metric="trajectory samples/sec (240 s uncor DBN, mixed batch over the six uncor_*_v1p2 files)",
                   workload="mixed batch over all uncor_*_v1p2 model files, model = contiguous block of the global index range, "
                            "%(n)d trajectories x %(T)d s per GPU (50 M on 8 GPUs)"),
-    "terminal": dict(models=[], n=2_000_000, seed=0x5EED0005, unit="encounters/s",
+    "terminal": dict(models=[], n=12_500_000, seed=0x5EED0005, unit="encounters/s",   # config 5's 100 M on 8 GPUs: one GPU's share (131 GB of tracks)
                      metric="terminal encounters/sec (geometry draw + forward/backward propagation of both aircraft)",
                      workload="CorTerminalModel: terminal_v3_radar geometry network + 10 synthetic trajectory models (the trained "
-                              "files are absent from the reference mount), %(n)d encounters x 4 tracks x <=121 s per GPU"),
+                              "files are absent from the reference mount), %(n)d encounters x 4 tracks x <=121 s per GPU (100 M on 8 GPUs)"),
 }
 
 
