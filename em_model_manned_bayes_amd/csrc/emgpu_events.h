@@ -346,14 +346,30 @@ __device__ __forceinline__ void ev_emit_block_wide(const CoopLds<ND, LB> &W, int
 // place in the list from its distance to the owner's first request, dt from the request before it, the bin by the stream's kind, ONE dediscretize draw in the row's own
 // slot (DEDISC_TRANS for a transition row, DEDISC_RES for every resample row: no row shares a result slot, so nothing is "hidden") -- and
 // stores it.  No result slots, no per-lane loop; 64 rows per pass whatever the lists' lengths.
-// Published per lane (the result slots are free in this mode), words of the lane's CoopLds row:
-// 4 rows so far, 5 time of the last row, 6 the bins the block began with, 7 the queue position of the lane's first request, 8-11 the static
+// Published per lane (the result slots are free in this mode), words of the lane's CoopLds row: 0 rows so far, 1 time of the last row,
+// 2 the bins the block began with, 3 the queue position of the lane's first request, 4-7 the static
 // variables' bins (ev_rows_publish_static); the mask itself stays with its lane.
-constexpr int kEvRowsQueue = 1024;   // requests per compaction round (uint16_t each; entry 0 of the array = the last request of the round before)
+// (Measured and dropped: rows held back in LDS until their aligned group of eight is complete, so that a list is written 64 bytes at a
+// time -- 10-15 % slower on every model: what looked like 6x write amplification on cor_v1's lists was the scratch traffic of a private
+// copy of the plan, emgpu_kernels_step2.h.)
+// LDS of the instances that build rows by the wave, and of no other instance: the stream table and a request queue per wave
+template <bool ON>
+__device__ __forceinline__ EvStream *ev_rows_stream_lds() {
+    if constexpr (ON) { __shared__ EvStream s[16]; return s; }
+    else return nullptr;
+}
+// requests per compaction round (uint16_t each; entry 0 of the array = the last request of the round before): 1024, or 512 where the
+// workgroup's LDS decides the occupancy (the 4-variable instances: 48 KB of cooperative state per workgroup, three workgroups per CU)
+template <int ND> constexpr int kEvRowsQueue = ND >= 4 ? 512 : 1024;
+template <bool ON, int ND>
+__device__ __forceinline__ uint16_t *ev_rows_queue_lds(int wave) {
+    if constexpr (ON) { __shared__ uint16_t q[4][kEvRowsQueue<ND> + 2]; return q[wave]; }
+    else return nullptr;
+}
 template <int ND>
 __device__ __forceinline__ void ev_rows_publish_static(CoopLds<ND, true> &W, int lane, const EvStateW &SW) {
     uint32_t *row = reinterpret_cast<uint32_t *>(&W.res[lane * CoopLds<ND, true>::kStride]);
-    row[8] = (uint32_t)SW.sb_lo; row[9] = (uint32_t)(SW.sb_lo >> 32); row[10] = (uint32_t)SW.sb_hi; row[11] = (uint32_t)(SW.sb_hi >> 32);
+    row[4] = (uint32_t)SW.sb_lo; row[5] = (uint32_t)(SW.sb_lo >> 32); row[6] = (uint32_t)SW.sb_hi; row[7] = (uint32_t)(SW.sb_hi >> 32);
 }
 // One pass: worker lane l builds the row of request q0 + l.  A lane's requests sit in the queue in list order, one after the other, from
 // position row[7] on: the row's rank in its block is its distance from there, and the row before it is the request before it.
@@ -367,18 +383,18 @@ __device__ __forceinline__ void ev_rows_worker(const CoopLds<ND, true> &W, const
         const uint32_t d = queue[q + 1u];
         const uint32_t owner = d & 63u, pos = d >> 6;
         const uint32_t *orow = reinterpret_cast<const uint32_t *>(&W.res[owner * L::kStride]);
-        const uint32_t rank = rb + q - orow[7];
+        const uint32_t rank = rb + q - orow[3];
         const uint32_t j = pos >> 4, b = pos & 15u;
         const uint32_t c = 8u * (uint32_t)g8 + j;
-        const uint32_t dt = rank ? j - ((uint32_t)queue[q] >> 10) : c - orow[5];
-        const uint32_t nrow = orow[4] + rank;
+        const uint32_t dt = rank ? j - ((uint32_t)queue[q] >> 10) : c - orow[1];
+        const uint32_t nrow = orow[0] + rank;
         const EvStream E = s_ev[b];
         const uint32_t var1 = E.var1, kd = E.kdyn, zb = E.zero;
         const uint8_t *bins8 = reinterpret_cast<const uint8_t *>(orow + L::kBins);
         uint32_t bin1, sec = EMGPU_SEC_DEDISC_RES;
         if (b >= NRES) { bin1 = bins8[8u * kd + j]; sec = EMGPU_SEC_DEDISC_TRANS; }                           // a transition row: the new bin
-        else if (kd != 0xFFu) bin1 = j ? bins8[8u * kd + j - 1u] : ((orow[6] >> (8u * kd)) & 0xFFu);           // a resample row: the bin before this second's transition
-        else bin1 = (orow[8u + (b >> 2)] >> (8u * (b & 3u))) & 0xFFu;                                          // ... of a static variable
+        else if (kd != 0xFFu) bin1 = j ? bins8[8u * kd + j - 1u] : ((orow[2] >> (8u * kd)) & 0xFFu);           // a resample row: the bin before this second's transition
+        else bin1 = (orow[4u + (b >> 2)] >> (8u * (b & 3u))) & 0xFFu;                                          // ... of a static variable
         float v = 0.f;
         if ((b < NRES && kd == 0xFFu && E.nb == 0u) || (A.flags & EMGPU_FLAG_NO_DEDISC)) v = (float)bin1;   // (plain dbn_sample.m: the value of a row is its bin)
         else if (bin1 != zb) {
@@ -404,8 +420,8 @@ __device__ __forceinline__ void ev_rows_block_wide(CoopLds<ND, true> &W, uint16_
     if (total == 0u) return;
     uint32_t *row = reinterpret_cast<uint32_t *>(&W.res[lane * L::kStride]);
     uint32_t a = inc - c;
-    row[4] = SW.S.count; row[5] = SW.S.last_t; row[6] = prevp; row[7] = a;
-    if (total <= (uint32_t)kEvRowsQueue) {
+    row[0] = SW.S.count; row[1] = SW.S.last_t; row[2] = prevp; row[3] = a;
+    if (total <= (uint32_t)kEvRowsQueue<ND>) {
         // the usual case, one round: the four words of the mask one after the other, leading bit first (a lane's requests stay in list order)
         uint16_t *qp = queue + 1 + a;
         const uint32_t w4[4] = {(uint32_t)(hi >> 32), (uint32_t)hi, (uint32_t)(lo >> 32), (uint32_t)lo};
@@ -426,9 +442,9 @@ __device__ __forceinline__ void ev_rows_block_wide(CoopLds<ND, true> &W, uint16_
     } else {
         const uint32_t aend = inc;
         uint64_t mh = hi, ml = lo;
-        for (uint32_t rb = 0u; rb < total; rb += (uint32_t)kEvRowsQueue) {
-            if (rb != 0u) { if (lane == 0) queue[0] = queue[kEvRowsQueue]; wave_sync(); }   // the request before this round's first
-            const uint32_t lim = min(aend, rb + (uint32_t)kEvRowsQueue);   // a lane is active while a < lim
+        for (uint32_t rb = 0u; rb < total; rb += (uint32_t)kEvRowsQueue<ND>) {
+            if (rb != 0u) { if (lane == 0) queue[0] = queue[kEvRowsQueue<ND>]; wave_sync(); }   // the request before this round's first
+            const uint32_t lim = min(aend, rb + (uint32_t)kEvRowsQueue<ND>);   // a lane is active while a < lim
             while (__ballot(a < lim) != 0ull) {
                 if (a < lim) {
                     uint32_t pos;
@@ -439,7 +455,7 @@ __device__ __forceinline__ void ev_rows_block_wide(CoopLds<ND, true> &W, uint16_
                 }
             }
             wave_sync();
-            const uint32_t cnt = min(total - rb, (uint32_t)kEvRowsQueue);
+            const uint32_t cnt = min(total - rb, (uint32_t)kEvRowsQueue<ND>);
             for (uint32_t q0 = 0u; q0 < cnt; q0 += 64u) ev_rows_worker<ND>(W, queue, lane, rb, q0, cnt, s_ev, rng, bnd, g8, A, i);
             wave_sync();
         }

@@ -329,7 +329,7 @@ __device__ __forceinline__ EvStream *evw_lds() {
 }
 template <int EVW>
 __device__ __forceinline__ uint16_t *evu_lds(int wave) {
-    if constexpr (EVW == 2) { __shared__ uint16_t q[4][kEvRowsQueue + 2]; return q[wave]; }
+    if constexpr (EVW == 2) { __shared__ uint16_t q[4][kEvRowsQueue<3> + 2]; return q[wave]; }
     else return nullptr;
 }
 // EVW: the event list of a model with more rated variables than the eight streams of EV hold (haa_v1): emgpu_events.h "WIDE lists"

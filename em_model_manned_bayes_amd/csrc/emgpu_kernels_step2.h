@@ -149,7 +149,9 @@ __device__ __forceinline__ bool s2_w4(const EmgpuPlan &P, int k) {
     return WMODE == 4 || (WMODE >= 16 ? (((WMODE - 16) >> k) & 1) != 0 : (WMODE == 0 && P.d_pw[k] == 4));
 }
 
-template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW, bool FRZ = false, bool EV = false>
+// EV: 0 the dense trace; 1 the event list as well (result slots + a row loop per lane, emgpu_events.h); 2 the list ALONE, its rows built
+// by the wave ("ROWS BY THE WAVE": no result slots, no fill)
+template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW, bool FRZ = false, int EV = 0>
 __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
     static_assert(!FRZ || NEW == 0u, "a fast-branch model has no (t+1) parents");
     // the instances built for a model family's parent masks are only launched with both dense outputs (launch_masked): no null tests at the stores
@@ -174,6 +176,9 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
     float cval[ND];
     EvPlan E{};
     EvState S{};
+    EvStateW SW{};
+    EvStream *const s_evs = ev_rows_stream_lds<EV == 2>();
+    uint16_t *const s_evq = ev_rows_queue_lds<EV == 2, ND>(tid >> 6);
     {
         int bin[NI];
         double val[NI];
@@ -191,9 +196,20 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
                 }
             }
         }
-        if constexpr (EV) {
-            E = ev_plan_of<NI, ND>(P);
-            S = ev_state_of<NI, ND>(P, A, bin, valid, i);
+        // The event-list set-up looks plan arrays up by run-time positions (P.i_zero[P.a_pos[b]], P.d_ivar[P.d_emit[e]]).  Done on the by-value
+        // kernel argument itself that made the 16-variable instances keep a private copy of the whole plan (2.6 KB of scratch per lane,
+        // every later P.x a scratch load, the table's buffer resource no longer provably uniform: a waterfall loop round every gather --
+        // cor_v1's lists at a third of the dense trace's rate); read through the kernel-argument segment the plan stays where it is.
+        const EmgpuPlan &Pk = *(const EmgpuPlan *)__builtin_amdgcn_kernarg_segment_ptr();
+        if constexpr (EV == 1) {
+            E = ev_plan_of<NI, ND>(Pk);
+            S = ev_state_of<NI, ND>(Pk, A, bin, valid, i);
+        }
+        if constexpr (EV == 2) {
+            ev_wide_plan<ND>(Pk, s_evs);          // (visible after the barrier below)
+            SW = ev_state_w_of<NI, ND>(Pk, A, bin, valid, i);
+            ev_rows_publish_static<ND>(W, lane, SW);
+            coop_publish_gidx<ND>(W, lane, gidx);
         }
 #pragma unroll
         for (int k = 0; k < ND; k++) {
@@ -490,8 +506,15 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
             kind |= (chg8[k] & 0xFFu) << (8 * k);
         }
         if (!valid) need = 0u;
-        if constexpr (EV) { if (A.flags & EMGPU_FLAG_NO_DEDISC) need = 0u; }   // (plain dbn_sample.m: no draw is due)
+        if constexpr (EV == 1) { if (A.flags & EMGPU_FLAG_NO_DEDISC) need = 0u; }   // (plain dbn_sample.m: no draw is due)
         EMGPU_COUNT(5, lane, 1);
+        if constexpr (EV == 2) {
+            uint32_t hitp = 0u;
+#pragma unroll
+            for (int k = 0; k < ND; k++) hitp |= (hit8[k] & 0xFFu) << (8 * k);
+            coop_publish_bins<ND>(W, lane, pbA, pbB);
+            ev_rows_block_wide<ND>(W, s_evq, lane, s_evs, P.nact, SW, rng, P.bnd, g8, T, valid, hitp, kind, prevp, A, i);
+        } else {
         coop_zero_results<ND, true>(W, lane);
         coop_publish_bins<ND>(W, lane, pbA, pbB);
         coop_dedisc<ND, true, true>(W, lane, gidx, rng, g8, need, kind, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
@@ -501,11 +524,12 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
             if (REG || k < P.nd)
                 coop_fill_store_msb<ND, true, kBoth>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
                                               REG ? (uint32_t)ND : (uint32_t)P.nd, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
-        if constexpr (EV) {
+        if constexpr (EV == 1) {
             uint32_t hitp = 0u;
 #pragma unroll
             for (int k = 0; k < ND; k++) hitp |= (hit8[k] & 0xFFu) << (8 * k);
             ev_emit_block<ND, true>(W, lane, E, S, rng, P.bnd, g8, T, valid, hitp, kind, prevp, (A.flags & EMGPU_FLAG_NO_DEDISC) != 0);
+        }
         }
         wave_sync();
     }
@@ -513,7 +537,10 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
         uint32_t curp = 0u;
 #pragma unroll
         for (int k = 0; k < ND; k++) curp |= cur1[k] << (8 * k);
-        ev_tail<ND>(E, S, rng, P.bnd, T, curp, A, valid, i);
+        if constexpr (EV == 2) {
+            ev_tail_wide<ND>(s_evs, P.nact, SW, rng, P.bnd, T, curp, A, valid, i);
+        }
+        else ev_tail<ND>(E, S, rng, P.bnd, T, curp, A, valid, i);
     }
 }
 
@@ -524,10 +551,17 @@ constexpr uint32_t kCurAll3 = 0x0777u, kNewAll3 = 0x0310u, kCurAll4 = 0xFFFFu, k
 // one instance, with or without the event list
 #define EMGPU_S2_LAUNCH(NI_, ND_, W_, REG_, C_, N_, FRZ_)                                                                      \
     do {                                                                                                                       \
-        if (A.ev_count != nullptr) hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, true>), g, b, 0, s, P, A, F); \
-        else hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, false>), g, b, 0, s, P, A, F);                    \
+        if (A.ev_count != nullptr && step2_rows_by_wave(P, A)) hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, 2>), g, b, 0, s, P, A, F); \
+        else if (A.ev_count != nullptr) hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, 1>), g, b, 0, s, P, A, F); \
+        else hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, 0>), g, b, 0, s, P, A, F);                        \
     } while (0)
 
+
+// a list asked for alone: its rows are built by the wave (EMGPU_DEBUG_EVENT_ROWS=lane: tests keep the per-lane row loop reachable)
+inline bool step2_rows_by_wave(const EmgpuPlan &P, const EmgpuRun &A) {
+    static const char *rows_env = getenv("EMGPU_DEBUG_EVENT_ROWS");
+    return A.dyn_bin == nullptr && A.dyn_val == nullptr && rows_env == nullptr && ev_plan_wide_ok(P, A);
+}
 
 // the instances built for the 3-variable families (emgpu_kernels_step2b.hip)
 bool launch_masked3(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args &F, hipStream_t s, uint32_t cur, uint32_t nw, const char **tag);

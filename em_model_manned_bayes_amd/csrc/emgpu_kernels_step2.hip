@@ -54,8 +54,11 @@ static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const Step2Arg
     const dim3 g((unsigned)((A.n + 255) / 256)), b(256);
     constexpr uint32_t C = ND == 4 ? kCurAll4 : kCurAll3, N = ND == 4 ? kNewAll4 : kNewAll3;
     if (A.ev_count != nullptr) {   // event lists: the per-variable-width instances only (half the instances for the rarer output)
-        if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N, false, true>), g, b, 0, s, P, A, F);
-        else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false, C, N, false, true>), g, b, 0, s, P, A, F);
+        if (step2_rows_by_wave(P, A)) {
+            if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N, false, 2>), g, b, 0, s, P, A, F);
+            else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false, C, N, false, 2>), g, b, 0, s, P, A, F);
+        } else if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N, false, 1>), g, b, 0, s, P, A, F);
+        else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false, C, N, false, 1>), g, b, 0, s, P, A, F);
         return hipGetLastError();
     }
     if (reg && wmode == 4) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 4, true, C, N>), g, b, 0, s, P, A, F);
@@ -89,7 +92,7 @@ hipError_t launch_dbn_step2(const EmgpuPlan &P0, const EmgpuRun &A, hipStream_t 
     const hipError_t e = launch_dbn_step2_inner(P, A, s, name);
     if (A.ev_count != nullptr) {   // the same kernel with the event list written as well
         static thread_local char evname[96];
-        snprintf(evname, sizeof evname, "%s+events", *name);
+        snprintf(evname, sizeof evname, "%s%s+events", *name, step2_rows_by_wave(P, A) ? "+rows-by-wave" : "");
         *name = evname;
     }
     return e;

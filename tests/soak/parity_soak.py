@@ -2,7 +2,8 @@
 it runs the oracle, so it lives under tests/; not collected by pytest).  For every packed model with dynamic variables: n trajectories
 x 240 s in chunks, GPU (emgpu_sample_dbn_host) vs oracle.uncor_sample_mt on every allowed core, compared BIT-EXACT (bins as u8, values
 as the oracle's f64 rounded to f32).  Also the first chunk under EMGPU_TRANSITION_PER_STEP, and 20 000 trajectories with everything a call
-returns (initial state, rejection attempts, dense trace AND event lists: tests/util.assert_uncor_parity, the single-thread oracle).  Prints one line per model and a total;
+returns (initial state, rejection attempts, dense trace AND event lists: tests/util.assert_uncor_parity, the single-thread oracle), the
+same lists asked for alone, and plain dbn_sample.m (no resample rows, values = bins).  Prints one line per model and a total;
 exit code 1 on the first mismatch.  Needs a GPU."""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -66,9 +67,35 @@ def main():
             print("MISMATCH %s (full outputs): %s" % (name, str(e)[:300]))
             return 1
         kernels.add(got["kernel"])
+        # the list asked for alone (round 4: the rows of a block built by the wave on the fast-branch models), against the same oracle run
+        alone = native.sample_dbn_host(ctx, nm, ne, T, 0x50AC1111, first_index=424_242, want_dense=False, want_events=True, event_cap=2048, **idx)
+        kernels.add(alone["kernel"])
+        if not np.array_equal(alone["ev_count"], np.array([len(e) for e in ref["events"]])):
+            print("MISMATCH %s (list alone): row counts" % name)
+            return 1
+        for i in range(ne):
+            g, r = alone["events"][i], ref["events"][i]
+            if not (np.array_equal(g["dt"], r[:, 0]) and np.array_equal(g["var"], r[:, 1]) and np.array_equal(g["bin"], r[:, 3])
+                    and np.array_equal(g["value"], r[:, 2].astype(np.float32))):
+                print("MISMATCH %s (list alone): trajectory %d" % (name, 424_242 + i))
+                return 1
+        # plain dbn_sample.m (no resample rows, values = bins, no terminator)
+        flags = L.FLAG_NO_RESAMPLE | L.FLAG_NO_DEDISC | L.FLAG_NO_TERMINATOR
+        plain = native.sample_dbn_host(ctx, nm, ne, T, 0x50AC2222, first_index=77, want_dense=False, want_events=True, flags=flags,
+                                       event_cap=nm.n_initial * T + 1, max_attempts=1)
+        kernels.add(plain["kernel"] + "(plain)")
+        rb0, rev = O.dbn_sample(om, ne, T, 0x50AC2222, first_index=77)
+        if not np.array_equal(plain["init_bin"], rb0):
+            print("MISMATCH %s (plain dbn_sample): initial bins" % name)
+            return 1
+        for i in range(ne):
+            g, r = plain["events"][i], rev[i]
+            if not (len(g["dt"]) == len(r) and np.array_equal(g["dt"], r[:, 0]) and np.array_equal(g["var"], r[:, 1]) and np.array_equal(g["bin"], r[:, 2])):
+                print("MISMATCH %s (plain dbn_sample): trajectory %d" % (name, 77 + i))
+                return 1
         total += done
         total_ev = ne
-        print("%-34s %8d trajectories x %d s dense bit-exact + %d with event lists  %5.1f s  %s" % (name, done, T, ne, time.time() - t0, ", ".join(sorted(kernels))), flush=True)
+        print("%-34s %8d trajectories x %d s dense bit-exact + %d with event lists (with the trace, alone, plain dbn_sample)  %5.1f s  %s" % (name, done, T, ne, time.time() - t0, ", ".join(sorted(kernels))), flush=True)
     print("TOTAL %d trajectories x %d s bit-exact on %d oracle threads in %.0f s" % (total, T, thr, time.time() - t_start))
     return 0
 

@@ -52,9 +52,8 @@ def test_event_lists_from_the_fast_kernel_match_oracle(name, T, n, cap, gpu_ctx,
         assert ei.value.code == L.ERR_EVENT_CAP
         return
     got = native.sample_dbn_host(gpu_ctx, nm, n, T, seed, first_index=first, want_dense=False, want_events=True, event_cap=cap, **idx)
-    assert got["kernel"].startswith("k_uncor_fast_ev") or got["kernel"].endswith("+events"), got["kernel"]
-    if name in FAST_MODELS:   # the list alone: the rows of a block are built 64 at a time by the wave (haa_v1's seven rated variables included)
-        assert got["kernel"].startswith("k_uncor_fast_evu"), got["kernel"]
+    # the list alone: the rows of a block are built 64 at a time by the wave (haa_v1's seven rated variables included)
+    assert got["kernel"].startswith("k_uncor_fast_evu") if name in FAST_MODELS else got["kernel"].endswith("+rows-by-wave+events"), got["kernel"]
     assert np.array_equal(got["ev_count"], ref_cnt)
     for i in range(n):
         g, r = got["events"][i], ref["events"][i]
@@ -1237,14 +1236,15 @@ from util import load_pair, uncor_indices
 ctx = native.Context(0)
 rows = %r
 for name in %r:
-    want = "k_uncor_fast_evw" if rows == "wide" or name == "haa_v1" else "k_uncor_fast_ev<"
+    fast = name in %r
+    want = ("k_uncor_fast_evw" if rows == "wide" or name == "haa_v1" else "k_uncor_fast_ev<") if fast else "k_dbn_step2"
     nm, pp, _ = load_pair(name, %r)
     idx = uncor_indices(pp)
     for T, n, cap in [(240, 1500, 1024), (8, 300, 64), (13, 500, 64), (1, 100, 8), (33, 700, 4096)]:
         seed, first = 0xE7E8, 2**35 + 7
         ref = O.uncor_sample(O.OracleModel(pp), n, T, seed, mode=O.RNG_PHILOX, first_index=first)
         got = native.sample_dbn_host(ctx, nm, n, T, seed, first_index=first, want_dense=False, want_events=True, event_cap=cap, **idx)
-        assert got["kernel"].startswith(want), got["kernel"]
+        assert got["kernel"].startswith(want) and "rows-by-wave" not in got["kernel"], got["kernel"]
         assert np.array_equal(got["ev_count"], np.array([len(e) for e in ref["events"]]))
         for i in range(n):
             g, r = got["events"][i], ref["events"][i]
@@ -1257,7 +1257,8 @@ for name in %r:
     except L.EmgpuError as e:
         assert e.code == L.ERR_EVENT_CAP
 print("wide ok")
-''' % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"), os.path.join(ROOT_DIR, "oracle"), rows, FAST_MODELS, str(model_dir))
+''' % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"), os.path.join(ROOT_DIR, "oracle"), rows, FAST_MODELS + (DEP_MODELS[:3] + ["cor_v1", "littoral_cor_v1"] if rows == "lane" else []),
+       FAST_MODELS, str(model_dir))
     env = dict(os.environ, EMGPU_DEBUG_EVENT_ROWS=rows)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "wide ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -12,7 +12,7 @@ def bench(name):
     labs = nm.get_labels(L.F_LABELS_INITIAL)
     idx = {k: (labs.index('"%s"' % v) + 1 if '"%s"' % v in labs else 0) for k, v in (("idx_L", "L"), ("idx_v", "v"), ("idx_dh", "\\dot h"))}
     n, T = 1_000_000, 240
-    for cap in (512, 2048):                  # (haa_v1: seven rated variables, lists of up to ~700 rows)
+    for cap in ((int(os.environ["EVCAP"]),) if "EVCAP" in os.environ else (512, 2048)):                  # (haa_v1: seven rated variables, lists of up to ~700 rows)
         try:
             return bench_cap(name, nm, idx, n, T, cap)
         except L.EmgpuError as e:

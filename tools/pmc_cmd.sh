@@ -5,7 +5,7 @@ K="$1"; shift
 C="$1"; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pmcc
-rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmcc -- python3 "$@" > /dev/null 2>&1
+timeout 150 rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmcc -- python3 "$@" > /dev/null 2>&1
 python3 - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)
