@@ -408,8 +408,8 @@ __device__ __forceinline__ void ev_rows_worker(const CoopLds<ND, true> &W, const
                 (uint64_t)(dt & 0xFFFFu) | ((uint64_t)var1 << 16) | ((uint64_t)bin1 << 24) | ((uint64_t)__float_as_uint(v) << 32);
     }
 }
-template <int ND>
-__device__ __forceinline__ void ev_rows_block_wide(CoopLds<ND, true> &W, uint16_t *queue, int lane, const EvStream *s_ev, int nact, EvStateW &SW, const Rng &rng,
+template <int ND, int KQ = kEvRowsQueue<ND>>
+__device__ __forceinline__ void ev_rows_block_wide(CoopLds<ND, true> &W, uint16_t *queue /* KQ + 2 entries */, int lane, const EvStream *s_ev, int nact, EvStateW &SW, const Rng &rng,
                                                    const double *bnd, int g8, int T, bool valid, uint32_t hitp, uint32_t chgp, uint32_t prevp, const EmgpuRun &A, int64_t i) {
     using L = CoopLds<ND, true>;
     uint64_t hi, lo;
@@ -421,7 +421,7 @@ __device__ __forceinline__ void ev_rows_block_wide(CoopLds<ND, true> &W, uint16_
     uint32_t *row = reinterpret_cast<uint32_t *>(&W.res[lane * L::kStride]);
     uint32_t a = inc - c;
     row[0] = SW.S.count; row[1] = SW.S.last_t; row[2] = prevp; row[3] = a;
-    if (total <= (uint32_t)kEvRowsQueue<ND>) {
+    if (total <= (uint32_t)KQ) {
         // the usual case, one round: the four words of the mask one after the other, leading bit first (a lane's requests stay in list order)
         uint16_t *qp = queue + 1 + a;
         const uint32_t w4[4] = {(uint32_t)(hi >> 32), (uint32_t)hi, (uint32_t)(lo >> 32), (uint32_t)lo};
@@ -442,9 +442,9 @@ __device__ __forceinline__ void ev_rows_block_wide(CoopLds<ND, true> &W, uint16_
     } else {
         const uint32_t aend = inc;
         uint64_t mh = hi, ml = lo;
-        for (uint32_t rb = 0u; rb < total; rb += (uint32_t)kEvRowsQueue<ND>) {
-            if (rb != 0u) { if (lane == 0) queue[0] = queue[kEvRowsQueue<ND>]; wave_sync(); }   // the request before this round's first
-            const uint32_t lim = min(aend, rb + (uint32_t)kEvRowsQueue<ND>);   // a lane is active while a < lim
+        for (uint32_t rb = 0u; rb < total; rb += (uint32_t)KQ) {
+            if (rb != 0u) { if (lane == 0) queue[0] = queue[KQ]; wave_sync(); }   // the request before this round's first
+            const uint32_t lim = min(aend, rb + (uint32_t)KQ);   // a lane is active while a < lim
             while (__ballot(a < lim) != 0ull) {
                 if (a < lim) {
                     uint32_t pos;
@@ -455,7 +455,7 @@ __device__ __forceinline__ void ev_rows_block_wide(CoopLds<ND, true> &W, uint16_
                 }
             }
             wave_sync();
-            const uint32_t cnt = min(total - rb, (uint32_t)kEvRowsQueue<ND>);
+            const uint32_t cnt = min(total - rb, (uint32_t)KQ);
             for (uint32_t q0 = 0u; q0 < cnt; q0 += 64u) ev_rows_worker<ND>(W, queue, lane, rb, q0, cnt, s_ev, rng, bnd, g8, A, i);
             wave_sync();
         }

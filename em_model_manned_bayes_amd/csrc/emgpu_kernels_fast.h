@@ -327,13 +327,17 @@ __device__ __forceinline__ EvStream *evw_lds() {
     if constexpr (EVW != 0) { __shared__ EvStream s[16]; return s; }
     else return nullptr;
 }
+// The request queue of the rows-by-the-wave form: EVW 2 -- the cooperative dediscretize's own queue, idle in that form: 254 requests per
+// round, the workgroup stays within 40 KB of LDS (four per CU) and 128 registers (four waves per SIMD); EVW 3 -- 1 024 requests per round in
+// LDS of its own (three workgroups per CU), for lists of several hundred rows per wave and block (haa_v1: ~900), where 254 mean four rounds
+constexpr int kFastRowsQueue = 254;
 template <int EVW>
 __device__ __forceinline__ uint16_t *evu_lds(int wave) {
-    if constexpr (EVW == 2) { __shared__ uint16_t q[4][kEvRowsQueue<3> + 2]; return q[wave]; }
+    if constexpr (EVW == 3) { __shared__ uint16_t q[4][kEvRowsQueue<3> + 2]; return q[wave]; }
     else return nullptr;
 }
 // EVW: the event list of a model with more rated variables than the eight streams of EV hold (haa_v1): emgpu_events.h "WIDE lists"
-// (1: result slots + a row loop per lane, any outputs; 2: events only, the rows built by the wave -- "ROWS BY THE WAVE")
+// (1: result slots + a row loop per lane, any outputs; 2, 3: events only, the rows built by the wave -- "ROWS BY THE WAVE")
 template <int NI, int M0, int M1, int M2, bool MIXED = false, bool EV = false, bool IDX = false, int EVW = 0>
 __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuRun &A, const FastArgs &F, const int64_t i0 /* trajectory of lane 0: wave-uniform, may be < 0 */) {
     // workers look the bin of a request up in LDS (the owner does not encode it into the request): -1.8 % on the
@@ -429,11 +433,12 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
         E = ev_plan_of<NI, 3>(P);
         S = ev_state_of<NI, 3>(P, A, bin, valid, i);
     }
-    uint16_t *s_evq = evu_lds<EVW>(tid >> 6);
+    uint16_t *s_evq = EVW == 3 ? evu_lds<EVW>(tid >> 6) : reinterpret_cast<uint16_t *>(W.queue);
+    static_assert(sizeof(W.queue) >= (kFastRowsQueue + 2) * sizeof(uint16_t), "rows queue");
     if constexpr (EVW != 0) {
         ev_wide_plan<3>(P, s_evw);
         SW = ev_state_w_of<NI, 3>(P, A, bin, valid, i);
-        if constexpr (EVW == 2) ev_rows_publish_static<3>(W, lane, SW);
+        if constexpr (EVW >= 2) ev_rows_publish_static<3>(W, lane, SW);
         __syncthreads();
     }
     const int G4 = (T + 3) >> 2, G8 = (T + 7) >> 3;
@@ -457,9 +462,9 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
         EMGPU_COUNT(5, lane, 1);
         const uint32_t need24 = valid ? (need8[0] | (need8[1] << 8) | (need8[2] << 16)) : 0u;
         const uint32_t kind24 = kind8[0] | (kind8[1] << 8) | (kind8[2] << 16);
-        if constexpr (EVW == 2) {   // events only: no result slots, no fill -- every row is one request of the wave's queue
+        if constexpr (EVW >= 2) {   // events only: no result slots, no fill -- every row is one request of the wave's queue
             coop_publish_bins<3>(W, lane, pbA, pbB);
-            ev_rows_block_wide<3>(W, s_evq, lane, s_evw, P.nact, SW, rng, P.bnd, g8, T, valid, hit24, kind24, prevw, A, i);
+            ev_rows_block_wide<3, EVW == 3 ? kEvRowsQueue<3> : kFastRowsQueue>(W, s_evq, lane, s_evw, P.nact, SW, rng, P.bnd, g8, T, valid, hit24, kind24, prevw, A, i);
         } else {
         coop_zero_results<3, LB>(W, lane);
         if constexpr (LB) coop_publish_bins<3>(W, lane, pbA, pbB);
@@ -501,8 +506,12 @@ __global__ void __launch_bounds__(256, 3) k_uncor_fast_evw(const EmgpuPlan P, co
 }
 // ... and its events-only form: the rows of a block built 64 at a time by the wave (emgpu_events.h "ROWS BY THE WAVE")
 template <int NI, int M0, int M1, int M2>
-__global__ void __launch_bounds__(256, 3) k_uncor_fast_evu(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
+__global__ void __launch_bounds__(256, 4) k_uncor_fast_evu(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
     uncor_fast_body<NI, M0, M1, M2, false, true, true, 2>(P, A, F, (int64_t)blockIdx.x * 256 - (A.col0 & 255));
+}
+template <int NI, int M0, int M1, int M2>
+__global__ void __launch_bounds__(256, 3) k_uncor_fast_evu_long(const EmgpuPlan P, const EmgpuRun A, const FastArgs F) {
+    uncor_fast_body<NI, M0, M1, M2, false, true, true, 3>(P, A, F, (int64_t)blockIdx.x * 256 - (A.col0 & 255));
 }
 // the dense kernel for an index list (the later rounds of UncorEncounterModel.track: the trajectories still rejected)
 template <int NI, int M0, int M1, int M2>

@@ -152,7 +152,7 @@ __device__ __forceinline__ bool s2_w4(const EmgpuPlan &P, int k) {
 // EV: 0 the dense trace; 1 the event list as well (result slots + a row loop per lane, emgpu_events.h); 2 the list ALONE, its rows built
 // by the wave ("ROWS BY THE WAVE": no result slots, no fill)
 template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW, bool FRZ = false, int EV = 0>
-__global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
+__global__ void __launch_bounds__(256, (ND == 4 || EV == 1) ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
     static_assert(!FRZ || NEW == 0u, "a fast-branch model has no (t+1) parents");
     // the instances built for a model family's parent masks are only launched with both dense outputs (launch_masked): no null tests at the stores
     constexpr bool kBoth = !EV && CUR != 0x0777u && CUR != 0xFFFFu;
@@ -178,7 +178,11 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
     EvState S{};
     EvStateW SW{};
     EvStream *const s_evs = ev_rows_stream_lds<EV == 2>();
-    uint16_t *const s_evq = ev_rows_queue_lds<EV == 2, ND>(tid >> 6);
+    // the rows' request queue: the cooperative dediscretize's own (idle in this form, 254 requests per round: the 3-variable instances stay
+    // within 40 KB of LDS and 128 registers, four waves per SIMD), or 512 requests in LDS of its own (the 4-variable instances)
+    constexpr int KQ = ND == 4 ? kEvRowsQueue<4> : 254;
+    uint16_t *const s_evq = ND == 4 ? ev_rows_queue_lds<EV == 2 && ND == 4, ND>(tid >> 6) : reinterpret_cast<uint16_t *>(W.queue);
+    static_assert(sizeof(W.queue) >= (254 + 2) * sizeof(uint16_t), "rows queue");
     {
         int bin[NI];
         double val[NI];
@@ -513,7 +517,7 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV) ? 3 : 4) k_dbn_step2(cons
 #pragma unroll
             for (int k = 0; k < ND; k++) hitp |= (hit8[k] & 0xFFu) << (8 * k);
             coop_publish_bins<ND>(W, lane, pbA, pbB);
-            ev_rows_block_wide<ND>(W, s_evq, lane, s_evs, P.nact, SW, rng, P.bnd, g8, T, valid, hitp, kind, prevp, A, i);
+            ev_rows_block_wide<ND, KQ>(W, s_evq, lane, s_evs, P.nact, SW, rng, P.bnd, g8, T, valid, hitp, kind, prevp, A, i);
         } else {
         coop_zero_results<ND, true>(W, lane);
         coop_publish_bins<ND>(W, lane, pbA, pbB);

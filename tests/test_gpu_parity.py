@@ -1220,12 +1220,13 @@ print("fallback ok")
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("rows", ["lane", "wide"])
+@pytest.mark.parametrize("rows", ["lane", "wide", "long"])
 def test_every_fast_model_through_the_per_lane_event_kernels(rows, model_dir):
     """A list asked for alone comes from k_uncor_fast_evu (rows built by the wave: the tests above); k_uncor_fast_ev / k_uncor_fast_evw
     (result slots + a row loop per lane) serve the calls that want the dense trace as well.  A child process with
     EMGPU_DEBUG_EVENT_ROWS sends every fast-branch model's lists through them too ("lane": ev, evw for haa_v1; "wide": evw, whose
-    instance takes any fast-branch shape): row for row against the oracle, lengths on and off the block boundary, an overrun capacity."""
+    instance takes any fast-branch shape; "long": k_uncor_fast_evu_long, the rows-by-the-wave form with the 1 024-request queue that only
+    haa_v1 takes by default): row for row against the oracle, lengths on and off the block boundary, an overrun capacity."""
     import subprocess, sys
     code = r'''
 import sys, numpy as np
@@ -1237,7 +1238,7 @@ ctx = native.Context(0)
 rows = %r
 for name in %r:
     fast = name in %r
-    want = ("k_uncor_fast_evw" if rows == "wide" or name == "haa_v1" else "k_uncor_fast_ev<") if fast else "k_dbn_step2"
+    want = ("k_uncor_fast_evu_long" if rows == "long" else "k_uncor_fast_evw" if rows == "wide" or name == "haa_v1" else "k_uncor_fast_ev<") if fast else "k_dbn_step2"
     nm, pp, _ = load_pair(name, %r)
     idx = uncor_indices(pp)
     for T, n, cap in [(240, 1500, 1024), (8, 300, 64), (13, 500, 64), (1, 100, 8), (33, 700, 4096)]:
