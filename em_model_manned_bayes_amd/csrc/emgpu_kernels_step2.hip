@@ -30,7 +30,11 @@ bool step2_eligible(const EmgpuPlan &P, const EmgpuRun &A) {
         B.flags &= ~EMGPU_FLAG_NO_RESAMPLE;
         return step2_eligible(Q, B);
     }
-    if (A.ev_count != nullptr || A.events != nullptr) {
+    if ((A.ev_count != nullptr || A.events != nullptr) && step2_rows_by_wave(P, A)) {
+        // a list asked for alone: 16 - ND streams of the instance (12 or 13 rated variables)
+        const bool inst4 = !(P.depend || A.per_step) || !(P.ni <= 9 && P.nd <= 3);
+        if (P.nact > (inst4 ? 12 : 13)) return false;
+    } else if (A.ev_count != nullptr || A.events != nullptr) {
         if (!ev_plan_ok(P, A)) return false;
         // the event streams of a block are 8 - ND resample + ND transition streams of the INSTANCE that runs the model (ND = 4 for
         // the frozen instances and the 16-variable shape, else 3), not of the model: a model with fewer dynamic variables than its

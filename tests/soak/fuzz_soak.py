@@ -1,6 +1,6 @@
 """tests/soak/fuzz_soak.py [n_models [first_seed]] -- the model fuzzer of tests/test_gpu_parity.py (tests/util.random_model) over many
-seeds and both widths (3-7 and 8-14 initial variables): event lists + dense REFERENCE_AUTO + dense PER_STEP of the HIP path against
-the CPU oracle, bit-exact.  Checker-side (runs the oracle; not collected by pytest).  Needs a GPU."""
+seeds and both widths (3-7 and 8-14 initial variables): event lists (with the dense trace, alone, plain dbn_sample.m) + dense
+REFERENCE_AUTO + dense PER_STEP of the HIP path against the CPU oracle, bit-exact.  Checker-side (runs the oracle; not collected by pytest).  Needs a GPU."""
 import os, sys, tempfile, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for q in ("", "tests", "oracle"):
@@ -39,6 +39,23 @@ def main():
             got = native.sample_dbn_host(ctx, nm, n, T, seed, want_dense=True, want_events=False)
             kernels[got["kernel"].split("<")[0]] += 1
             assert_uncor_parity(got, ref, T, check_events=False)
+            # the list asked for alone (round 4: its rows built by the wave), and plain dbn_sample.m
+            got = native.sample_dbn_host(ctx, nm, n, T, seed, want_dense=False, want_events=True)
+            kernels[got["kernel"].split("<")[0] + ("+rows-by-wave" if "rows-by-wave" in got["kernel"] else "") + " (list alone)"] += 1
+            assert np.array_equal(got["ev_count"], np.array([len(e) for e in ref["events"]])), "list alone: counts"
+            for i in range(n):
+                g, r = got["events"][i], ref["events"][i]
+                assert np.array_equal(g["dt"], r[:, 0]) and np.array_equal(g["var"], r[:, 1]) and np.array_equal(g["bin"], r[:, 3]) \
+                    and np.array_equal(g["value"], r[:, 2].astype(np.float32)), "list alone: trajectory %d" % i
+            flags = L.FLAG_NO_RESAMPLE | L.FLAG_NO_DEDISC | L.FLAG_NO_TERMINATOR
+            got = native.sample_dbn_host(ctx, nm, n, T, seed, want_dense=False, want_events=True, flags=flags, event_cap=nm.n_initial * T + 1, max_attempts=1)
+            kernels[got["kernel"].split("<")[0] + ("+rows-by-wave" if "rows-by-wave" in got["kernel"] else "") + " (plain dbn_sample)"] += 1
+            rb0, rev = O.dbn_sample(om, n, T, seed)
+            assert np.array_equal(got["init_bin"], rb0), "plain dbn_sample: initial bins"
+            for i in range(n):
+                g, r = got["events"][i], rev[i]
+                assert len(g["dt"]) == len(r) and np.array_equal(g["dt"], r[:, 0]) and np.array_equal(g["var"], r[:, 1]) and np.array_equal(g["bin"], r[:, 2]), \
+                    "plain dbn_sample: trajectory %d" % i
             refp = O.uncor_sample(om, n, T, seed, per_step=True, want_events=False)
             got = native.sample_dbn_host(ctx, nm, n, T, seed, want_dense=True, want_events=False, transition_mode=L.TRANSITION_PER_STEP)
             assert_uncor_parity(got, refp, T, check_events=False)
@@ -49,7 +66,7 @@ def main():
         except AssertionError as e:
             print("MISMATCH seed %d (ni %d, nd %d, T %d, kernel %s): %s" % (seed, parms["n_initial"], parms["n_transition"] - parms["n_initial"], T, got["kernel"], str(e)[:200]))
             return 1
-    print("%d generated models (seeds %d..%d), event lists + dense + PER_STEP bit-exact; kernels: %s" % (count, first, first + count - 1, dict(kernels)))
+    print("%d generated models (seeds %d..%d), event lists (with the trace / alone / plain dbn_sample) + dense + PER_STEP bit-exact; kernels: %s" % (count, first, first + count - 1, dict(kernels)))
     return 0
 
 
