@@ -571,6 +571,23 @@ class GpuTelemetry:
             out["power_cap_w"] = int(open(os.path.join(self.dir, "power1_cap")).read()) / 1e6
         except (OSError, ValueError):
             pass
+        # the board's temperature sensors at the end of the probe (junction / memory: a hot HBM stack refreshes more often), and the memory clock
+        import glob
+        temps = {}
+        for f in glob.glob(os.path.join(self.dir, "temp*_input")):
+            try:
+                lab = open(f.replace("_input", "_label")).read().strip()
+                temps[lab] = int(open(f).read()) / 1000.0
+            except (OSError, ValueError):
+                pass
+        if temps:
+            out["temperature_c"] = temps
+        for f in glob.glob(os.path.join(self.dir, "freq*_label")):
+            try:
+                if open(f).read().strip() == "mclk":
+                    out["mclk_mhz"] = int(open(f.replace("_label", "_input")).read()) / 1e6
+            except (OSError, ValueError):
+                pass
         return out
 
 
