@@ -82,6 +82,10 @@ def parse_args(argv=None):
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each entry of `configs` (2 warm-up steps before)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="minimum units timed on the CPU oracle (scaled up to ~10 s)")
     ap.add_argument("--local-smooth", action="store_true", help="terminal: add the smoothing pass of createEncounter.m:88-89 (k_terminal_smooth: the flagged stand-in for em-core's local_smooth; a second pass over the tracks)")
+    ap.add_argument("--prewarm-s", type=float, default=0.0,
+                    help="diagnostic: seconds of the same step launched back to back BEFORE the warm-up steps, untimed and reported in the line. "
+                         "(Measured with it, tools/thermal_probe.sh: a box's slow spells -- 7.1 ms per step at 1 270 W and 2 330 MHz instead of 6.0 ms "
+                         "at 1 346 W and 2 195 MHz -- are not a warm-up effect: three seconds of load ahead of the timed region change nothing.)")
     ap.add_argument("--telemetry-s", type=float, default=2.5,
                     help="seconds of untimed back-to-back steps after the timed region during which the shader clock and socket power are read (0: skip)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -595,6 +599,18 @@ class GpuTelemetry:
 def measure(w, pl, args, warmup, steps):
     """warmup untimed steps, then `steps` timed ones bracketed by barrier + device synchronisation on both sides; the launch
     durations come from HIP events on the stream the kernels are launched on.  Returns (elapsed_s max over ranks, [ms per step])."""
+    prewarm_s = float(getattr(args, "prewarm_s", 0.0) or 0.0)
+    if prewarm_s > 0.0 and hasattr(pl, "torch"):   # the device's sustained state first (untimed; the line says so)
+        t_end, k, first = time.perf_counter() + prewarm_s, 0, []
+        while time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            for _ in range(8):
+                w.step(1_000_000 + k)   # (global indices far from the timed steps')
+                k += 1
+            w.sync()
+            if len(first) < 4:
+                first.append(round((time.perf_counter() - t0) * 1e3 / 8, 3))
+        w.prewarm = {"seconds": prewarm_s, "steps": k, "ms_per_step_of_its_first_rounds": first}
     for k in range(warmup):
         w.step(k)
     w.sync()
@@ -662,6 +678,8 @@ def roofline_of(w, step_ms, lib_version):
          "avg_launch_ms": avg_step_s * 1e3 / w.launches_per_step, "launches_per_step": w.launches_per_step,
          "avg_step_ms": avg_step_s * 1e3, "step_ms": [round(x, 3) for x in step_ms], "algorithmic_bytes_per_launch": per_launch,
          "algorithmic_bytes_per_unit": w.bytes_per_unit}
+    if getattr(w, "prewarm", None):     # untimed launches ahead of the warm-up steps (--prewarm-s)
+        r["prewarm"] = w.prewarm
     if getattr(w, "telemetry", None):   # the box, while it ran the timed region
         r["sclk_mhz"] = w.telemetry["sclk_mhz"]["median"]
         r["gpu_telemetry"] = w.telemetry
@@ -686,6 +704,7 @@ def other_configs(args, pl, lib_version):
     for name in OTHER_CONFIGS:
         a = copy.copy(args)
         a.config, a.n, a.model, a.per_step = name, 0, None, False
+        a.prewarm_s = min(1.5, float(getattr(args, "prewarm_s", 0.0) or 0.0))   # (the CPU leg of the entry before left the GPU idle for seconds)
         cfg = CONFIGS[name]
         try:
             w = (TerminalWorkload if name == "terminal" else DbnWorkload)(a, cfg, pl, 0, 1)
