@@ -493,6 +493,10 @@ class TerminalWorkload:
 
 
 def make_workload(args, pl, rank, world):
+    shift_mb = int(os.environ.get("EMGPU_BENCH_SHIFT_MB", "0") or 0)   # diagnostic: move the step's buffers to other addresses
+    if shift_mb > 0 and hasattr(pl, "torch"):
+        pl._shift = pl.empty((shift_mb, 1 << 20), "uint8")
+        pl._shift.zero_()
     cfg = CONFIGS[args.config]
     return (TerminalWorkload if args.config == "terminal" else DbnWorkload)(args, cfg, pl, rank, world)
 
