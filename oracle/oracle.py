@@ -22,6 +22,8 @@ RNG_PHILOX = 1
 
 
 def build(force=False):
+    if os.environ.get("EM_ORACLE_LIB"):   # another build of the same oracle (tools/check_philox10.sh: the 10-round generator)
+        return os.environ["EM_ORACLE_LIB"]
     so = os.path.join(_HERE, "libem_oracle.so")
     src = os.path.join(_HERE, "em_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
