@@ -219,6 +219,83 @@ __device__ __forceinline__ void coop_dedisc(CoopLds<ND, LB> &W, int lane, uint64
     }
 }
 
+// ---- Self-contained requests on the prefix-sum queue (round 4; the dense 16-variable instances of k_dbn_step2).  A request is 16 bits:
+// owner lane (6) | bit of the owner's need mask (5) | kind (1) | bin - 1 (4: at most 15 bins, step2_eligible) -- the owner looks its own
+// bin up when it writes the request, nothing is published per lane, and the lane's LDS row is its 8 ND result slots + 4 words: 36 words
+// for ND = 4 where the published-bins form needs 44.  Queue positions come from ONE prefix sum like the LB form (CoopLds<ND, false>'s 512
+// queue bytes hold 256 of these requests).
+template <int ND, bool MSBFIRST>
+__device__ __forceinline__ void coop_worker_pass_sc(CoopLds<ND, false> &W, const uint16_t *q16, int lane, uint32_t q0, uint32_t cnt, uint64_t gidx, const Rng &rng, int g8,
+                                                    uint32_t ivpack, const double (*s_bnd)[16]) {
+    using L = CoopLds<ND, false>;
+    const uint32_t q = q0 + (uint32_t)lane;
+    if (q < cnt) {
+        const uint32_t d = q16[q];
+        const uint32_t owner = d & 63u, sb = (d >> 6) & 31u, kind = (d >> 11) & 1u, b1 = ((d >> 12) & 15u) + 1u;
+        const uint32_t s = MSBFIRST ? (sb ^ 7u) : sb;
+        const uint32_t k = s >> 3, j = s & 7u;
+        const uint64_t go = gidx - (uint64_t)lane + (uint64_t)owner;
+        const uint32_t iv = (ivpack >> (8u * k)) & 0xFFu;
+        const uint32_t sec = kind ? EMGPU_SEC_DEDISC_TRANS : EMGPU_SEC_DEDISC_RES;
+        const uint4 r4 = philox4x32((uint32_t)go, (uint32_t)(go >> 32), W.attempt[owner],
+                                       (sec << 28) | (iv << 20) | (uint32_t)(2 * g8 + (int)(j >> 2)), rng.k0, rng.k1);
+        const uint32_t w = j & 3u;
+        const uint32_t x = w == 0 ? r4.x : (w == 1 ? r4.y : (w == 2 ? r4.z : r4.w));
+        double v;
+        {
+#pragma clang fp contract(off)
+            const double a = s_bnd[k][b1 - 1u], b = s_bnd[k][b1];
+            const double dd = b - a;
+            const double mm = dd * uniform32(x);
+            v = a + mm;
+        }
+        W.res[owner * L::kStride + s] = (float)v;
+    }
+}
+template <int ND, bool MSBFIRST>
+__device__ __forceinline__ void coop_dedisc_sc(CoopLds<ND, false> &W, int lane, uint64_t gidx, const Rng &rng, int g8,
+                                               uint32_t needmask, uint32_t kindmask, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND],
+                                               const uint32_t (&ivar)[ND], const double (*s_bnd)[16]) {
+    constexpr uint32_t kCap = 256u;
+    static_assert(sizeof(W.queue) >= kCap * sizeof(uint16_t), "queue bytes");
+    uint32_t ivpack = 0u; // wave-uniform byte table of the variables' RNG ids
+#pragma unroll
+    for (int q = 0; q < ND; q++) ivpack |= ivar[q] << (8 * q);
+    uint32_t m = needmask;
+    if (__ballot(m != 0u) == 0ull) return;
+    const uint32_t c = (uint32_t)__popc(m);
+    const uint32_t inc = wave_inclusive_add(c);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    uint16_t *const q16 = reinterpret_cast<uint16_t *>(W.queue);
+    uint32_t a = inc - c;
+    const uint32_t aend = inc;
+    EMGPU_COUNT(4, lane, total);
+    for (uint32_t rb = 0u; rb < total; rb += kCap) {
+        EMGPU_COUNT(1, lane, 1);
+        const uint32_t lim = min(aend, rb + kCap);   // a lane is active while a < lim
+        while (__ballot(a < lim) != 0ull) {
+            EMGPU_COUNT(2, lane, 1);
+            if (a < lim) {
+                const uint32_t sb = (uint32_t)__ffs((int)m) - 1u;
+                const uint32_t s = MSBFIRST ? (sb ^ 7u) : sb;
+                const uint32_t k = s >> 3, j = s & 7u;
+                const uint32_t wd = (j & 4u) ? pick_word<ND>(pbB, k) : pick_word<ND>(pbA, k);
+                const uint32_t b1 = (wd >> (8u * (j & 3u))) & 0xFFu;
+                q16[a - rb] = (uint16_t)((uint32_t)lane | (sb << 6) | (((kindmask >> sb) & 1u) << 11) | ((b1 - 1u) << 12));
+                a++;
+                m &= m - 1u;
+            }
+        }
+        wave_sync();
+        const uint32_t cnt = min(total - rb, kCap);
+        for (uint32_t q0 = 0u; q0 < cnt; q0 += 64u) {
+            EMGPU_COUNT(3, lane, 1);
+            coop_worker_pass_sc<ND, MSBFIRST>(W, q16, lane, q0, cnt, gidx, rng, g8, ivpack, s_bnd);
+        }
+        wave_sync();
+    }
+}
+
 // Forward fill of variable k across the 8 seconds of the block (value changes only where a draw was
 // due or the bin became the zero bin) and the two 4-second output blocks of the time-blocked SoA.
 template <int ND>

@@ -149,17 +149,108 @@ __device__ __forceinline__ bool s2_w4(const EmgpuPlan &P, int k) {
     return WMODE == 4 || (WMODE >= 16 ? (((WMODE - 16) >> k) & 1) != 0 : (WMODE == 0 && P.d_pw[k] == 4));
 }
 
+// init_network (emgpu_device.h) for the dense 16-variable instances, reading the plan through the kernel-argument segment with the pointer
+// laundered once per attempt.  The initial network of 16 variables uses 120 parent strides + five small tables: as loop invariants of the
+// attempt loop they are loaded ahead of it, outlive the scalar register file (657 v_writelane ahead of the loop, 708 v_readlane inside it) and
+// keep 30 vector registers as spill space for the whole kernel: 155 registers, three waves per SIMD.  Loaded where they are used they are
+// scalar loads and nothing else: <= 128 registers, which (with the 36-word LDS rows of coop_dedisc_sc) is a fourth wave.
+typedef const __attribute__((address_space(4))) EmgpuPlan *KargPlan;
+template <int NI>
+__device__ __forceinline__ int32_t init_network_karg(KargPlan Pk, const EmgpuRun &A, Rng &rng, int (&bin)[NI], double (&val)[NI]) {
+    int32_t attempts_used = -1;
+    const bool no_dedisc = (A.flags & EMGPU_FLAG_NO_DEDISC) != 0;
+    for (uint32_t attempt = 0; attempt < (uint32_t)A.max_attempts; attempt++) {
+        KargPlan P = Pk;
+        asm volatile("" : "+s"(P));   // (the plan's entries are loaded where this attempt uses them)
+        rng.attempt = attempt;
+        uint4 wc = make_uint4(0, 0, 0, 0);
+        int wblk = -1;
+#pragma unroll
+        for (int p = 0; p < NI; p++) {
+            if (p < P->ni && P->i_start[p] != 0) { // bn_sample.m:44-50
+                bin[p] = (int)P->i_start[p] - 1;
+            } else if (p < P->ni) {
+                uint32_t col = 0; // asub2ind.m:13-14 as strides
+#pragma unroll
+                for (int q = 0; q < p; q++) col += P->i_stride[p][q] * (uint32_t)bin[q];
+                const int r = P->i_r[p];
+                const int var = P->i_var[p];
+                if ((var >> 2) != wblk) { wblk = var >> 2; wc = rng.block(EMGPU_SEC_INIT, 0u, (uint32_t)wblk); }
+                bin[p] = draw_bin(P->thr + P->i_off[p] + (size_t)col * (uint32_t)(r - 1), r, word_of(wc, var & 3)); // bn_sample.m:55
+            }
+        }
+        // dbn_hierarchical_sample.m:25-31
+        wblk = -1;
+#pragma unroll
+        for (int p = 0; p < NI; p++) {
+            double v = (double)(bin[p] + 1);
+            if (p < P->ni && !no_dedisc && P->i_nb[p] != 0 && !P->i_skip[p]) {
+                const int var = P->i_var[p];
+                if ((var >> 2) != wblk) { wblk = var >> 2; wc = rng.block(EMGPU_SEC_DEDISC_INIT, 0u, (uint32_t)wblk); }
+                v = (P->i_zero[p] == bin[p] + 1) ? 0.0 : dedisc_f64(P->bnd, P->i_boff[p], bin[p], word_of(wc, var & 3));
+            }
+            val[p] = v;
+        }
+        // UncorEncounterModel.m:259-272
+        if (A.pos_L >= 0 && (A.layers != nullptr || (A.flags & EMGPU_FLAG_QUANTIZE500))) {
+            double h_ft = pick<NI>(val, A.pos_L);
+            if (A.layers != nullptr) {
+                int b = (int)h_ft;
+                b = b < 1 ? 1 : (b > A.n_layers ? A.n_layers : b);
+                const double lo = A.layers[2 * (b - 1)], hi = A.layers[2 * (b - 1) + 1];
+                const uint4 wl = rng.block(EMGPU_SEC_LAYER, 0u, 0u);
+                {
+#pragma clang fp contract(off)
+                    const double d = hi - lo;
+                    const double m = uniform32(wl.x) * d;
+                    h_ft = lo + m;
+                }
+            }
+            if ((A.flags & EMGPU_FLAG_QUANTIZE500) && A.pos_dh >= 0 && pick<NI>(val, A.pos_dh) == 0.0) h_ft = round500(h_ft);
+            put<NI>(val, A.pos_L, h_ft);
+        }
+        bool good = true;
+        if (A.pos_v >= 0 && A.pos_dh >= 0) { // :275
+#pragma clang fp contract(off)
+            const double lhs = pick<NI>(val, A.pos_v) * 1.68781;
+            const double rhs = fabs(pick<NI>(val, A.pos_dh)) / 60.0;
+            good = lhs > rhs;
+        }
+        if (good) { attempts_used = (int32_t)attempt + 1; break; }
+    }
+    return attempts_used;
+}
+
+
+// EMGPU_DEBUG_EXTRA_LDS: bytes of unused dynamic LDS per workgroup (tools/occupancy_probe.sh: what does a kernel lose with one wave less?)
+inline size_t step2_extra_lds() {
+    static const int extra = getenv("EMGPU_DEBUG_EXTRA_LDS") ? atoi(getenv("EMGPU_DEBUG_EXTRA_LDS")) : 0;
+    return (size_t)extra;
+}
+
+// Which dense 16-variable instances take the fourth wave (self-contained requests, coop_dedisc_sc; the initial network through the
+// kernel-argument segment).  Measured per instance, same box (tools/ab_bench.sh): cor_v1 `[cor] w4` 11.41 -> 11.13 ms, the run-time-width
+// instances (balloon_v1 on `<16,4>[frozen]`) 7.29 -> 6.16; NOT cor_v2p1_like's `[cor] w8` (14.67 -> 14.73) nor littoral_cor_v1's
+// `[frozen] w4` (11.01 -> 11.22): the owner's look-up of its own bin costs those what the wave brings.
+constexpr bool step2_sc_form(int NI, int ND, int WMODE, bool FRZ, int EV) {
+    return ND == 4 && NI == 16 && EV == 0 && ((WMODE == 4 && !FRZ) || WMODE == 0);
+}
+
 // EV: 0 the dense trace; 1 the event list as well (result slots + a row loop per lane, emgpu_events.h); 2 the list ALONE, its rows built
 // by the wave ("ROWS BY THE WAVE": no result slots, no fill)
 template <int NI, int ND, int WMODE, bool REG, uint32_t CUR, uint32_t NEW, bool FRZ = false, int EV = 0>
-__global__ void __launch_bounds__(256, (ND == 4 || EV == 1) ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
+__global__ void __launch_bounds__(256, ((ND == 4 && !step2_sc_form(NI, ND, WMODE, FRZ, EV)) || EV == 1) ? 3 : 4) k_dbn_step2(const EmgpuPlan P, const EmgpuRun A, const Step2Args F) {
     static_assert(!FRZ || NEW == 0u, "a fast-branch model has no (t+1) parents");
     // the instances built for a model family's parent masks are only launched with both dense outputs (launch_masked): no null tests at the stores
     constexpr bool kBoth = !EV && CUR != 0x0777u && CUR != 0xFFFFu;
-    __shared__ CoopLds<ND, true> s_wave[4];
+    // LBK: the workers look a request's bin up in the owner's LDS row (emgpu_coop.h).  The dense 16-variable instances carry it in the request
+    // instead (coop_dedisc_sc): their rows are 36 words instead of 44, FOUR workgroups fit a CU's LDS instead of three, and with the initial
+    // network read through the kernel-argument segment they have the registers for it
+    constexpr bool LBK = !step2_sc_form(NI, ND, WMODE, FRZ, EV);
+    __shared__ CoopLds<ND, LBK> s_wave[4];
     __shared__ double s_bnd[ND][16];
     const int tid = threadIdx.x, lane = tid & 63;
-    CoopLds<ND, true> &W = s_wave[tid >> 6];
+    CoopLds<ND, LBK> &W = s_wave[tid >> 6];
     const int64_t i = (int64_t)blockIdx.x * 256 + tid;
     const bool valid = i < A.n; // lanes past the end stay alive: they serve as workers for their wave
     const uint64_t gidx = A.first_index + (uint64_t)i;
@@ -188,7 +279,9 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV == 1) ? 3 : 4) k_dbn_step2
         double val[NI];
 #pragma unroll
         for (int p = 0; p < NI; p++) { bin[p] = 0; val[p] = 0.0; }
-        const int32_t attempts_used = init_network<NI>(P, A, rng, bin, val);
+        int32_t attempts_used;
+        if constexpr (!LBK) attempts_used = init_network_karg<NI>((KargPlan)__builtin_amdgcn_kernarg_segment_ptr(), A, rng, bin, val);
+        else attempts_used = init_network<NI>(P, A, rng, bin, val);
         if (valid) {
             if (attempts_used < 0) atomicOr(A.status, 1u);
             if (A.attempts) A.attempts[i] = attempts_used;
@@ -519,14 +612,16 @@ __global__ void __launch_bounds__(256, (ND == 4 || EV == 1) ? 3 : 4) k_dbn_step2
             coop_publish_bins<ND>(W, lane, pbA, pbB);
             ev_rows_block_wide<ND, KQ>(W, s_evq, lane, s_evs, P.nact, SW, rng, P.bnd, g8, T, valid, hitp, kind, prevp, A, i);
         } else {
-        coop_zero_results<ND, true>(W, lane);
-        coop_publish_bins<ND>(W, lane, pbA, pbB);
-        coop_dedisc<ND, true, true>(W, lane, gidx, rng, g8, need, kind, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
+        coop_zero_results<ND, LBK>(W, lane);
+        if constexpr (LBK) {
+            coop_publish_bins<ND>(W, lane, pbA, pbB);
+            coop_dedisc<ND, true, true>(W, lane, gidx, rng, g8, need, kind, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
+        } else coop_dedisc_sc<ND, true>(W, lane, gidx, rng, g8, need, kind, pbA, pbB, ivs, s_bnd);
         if (!EV || A.dyn_bin != nullptr || A.dyn_val != nullptr)   // (an event-list call without the dense trace: no forward fill at all)
 #pragma unroll
         for (int k = 0; k < ND; k++)
             if (REG || k < P.nd)
-                coop_fill_store_msb<ND, true, kBoth>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
+                coop_fill_store_msb<ND, LBK, kBoth>(W, lane, k, g8, T, G4, valid, fill8[k], cval[k], pbA[k], pbB[k],
                                               REG ? (uint32_t)ND : (uint32_t)P.nd, F.slot[k], (int64_t)blockIdx.x * 256, (uint32_t)tid, A.ld, A.dyn_bin, A.dyn_val);
         if constexpr (EV == 1) {
             uint32_t hitp = 0u;
@@ -555,9 +650,9 @@ constexpr uint32_t kCurAll3 = 0x0777u, kNewAll3 = 0x0310u, kCurAll4 = 0xFFFFu, k
 // one instance, with or without the event list
 #define EMGPU_S2_LAUNCH(NI_, ND_, W_, REG_, C_, N_, FRZ_)                                                                      \
     do {                                                                                                                       \
-        if (A.ev_count != nullptr && step2_rows_by_wave(P, A)) hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, 2>), g, b, 0, s, P, A, F); \
-        else if (A.ev_count != nullptr) hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, 1>), g, b, 0, s, P, A, F); \
-        else hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, 0>), g, b, 0, s, P, A, F);                        \
+        if (A.ev_count != nullptr && step2_rows_by_wave(P, A)) hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, 2>), g, b, step2_extra_lds(), s, P, A, F); \
+        else if (A.ev_count != nullptr) hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, 1>), g, b, step2_extra_lds(), s, P, A, F); \
+        else hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, W_, REG_, C_, N_, FRZ_, 0>), g, b, step2_extra_lds(), s, P, A, F);                        \
     } while (0)
 
 

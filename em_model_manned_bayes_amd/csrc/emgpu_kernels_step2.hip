@@ -59,16 +59,16 @@ static hipError_t launch_t(const EmgpuPlan &P, const EmgpuRun &A, const Step2Arg
     constexpr uint32_t C = ND == 4 ? kCurAll4 : kCurAll3, N = ND == 4 ? kNewAll4 : kNewAll3;
     if (A.ev_count != nullptr) {   // event lists: the per-variable-width instances only (half the instances for the rarer output)
         if (step2_rows_by_wave(P, A)) {
-            if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N, false, 2>), g, b, 0, s, P, A, F);
-            else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false, C, N, false, 2>), g, b, 0, s, P, A, F);
-        } else if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N, false, 1>), g, b, 0, s, P, A, F);
-        else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false, C, N, false, 1>), g, b, 0, s, P, A, F);
+            if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N, false, 2>), g, b, step2_extra_lds(), s, P, A, F);
+            else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false, C, N, false, 2>), g, b, step2_extra_lds(), s, P, A, F);
+        } else if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N, false, 1>), g, b, step2_extra_lds(), s, P, A, F);
+        else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false, C, N, false, 1>), g, b, step2_extra_lds(), s, P, A, F);
         return hipGetLastError();
     }
-    if (reg && wmode == 4) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 4, true, C, N>), g, b, 0, s, P, A, F);
-    else if (reg && wmode == 8) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 8, true, C, N>), g, b, 0, s, P, A, F);
-    else if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N>), g, b, 0, s, P, A, F);
-    else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false, C, N>), g, b, 0, s, P, A, F);
+    if (reg && wmode == 4) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 4, true, C, N>), g, b, step2_extra_lds(), s, P, A, F);
+    else if (reg && wmode == 8) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 8, true, C, N>), g, b, step2_extra_lds(), s, P, A, F);
+    else if (reg) hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, true, C, N>), g, b, step2_extra_lds(), s, P, A, F);
+    else hipLaunchKernelGGL((k_dbn_step2<NI, ND, 0, false, C, N>), g, b, step2_extra_lds(), s, P, A, F);
     return hipGetLastError();
 }
 

@@ -19,7 +19,7 @@ bool launch_masked3(const EmgpuPlan &P, const EmgpuRun &A, const Step2Args &F, h
     for (int k = 0; k < P.nd; k++) wm |= (P.d_pw[k] == 4 ? 1u : 0u) << k;
 #define EMGPU_S2_CASE_W(NI_, ND_, WM_, C_, N_, TAG_)                                                               \
     if (A.ev_count == nullptr && P.ni <= NI_ && P.nd == ND_ && wm == WM_ && cur == C_ && nw == N_) {               \
-        hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, 16 + WM_, true, C_, N_, false, false>), g, b, 0, s, P, A, F);    \
+        hipLaunchKernelGGL((k_dbn_step2<NI_, ND_, 16 + WM_, true, C_, N_, false, false>), g, b, step2_extra_lds(), s, P, A, F);    \
         *tag = TAG_;                                                                                               \
         return true;                                                                                               \
     }
