@@ -252,24 +252,62 @@ __device__ __forceinline__ void coop_worker_pass_sc(CoopLds<ND, false> &W, const
         W.res[owner * L::kStride + s] = (float)v;
     }
 }
+// (clears the lane's result slots itself: while the requests are written, the slots -- not yet anybody's -- hold the lane's packed bins, so
+// that the owner's look-up of a request's bin is one byte read instead of a select over the variables' registers)
 template <int ND, bool MSBFIRST>
 __device__ __forceinline__ void coop_dedisc_sc(CoopLds<ND, false> &W, int lane, uint64_t gidx, const Rng &rng, int g8,
                                                uint32_t needmask, uint32_t kindmask, const uint32_t (&pbA)[ND], const uint32_t (&pbB)[ND],
                                                const uint32_t (&ivar)[ND], const double (*s_bnd)[16]) {
+    using L = CoopLds<ND, false>;
     constexpr uint32_t kCap = 256u;
     static_assert(sizeof(W.queue) >= kCap * sizeof(uint16_t), "queue bytes");
     uint32_t ivpack = 0u; // wave-uniform byte table of the variables' RNG ids
 #pragma unroll
     for (int q = 0; q < ND; q++) ivpack |= ivar[q] << (8 * q);
     uint32_t m = needmask;
-    if (__ballot(m != 0u) == 0ull) return;
+    float4 *const rp = reinterpret_cast<float4 *>(&W.res[lane * L::kStride]);
+    if (__ballot(m != 0u) == 0ull) {
+#pragma unroll
+        for (int q = 0; q < 2 * ND; q++) rp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const uint32_t c = (uint32_t)__popc(m);
     const uint32_t inc = wave_inclusive_add(c);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     uint16_t *const q16 = reinterpret_cast<uint16_t *>(W.queue);
     uint32_t a = inc - c;
-    const uint32_t aend = inc;
     EMGPU_COUNT(4, lane, total);
+    if (total <= kCap) {
+        // the usual case, one round
+        EMGPU_COUNT(1, lane, 1);
+        uint2 *const bp = reinterpret_cast<uint2 *>(rp);
+#pragma unroll
+        for (int k = 0; k < ND; k++) bp[k] = make_uint2(pbA[k], pbB[k]);    // byte s = 8 k + j: the bin of (variable k, second j)
+        const uint8_t *const mybins = reinterpret_cast<const uint8_t *>(rp);
+        uint16_t *qp = q16 + a;
+        while (__ballot(m != 0u) != 0ull) {
+            EMGPU_COUNT(2, lane, 1);
+            if (m != 0u) {
+                const uint32_t sb = (uint32_t)__ffs((int)m) - 1u;
+                const uint32_t b1 = mybins[MSBFIRST ? (sb ^ 7u) : sb];
+                *qp++ = (uint16_t)((uint32_t)lane | (sb << 6) | (((kindmask >> sb) & 1u) << 11) | ((b1 - 1u) << 12));
+                m &= m - 1u;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * ND; q++) rp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        wave_sync();
+        for (uint32_t q0 = 0u; q0 < total; q0 += 64u) {
+            EMGPU_COUNT(3, lane, 1);
+            coop_worker_pass_sc<ND, MSBFIRST>(W, q16, lane, q0, total, gidx, rng, g8, ivpack, s_bnd);
+        }
+        wave_sync();
+        return;
+    }
+    // more than kCap requests in the wave-block: rounds of kCap positions, the bins looked up in the registers
+#pragma unroll
+    for (int q = 0; q < 2 * ND; q++) rp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t aend = inc;
     for (uint32_t rb = 0u; rb < total; rb += kCap) {
         EMGPU_COUNT(1, lane, 1);
         const uint32_t lim = min(aend, rb + kCap);   // a lane is active while a < lim

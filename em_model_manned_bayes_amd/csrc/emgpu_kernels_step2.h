@@ -228,12 +228,13 @@ inline size_t step2_extra_lds() {
     return (size_t)extra;
 }
 
-// Which dense 16-variable instances take the fourth wave (self-contained requests, coop_dedisc_sc; the initial network through the
-// kernel-argument segment).  Measured per instance, same box (tools/ab_bench.sh): cor_v1 `[cor] w4` 11.41 -> 11.13 ms, the run-time-width
-// instances (balloon_v1 on `<16,4>[frozen]`) 7.29 -> 6.16; NOT cor_v2p1_like's `[cor] w8` (14.67 -> 14.73) nor littoral_cor_v1's
-// `[frozen] w4` (11.01 -> 11.22): the owner's look-up of its own bin costs those what the wave brings.
+// The dense 16-variable instances take a fourth wave: self-contained requests (coop_dedisc_sc: LDS rows of 36 words instead of 44, four
+// workgroups per CU) and the initial network through the kernel-argument segment (155 -> <= 128 registers).  Same box, tools/ab_bench.sh:
+// cor_v1 `[cor] w4` 11.42 -> 10.98 ms, cor_v2p1_like `[cor] w8` 14.72 -> 14.48, littoral_cor_v1 `[frozen] w4` 11.02 -> 10.65, balloon_v1 /
+// weatherballoon_v1 on the run-time-width instance 7.29 -> 6.13 / 7.48 -> 6.49.  (With the owner's bin looked up in registers -- a select
+// over the variables -- instead of in its own, not yet used, result slots, only the first and the last of these gained.)
 constexpr bool step2_sc_form(int NI, int ND, int WMODE, bool FRZ, int EV) {
-    return ND == 4 && NI == 16 && EV == 0 && ((WMODE == 4 && !FRZ) || WMODE == 0);
+    return ND == 4 && NI == 16 && EV == 0;
 }
 
 // EV: 0 the dense trace; 1 the event list as well (result slots + a row loop per lane, emgpu_events.h); 2 the list ALONE, its rows built
@@ -612,8 +613,8 @@ __global__ void __launch_bounds__(256, ((ND == 4 && !step2_sc_form(NI, ND, WMODE
             coop_publish_bins<ND>(W, lane, pbA, pbB);
             ev_rows_block_wide<ND, KQ>(W, s_evq, lane, s_evs, P.nact, SW, rng, P.bnd, g8, T, valid, hitp, kind, prevp, A, i);
         } else {
-        coop_zero_results<ND, LBK>(W, lane);
         if constexpr (LBK) {
+            coop_zero_results<ND, LBK>(W, lane);
             coop_publish_bins<ND>(W, lane, pbA, pbB);
             coop_dedisc<ND, true, true>(W, lane, gidx, rng, g8, need, kind, pbA, pbB, ivs, s_bnd);   // dediscretize.m:39
         } else coop_dedisc_sc<ND, true>(W, lane, gidx, rng, g8, need, kind, pbA, pbB, ivs, s_bnd);
