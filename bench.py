@@ -507,13 +507,13 @@ class GpuTelemetry:
     2 ms.  The benchmark kernel runs at the board's power limit; how far a box lets the clock drop there differs from box to box by up to
     20 %: with the clock in the line a reader can tell a slow box from a regression."""
 
-    def __init__(self, local_index=0, pci=None):
+    def __init__(self, local_index=0, pci=None, sysfs_root="/sys"):
         """`pci` = "dddd:bb:dd.f" of the device this rank computes on: a box may list more cards in sysfs than the process can see
         (a 1-GPU slice of an 8-GPU node), so the visible device's index says nothing about the card number; without it the
         `local_index`-th card with an sclk sensor is read."""
         import glob
         cards = []
-        for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"):
+        for f in glob.glob(os.path.join(sysfs_root, "class/drm/card*/device/hwmon/hwmon*/freq1_input")):
             try:
                 if open(os.path.join(os.path.dirname(f), "freq1_label")).read().strip() == "sclk":
                     dev = os.path.realpath(f.split("/hwmon/")[0])

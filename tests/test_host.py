@@ -769,3 +769,30 @@ print(len([x for x in libs if "libamdhip64" in x]), len([x for x in libs if "lib
         out = subprocess.run([sys.executable, "-c", code, order], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         assert out.stdout.split() == ["1", "1"], (order, out.stdout)
+
+
+def test_bench_telemetry_reads_the_card_with_this_ranks_pci_address(tmp_path):
+    """bench.py's GpuTelemetry: a box lists more cards in sysfs than the process can see (a 1-GPU slice of an 8-GPU node), so the sensor
+    is chosen by the PCI address of the rank's device, not by its index -- round 4 first read an idle neighbour's 94 MHz."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    root = tmp_path / "sys"
+    for card, addr, mhz, watts in ((0, "0000:05:00.0", 94, 246), (8, "0000:0d:00.0", 2240, 1350)):
+        dev = root / "devices" / "pci0000:00" / addr
+        hw = dev / "hwmon" / ("hwmon%d" % card)
+        hw.mkdir(parents=True)
+        (hw / "freq1_label").write_text("sclk\n"); (hw / "freq1_input").write_text("%d\n" % (mhz * 1000000))
+        (hw / "power1_input").write_text("%d\n" % (watts * 1000000)); (hw / "power1_cap").write_text("1400000000\n")
+        (hw / "temp1_label").write_text("mem\n"); (hw / "temp1_input").write_text("66000\n")
+        drm = root / "class" / "drm" / ("card%d" % card)
+        drm.mkdir(parents=True)
+        os.symlink(str(dev), str(drm / "device"))
+    t = bench.GpuTelemetry(0, "0000:0D:00.0", sysfs_root=str(root))
+    assert t.card.startswith("card8") and t._read() == (2240.0, 1350.0)
+    t.samples = [t._read()] * 5
+    out = t.summary()
+    assert out["sclk_mhz"]["median"] == 2240.0 and out["socket_power_w"]["median"] == 1350.0 and out["power_cap_w"] == 1400.0 and out["temperature_c"] == {"mem": 66.0}
+    assert bench.GpuTelemetry(0, "0000:ff:00.0", sysfs_root=str(root)).dir is None       # an address no card has: no sensor rather than a neighbour's
+    assert bench.GpuTelemetry(0, None, sysfs_root=str(root)).card.startswith("card0")     # no address known: by index, and the line says so
