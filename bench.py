@@ -79,7 +79,11 @@ def parse_args(argv=None):
                     help="skip the `configs` object (BASELINE.json configs[2..4] measured in the same process after the headline)")
     ap.add_argument("--step-gap-ms", type=float, default=0.0,
                     help="DIAGNOSTIC (tools/power_probe.sh): idle this long after every launch; the line then says so and is no benchmark line")
-    ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each entry of `configs` (2 warm-up steps before)")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each entry of `configs` (after --other-warmup untimed steps and the settle phase)")
+    ap.add_argument("--other-warmup", type=int, default=5, help="untimed steps ahead of each entry of `configs`")
+    ap.add_argument("--settle-max", type=int, default=48,
+                    help="entries of `configs`: after the warm-up steps, untimed steps are launched back to back in groups of four until the last two of a "
+                         "group agree within 1 %% (the GPU's clocks ramp for several launches after the idle seconds of a CPU leg), at most this many")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="minimum units timed on the CPU oracle (scaled up to ~10 s)")
     ap.add_argument("--local-smooth", action="store_true", help="terminal: add the smoothing pass of createEncounter.m:88-89 (k_terminal_smooth: the flagged stand-in for em-core's local_smooth; a second pass over the tracks)")
     ap.add_argument("--prewarm-s", type=float, default=0.0,
@@ -87,7 +91,8 @@ def parse_args(argv=None):
                          "(Measured with it, tools/thermal_probe.sh: a box's slow spells -- 7.1 ms per step at 1 270 W and 2 330 MHz instead of 6.0 ms "
                          "at 1 346 W and 2 195 MHz -- are not a warm-up effect: three seconds of load ahead of the timed region change nothing.)")
     ap.add_argument("--telemetry-s", type=float, default=2.5,
-                    help="seconds of untimed back-to-back steps after the timed region during which the shader clock and socket power are read (0: skip)")
+                    help="seconds of untimed back-to-back steps AFTER the timed region during which the shader clock and socket power are read (0: skip); "
+                         "nothing is sampled inside the timed region")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: allow more ranks than GPUs (ranks share devices, gloo barrier); the line says so")
     return ap.parse_args(argv)
@@ -129,7 +134,8 @@ def visible_gpu_count():
 
 def launch_ranks(args, argv):
     """Start args.gpus rank processes of this script and relay rank 0's JSON line.  Nothing in this
-    process touches a GPU or imports torch: the devices are counted from sysfs (visible_gpu_count)."""
+    process touches a GPU or imports torch: the devices are counted by a child process that asks the library (visible_gpu_count;
+    the KFD topology in sysfs only when that child cannot run)."""
     have = visible_gpu_count()
     if have < args.gpus and not args.oversubscribe:
         sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
@@ -427,9 +433,11 @@ class TerminalWorkload:
         self.att = pl.empty((n,), "int32")
         self.bs = None if np.all(np.isinf(self.t.bounds_sample)) else self.t.bounds_sample
         self.local_smooth = bool(getattr(args, "local_smooth", False))
-        self.bytes_bound = 75 + 4 * 122 * 20      # geometry 5 B x 15 variables + 2 x 2 x <= 122 rows x 20 B
+        # geometry 5 B x 15 variables + 5 B (u8 bin + f32 value) x 3 dynamic variables per track-second (<= 4 x 122 of them)
+        self.bytes_bound = 75 + 4 * 122 * 15
         self.bytes_data_dependent = True
-        self.bytes_per_unit = self.bytes_bound   # replaced in check() by 75 + 20 B x the track-seconds the run really produced
+        self.bytes_per_unit = self.bytes_bound   # replaced in check() by 75 + 15 B x the track-seconds the run really produced
+        self.bytes_stored_per_unit = None        # 75 + 20 B x the rows the run really wrote (what the kernel stores: five f32 per row)
         self.launches_per_step = 1
 
     def step(self, k):
@@ -450,16 +458,21 @@ class TerminalWorkload:
         # rows < 0: a track whose inner re-draw loop hit max_resample (the reference would spin on it, createEncounter.m:218-262)
         self.failed = int((self.rows < 0).sum())
         self.track_seconds = float(self.rows.clamp(min=0).sum().item()) / self.n
-        # the joined track stores the t = 0 row of an aircraft once: rows written = track-seconds - 2 per encounter
-        self.bytes_per_unit = 75.0 + 20.0 * (self.track_seconds - 2.0)
+        # `frac` follows SURVEY.md 8(d): 15 B per track-second (a u8 bin + f32 value for each of heading, altitude, speed) -- the unit rounds
+        # 1-3 used.  What the kernel actually STORES is the reference's output, createEncounter.m:162-167: x y z heading speed as five f32 per
+        # row of the joined track (the t = 0 row of an aircraft once: rows written = track-seconds - 2 per encounter) = 20 B per row: reported
+        # beside it as `output_bytes_per_unit` / `frac_of_output_bytes` (round 4 had silently made that the numerator).
+        self.bytes_per_unit = 75.0 + 15.0 * self.track_seconds
+        self.bytes_stored_per_unit = 75.0 + 20.0 * (self.track_seconds - 2.0)
         self.geom_attempts = float(self.att.float().mean().item())
         assert int(self.rows.max()) <= self.cap and int(self.rows.max()) >= 2 and self.failed <= 0.01 * 4 * self.n, (int(self.rows.min()), self.failed)
 
     def config(self):
         return {"workload": self.cfg["workload"] % dict(n=self.n),
                 "output": "geometry sample f32 [15][n] + joined tracks f32 [2n][%d][5] (x y z heading speed per track-second; t_s = row number) + rows; "
-                          "algorithmic bytes = 75 + 20 B x rows written = %.0f B/encounter as measured (bound: %d)"
-                          % (2 * self.native.terminal_t0_row(self.cap), self.bytes_per_unit, self.bytes_bound),
+                          "algorithmic bytes (SURVEY.md 8d) = 75 + 15 B x track-seconds = %.0f B/encounter as measured (bound: %d); bytes the kernel stores = "
+                          "75 + 20 B x rows written = %.0f B/encounter"
+                          % (2 * self.native.terminal_t0_row(self.cap), self.bytes_per_unit, self.bytes_bound, self.bytes_stored_per_unit or 0.0),
                 "launches_per_step": 4 if self.local_smooth else 3, "kernels": self.ctx.last_kernel(),
                 "timed_region": "k_bn (fresh geometry draw with rejection) + k_terminal_geo + k_terminal_propagate%s, every step"
                                 % (" + k_terminal_smooth (createEncounter.m:88-89 through the documented stand-in for em-core's local_smooth)" if self.local_smooth else ""),
@@ -481,15 +494,38 @@ class TerminalWorkload:
         for f in files:
             pp = O.parse_model_txt(f)
             oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
-        n_cpu = 2000 if seconds >= 10.0 else 600
-        geo_h = self.geo[:n_cpu].cpu().numpy()
-        mo_h = self.mof[: 4 * n_cpu].cpu().numpy()
+        geo_all, mo_all = self.geo.cpu().numpy(), self.mof.cpu().numpy()
+        n_have = geo_all.shape[0]
+        dl = self.t._dyn_rows()
+
+        def sample(m):          # the first m encounters of the step the GPU just ran (repeated when the GPU batch is smaller than the CPU sample)
+            reps = -(-m // n_have)
+            return (np.tile(geo_all, (reps, 1))[:m], np.tile(mo_all.reshape(-1, 4), (reps, 1))[:m].reshape(-1))
+        # one thread: calibrate on 300 encounters, then about `seconds` of work
+        g, mo = sample(300)
         t0 = time.perf_counter()
-        O.propagate(oms, mo_h, geo_h, self.seed, self.t._dyn_rows())
-        dt = time.perf_counter() - t0
-        return {"value": n_cpu / dt, "unit": self.cfg["unit"], "cores": 1, "kind": "port",
-                "sample": "oracle/em_oracle.c em_propagate_batch (scalar port of createEncounter.m:93-329, one thread), propagation of %d encounters "
-                          "in %.1f s (the geometry draw, <1 %% of the work, is not in this figure); MATLAB itself is not installed and cannot be timed" % (n_cpu, dt)}
+        O.propagate(oms, mo, g, self.seed, dl)
+        n1 = int(min(max(300, 300 / (time.perf_counter() - t0) * seconds), 200_000))
+        g, mo = sample(n1)
+        t0 = time.perf_counter()
+        O.propagate(oms, mo, g, self.seed, dl)
+        dt1 = time.perf_counter() - t0
+        # all allowed cores (the cgroup quota, like the DBN configs): thread-private track buffers, about `seconds` of work
+        cores, cores_note = usable_cores()
+        n_cal = max(cores * 128, 1024)
+        g, mo = sample(n_cal)
+        t0 = time.perf_counter()
+        O.propagate_throughput_mt(oms, mo, g, self.seed, dl, cores)
+        n_mt = int(min(max(n_cal, n_cal / (time.perf_counter() - t0) * seconds), 2_000_000))
+        g, mo = sample(n_mt)
+        t0 = time.perf_counter()
+        O.propagate_throughput_mt(oms, mo, g, self.seed, dl, cores)
+        dtm = time.perf_counter() - t0
+        return {"value": n_mt / dtm, "unit": self.cfg["unit"], "cores": cores, "kind": "port",
+                "single_thread_value": n1 / dt1, "thread_scaling": (n_mt / dtm) / (n1 / dt1), "cores_note": cores_note,
+                "sample": "oracle/em_oracle.c em_propagate_trajectory (scalar port of createEncounter.m:93-329), Philox mode: propagation of %d encounters "
+                          "on %d threads in %.1f s (thread-private track buffers); 1 thread: %d encounters in %.1f s (the geometry draw, <1 %% of the "
+                          "work, is not in these figures); MATLAB itself is not installed and cannot be timed" % (n_mt, cores, dtm, n1, dt1)}
 
 
 def make_workload(args, pl, rank, world):
@@ -502,7 +538,7 @@ def make_workload(args, pl, rank, world):
 
 
 class GpuTelemetry:
-    """Shader clock and socket power of this rank's GPU DURING the timed region, read from amdgpu's hwmon files in sysfs (freq1_input =
+    """Shader clock and socket power of this rank's GPU under the benchmark's own back-to-back launches (an untimed run AFTER the timed region), read from amdgpu's hwmon files in sysfs (freq1_input =
     sclk in Hz, power1_input = package power in microwatts: 0.03 ms per read, no profiler, no privileges) by a thread that samples every
     2 ms.  The benchmark kernel runs at the board's power limit; how far a box lets the clock drop there differs from box to box by up to
     20 %: with the clock in the line a reader can tell a slow box from a regression."""
@@ -600,9 +636,11 @@ class GpuTelemetry:
 
 
 # ------------------------------------------------------------------------------------------------
-def measure(w, pl, args, warmup, steps):
+def measure(w, pl, args, warmup, steps, settle_max=0):
     """warmup untimed steps, then `steps` timed ones bracketed by barrier + device synchronisation on both sides; the launch
-    durations come from HIP events on the stream the kernels are launched on.  Returns (elapsed_s max over ranks, [ms per step])."""
+    durations come from HIP events on the stream the kernels are launched on.  Returns (elapsed_s max over ranks, [ms per step]).
+    settle_max > 0 (the entries of `configs`, which start after seconds of GPU idleness): between the warm-up and the timed region, untimed
+    groups of four back-to-back steps until the last two of a group agree within 1 % (w.settle says how many it took)."""
     prewarm_s = float(getattr(args, "prewarm_s", 0.0) or 0.0)
     if prewarm_s > 0.0 and hasattr(pl, "torch"):   # the device's sustained state first (untimed; the line says so)
         t_end, k, first = time.perf_counter() + prewarm_s, 0, []
@@ -618,6 +656,20 @@ def measure(w, pl, args, warmup, steps):
     for k in range(warmup):
         w.step(k)
     w.sync()
+    if settle_max > 0 and hasattr(pl, "torch"):
+        used, last = 0, None
+        while used < settle_max:
+            evs = [(pl.event(), pl.event()) for _ in range(4)]
+            for a, b in evs:
+                pl.record(a)
+                w.step(500_000 + used)      # (global indices away from the warm-up's and the timed steps')
+                pl.record(b)
+                used += 1
+            w.sync()
+            last = [pl.elapsed_ms(a, b) for a, b in evs]
+            if abs(last[3] - last[2]) <= 0.01 * last[2]:
+                break
+        w.settle = {"untimed_steps": used, "last_group_ms": [round(x, 3) for x in last], "rule": "groups of 4 until the last two agree within 1 %%, at most %d" % settle_max}
     pl.barrier()
     ev = [(pl.event(), pl.event()) for _ in range(steps)]
     tel = None
@@ -628,9 +680,7 @@ def measure(w, pl, args, warmup, steps):
             pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
         except (AttributeError, RuntimeError):
             pci = None
-        tel = GpuTelemetry(idx, pci)
-    if tel:
-        tel.start()
+        tel = GpuTelemetry(idx, pci)   # (started after the timed region: a 2 ms sampling thread would share the interpreter with the launch loop)
     t0 = time.perf_counter()
     for k in range(steps):
         pl.record(ev[k][0])
@@ -641,10 +691,6 @@ def measure(w, pl, args, warmup, steps):
             time.sleep(args.step_gap_ms * 1e-3)
     pl.barrier()
     t1 = time.perf_counter()
-    in_region = None
-    if tel:
-        tel.stop()
-        in_region = tel.summary()
     w.sync()
     elapsed = pl.max_over_ranks(t1 - t0)
     step_ms = [pl.elapsed_ms(a, b) for a, b in ev]
@@ -665,9 +711,24 @@ def measure(w, pl, args, warmup, steps):
         if w.telemetry:
             w.telemetry["how"] = ("amdgpu hwmon in sysfs (freq1_input, power1_input), every 2 ms during %.1f s of the same step launched back to back after the timed "
                                   "region; statistics of the last 40 %% (the readings trail the load by over a second)" % args.telemetry_s)
-            w.telemetry["inside_the_timed_region"] = in_region
             w.telemetry["sensor"] = tel.card
     return elapsed, step_ms
+
+
+def box_state(tel):
+    """"fast" / "slow" by the telemetry rule of DESIGN.md section 7 (round 4: one and the same box spends minutes in either state): under the
+    headline kernel, which runs the socket at its power limit, the FAST state reads >= 1 310 W with the shader clock sagging below 2 280 MHz;
+    the SLOW state reads 1 27x W at 2 3xx MHz (something other than socket power holds the chip back while the reported clock stays up;
+    the kernel loses 17 %).  A kernel that does not reach the limit in either state cannot tell them apart: "below-the-power-limit"."""
+    try:
+        w_, mhz = tel["socket_power_w"]["median"], tel["sclk_mhz"]["median"]
+    except (KeyError, TypeError):
+        return "unknown (no telemetry)"
+    if w_ >= 1310.0:
+        return "fast"
+    if w_ >= 1200.0 and mhz >= 2280.0:
+        return "slow"
+    return "below-the-power-limit"
 
 
 def roofline_of(w, step_ms, lib_version):
@@ -682,6 +743,13 @@ def roofline_of(w, step_ms, lib_version):
          "avg_launch_ms": avg_step_s * 1e3 / w.launches_per_step, "launches_per_step": w.launches_per_step,
          "avg_step_ms": avg_step_s * 1e3, "step_ms": [round(x, 3) for x in step_ms], "algorithmic_bytes_per_launch": per_launch,
          "algorithmic_bytes_per_unit": w.bytes_per_unit}
+    if getattr(w, "bytes_stored_per_unit", None):   # terminal: the bytes the kernel stores (five f32 per row of the joined tracks), beside SURVEY 8(d)'s unit
+        r["algorithmic_bytes_unit"] = "SURVEY.md 8(d): 75 B geometry + 15 B per track-second (u8 bin + f32 value of heading, altitude, speed)"
+        r["output_bytes_per_unit"] = w.bytes_stored_per_unit
+        r["output_bytes_unit"] = "75 B geometry + 20 B per row written (x y z heading speed as f32: createEncounter.m:162-167, the t = 0 row of an aircraft once)"
+        r["frac_of_output_bytes"] = w.bytes_stored_per_unit * w.n / avg_step_s / 1e9 / HBM_PEAK_GBS
+    if getattr(w, "settle", None):
+        r["settle"] = w.settle
     if getattr(w, "prewarm", None):     # untimed launches ahead of the warm-up steps (--prewarm-s)
         r["prewarm"] = w.prewarm
     if getattr(w, "telemetry", None):   # the box, while it ran the timed region
@@ -712,10 +780,11 @@ def other_configs(args, pl, lib_version):
         cfg = CONFIGS[name]
         try:
             w = (TerminalWorkload if name == "terminal" else DbnWorkload)(a, cfg, pl, 0, 1)
-            elapsed, step_ms = measure(w, pl, a, 2, args.other_steps)
+            elapsed, step_ms = measure(w, pl, a, args.other_warmup, args.other_steps, settle_max=args.settle_max)
             res[name] = {"metric": cfg["metric"], "value": w.n * args.other_steps / elapsed, "unit": cfg["unit"],
-                         "ms_per_step": elapsed / args.other_steps * 1e3, "steps": args.other_steps, "warmup": 2,
-                         "kernel": w.kernel_name(), "config": w.config(), "roofline": roofline_of(w, step_ms, lib_version)}
+                         "ms_per_step": elapsed / args.other_steps * 1e3, "steps": args.other_steps, "warmup": args.other_warmup,
+                         "kernel": w.kernel_name(), "config": dict(w.config(), box_state=box_state(getattr(w, "telemetry", None))),
+                         "roofline": roofline_of(w, step_ms, lib_version)}
             if not args.no_cpu_baseline:   # the same oracle beside every config, on a smaller sample (about 3 s per leg)
                 res[name]["cpu_baseline"] = w.cpu_baseline(args.cpu_sample, seconds=3.0)
         except Exception as e:   # an entry that cannot run says so; the headline line is still printed
@@ -741,7 +810,8 @@ def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
             "metric": cfg["metric"], "value": total / elapsed, "unit": cfg["unit"], "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 draws and compares; f64 dediscretize; f32 values stored", "data": "synthetic",
-            "config": dict(w.config(), kernel=kernel, lib=lib_version),
+            "config": dict(w.config(), kernel=kernel, lib=lib_version, philox_rounds=int(L.lib().emgpu_philox_rounds()),
+                           box_state=box_state(getattr(w, "telemetry", None)), rank_ranges="step k of rank r of W samples global indices [(k W + r) n, (k W + r + 1) n)"),
             "roofline": roofline_of(w, step_ms, lib_version),
         }
         if getattr(pl, "shared", False):

@@ -274,6 +274,9 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
 #endif
 constexpr int kRows = EMGPU_TERM_ROWS;        // rows a lane collects in LDS before the wave writes them out as ONE contiguous piece of its track
 constexpr int kLaneStride = 5 * kRows + 1;    // dwords of a lane's staging area (odd: the lanes' rows fall on different banks)
+// the flush packs a piece's source offset (dwords into the wave's staging area) into 11 bits and its length (dwords) into 5 bits of the
+// address's high dword (bits 48-63: device addresses stay below 2^48): a larger EMGPU_TERM_ROWS needs a wider descriptor
+static_assert(64 * kLaneStride <= 2048 && 5 * kRows < 32, "EMGPU_TERM_ROWS: a piece's offset / length no longer fit the flush descriptor (11 + 5 bits)");
 #ifndef EMGPU_TERM_REFILL
 #define EMGPU_TERM_REFILL 8
 #endif

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <queue>
 
 #include "../../include/emgpu.h"
@@ -402,10 +403,21 @@ Model *load_txt(const char *path, const int32_t *idx_zero, int n_idx, bool overw
 }
 
 // ---------------------------------------------------------------------------------------------
-// Binary model cache: [magic "EMGPUBIN"][u32 format][source hash, 0-terminated, 32 bytes][model][u8 has_plan][plan]
+// Binary model cache: [magic "EMGPUBIN"][u32 format][source hash, 0-terminated, 32 bytes][u64 checksum of what follows][model][u8 has_plan][plan]
+// The source hash says WHO wrote the file (the plan's layout belongs to one build); the checksum says the bytes are the ones that were
+// written (a truncated copy, a flipped bit: the plan's raw offsets index host and device tables, so a damaged file is refused as a whole
+// and the caller reads the .txt again); the range checks in load_bin cover what the host code indexes with before any plan is used.
 // ---------------------------------------------------------------------------------------------
 namespace {
-constexpr uint32_t kBinFormat = 1;
+constexpr uint32_t kBinFormat = 2;
+constexpr size_t kBinHeader = 8 + 4 + 32 + 8;   // magic, format, tag, checksum
+uint64_t payload_checksum(const char *p, size_t n) {   // FNV-1a over 8-byte words (the tail byte by byte), folded with the length
+    uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)n;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0x100000001b3ull; h ^= h >> 29; }
+    for (; i < n; i++) h = (h ^ (uint8_t)p[i]) * 0x100000001b3ull;
+    return h;
+}
 struct Writer {
     std::string buf;
     void raw(const void *p, size_t n) { buf.append((const char *)p, n); }
@@ -437,6 +449,11 @@ void get_tables(Reader &r, std::vector<std::vector<double>> &t) { const uint64_t
 } // namespace
 
 std::shared_ptr<const CompiledPlan> plan_of(const Model &m) {
+    // One lock for every model: the multi-device entry points run one host thread per device on the SAME model, and each of them comes
+    // here (get_uploaded); unguarded, the threads of a cold model would compile and assign the shared_ptr while the others copy it.
+    // Compiling under the lock means the second thread waits for the first one's plan instead of compiling its own.
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (!m.plan_cache || m.plan_version != m.version) {
         m.plan_cache = std::make_shared<const CompiledPlan>(compile_plan(m));
         m.plan_version = m.version;
@@ -451,6 +468,7 @@ void save_bin(const Model &m, const char *path, const char *src_hash) {
     char tag[32] = {0};
     strncpy(tag, src_hash ? src_hash : "", sizeof tag - 1);
     w.raw(tag, sizeof tag);
+    w.pod<uint64_t>(0);   // the checksum, filled in below
     w.pod<int32_t>(m.n_initial); w.pod<int32_t>(m.n_transition);
     w.pod<uint64_t>(m.labels_initial.size()); for (auto &t : m.labels_initial) w.str(t);
     w.pod<uint64_t>(m.labels_transition.size()); for (auto &t : m.labels_transition) w.str(t);
@@ -472,6 +490,8 @@ void save_bin(const Model &m, const char *path, const char *src_hash) {
         w.pod(P);
         w.vec(cp->thr); w.vec(cp->cthr); w.vec(cp->pthr); w.vec(cp->bnd); w.vec(cp->pos_of_var);
     }
+    const uint64_t sum = payload_checksum(w.buf.data() + kBinHeader, w.buf.size() - kBinHeader);
+    memcpy(&w.buf[kBinHeader - 8], &sum, 8);
     const std::string tmp = std::string(path) + ".tmp";
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) throw Error(EMGPU_ERR_IO, std::string("cannot write ") + tmp);
@@ -496,6 +516,8 @@ Model *load_bin(const char *path, const char *src_hash) {
     tag[sizeof tag - 1] = 0;
     if (strcmp(tag, src_hash ? src_hash : "") != 0)
         throw Error(EMGPU_ERR_PARSE, std::string("binary model cache written by other sources (") + tag + "): read the .txt again");
+    if (r.pod<uint64_t>() != payload_checksum(r.p, (size_t)(r.end - r.p)))
+        throw Error(EMGPU_ERR_PARSE, "binary model cache: checksum mismatch (damaged file): read the .txt again");
     std::unique_ptr<Model> m(new Model());
     m->n_initial = r.pod<int32_t>(); m->n_transition = r.pod<int32_t>();
     if (m->n_initial < 1 || m->n_initial > 4096 || m->n_transition < 0 || m->n_transition > 4096) throw Error(EMGPU_ERR_PARSE, "binary model cache: bad sizes");
@@ -513,6 +535,29 @@ Model *load_bin(const char *path, const char *src_hash) {
         m->zero_bins.size() != ni || m->resample_rates.size() != ni || m->start.size() != ni || m->order_initial.size() != ni || m->q_initial.size() != ni ||
         m->G_transition.size() != nt * nt || m->r_transition.size() != nt || (nt && (m->N_transition.size() != nt || m->A_transition.size() != nt || m->q_transition.size() != nt)))
         throw Error(EMGPU_ERR_PARSE, "binary model cache: inconsistent sizes");
+    // what host code indexes with: orders are permutations of 1..n, a node's tables hold r x q entries, boundaries r + 1 values or none
+    auto is_perm = [](const std::vector<int> &o, size_t n) {
+        if (o.size() != n) return false;
+        std::vector<uint8_t> seen(n, 0);
+        for (int v : o) { if (v < 1 || (size_t)v > n || seen[(size_t)v - 1]) return false; seen[(size_t)v - 1] = 1; }
+        return true;
+    };
+    bool ok = is_perm(m->order_initial, ni) && (m->order_transition.empty() || is_perm(m->order_transition, nt));
+    for (size_t v = 0; ok && v < ni; v++) {
+        const int64_t r_ = m->r_initial[v], q_ = m->q_initial[v];
+        ok = r_ >= 1 && r_ <= EMGPU_MAX_R && q_ >= 1 && q_ <= ((int64_t)1 << 40) / r_ && m->N_initial[v].size() == (size_t)(r_ * q_) && m->A_initial[v].size() == (size_t)(r_ * q_) &&
+             (m->boundaries[v].empty() || m->boundaries[v].size() == (size_t)r_ + 1) && m->zero_bins[v] >= 0 && m->zero_bins[v] <= r_ && m->start[v] >= 0 && m->start[v] <= r_;
+    }
+    for (size_t v = 0; ok && v < nt; v++) {
+        const int64_t r_ = m->r_transition[v];
+        ok = r_ >= 1 && r_ <= EMGPU_MAX_R;
+        if (ok && !m->N_transition[v].empty()) {
+            const int64_t q_ = m->q_transition[v];
+            ok = q_ >= 1 && q_ <= ((int64_t)1 << 40) / r_ && m->N_transition[v].size() == (size_t)(r_ * q_) && m->A_transition[v].size() == (size_t)(r_ * q_);
+        }
+    }
+    for (auto &a : m->temporal_map) ok = ok && a[0] >= 1 && (size_t)a[0] <= ni && a[1] > (int)ni && (size_t)a[1] <= nt;
+    if (!ok) throw Error(EMGPU_ERR_PARSE, "binary model cache: values out of range");
     static std::atomic<uint64_t> bin_uid{1ull << 40};   // (finalize() numbers the models it builds from 1: two ranges, never equal)
     m->uid = bin_uid.fetch_add(1);
     m->version = 1;
@@ -520,7 +565,12 @@ Model *load_bin(const char *path, const char *src_hash) {
         auto cp = std::make_shared<CompiledPlan>();
         cp->plan = r.pod<EmgpuPlan>();
         r.vec(cp->thr); r.vec(cp->cthr); r.vec(cp->pthr); r.vec(cp->bnd); r.vec(cp->pos_of_var);
-        if (cp->plan.ni != m->n_initial || cp->thr.size() < cp->plan.thr_total || cp->pos_of_var.size() != ni) throw Error(EMGPU_ERR_PARSE, "binary model cache: plan does not fit the model");
+        bool fits = cp->plan.ni == m->n_initial && cp->thr.size() >= cp->plan.thr_total && cp->cthr.size() >= cp->plan.cthr_total && cp->pthr.size() >= cp->plan.pthr_total &&
+                    cp->pos_of_var.size() == ni;
+        for (size_t v = 0; fits && v < ni; v++) fits = cp->pos_of_var[v] >= 0 && (size_t)cp->pos_of_var[v] < ni;
+        for (int q = 0; fits && q < cp->plan.ni; q++)
+            fits = cp->plan.i_var[q] < ni && cp->plan.i_off[q] <= cp->thr.size() && (size_t)cp->plan.i_boff[q] + cp->plan.i_nb[q] <= cp->bnd.size();
+        if (!fits) throw Error(EMGPU_ERR_PARSE, "binary model cache: plan does not fit the model");
         m->plan_cache = cp;
         m->plan_version = m->version;
     }

@@ -1017,6 +1017,46 @@ int64_t em_propagate_batch(const em_model_t *const *models, const int32_t *model
     return 0;
 }
 
+/* bench.py's CPU leg for config 5: the work of em_propagate_batch on `threads` threads.  Philox mode only (an encounter's draws depend
+ * on its global index alone, so encounters can be dealt to threads); every thread overwrites ONE private encounter's worth of tracks
+ * (4 x cap x 6 doubles) -- the leg measures the rate, the results are the ones em_propagate_batch returns.  Returns the track rows
+ * produced (sum over the batch), or a negative error. */
+int64_t em_propagate_throughput_mt(const em_model_t *const *models, const int32_t *model_of, uint64_t seed, uint64_t first_index,
+                                   int64_t n, const double *geo, const em_dynlims_t *dl /* [2] */, double tmax_s, int max_resample,
+                                   int threads, int cap) {
+    int64_t total = 0;
+    int err = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads) reduction(+ : total)
+    {
+        em_rng_t g;
+        em_rng_init(&g, EM_RNG_PHILOX, seed);
+        double *buf = (double *)malloc((size_t)4 * cap * 6 * sizeof(double));
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t e = 0; e < n; e++) {
+            if (!buf || err) continue;
+            g.gidx = first_index + (uint64_t)e;
+            for (int role = 0; role < 4; role++) {
+                const int ac = role >> 1, bck = role & 1;
+                const double *q = geo + e * 12 + ac * 6;
+                const int r = em_propagate_trajectory(models[model_of[e * 4 + role]], &g, role, ac == 0, bck ? -1.0 : 1.0,
+                                                      q[0], q[1], q[2], q[3], q[4], (int)q[5], tmax_s, &dl[ac], max_resample,
+                                                      buf + (size_t)role * cap * 6, cap);
+                if (r < 0) {
+#pragma omp atomic write
+                    err = r;
+                } else total += r;
+            }
+        }
+        if (!buf) {
+#pragma omp atomic write
+            err = -1;
+        }
+        free(buf);
+    }
+    return err ? err : total;
+}
+
 /* sample2track.m:183-243 -- the 1 Hz dead-reckoning track and its rejection tests.
  * alt0/speed0 [n] and updates [n][T][3] (vertical rate, acceleration, turn rate) in model units, as
  * read from initial.txt / transition.txt; unit ratios as :113-123; min/max speed = boundaries{v}([1 end]).

@@ -544,6 +544,27 @@ def propagate(oms, model_of, geo, seed, dyn_limits, mode=RNG_PHILOX, first_index
     return out, rows
 
 
+def propagate_throughput_mt(oms, model_of, geo, seed, dyn_limits, threads, first_index=0, tmax_s=120.0, max_resample=100000, cap=None):
+    """em_propagate_throughput_mt: the work of `propagate` on `threads` threads with thread-private track buffers (bench.py's CPU leg
+    for config 5; Philox mode).  Returns the track rows produced."""
+    L = lib()
+    L.em_propagate_throughput_mt.restype = C.c_int64
+    geo = np.ascontiguousarray(np.asarray(geo, dtype=np.float64).reshape(-1, 12))
+    n = geo.shape[0]
+    model_of = np.ascontiguousarray(np.asarray(model_of, dtype=np.int32).reshape(-1))
+    cap = int(cap or (int(tmax_s) + 3))
+    ptrs = (C.c_void_p * len(oms))(*[C.addressof(om.c) for om in oms])
+    dl = (_DynLims * 2)()
+    d = np.asarray(dyn_limits, dtype=np.float64).reshape(2, 5)
+    for a in range(2):
+        dl[a].minVel_ft_s, dl[a].maxVel_ft_s, dl[a].maxTurnRate_deg_s, dl[a].maxAltitude_ft, dl[a].maxVertRate_ft_s = [float(x) for x in d[a]]
+    rc = L.em_propagate_throughput_mt(ptrs, _ptr(model_of), C.c_uint64(seed), C.c_uint64(first_index), C.c_int64(n), _ptr(geo), dl,
+                                      C.c_double(tmax_s), C.c_int(max_resample), C.c_int(int(threads)), C.c_int(cap))
+    if rc < 0:
+        raise RuntimeError("em_propagate_throughput_mt failed rc=%d" % rc)
+    return int(rc)
+
+
 def sample2track(alt0, speed0, updates, ur_speed, ur_vertrate, ur_heading, min_speed, max_speed):
     """sample2track.m:183-243 restated: (xyz [n, T+1, 3], flags [n], speed_minmax [n, 2])."""
     L = lib()

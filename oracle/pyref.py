@@ -446,6 +446,23 @@ def local_smooth(x, w):
     return out
 
 
+def create_encounter_inputs(sample_geo):
+    """createEncounter.m:13-49: what the four PropagateTrajectory calls of one encounter are handed.  sample_geo: dict by label (one geometry
+    sample).  Returns (geo[12] = x0_nm y0_nm z0_ft v0_ft_s heading0_deg intent for aircraft 1, then 2 (:41-45, :60,:67),
+    model_of[4] = [own fwd, own bck, int fwd, int bck] as positions in CorTerminalModel.m:84-100's list of ten (:13-38))."""
+    geo = []
+    for pre in ("own", "int"):
+        s, c = sincosd(sample_geo[pre + "_bearing"])
+        geo += [sample_geo[pre + "_distance"] * c, sample_geo[pre + "_distance"] * s, sample_geo[pre + "_alt"], sample_geo[pre + "_speed"],
+                sample_geo[pre + "_heading"], float(int(sample_geo[pre + "_intent"]))]
+    oi, ii = int(sample_geo["own_intent"]), int(sample_geo["int_intent"])
+    if oi not in (1, 2):
+        raise ValueError("Unknown own_intent = %d" % oi)                  # :21-22
+    if ii not in (1, 2, 3):
+        raise ValueError("Unknown int_intent = %d" % ii)                  # :36-37
+    return geo, [2 * (oi - 1), 2 * (oi - 1) + 1, 4 + 2 * (ii - 1), 4 + 2 * (ii - 1) + 1]
+
+
 def create_encounter(traj_models, model_of, sample_geo, tmax_s, dynlims_pair, R, smooth=False):
     """createEncounter.m:40-91.  traj_models: the 10 parsed trajectory models; model_of: the 4 indices [own fwd, own bck, int fwd, int bck]
     (createEncounter.m:21-38 picks them by intent); sample_geo: dict by label.  Returns [own, int] dicts of numpy arrays sorted in time."""

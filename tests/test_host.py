@@ -220,7 +220,10 @@ def test_binary_cache_equals_the_txt_load(name, model_dir, tmp_path):
     # refused files
     raw = open(binp, "rb").read()
     bad = str(tmp_path / "bad.emgpubin")
-    for blob in (raw[:12] + b"0123456789ab" + raw[24:], raw[: len(raw) // 2], b"not a model", raw + b"x"):
+    def flip(k):                                    # one bit of byte k: caught by the payload checksum wherever it is
+        return raw[:k] + bytes([raw[k] ^ 0x10]) + raw[k + 1:]
+    damaged = [flip(60), flip(len(raw) // 3), flip(len(raw) - 40), flip(len(raw) - 1), flip(47)]   # model fields, tables, the plan's tail, the checksum itself
+    for blob in [raw[:12] + b"0123456789ab" + raw[24:], raw[: len(raw) // 2], b"not a model", raw + b"x"] + damaged:
         open(bad, "wb").write(blob)
         with pytest.raises(L.EmgpuError) as e:
             native.NativeModel.load_bin(bad)
@@ -228,6 +231,51 @@ def test_binary_cache_equals_the_txt_load(name, model_dir, tmp_path):
     with pytest.raises(L.EmgpuError) as e:
         native.NativeModel.load_bin(str(tmp_path / "missing.emgpubin"))
     assert e.value.code == L.ERR_IO
+
+
+def test_plan_of_a_cold_model_from_many_threads(model_dir):
+    """ADVICE r4: the multi-device entry points run one host thread per device on the SAME model and each resolves the model's plan;
+    on a cold model (or after a setter) they all arrive at an empty cache at once.  emgpu_debug_padded_column goes through the same
+    plan_of: eight threads on a freshly loaded model, then again after a setter, must all see one and the same plan."""
+    import threading
+    path = em_io.materialize_model("uncor_1200code_v2p1", model_dir)
+    for round_ in range(3):
+        m = native.NativeModel.load_txt(path)
+        for phase in range(2):
+            if phase:
+                m.set_prior(1.0)                     # bumps the version: the cache is stale for every thread at once
+            got, errs = [None] * 8, []
+            gate = threading.Barrier(8)
+
+            def work(i):
+                try:
+                    gate.wait()
+                    got[i] = _plan_columns(m)
+                except Exception as e:              # noqa
+                    errs.append(e)
+            ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            assert not errs, errs
+            assert all(g == got[0] for g in got)
+
+
+def test_plan_of_is_clean_under_thread_sanitizer(model_dir, tmp_path):
+    """The same scenario in a ThreadSanitizer build of the host-side model code (csrc/emgpu_model.cpp has no HIP in it): the unguarded
+    plan_of of round 4 gives 22 race reports here, the locked one none."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "plan_of_race")
+    csrc = os.path.join(ROOT, "em_model_manned_bayes_amd", "csrc")
+    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I", csrc, os.path.join(ROOT, "tools", "tsan", "plan_of_race.cpp"),
+                         os.path.join(csrc, "emgpu_model.cpp"), "-o", exe, "-lpthread"], capture_output=True, text=True)
+    if cc.returncode != 0 and "tsan" in cc.stderr.lower():
+        pytest.skip("no ThreadSanitizer runtime: " + cc.stderr[-200:])
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([exe, em_io.materialize_model("uncor_1200code_v2p1", model_dir)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "ThreadSanitizer" not in run.stderr and run.stdout.strip().endswith("ok"), run.stderr[-3000:]
 
 
 def test_load_cached_writes_reads_and_refreshes(model_dir, tmp_path):
@@ -796,3 +844,53 @@ def test_bench_telemetry_reads_the_card_with_this_ranks_pci_address(tmp_path):
     assert out["sclk_mhz"]["median"] == 2240.0 and out["socket_power_w"]["median"] == 1350.0 and out["power_cap_w"] == 1400.0 and out["temperature_c"] == {"mem": 66.0}
     assert bench.GpuTelemetry(0, "0000:ff:00.0", sysfs_root=str(root)).dir is None       # an address no card has: no sensor rather than a neighbour's
     assert bench.GpuTelemetry(0, None, sysfs_root=str(root)).card.startswith("card0")     # no address known: by index, and the line says so
+
+
+def test_host_discretisers_known_answers():
+    """The host mirrors of SURVEY.md section 8 row a16 against answers derived by hand from the reference's lines (no RNG, no oracle):
+    discretize_bayes.m:17-21 through the C ABI (emgpu_discretize_bayes), the worked example of hierarchical_discretize.m:4-8,
+    hierarchical_cutpoints.m:5-15 and aind2sub.m:8-18 (the inverse of asub2ind.m:13-14)."""
+    from em_model_manned_bayes_amd import functions as F
+    lib = L.lib()
+    lib.emgpu_discretize_bayes.restype = C.c_int32
+    th = np.array([1.0, 2.0, 3.0])
+
+    def d(x, t=th):
+        return int(lib.emgpu_discretize_bayes(C.c_double(x), t.ctypes.data_as(C.c_void_p), C.c_int32(t.size)))
+    # :17-18 `x >= thresholds(end)` -> numel + 1; :20 `find(x < thresholds, 1)`: a value ON a cut point belongs to the bin above it
+    assert [d(-np.inf), d(0.5), d(1.0), d(1.5), d(2.0), d(2.999999), d(3.0), d(10.0), d(np.inf)] == [1, 1, 2, 2, 3, 3, 4, 4, 4]
+    one = np.array([5.0])
+    assert [d(4.0, one), d(5.0, one), d(6.0, one)] == [1, 2, 2]
+    assert np.array_equal(F.discretize_bayes([0.5, 1.0, 3.0], th), [1, 2, 4]) and F.discretize_bayes(2.5, th) == 3.0
+    bearing = np.arange(10.0, 360.0, 10.0)                       # the 36-bin grids of the terminal model: 35 cut points
+    assert [d(0.0, bearing), d(9.99, bearing), d(10.0, bearing), d(349.99, bearing), d(350.0, bearing), d(360.0, bearing)] == [1, 1, 2, 35, 36, 36]
+
+    # hierarchical_cutpoints.m:9-14: thresholds = [60 80 100 120 140 160 180], fine{i} = a + (1:n-1) * (b - a) / n
+    coarse = np.arange(80.0, 161.0, 20.0)
+    fine = F.hierarchical_cutpoints(coarse, [60.0, 180.0], 4)
+    assert len(fine) == 6
+    for i, a in enumerate([60.0, 80.0, 100.0, 120.0, 140.0, 160.0]):
+        assert np.array_equal(fine[i], [a + 5.0, a + 10.0, a + 15.0])
+    assert np.array_equal(F.hierarchical_cutpoints([0.0], [-1.0, 1.0], 2)[0], [-0.5]) and np.array_equal(F.hierarchical_cutpoints([0.0], [-1.0, 1.0], 2)[1], [0.5])
+    assert all(c.size == 0 for c in F.hierarchical_cutpoints([1.0, 2.0], [0.0, 3.0], 1))      # n = 1: (1:0) is empty
+
+    # hierarchical_discretize.m:4-8 -- by hand from :25-48: d = coarse bins; fine bins f = [2 1 1 1 1 3 3 4];
+    # neighbours in the same coarse bin: (3,3) x 3 with equal f -> repeat 3; (1,1) f 3,3 -> repeat 4; (1,1) f 3,4 -> change 1
+    x = [65, 100, 100, 100, 100, 72, 71, 78]
+    dd, repeat, change = F.hierarchical_discretize(x, coarse, fine)
+    assert np.array_equal(dd, [1, 3, 3, 3, 3, 1, 1, 1]) and (repeat, change) == (4, 1)
+    dd, repeat, change = F.hierarchical_discretize(x, coarse, fine, zero_bins=[3])            # :41 `~any(zero_bins == d(ii))`: bin 3's pairs do not count
+    assert np.array_equal(dd, [1, 3, 3, 3, 3, 1, 1, 1]) and (repeat, change) == (1, 1)
+    dd, repeat, change = F.hierarchical_discretize(x, coarse, [])                             # :16-21 no fine cut points
+    assert np.array_equal(dd, [1, 3, 3, 3, 3, 1, 1, 1]) and (repeat, change) == (0, 0)
+    dd, _, _ = F.hierarchical_discretize([170.0, 65.0], coarse[:-1], F.hierarchical_cutpoints(coarse[:-1], [60.0, 160.0], 4), wrap=1)
+    assert np.array_equal(dd, [1, 1])                                                         # :27-30 wrap: bin 5 of 4 cut points -> 1
+
+    # aind2sub.m:12-18 undoes asub2ind.m:13-14 (k = [1 4 12] for siz = [4 3 2])
+    siz = [4, 3, 2]
+    assert np.array_equal(F.aind2sub(siz, 1), [1, 1, 1]) and np.array_equal(F.aind2sub(siz, 10), [2, 3, 1])
+    assert np.array_equal(F.aind2sub(siz, 13), [1, 1, 2]) and np.array_equal(F.aind2sub(siz, 24), [4, 3, 2])
+    assert F.asub2ind(siz, [2, 3, 1]) == 10 and F.asub2ind(siz, [4, 3, 2]) == 24
+    for ndx in range(1, 25):
+        assert F.asub2ind(siz, F.aind2sub(siz, ndx)) == ndx
+    assert np.array_equal(F.aind2sub([7], 5), [5])

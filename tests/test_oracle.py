@@ -313,6 +313,10 @@ def test_propagate_trajectory_restatement_properties(tmp_path):
     a, ra = O.propagate(oms, mo[:10], geo[:10], 5, dl, first_index=100)
     b, rb = O.propagate(oms, mo[5:10], geo[5:10], 5, dl, first_index=105)
     assert np.array_equal(ra[20:], rb) and np.array_equal(a[20:], b)
+    # bench.py's all-cores CPU leg does the same work (thread-private buffers): the same number of track rows, whatever the thread count
+    _, rows = O.propagate(oms, mo, geo, 11, dl, first_index=7)
+    for threads in (1, 3, 8):
+        assert O.propagate_throughput_mt(oms, mo, geo, 11, dl, threads, first_index=7) == int(rows.sum())
 
 
 def test_sample2track_known_answers():

@@ -143,3 +143,29 @@ def assert_parting_only_on_a_threshold(got_attempts, ref_attempts, margins, tol,
         assert m < tol, ("%s %d: GPU accepted attempt %d, oracle attempt %d, but no decision of attempt %d was closer than %.3g "
                          "to its threshold (tolerance %.3g): a real accept/reject difference" % (what, i, g, r, j, m, tol))
     return same
+
+
+def f32_ulp_distance(a, b):
+    """|a - b| counted in f32 representation steps (a, b: f32 arrays of one shape; +0 and -0 are 0 apart)."""
+    ia = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    ib = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+def assert_f32_of_f64(got, ref, what="", abs_floor=1e-9):
+    """`got` (f32, what the device stored) against `ref` (the oracle's f64): equal after rounding the oracle's value to f32, or ONE f32 step
+    apart -- the device's and the host's f64 transcendental functions differ in their last bits (1e-15 relative), which moves a value
+    across an f32 rounding boundary now and then but never further.  abs_floor: a value that is a difference of larger quantities (x_nm
+    near the runway, a heading just past 0) carries their absolute error; below abs_floor the absolute difference is compared instead.
+    Replaces rtol = atol = 1e-6 on the terminal tracks (the soak's worst observation was 6e-8 relative = half an f32 step)."""
+    got = np.asarray(got, dtype=np.float32)
+    ref = np.asarray(ref, dtype=np.float64)
+    d = f32_ulp_distance(got, ref.astype(np.float32))
+    bad = (d > 1) & (np.abs(got.astype(np.float64) - ref) > abs_floor)
+    if bad.any():
+        k = np.argwhere(bad)[0]
+        raise AssertionError("%s: %d of %d values more than one f32 step from the oracle, first at %s: %r vs %r"
+                             % (what, int(bad.sum()), bad.size, tuple(k), got[tuple(k)], ref[tuple(k)]))
+    return int(d.max()) if d.size else 0
