@@ -93,6 +93,10 @@ def parse_args(argv=None):
     ap.add_argument("--telemetry-s", type=float, default=2.5,
                     help="seconds of untimed back-to-back steps AFTER the timed region during which the shader clock and socket power are read (0: skip); "
                          "nothing is sampled inside the timed region")
+    ap.add_argument("--ranges-out", default=None,
+                    help="TEST HOOK: a directory into which every rank writes rank<r>.json = the global index range (and model blocks) of every step it "
+                         "launched + a digest of its last step's output (tests check the ranks' ranges are disjoint and the digests are what one "
+                         "process computes for those ranges)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: allow more ranks than GPUs (ranks share devices, gloo barrier); the line says so")
     return ap.parse_args(argv)
@@ -306,6 +310,7 @@ class DbnWorkload:
         self.ctx = pl.context()
         self.launches_per_step = 1
         self.kernels = []
+        self.ranges = []       # (step, first global index, n[, model blocks]) of every step launched (--ranges-out)
 
     def ptrs(self):
         return dict(init_bin=self.init_bin.data_ptr(), init_val=self.init_val.data_ptr(),
@@ -319,6 +324,7 @@ class DbnWorkload:
         if len(self.models) == 1:
             p, _ = native.make_params(n, self.T, self.seed, first_index=first, transition_mode=self.mode, **self.idx[0])
             native.sample_dbn_device(self.ctx, self.models[0], p, **self.ptrs())
+            self.ranges.append({"step": k, "first": first, "n": n})
             return
         # mixed batch: model m owns the m-th contiguous block of the step's global range; this rank's shard of that
         # range intersects one or two blocks -> one launch each into the rank's ONE trace
@@ -327,11 +333,18 @@ class DbnWorkload:
         blocks = [(m, base + f, c) for (m, f, c) in native.mixed_blocks(total, len(self.models), first - base, first - base + n)]
         p, _ = native.make_params(n, self.T, self.seed, first_index=first, transition_mode=self.mode, **self.idx[0])
         native.sample_dbn_blocks_device(self.ctx, self.models, p, blocks, **self.ptrs())
+        self.ranges.append({"step": k, "first": first, "n": n, "blocks": [[int(a), int(b), int(c)] for a, b, c in blocks]})
         self.blocks_per_step = max(getattr(self, "blocks_per_step", 0), len(blocks))
         self.launches_per_step = max(self.launches_per_step, self.ctx.last_launches())   # models that share a kernel instance share ONE launch
 
     def sync(self):
         self.ctx.sync()  # surfaces deferred rejection-cap errors
+
+    def digest(self):
+        """Sums over the last step's output (int64, exact): what a test compares with one process's result for the same global range."""
+        n = self.n
+        return {"init_bin": int(self.init_bin[:, :n].long().sum()), "dyn_bin": int(self.dyn_bin[:, :, :n].long().sum()),
+                "init_val_bits": int(self.init_val[:, :n].contiguous().view(self.pl.torch.int32).long().sum())}
 
     def kernel_name(self):
         return self.ctx.last_kernel()
@@ -439,10 +452,17 @@ class TerminalWorkload:
         self.bytes_per_unit = self.bytes_bound   # replaced in check() by 75 + 15 B x the track-seconds the run really produced
         self.bytes_stored_per_unit = None        # 75 + 20 B x the rows the run really wrote (what the kernel stores: five f32 per row)
         self.launches_per_step = 1
+        self.ranges = []
+
+    def digest(self):
+        t = self.pl.torch
+        return {"rows": int(self.rows.long().sum()), "model_of": int(self.mof.long().sum()), "geom_val_bits": int(self.geom_val.view(t.int32).long().sum()),
+                "attempts": int(self.att.long().sum())}
 
     def step(self, k):
         from em_model_manned_bayes_amd import sharding
         first = sharding.step_first_index(k, self.rank, self.world, self.n)
+        self.ranges.append({"step": k, "first": first, "n": self.n})
         p, self._keep = self.native.terminal_sample_params(self.t.native, self.n, self.seed, self.t._dyn_rows(), first_index=first, tmax_s=120.0,
                                                            cap=self.cap, bounds_sample=self.bs, local_smooth=self.local_smooth)
         self.native.sample_terminal_device(self.ctx, self.t.native, [x.native for x in self.t._traj], p, self.geom_val.data_ptr(), self.geo.data_ptr(),
@@ -799,6 +819,10 @@ def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
     pl = pl or TorchRocm(rank, local_rank, world, args.oversubscribe)
     w = make_workload(args, pl, rank, world)
     elapsed, step_ms = measure(w, pl, args, args.warmup, args.steps)
+    if getattr(args, "ranges_out", None) and hasattr(w, "digest") and hasattr(pl, "torch"):
+        os.makedirs(args.ranges_out, exist_ok=True)
+        with open(os.path.join(args.ranges_out, "rank%d.json" % rank), "w") as f:
+            json.dump({"rank": rank, "world": world, "n": w.n, "ranges": w.ranges, "digest": w.digest()}, f)
     line = None
     if rank == 0:
         from em_model_manned_bayes_amd import _lib as L

@@ -558,6 +558,19 @@ class CorTerminalModel(EncounterModel):
                         out.append([ii, jj, kk] + [None] * (self.n_initial - 3))
         return out
 
+    _warned_smooth = False
+
+    @classmethod
+    def _note_smooth(cls, local_smooth):
+        """createEncounter.m:88-89 smooth through em-core's local_smooth, which the reference does not vendor: the default (True, like the
+        reference) runs the library's documented stand-in.  Said once per process, so nobody takes the smoothed columns for pinned ones."""
+        if local_smooth and not cls._warned_smooth:
+            import warnings
+            cls._warned_smooth = True
+            warnings.warn("CorTerminalModel: speed and altitude are smoothed like createEncounter.m:88-89, but em-core's local_smooth is not part of the "
+                          "reference checkout: this is the library's stand-in (EMGPU_FLAG_LOCAL_SMOOTH, a centred moving average; UNPINNED). "
+                          "Pass local_smooth=False for the propagated values as they are.", stacklevel=3)
+
     # ---- createEncounter.m:1-91 without em-core's local_smooth (:88-89)
     @staticmethod
     def _sincosd(deg):
@@ -599,6 +612,7 @@ class CorTerminalModel(EncounterModel):
         if self._traj is None:
             raise NotImplementedError("the terminal trajectory-model files are not in parameters_directory (they are absent from the "
                                       "reference mount); synthetic.write_terminal_directory builds stand-ins")
+        self._note_smooth(local_smooth)
         single = isinstance(sample_geo, dict)
         samples = [sample_geo] if single else list(sample_geo)
         s, first = _take(seed, len(samples))
@@ -643,6 +657,7 @@ class CorTerminalModel(EncounterModel):
             raise NotImplementedError("the terminal trajectory-model files are not in parameters_directory (they are absent from the "
                                       "reference mount); synthetic.write_terminal_directory builds stand-ins")
         import time
+        self._note_smooth(local_smooth)
         t0 = time.perf_counter()
         s, first = _take(initialSeed, nSamples)
         if first_index is not None:

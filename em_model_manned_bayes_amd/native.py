@@ -551,9 +551,14 @@ def sample_terminal_device(ctx, geom_model, traj_models, p, geom_val, geo, model
 
 def track_terminal_host(ctx, geom_model, traj_models, n, seed, dyn_limits, max_cum_turn_deg, pitch_deg, first_index=0, tmax_s=120.0,
                         min_enc_time_s=30.0, thres_dist_ft=2.5 * 6076, thres_alt_low_ft=750.0, thres_vertrate_ft_s=300.0 / 60.0,
-                        bounds_sample=None, max_track_attempts=500, max_attempts=100000, max_resample=100000, allow_cap=False, local_smooth=False):
+                        bounds_sample=None, max_track_attempts=500, max_attempts=100000, max_resample=100000, allow_cap=False, local_smooth=True):
     """emgpu_track_terminal_host: CorTerminalModel.track (track.m:45-150) on the GPU.  Returns dict: sample [n, n_i], traj [n, 2, cap2, 6]
-    (t_s x_nm y_nm z_ft heading_deg v_ft_s, time-ordered), len [n, 2], meta [n, 4] (tcpa_s hmd_ft vmd_ft enc_time_s), attempts [n]."""
+    (t_s x_nm y_nm z_ft heading_deg v_ft_s, time-ordered), len [n, 2], meta [n, 4] (tcpa_s hmd_ft vmd_ft enc_time_s), attempts [n].
+    local_smooth -- ONE rule for every Python layer: a function smooths by default exactly when the reference function it mirrors does.
+    track.m calls createEncounter, whose lines 88-89 smooth speed and altitude, so this helper, CorTerminalModel.track and
+    CorTerminalModel.createEncounter default to True; PropagateTrajectory (createEncounter.m:93-265) does not smooth, so
+    propagate_terminal_host / _joined_host default to False.  The C ABI has no defaults (a zeroed `flags` field is off: set
+    EMGPU_FLAG_LOCAL_SMOOTH).  The smoother itself is the library's documented stand-in for em-core's un-vendored local_smooth: UNPINNED."""
     labels = [s.strip('"') for s in geom_model.get_labels(L.F_LABELS_INITIAL)]
     p = L.TTrackParams()
     p.seed, p.first_index, p.n, p.tmax_s = int(seed) & (2**64 - 1), int(first_index), int(n), float(tmax_s)

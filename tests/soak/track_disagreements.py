@@ -36,7 +36,7 @@ for act, cum_override in ((("GENERIC", "GENERIC"), None), (("GENERIC", "RTCA228_
         cum = list(cum_override)
     n, cap = 4000, 150
     ref = O.terminal_track(gom, oms, n, 0xF2, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap)
-    got = native.track_terminal_host(ctx, t.native, [m.native for m in t._traj], n, 0xF2, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap, allow_cap=True)
+    got = native.track_terminal_host(ctx, t.native, [m.native for m in t._traj], n, 0xF2, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap, allow_cap=True, local_smooth=False)
     d = np.flatnonzero(got["attempts"] != ref["attempts"])
     print("terminal.track %s cum %s: %d of %d part (%d accepted, %d attempt-encounters); margins: %s" % (act, cum, len(d), n, (ref["attempts"] > 0).sum(),
           np.where(ref["attempts"] > 0, ref["attempts"], cap).sum(),

@@ -796,6 +796,64 @@ def test_bench_launches_its_own_ranks(tmp_path):
         assert rf["sclk_mhz"] > 1000 and rf["gpu_telemetry"]["samples"] >= 1
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,n", [("terminal", 200000), ("mixed", 300000)])
+def test_bench_ranks_of_the_other_configs_cover_disjoint_ranges(config, n, terminal_dir, model_dir, tmp_path):
+    """8-GPU readiness without the node: `bench.py --gpus 2 --oversubscribe --config terminal / mixed` -- the configs
+    the driver's SCALE run would shard, through the launcher on hardware.  Every rank writes the global range of every step it launched
+    (--ranges-out): the ranks' ranges of a step are disjoint and tile [k W n, (k + 1) W n); the line's value is the whole job's units over
+    the slowest rank's time; and each rank's last step digests to what ONE process computes for that global range (results do not depend
+    on which rank ran an index)."""
+    import json
+    import subprocess
+    import torch
+    out_dir = str(tmp_path / "ranges")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    W, steps, warm = 2, 2, 1
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(W), "--oversubscribe", "--config", config, "--n", str(n), "--steps", str(steps),
+           "--warmup", str(warm), "--no-cpu-baseline", "--telemetry-s", "0", "--ranges-out", out_dir]
+    r = subprocess.run(cmd, env=env, capture_output=True, timeout=1200)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == W and line["oversubscribed"] is True and line["scaling"] == "weak"
+    assert abs(line["value"] - W * n * steps / (line["ms_per_step"] * steps * 1e-3)) < 1e-6 * line["value"]
+    assert line["config"]["philox_rounds"] == O.philox_rounds() and "box_state" in line["config"]
+    ranks = [json.load(open(os.path.join(out_dir, "rank%d.json" % q))) for q in range(W)]
+    for k in range(warm + steps):
+        spans = sorted((rk["ranges"][k]["first"], rk["ranges"][k]["first"] + rk["ranges"][k]["n"]) for rk in ranks)
+        assert all(rk["ranges"][k]["step"] == k for rk in ranks)
+        assert spans[0][0] == k * W * n and spans[-1][1] == (k + 1) * W * n
+        assert all(spans[q][1] == spans[q + 1][0] for q in range(W - 1))                 # disjoint and gap-free
+    dev = torch.device("cuda", 0)
+    if config == "terminal":
+        t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=terminal_dir)
+        f = _FusedTerminal(t, n)
+        for rk in ranks:
+            f.run(0x5EED0005, rk["ranges"][-1]["first"])
+            got = {"rows": int(f.rows.long().sum()), "model_of": int(f.mof.long().sum()), "geom_val_bits": int(f.gval.view(torch.int32).long().sum()),
+                   "attempts": int(f.att.long().sum())}
+            assert got == rk["digest"], (rk["rank"], got, rk["digest"])
+    else:
+        names = line["config"]["models"]
+        assert len(names) == 6 and all(nm.endswith("_v1p2") for nm in names)
+        pairs = [load_pair(nm, model_dir) for nm in names]
+        ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+        T, G4 = 240, 60
+        for rk in ranks:
+            last = rk["ranges"][-1]
+            blocks = [tuple(b) for b in last["blocks"]]
+            assert sum(c for _, _, c in blocks) == n and blocks[0][1] == last["first"]
+            assert all(blocks[q][1] + blocks[q][2] == blocks[q + 1][1] for q in range(len(blocks) - 1))
+            ib = torch.zeros((7, n), dtype=torch.uint8, device=dev); iv = torch.zeros((7, n), dtype=torch.float32, device=dev)
+            db = torch.zeros((G4, 3, n), dtype=torch.int32, device=dev); dv = torch.zeros((G4, 3, n, 4), dtype=torch.float32, device=dev)
+            p, _k = native.make_params(n, T, 0x5EED0004, first_index=last["first"], **uncor_indices(pairs[0][1]))
+            native.sample_dbn_blocks_device(ctx, [pr[0] for pr in pairs], p, blocks, init_bin=ib.data_ptr(), init_val=iv.data_ptr(),
+                                            dyn_bin=db.data_ptr(), dyn_val=dv.data_ptr(), ld=n)
+            ctx.sync()
+            got = {"init_bin": int(ib.long().sum()), "dyn_bin": int(db.long().sum()), "init_val_bits": int(iv.view(torch.int32).long().sum())}
+            assert got == rk["digest"], (rk["rank"], got, rk["digest"])
+
+
 def test_bench_launcher_with_eight_ranks(tmp_path):
     """The node layout of SCALE runs, executed on hardware before a driver ever needs it: `python bench.py --gpus 8` as its own launcher --
     eight rank processes (spawned, watched, rank 0's line relayed), here sharing the box's one GPU behind a gloo barrier (--oversubscribe,
@@ -1111,7 +1169,10 @@ def test_fused_terminal_call_at_the_benchmark_shape(terminal_dir):
         v = blk[:, :, 4]
         assert bool((((v >= lim[:, 0][:, None] - 1e-2) & (v <= lim[:, 1][:, None] + 1e-2)) | ~valid).all())
         hdg = blk[:, :, 3]
-        assert bool((((hdg > 0) & (hdg <= 360)) | ~valid).all())
+        # wrapTo360(atan2d(v)) (:176) is in [0, 360) -- 0 itself when the velocity points along +x exactly: a geometry heading within half an f32
+        # step of 360 is stored as 360.0f, cosd / sind(360) are (1, 0) exactly, atan2d(0, v) = 0 (met at this batch size, never on 8 192 tiled
+        # geometries); a value just below 360 rounds to 360.0f on store
+        assert bool((((hdg >= 0) & (hdg <= 360)) | ~valid).all())
         dz = (blk[:, 1:, 2] - blk[:, :-1, 2]).abs()
         assert bool(((dz <= lim[:, 4][:, None] * 1.0001 + 1e-2) | ~(valid[:, 1:] & valid[:, :-1])).all())
         # t = 0 row = the geometry sample (createEncounter.m:41-45): z, heading, speed of aircraft 2e + a
@@ -1162,7 +1223,8 @@ def test_terminal_track_matches_oracle(actypes, n, cap, cum_override, smooth, te
     assert ("k_terminal_smooth" in got["kernel"]) == smooth
     if (ref["attempts"] < 0).any() and n <= 200:
         with pytest.raises(L.EmgpuError) as ei:
-            native.track_terminal_host(gpu_ctx, t.native, [m.native for m in t._traj], n, seed, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap)
+            native.track_terminal_host(gpu_ctx, t.native, [m.native for m in t._traj], n, seed, t._dyn_rows(), cum, pitch, first_index=5, max_track_attempts=cap,
+                                       local_smooth=smooth)
         assert ei.value.code == L.ERR_REJECT_CAP
     assert "k_terminal_filter" in got["kernel"] and "k_terminal_propagate" in got["kernel"]
     same = assert_parting_only_on_a_threshold(got["attempts"], ref["attempts"], ref["margins"], 2.0 ** -22, "encounter")

@@ -894,3 +894,12 @@ def test_host_discretisers_known_answers():
     for ndx in range(1, 25):
         assert F.asub2ind(siz, F.aind2sub(siz, ndx)) == ndx
     assert np.array_equal(F.aind2sub([7], 5), [5])
+
+
+def test_local_smooth_defaults_follow_the_reference_function_each_layer_mirrors():
+    """one rule instead of per-layer habits -- a Python entry point smooths by default exactly when the reference function it
+    mirrors does (createEncounter.m:88-89 is inside createEncounter, hence inside track.m; PropagateTrajectory, :93-265, has no smoothing)."""
+    import inspect
+    d = lambda f: inspect.signature(f).parameters["local_smooth"].default
+    assert d(E.CorTerminalModel.createEncounter) is True and d(E.CorTerminalModel.track) is True and d(native.track_terminal_host) is True
+    assert d(native.propagate_terminal_host) is False and d(native.propagate_terminal_joined_host) is False and d(native.terminal_sample_params) is False
