@@ -176,6 +176,8 @@ __device__ __forceinline__ int t_discretize8(double x, const double *__restrict_
 typedef const uint32_t __attribute__((address_space(1))) *gptr_t;   // a global-memory pointer (the compiler cannot tell from a loaded one)
 typedef uint32_t uint4u_t __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t uint2u_t __attribute__((ext_vector_type(2), aligned(4)));
+typedef float float4u_t __attribute__((ext_vector_type(4), aligned(4)));   // a 20-byte row grid: pieces start on 4-byte boundaries
+typedef float float2u_t __attribute__((ext_vector_type(2), aligned(4)));
 struct Draw3 { int bin[3]; };
 // c8: the compact form of a long row (EmgpuPlan::d_c8off; null: the variable has none): six distinct thresholds + the byte map decide
 // the draw from ONE 32-byte gather; a row with more than six (flag byte) sends its lane down the pivot path
@@ -184,13 +186,22 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         if (has_c8[k]) {                                      // wave-uniform
+#ifdef EMGPU_TERM_ABL_LOADS   // (measurement only: one 16-byte gather per variable instead of 5.3 per step -- what the address unit is worth)
+            const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)c8[k]; uint4u_t b = {0xFFFFFFFFu, 0xFFFFFFFFu, 0x04030201u + (a.x & 0x01010101u), 0x00070605u};
+#else
             const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)c8[k], b = *(const uint4u_t __attribute__((address_space(1))) *)(c8[k] + 4);
+#endif
             first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
             first[k][4] = b.x; first[k][5] = b.y; first[k][6] = b.z; first[k][7] = b.w;
         } else if (rm1[k] <= 8) {                             // wave-uniform
             // eight consecutive words from a 4-byte aligned address: two 16-byte loads
             const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)row[k];
             uint4u_t b = {0u, 0u, 0u, 0u};
+#ifdef EMGPU_TERM_ABL_LOADS
+            if (false) {}
+            else if (rm1[k] > 4) { b.x = 0xFFFFFFFFu; b.y = 0xFFFFFFFFu; }
+            else
+#endif
             if (rm1[k] > 6) b = *(const uint4u_t __attribute__((address_space(1))) *)(row[k] + 4);   // (wave-uniform; masked below either way)
             else if (rm1[k] > 4) { const uint2u_t b2 = *(const uint2u_t __attribute__((address_space(1))) *)(row[k] + 4); b.x = b2.x; b.y = b2.y; }
             first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
@@ -274,9 +285,9 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
 #endif
 constexpr int kRows = EMGPU_TERM_ROWS;        // rows a lane collects in LDS before the wave writes them out as ONE contiguous piece of its track
 constexpr int kLaneStride = 5 * kRows + 1;    // dwords of a lane's staging area (odd: the lanes' rows fall on different banks)
-// the flush packs a piece's source offset (dwords into the wave's staging area) into 11 bits and its length (dwords) into 5 bits of the
-// address's high dword (bits 48-63: device addresses stay below 2^48): a larger EMGPU_TERM_ROWS needs a wider descriptor
-static_assert(64 * kLaneStride <= 2048 && 5 * kRows < 32, "EMGPU_TERM_ROWS: a piece's offset / length no longer fit the flush descriptor (11 + 5 bits)");
+// the flush copies a piece with one dword per lane of a half-wave, and packs its source offset (dwords into the wave's staging area) into
+// 11 bits and its length (dwords) into 5 bits of the address's high dword (bits 48-63: device addresses stay below 2^48)
+static_assert(64 * kLaneStride <= 2048 && 5 * kRows < 32, "EMGPU_TERM_ROWS: a piece no longer fits a half-wave / the flush descriptor (11 + 5 bits)");
 #ifndef EMGPU_TERM_REFILL
 #define EMGPU_TERM_REFILL 8
 #endif
@@ -303,7 +314,8 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     __shared__ double s_bnd[5 * kBndStride];
     __shared__ CutGrid s_grid[5];
     __shared__ double s_cut8[5][8];   // the cut points of a grid with at most 8 of them, padded with +inf
-    __shared__ float s_stage[4][64 * kLaneStride];   // per wave and lane: up to kRows recorded rows (x y z heading speed) waiting to be written
+    __shared__ float s_stage[4 * 64 * kLaneStride + 32];   // per wave and lane: up to kRows recorded rows (x y z heading speed) waiting to be written (+ slack: the flush reads whole 16-byte parts)
+    __shared__ uint2 s_desc[4][64];                        // per wave: the pieces of one flush, in lane order
     __shared__ double2 s_dir[kBndStride];       // (cosd, sind) of the bearing variable's cut points
     __shared__ double s_cut8sq[8];              // squares of the distance variable's cut points (when it has at most 8)
     // Wave-uniform values the loop needs now and then.  Held in scalar registers across the loop they do not fit (the kernel had 97 scalar
@@ -366,7 +378,8 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     }
     __syncthreads();
     const int lane = (int)(threadIdx.x & 63);
-    float *const stage = s_stage[threadIdx.x >> 6];
+    float *const stage = s_stage + (threadIdx.x >> 6) * (64 * kLaneStride);
+    uint2 *const desc = s_desc[threadIdx.x >> 6];
     float *const mine = stage + lane * kLaneStride;
     const uint32_t total = (uint32_t)(4 * A.n);
     // the aircraft's limits are picked from the kernel arguments where they are used (kept per lane they cost ten registers)
@@ -553,13 +566,14 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
             // ---- one attempt at the step's transition draw (attempt number in the Philox key)
             if (att >= A.max_resample) { failed = true; done = true; break; }
             rng.attempt = (L & 3u) + 4u * (uint32_t)att;
-            uint32_t xw[3];
+            uint32_t xw[3], spare;
             {   // block = the step, word = the variable's row of the temporal map: one Philox call for the three draws
                 // (the round keys are scalar adds at the call, not 14 registers kept for the loop)
                 { uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32); asm volatile("" : "+s"(k0), "+s"(k1)); rng.k0 = k0; rng.k1 = k1; }
                 const uint4 tw = rng.block(11u /* TERM_TRANS */, 0u, (uint32_t)ii);
 #pragma unroll
                 for (int k = 0; k < 3; k++) xw[k] = word_of(tw, drow[k]);
+                spare = tw.w;   // (the temporal map has three rows: words 0-2)
             }
             gptr_t row[3], piv[3], c8[3];
 #pragma unroll
@@ -568,47 +582,61 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 piv[k] = (rm1[k] > 8 && rm1[k] <= 48) ? thr + (P.d_pivoff[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;   // wave-uniform
                 c8[k] = has_c8[k] ? thr + (P.d_c8off[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;
             }
+#ifdef EMGPU_TERM_ABL_NOEVENTS   // (measurement only: every draw "stays": no event, no re-draw, no turn)
+            Draw3 nb3 = t_draw3(row, piv, c8, has_c8, rm1, xw);
+            if (nb3.bin[0] != 999) { nb3.bin[kh] = st[3] + 1; nb3.bin[ka] = st[4] + 1; nb3.bin[ks] = st[5] + 1; }
+#else
             const Draw3 nb3 = t_draw3(row, piv, c8, has_c8, rm1, xw);
+#endif
             // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude
             // or speed bin makes the step be drawn again -- the events applied before it stay applied, as in the reference's loop
             bool resample = false;
             const int dH = kh == 0 ? nb3.bin[0] : (kh == 1 ? nb3.bin[1] : nb3.bin[2]), dA = ka == 0 ? nb3.bin[0] : (ka == 1 ? nb3.bin[1] : nb3.bin[2]),
                       dS = ks == 0 ? nb3.bin[0] : (ks == 1 ? nb3.bin[1] : nb3.bin[2]);
-            uint4 dw = make_uint4(0u, 0u, 0u, 0u);   // the step's dediscretize draws (one Philox call, made by the lanes that have an event)
             TCNT(3, dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1); TCNT(4, dH != st[3] + 1); TCNT(5, dA != st[4] + 1); TCNT(6, dS != st[5] + 1);
 #ifdef EMGPU_TERM_COUNTERS
             if (__ballot(dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1)) TCNT1(15);
             if (__ballot(dS != st[5] + 1)) TCNT1(18);
 #endif
-            { uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32); asm volatile("" : "+s"(k0), "+s"(k1)); rng.k0 = k0; rng.k1 = k1; }
-            if (dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1) dw = rng.block(12u /* TERM_DEDISC */, 0u, (uint32_t)ii);
-            if (dH != st[3] + 1) {
-                heading_deg = t_dedisc(s_bnd + 2 * kBndStride, dH, word_of(dw, kh == 0 ? drow[0] : (kh == 1 ? drow[1] : drow[2])));
+            // The step's dediscretize draws (slot map, round 5).  The FIRST one an attempt makes is the fourth word of the TERM_TRANS block the
+            // attempt has in hand (words 0-2 are the three transition draws); only a lane with a SECOND one -- two events in one step, 0.5 % of
+            // the steps -- calls Philox again (TERM_DEDISC, the variable's own word, as before).  Round 4 made that second call for every lane
+            // with an event: 93 % of the wave-iterations ran it (measured without it: -4.3 %).
+            const bool evH = dH != st[3] + 1, evA = dA != st[4] + 1, evS = dS != st[5] + 1;
+            // MATLAB: 1:[] is empty, so with no boundary at or below the limit no altitude event is valid; []:1:e likewise for the speed
+            const int alt_last = U(alt_last[ac]);
+            const bool okA = evA && alt_last >= 1 && dA >= 1 && dA <= alt_last;
+            resample = evA && !okA;
+            const int spd_first = U(spd_first[ac]), spd_last = U(spd_last[ac]);
+            const bool tryS = !resample && evS;
+            const bool okS = tryS && spd_first >= 1 && dS >= spd_first && dS <= spd_last;
+            resample = resample || (tryS && !okS);
+            uint4 dw = make_uint4(0u, 0u, 0u, 0u);
+            if ((int)evH + (int)okA + (int)okS >= 2) {
+                { uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32); asm volatile("" : "+s"(k0), "+s"(k1)); rng.k0 = k0; rng.k1 = k1; }
+                dw = rng.block(12u /* TERM_DEDISC */, 0u, (uint32_t)ii);
+                TCNT(21, true);
+            }
+            if (evH) {
+                heading_deg = t_dedisc(s_bnd + 2 * kBndStride, dH, spare);
                 const int b = t_in_bin(s_bnd + 2 * kBndStride, (int)P.i_nb[3], dH, heading_deg) ? dH : t_discretize(heading_deg, s_bnd, s_grid[2]);
                 pend = (pend & 0xFFFFFF00u) | (uint32_t)(b - 1);
             }
-            if (dA != st[4] + 1) {
-                // MATLAB: 1:[] is empty, so with no boundary at or below the limit no altitude event is valid
-                const int alt_last = U(alt_last[ac]);
-                if (alt_last >= 1 && dA >= 1 && dA <= alt_last) {
-                    z_ft = t_dedisc(s_bnd + 3 * kBndStride, dA, word_of(dw, ka == 0 ? drow[0] : (ka == 1 ? drow[1] : drow[2])));
-                    const int b = t_in_bin(s_bnd + 3 * kBndStride, (int)P.i_nb[4], dA, z_ft) ? dA : t_discretize(z_ft, s_bnd, s_grid[3]);
-                    pend = (pend & 0xFFFF00FFu) | ((uint32_t)(b - 1) << 8);
-                } else resample = true;
+            if (okA) {
+                z_ft = t_dedisc(s_bnd + 3 * kBndStride, dA, evH ? word_of(dw, ka == 0 ? drow[0] : (ka == 1 ? drow[1] : drow[2])) : spare);
+                const int b = t_in_bin(s_bnd + 3 * kBndStride, (int)P.i_nb[4], dA, z_ft) ? dA : t_discretize(z_ft, s_bnd, s_grid[3]);
+                pend = (pend & 0xFFFF00FFu) | ((uint32_t)(b - 1) << 8);
             }
-            if (!resample && dS != st[5] + 1) {
-                const int spd_first = U(spd_first[ac]), spd_last = U(spd_last[ac]);
-                if (spd_first >= 1 && dS >= spd_first && dS <= spd_last) {
-                    double s1 = t_dedisc(s_bnd + 4 * kBndStride, dS, word_of(dw, ks == 0 ? drow[0] : (ks == 1 ? drow[1] : drow[2])));
-                    const double minVel = T_LIM(0), maxVel = T_LIM(1);
-                    const bool inside = !(s1 < minVel) && !(s1 > maxVel) && t_in_bin(s_bnd + 4 * kBndStride, (int)P.i_nb[5], dS, s1);
-                    if (s1 < minVel) s1 = minVel;
-                    if (s1 > maxVel) s1 = maxVel;
-                    const int b = inside ? dS : t_discretize(s1, s_bnd, s_grid[4]);   // (a clamped speed may have left its bin)
-                    pend = (pend & 0x0000FFFFu) | ((uint32_t)(b - 1) << 16);
-                    vang = heading_deg; vdirty = true;     // v = rotationmatrix(heading_deg) * [s1; 0]  (:246-247)
-                    speed = s1;
-                } else resample = true;
+            if (okS) {
+                double s1 = t_dedisc(s_bnd + 4 * kBndStride, dS, (evH || okA) ? word_of(dw, ks == 0 ? drow[0] : (ks == 1 ? drow[1] : drow[2])) : spare);
+                const double minVel = T_LIM(0), maxVel = T_LIM(1);
+                const bool inside = !(s1 < minVel) && !(s1 > maxVel) && t_in_bin(s_bnd + 4 * kBndStride, (int)P.i_nb[5], dS, s1);
+                if (s1 < minVel) s1 = minVel;
+                if (s1 > maxVel) s1 = maxVel;
+                const int b = inside ? dS : t_discretize(s1, s_bnd, s_grid[4]);   // (a clamped speed may have left its bin)
+                pend = (pend & 0x0000FFFFu) | ((uint32_t)(b - 1) << 16);
+                vang = heading_deg; vdirty = true;     // v = rotationmatrix(heading_deg) * [s1; 0]  (:246-247)
+                speed = s1;
             }
 #ifdef EMGPU_TERM_COUNTERS
             if (__ballot(resample)) TCNT1(17);
@@ -635,38 +663,73 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
         }
         // ---- staged rows leave for memory: a lane whose staging area is full, or whose track has just ended, hands its rows to the wave,
         // which writes them as one contiguous piece (lane j = dword j of the piece)
+#ifdef EMGPU_TERM_ABL_NOFLUSH   // (measurement only: rows are staged and dropped)
+        const bool fl = false;
+        if (cnt == kRows || done) cnt = 0;
+#else
         const bool fl = cnt == kRows || (done && cnt > 0);
-        uint64_t fm = __ballot(fl);
+#endif
+        const uint64_t fm = __ballot(fl);
         if (fm != 0ull) {
-            uint32_t dlo = 0u, dhi = 0u;   // the piece's address; bits 48-63: its source in the staging area (11 bits: dword) and its length (5 bits: dwords)
+            // Round 5: FOUR PIECES PER TRIP.  Round 4 walked the flagged lanes one by one (find the lane, read its descriptor into scalar
+            // registers, 30 lanes copy its piece a dword each: 9.2 trips per wave-iteration, each a scalar dependency chain through an LDS
+            // round trip -- measured: 23 % of the kernel's time, none of it the stores themselves).  Now the flagged lanes put their
+            // descriptors into a small table in lane order and the wave copies four pieces per trip: each half-wave serves two, lane i of
+            // the half = dword i of the piece, both pieces' reads in flight together.  The stores stay what the memory system takes for free:
+            // 4 bytes per lane, a piece's lanes contiguous (measured on the way: sixteen pieces per pass as 16-byte parts, four lanes per
+            // piece -- non-temporal 20.2 ms per 2 M encounters, plain stores 16.8, the pass without its stores 14.3; round 4's loop 17.5).
             if (fl) {
                 // rows [rows - cnt, rows) of this direction: the piece starts at the joined track's row C + (rows - cnt) (forward) or
                 // C - (rows - 1) (backward)
                 const size_t r0 = (size_t)(bck ? C - (rows - 1) : C + (rows - cnt));
                 const uint64_t dst = (uint64_t)(A.traj + ((size_t)(L >> 1) * Wrows + r0) * 5);
-                dlo = (uint32_t)dst;
-                dhi = (uint32_t)(dst >> 32) | ((uint32_t)(lane * kLaneStride + (bck ? 5 * (kRows - cnt) : 0)) << 16) | ((uint32_t)(5 * cnt) << 27);
+                // the piece's address; bits 48-63: its source in the staging area (11 bits: dword) and its length (5 bits: dwords)
+                // (measured and dropped: 16-byte descriptors with the address carried from piece to piece -- fewer instructions, +4 % time)
+                const uint32_t dhi = (uint32_t)(dst >> 32) | ((uint32_t)(lane * kLaneStride + (bck ? 5 * (kRows - cnt) : 0)) << 16) | ((uint32_t)(5 * cnt) << 27);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                desc[rank] = make_uint2((uint32_t)dst, dhi);
                 cnt = 0;
             }
             __builtin_amdgcn_wave_barrier();
-            do {
-                TCNT1(9);
-                const int l = (int)__builtin_ctzll(fm);
-                fm &= fm - 1ull;
-                const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)dlo, l), shi = (uint32_t)__builtin_amdgcn_readlane((int)dhi, l);
-                const uint32_t sm = ((shi >> 16) & 0x7FFu) | ((shi >> 27) << 16);
-                float *d = (float *)(((uint64_t)(shi & 0xFFFFu) << 32) | slo);
-#if defined(EMGPU_TERM_NOSTORE)
-                if (lane < (int)(sm >> 16) && stage[(sm & 0xFFFFu) + lane] == 1.2345e-30f) d[lane] = 0.f;   // (measurement only: the loop without its stores)
-#elif defined(EMGPU_TERM_PLAIN_STORES)
-                if (lane < (int)(sm >> 16)) d[lane] = stage[(sm & 0xFFFFu) + lane];
-#else
-                // nontemporal: a piece is a part of a line that nobody reads back here; written through L2 as ordinary stores the 260 000
-                // half-written lines of the lanes in flight crowd the trajectory tables out of it (measured: table fetches 13 -> 30 GB per
-                // 2 M encounters, +3 % run time)
-                if (lane < (int)(sm >> 16)) __builtin_nontemporal_store(stage[(sm & 0xFFFFu) + lane], &d[lane]);
+            const int np = __popcll(fm);
+            const int half = lane >> 5, li = lane & 31;
+            typedef float __attribute__((address_space(1))) gf_t;   // (global, not flat: the address is assembled from integers)
+#ifndef EMGPU_TERM_FLUSH_SLOTS
+#define EMGPU_TERM_FLUSH_SLOTS 4
 #endif
-            } while (fm != 0ull);
+            constexpr int kSlots = EMGPU_TERM_FLUSH_SLOTS;   // pieces per half-wave and trip
+            for (int base = 0; base < np; base += 2 * kSlots) {
+                TCNT1(9);
+                uint2 d[kSlots];
+                float v[kSlots];
+                bool w[kSlots];
+#pragma unroll
+                for (int s_ = 0; s_ < kSlots; s_++) {
+                    const int pp = base + 2 * s_ + half;
+                    d[s_] = make_uint2(0u, 0u);   // (length 0: nothing to copy)
+                    if (pp < np) d[s_] = desc[pp];
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < kSlots; s_++) {
+                    w[s_] = li < (int)(d[s_].y >> 27);
+                    v[s_] = 0.f;
+                    if (w[s_]) v[s_] = stage[((d[s_].y >> 16) & 0x7FFu) + li];
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < kSlots; s_++) {
+                    gf_t *q = (gf_t *)(((uint64_t)(d[s_].y & 0xFFFFu) << 32) | d[s_].x) + li;
+#if defined(EMGPU_TERM_NOSTORE)
+                    if (w[s_] && v[s_] == 1.2345e-30f) *q = v[s_];   // (measurement only: the trips without their stores)
+#elif defined(EMGPU_TERM_PLAIN_STORES)
+                    if (w[s_]) *q = v[s_];
+#else
+                    // nontemporal: a piece is a part of a line that nobody reads back here; written through L2 as ordinary stores the 260 000
+                    // half-written lines of the lanes in flight crowd the trajectory tables out of it (round 4, measured: table fetches 13 -> 30 GB
+                    // per 2 M encounters, +3 % run time)
+                    if (w[s_]) __builtin_nontemporal_store(v[s_], q);
+#endif
+                }
+            }
             __builtin_amdgcn_wave_barrier();
         }
     }

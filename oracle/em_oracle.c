@@ -948,6 +948,12 @@ int em_propagate_trajectory(const em_model_t *m, em_rng_t *g, int role, int is_o
                 newbin[k] = em_select_random_r(w, r, em_rand(g, EM_SEC_TERM_TRANS, 0u, 4u * (uint32_t)ii + (uint32_t)k));
             }
             is_resample = 0;
+            /* The dediscretize draws of one attempt (Philox slot map, round 5): the FIRST one made takes the fourth word of the attempt's
+             * TERM_TRANS block (the block's words 0-2 are the three transition draws; word 3 was unused), any further one -- two events in one
+             * step: 0.5 % of the steps -- its own word of the TERM_DEDISC block as before.  One Philox call per attempt for almost every step
+             * instead of two.  (MT19937 mode draws sequentially and does not notice.) */
+            int n_dedisc = 0;
+#define EM_TERM_DEDISC_RAND(k_) ((n_dedisc++ == 0) ? em_rand(g, EM_SEC_TERM_TRANS, 0u, 4u * (uint32_t)ii + 3u) : em_rand(g, EM_SEC_TERM_DEDISC, 0u, 4u * (uint32_t)ii + (uint32_t)(k_)))
             /* events rows in ascending variable id: 4 heading, 5 altitude, 6 speed (:198-238) */
             for (int k = 0; k < 3 && !is_resample; k++) {
                 const int var = m->temporal_map[2 * k];
@@ -955,17 +961,17 @@ int em_propagate_trajectory(const em_model_t *m, em_rng_t *g, int role, int is_o
                 const int d = newbin[k];
                 if (var == IDX_HEAD) {
                     if (d != heading_discrete) {
-                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, 0u, 4u * (uint32_t)ii + (uint32_t)k);
+                        const double u = EM_TERM_DEDISC_RAND(k);
                         heading_deg = bnd[var][d - 1] + (bnd[var][d] - bnd[var][d - 1]) * u;
                     }
                 } else if (var == IDX_ALT) {
                     if (alt_last >= 1 && d >= 1 && d <= alt_last) {      /* 1:[] is empty in MATLAB */
-                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, 0u, 4u * (uint32_t)ii + (uint32_t)k);
+                        const double u = EM_TERM_DEDISC_RAND(k);
                         z_ft = bnd[var][d - 1] + (bnd[var][d] - bnd[var][d - 1]) * u;
                     } else is_resample = 1;
                 } else if (var == IDX_SPD) {
                     if (spd_first >= 1 && d >= spd_first && d <= spd_last) { /* []:1:e is empty: no speed event is ever valid */
-                        const double u = em_rand(g, EM_SEC_TERM_DEDISC, 0u, 4u * (uint32_t)ii + (uint32_t)k);
+                        const double u = EM_TERM_DEDISC_RAND(k);
                         double s1 = bnd[var][d - 1] + (bnd[var][d] - bnd[var][d - 1]) * u;
                         if (s1 < dl->minVel_ft_s) s1 = dl->minVel_ft_s;
                         if (s1 > dl->maxVel_ft_s) s1 = dl->maxVel_ft_s;
@@ -975,6 +981,7 @@ int em_propagate_trajectory(const em_model_t *m, em_rng_t *g, int role, int is_o
                 }
             }
         }
+#undef EM_TERM_DEDISC_RAND
         /* turn toward the desired heading at no more than maxTurnRate (:241-256) */
         const double turn1 = em_round2(heading_deg - curr_hdg_deg);
         const double delta = fmin(fabs(turn1), dl->maxTurnRate_deg_s) * em_sign(turn1);

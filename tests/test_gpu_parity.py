@@ -1563,7 +1563,7 @@ got, rows = native.propagate_terminal_host(ctx, [m.native for m in t._traj], geo
 assert ctx.last_kernel() == "k_terminal_propagate", ctx.last_kernel()
 assert np.array_equal(rows, ref_rows)
 for L_ in range(4 * n):
-    assert_f32_of_f64(got[L_, :rows[L_]], ref[L_, :rows[L_]], "track %d" % L_)
+    assert_f32_of_f64(got[L_, :rows[L_]], ref[L_, :rows[L_]], "track " + str(L_))
 print("generic ok")
 ''' % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"), os.path.join(ROOT_DIR, "oracle"), str(terminal_dir))
     env = dict(os.environ, EMGPU_DEBUG_TERM_GENERIC="1")
