@@ -293,6 +293,16 @@ static_assert(64 * kLaneStride <= 2048 && 5 * kRows < 32, "EMGPU_TERM_ROWS: a pi
 #endif
 constexpr int kRefillMin = EMGPU_TERM_REFILL; // idle lanes a wave collects before it spends the (divergent) track set-up on them
 constexpr uint32_t kChunk = 128;              // tracks a wave takes from the launch's queue at a time (>= 64)
+// THE WAVE-LEVEL EVENT QUEUE (round 5; VERDICT r4 next #3: "build it this time").  -DEMGPU_TERM_EVQ=N: a lane whose draw produced an event
+// (createEncounter.m:196-243) does not run the event code at once -- it parks with its three drawn bins, takes no part in the following
+// wave-iterations, and the event code runs ONCE for all parked lanes when N of them have collected (or when no lane of the wave can do
+// anything else).  The event code then runs on >= N lanes instead of ~12 and in fewer wave-iterations; the price is the parked lanes'
+// idle iterations.  Measured (profiles/r05_terminal_event_queue.txt; parity green at every N): it does not pay -- 15.7 ms per 2 M
+// encounters without it, 16.1 / 16.6 / 17.2 ms at N = 8 / 16 / 24 -- so 0 (off) is the default and compiles the straight-line step.
+#ifndef EMGPU_TERM_EVQ
+#define EMGPU_TERM_EVQ 0
+#endif
+constexpr int kEvq = EMGPU_TERM_EVQ;
 
 // RM1_k: thresholds per row of dynamic variable k as a compile-time constant (0: read from the plan).  The instance built for the
 // terminal model's shape (36 headings, 7 altitude and 5 speed bins) folds every "is this index inside the row" test; left to run
@@ -441,6 +451,10 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     double sh, chh;
     int ii = 1, rows = 0, cnt = 0;  // rows: recorded so far; cnt: of them staged in LDS, not yet written
     int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
+#if EMGPU_TERM_EVQ > 0
+    bool parked = false;                   // (event queue) the lane holds drawn bins whose events are yet to be applied
+    uint32_t held = 0u, held_spare = 0u;   // (event queue) dH | dA << 8 | dS << 16, and the attempt's spare uniform
+#endif
     uint32_t colk[3] = {0u, 0u, 0u};   // the step's CPT columns; the row addresses are formed at the draw (nine 64-bit pointers kept per lane cost 18 registers)
 #ifdef EMGPU_TERM_COUNTERS
     unsigned long long dbg[24];
@@ -482,7 +496,11 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                     rng.c0 = (uint32_t)gidx; rng.c1 = (uint32_t)(gidx >> 32);
                     const double *g = U(geo) + (size_t)e * 12 + ac * 6;
                     intent = (int)g[5];
+#ifdef EMGPU_TERM_ABL_ONEMODEL   // (measurement only: every track reads ONE model's tables -- what the tables' cache footprint costs)
+                    thr = (gptr_t)U(thr_base)[U(model_of)[L] & 0];
+#else
                     thr = (gptr_t)U(thr_base)[U(model_of)[L]];
+#endif
                     xy0 = g[0]; xy1 = g[1]; z_ft = g[2]; heading_deg = g[4]; prev_z_rec = 0;
                     speed = g[3];   // norm(v_ft_s), carried: the velocity is only ever speed * (cosd, sind) of a direction (its norm to 1e-16)
                     // The velocity is (speed, direction): it is only ever set to speed * (cosd, sind)(heading) (:96, :238-247) and rotated by the
@@ -492,6 +510,9 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                     // (v = 0 would give atan2d = 0: speeds are clamped to minVel > 0.)
                     vang = heading_deg; vdirty = true; fresh = true;
                     ii = 1; rows = 0; cnt = 0; att = 0; failed = false;
+#if EMGPU_TERM_EVQ > 0
+                    parked = false;
+#endif
                     active = true;
                     TCNT(11, true);
                 }
@@ -506,6 +527,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
         // step) comes round again with att + 1 while its neighbours start their next step
         bool done = false;
         const bool bck = dt_s < 0.0;
+#if EMGPU_TERM_EVQ == 0
         if (active) do {
             if (att == 0) {
                 // ---- the step begins: record the state, move, discretize (createEncounter.m:156-200)
@@ -593,69 +615,124 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
             bool resample = false;
             const int dH = kh == 0 ? nb3.bin[0] : (kh == 1 ? nb3.bin[1] : nb3.bin[2]), dA = ka == 0 ? nb3.bin[0] : (ka == 1 ? nb3.bin[1] : nb3.bin[2]),
                       dS = ks == 0 ? nb3.bin[0] : (ks == 1 ? nb3.bin[1] : nb3.bin[2]);
-            TCNT(3, dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1); TCNT(4, dH != st[3] + 1); TCNT(5, dA != st[4] + 1); TCNT(6, dS != st[5] + 1);
-#ifdef EMGPU_TERM_COUNTERS
-            if (__ballot(dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1)) TCNT1(15);
-            if (__ballot(dS != st[5] + 1)) TCNT1(18);
-#endif
-            // The step's dediscretize draws (slot map, round 5).  The FIRST one an attempt makes is the fourth word of the TERM_TRANS block the
-            // attempt has in hand (words 0-2 are the three transition draws); only a lane with a SECOND one -- two events in one step, 0.5 % of
-            // the steps -- calls Philox again (TERM_DEDISC, the variable's own word, as before).  Round 4 made that second call for every lane
-            // with an event: 93 % of the wave-iterations ran it (measured without it: -4.3 %).
-            const bool evH = dH != st[3] + 1, evA = dA != st[4] + 1, evS = dS != st[5] + 1;
-            // MATLAB: 1:[] is empty, so with no boundary at or below the limit no altitude event is valid; []:1:e likewise for the speed
-            const int alt_last = U(alt_last[ac]);
-            const bool okA = evA && alt_last >= 1 && dA >= 1 && dA <= alt_last;
-            resample = evA && !okA;
-            const int spd_first = U(spd_first[ac]), spd_last = U(spd_last[ac]);
-            const bool tryS = !resample && evS;
-            const bool okS = tryS && spd_first >= 1 && dS >= spd_first && dS <= spd_last;
-            resample = resample || (tryS && !okS);
-            uint4 dw = make_uint4(0u, 0u, 0u, 0u);
-            if ((int)evH + (int)okA + (int)okS >= 2) {
-                { uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32); asm volatile("" : "+s"(k0), "+s"(k1)); rng.k0 = k0; rng.k1 = k1; }
-                dw = rng.block(12u /* TERM_DEDISC */, 0u, (uint32_t)ii);
-                TCNT(21, true);
-            }
-            if (evH) {
-                heading_deg = t_dedisc(s_bnd + 2 * kBndStride, dH, spare);
-                const int b = t_in_bin(s_bnd + 2 * kBndStride, (int)P.i_nb[3], dH, heading_deg) ? dH : t_discretize(heading_deg, s_bnd, s_grid[2]);
-                pend = (pend & 0xFFFFFF00u) | (uint32_t)(b - 1);
-            }
-            if (okA) {
-                z_ft = t_dedisc(s_bnd + 3 * kBndStride, dA, evH ? word_of(dw, ka == 0 ? drow[0] : (ka == 1 ? drow[1] : drow[2])) : spare);
-                const int b = t_in_bin(s_bnd + 3 * kBndStride, (int)P.i_nb[4], dA, z_ft) ? dA : t_discretize(z_ft, s_bnd, s_grid[3]);
-                pend = (pend & 0xFFFF00FFu) | ((uint32_t)(b - 1) << 8);
-            }
-            if (okS) {
-                double s1 = t_dedisc(s_bnd + 4 * kBndStride, dS, (evH || okA) ? word_of(dw, ks == 0 ? drow[0] : (ks == 1 ? drow[1] : drow[2])) : spare);
-                const double minVel = T_LIM(0), maxVel = T_LIM(1);
-                const bool inside = !(s1 < minVel) && !(s1 > maxVel) && t_in_bin(s_bnd + 4 * kBndStride, (int)P.i_nb[5], dS, s1);
-                if (s1 < minVel) s1 = minVel;
-                if (s1 > maxVel) s1 = maxVel;
-                const int b = inside ? dS : t_discretize(s1, s_bnd, s_grid[4]);   // (a clamped speed may have left its bin)
-                pend = (pend & 0x0000FFFFu) | ((uint32_t)(b - 1) << 16);
-                vang = heading_deg; vdirty = true;     // v = rotationmatrix(heading_deg) * [s1; 0]  (:246-247)
-                speed = s1;
-            }
-#ifdef EMGPU_TERM_COUNTERS
-            if (__ballot(resample)) TCNT1(17);
-            TCNT(19, resample);
-#endif
+#include "emgpu_term_events.h"
             if (resample) { att++; break; }
-            att = 0;
-            // ---- the step ends: turn towards the new heading, advance the clock, stop conditions
-            const double turn1 = round((heading_deg - curr_hdg) * t_k(100.0)) * t_k(0.01);
-            const double delta = fmin(fabs(turn1), T_LIMS(2)) * t_sign(turn1);
-            TCNT(8, delta != 0.0);
-#ifdef EMGPU_TERM_COUNTERS
-            if (__ballot(delta != 0.0)) TCNT1(16);
-#endif
-            if (delta != 0.0) { vang += delta; vdirty = true; }  // v = rotationmatrix(delta) * v  (:262; rotationmatrix(0) is the identity)
-            ii++;
-            const double d2_nm = xy0 * xy0 + xy1 * xy1;   // (the position has not moved since the step began: recomputed, not carried)
-            done = ((double)(ii - 1) > A.tmax_s) || (d2_nm > dist_hi2) || ((intent == 1 || intent == 2) && d2_nm <= 0.0625) || (ac == 0 && xy1 > 0.25);
+#include "emgpu_term_endstep.h"
         } while (false);
+#else
+        // ---- THE WAVE-LEVEL EVENT QUEUE: a lane whose draw produced an event parks; the event code runs for all parked lanes at once
+        bool to_end = false;            // the lane's step reaches its end in this wave-iteration (no event, or its events were applied and accepted)
+        int dH = 0, dA = 0, dS = 0;
+        uint32_t spare = 0u;
+        if (active && !parked) do {
+            if (att == 0) {
+                // ---- the step begins: record the state, move, discretize (createEncounter.m:156-200)
+                if (rows >= A.cap) { failed = true; done = true; break; }
+                if (vdirty) {
+                    t_sincosd(vang, sh, chh);
+                    v0 = chh * speed; v1 = sh * speed;
+                    vdirty = false;
+                }
+                // forward lanes fill their staging area upwards, backward lanes downwards: either way it holds ascending rows of the
+                // joined track; the backward track's row 0 is the forward track's (bck(1, 2:end), createEncounter.m:77) and is not kept
+                float *rec = mine + 5 * (bck ? kRows - 1 - cnt : cnt);
+                rec[0] = (float)xy0; rec[1] = (float)xy1; rec[4] = (float)speed;
+                xy0 += (v0 * dt_s) * t_k(1.0 / 6076.1154855643);
+                xy1 += (v1 * dt_s) * t_k(1.0 / 6076.1154855643);
+                curr_hdg = (speed > 0.0) ? t_mod360(vang) : 0.0;
+                double rec_z = z_ft;
+                if (ii > 1) {
+                    const double alt_diff = z_ft - prev_z_rec;
+                    rec_z = prev_z_rec + t_sign(alt_diff) * fmin(T_LIMS(4), fabs(alt_diff));
+                }
+                prev_z_rec = rec_z;
+                rec[2] = (float)rec_z; rec[3] = (float)curr_hdg;
+                cnt += (bck && rows == 0) ? 0 : 1;
+                rows++;
+                // CreateStartDistribution (0-based bins), createEncounter.m:268-294
+                const double d2_nm = xy0 * xy0 + xy1 * xy1;
+                st[0] = intent - 1;
+                st[1] = (dist8 ? t_discretize8(d2_nm, s_cut8sq) : t_discretize(sqrt(d2_nm), s_bnd, gDist)) - 1;     // wave-uniform choices
+                int kb0 = st[2];
+                if (fresh) {   // a track's first step: the full discretize (once); from then on events keep `pend` and the bearing is walked
+                    const CutGrid gB = s_grid[1];
+                    kb0 = t_bearing_bin(xy0, xy1, s_bnd + gB.off + 1, s_dir, gB.n, gB.lo, gB.inv_step) - 1;
+                    pend = (uint32_t)(t_discretize(heading_deg, s_bnd, s_grid[2]) - 1) | ((uint32_t)(t_discretize(z_ft, s_bnd, s_grid[3]) - 1) << 8) |
+                           ((uint32_t)(t_discretize(speed, s_bnd, s_grid[4]) - 1) << 16);
+                    fresh = false;
+                }
+                st[2] = t_bearing_walk(xy0, xy1, s_bnd + kBndStride + 1, s_dir, bear_n, bear_kA, bear_kB, kb0) - 1;
+                st[3] = (int)(pend & 0xFFu); st[4] = (int)((pend >> 8) & 0xFFu); st[5] = (int)(pend >> 16);   // (speed: norm(v_ft_s) is `speed`)
+                // CPT column of each dynamic variable (asub2ind.m:13-14 as strides); topological position == variable id
+                uint32_t cstr[3][6];
+                {
+                    int z = 0;
+                    asm volatile("" : "+v"(z));   // (keeps these loads inside the loop: hoisted they would be 18 registers for its whole length)
+#pragma unroll
+                    for (int q = 0; q < 18; q++) cstr[q / 6][q % 6] = s_cstr[z + q];
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    uint32_t c = 0u;
+#pragma unroll
+                    for (int p = 0; p < 6; p++)   // st[0]: the intent, which never changes
+                        c = kShipped ? __umul24(cstr[k][p], (uint32_t)st[p]) + c   // one v_mad_u32_u24 (launch_terminal_propagate checks the strides fit 24 bits)
+                                     : cstr[k][p] * (uint32_t)st[p] + c;
+                    colk[k] = c;
+                }
+            }
+            // ---- one attempt at the step's transition draw (attempt number in the Philox key)
+            if (att >= A.max_resample) { failed = true; done = true; break; }
+            rng.attempt = (L & 3u) + 4u * (uint32_t)att;
+            uint32_t xw[3];
+            {   // block = the step, word = the variable's row of the temporal map: one Philox call for the three draws
+                // (the round keys are scalar adds at the call, not 14 registers kept for the loop)
+                { uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32); asm volatile("" : "+s"(k0), "+s"(k1)); rng.k0 = k0; rng.k1 = k1; }
+                const uint4 tw = rng.block(11u /* TERM_TRANS */, 0u, (uint32_t)ii);
+#pragma unroll
+                for (int k = 0; k < 3; k++) xw[k] = word_of(tw, drow[k]);
+                spare = tw.w;   // (the temporal map has three rows: words 0-2)
+            }
+            gptr_t row[3], piv[3], c8[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                row[k] = thr + (P.d_off[k] - P.d_off[0]) + (size_t)colk[k] * (uint32_t)rm1[k];
+                piv[k] = (rm1[k] > 8 && rm1[k] <= 48) ? thr + (P.d_pivoff[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;   // wave-uniform
+                c8[k] = has_c8[k] ? thr + (P.d_c8off[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;
+            }
+#ifdef EMGPU_TERM_ABL_NOEVENTS   // (measurement only: every draw "stays": no event, no re-draw, no turn)
+            Draw3 nb3 = t_draw3(row, piv, c8, has_c8, rm1, xw);
+            if (nb3.bin[0] != 999) { nb3.bin[kh] = st[3] + 1; nb3.bin[ka] = st[4] + 1; nb3.bin[ks] = st[5] + 1; }
+#else
+            const Draw3 nb3 = t_draw3(row, piv, c8, has_c8, rm1, xw);
+#endif
+            // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude
+            // or speed bin makes the step be drawn again -- the events applied before it stay applied, as in the reference's loop
+            dH = kh == 0 ? nb3.bin[0] : (kh == 1 ? nb3.bin[1] : nb3.bin[2]); dA = ka == 0 ? nb3.bin[0] : (ka == 1 ? nb3.bin[1] : nb3.bin[2]);
+            dS = ks == 0 ? nb3.bin[0] : (ks == 1 ? nb3.bin[1] : nb3.bin[2]);
+            if (dH == st[3] + 1 && dA == st[4] + 1 && dS == st[5] + 1) to_end = true;   // no event: the step ends here
+            else { parked = true; held = (uint32_t)dH | ((uint32_t)dA << 8) | ((uint32_t)dS << 16); held_spare = spare; }
+        } while (false);
+        {
+            const int n_parked = __popcll(__ballot(parked)), n_active = __popcll(__ballot(active));
+            const bool run_events = n_parked >= kEvq || n_parked == n_active;   // enough lanes have collected, or nobody else can run
+            TCNT(22, parked);
+#ifdef EMGPU_TERM_COUNTERS
+            if (run_events && n_parked > 0) TCNT1(23);
+#endif
+            if (parked && run_events) do {
+                dH = (int)(held & 0xFFu); dA = (int)((held >> 8) & 0xFFu); dS = (int)(held >> 16); spare = held_spare;
+                parked = false;
+                bool resample = false;
+#include "emgpu_term_events.h"
+                if (resample) { att++; break; }
+                to_end = true;
+            } while (false);
+        }
+        if (to_end) {
+#include "emgpu_term_endstep.h"
+        }
+#endif
         if (done) {
             if (failed && !U(quiet)) atomicOr(U(status), 1u);
             U(rows)[L] = failed ? -rows - 1 : rows;
