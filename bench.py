@@ -561,7 +561,7 @@ class GpuTelemetry:
     """Shader clock and socket power of this rank's GPU under the benchmark's own back-to-back launches (an untimed run AFTER the timed region), read from amdgpu's hwmon files in sysfs (freq1_input =
     sclk in Hz, power1_input = package power in microwatts: 0.03 ms per read, no profiler, no privileges) by a thread that samples every
     2 ms.  The benchmark kernel runs at the board's power limit; how far a box lets the clock drop there differs from box to box by up to
-    20 %: with the clock in the line a reader can tell a slow box from a regression."""
+    20 % (HISTORY.md section 7): with the clock in the line a reader can tell a slow box from a regression."""
 
     def __init__(self, local_index=0, pci=None, sysfs_root="/sys"):
         """`pci` = "dddd:bb:dd.f" of the device this rank computes on: a box may list more cards in sysfs than the process can see
@@ -736,7 +736,7 @@ def measure(w, pl, args, warmup, steps, settle_max=0):
 
 
 def box_state(tel):
-    """"fast" / "slow" by the telemetry rule of DESIGN.md section 7 (round 4: one and the same box spends minutes in either state): under the
+    """"fast" / "slow" by the telemetry rule of HISTORY.md section 7 (round 4: one and the same box spends minutes in either state): under the
     headline kernel, which runs the socket at its power limit, the FAST state reads >= 1 310 W with the shader clock sagging below 2 280 MHz;
     the SLOW state reads 1 27x W at 2 3xx MHz (something other than socket power holds the chip back while the reported clock stays up;
     the kernel loses 17 %).  A kernel that does not reach the limit in either state cannot tell them apart: "below-the-power-limit"."""

@@ -20,7 +20,7 @@
 //     per wave serves them all instead of one divergent call per event.
 //   * 2 x (4-byte + 16-byte) stores per variable: time-blocked SoA, 1 KiB contiguous per wave store.
 // Bound: HBM writes (3635 B / trajectory) co-limited by the integer multiplies of Philox4x32
-// (DESIGN.md section 5).  No MFMA: there is no contraction on this path.
+// (HISTORY.md section 5).  No MFMA: there is no contraction on this path.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,6 +29,7 @@
 #include "emgpu_coop.h"
 #include "emgpu_device.h"
 #include "emgpu_events.h"
+#include "emgpu_init_karg.h"
 #include "emgpu_launch.h"
 
 namespace emgpu {
@@ -367,7 +368,11 @@ __device__ __forceinline__ void uncor_fast_body(const EmgpuPlan &P, const EmgpuR
     double val[NI];
 #pragma unroll
     for (int p = 0; p < NI; p++) { bin[p] = 0; val[p] = 0.0; }
+#ifdef EMGPU_FAST_INIT_KARG   // measuring variant (HISTORY.md section 9): -1.9 % vector instructions, judged in both box states
+    const int32_t attempts_used = init_network_karg<NI>((KargPlan)__builtin_amdgcn_kernarg_segment_ptr(), A, rng, bin, val);
+#else
     const int32_t attempts_used = init_network<NI>(P, A, rng, bin, val);
+#endif
     if (valid) {
         if (attempts_used < 0) atomicOr(A.status, 1u);
         if (A.attempts) A.attempts[i] = attempts_used;

@@ -5,7 +5,7 @@
 // continuous state (discretize_bayes.m:14-22), one transition step of the trajectory DBN with the
 // "stay" prior (dbn_sample.m with t_max = 2 and every initial variable preset; a column's thresholds gathered
 // from the per-model table in one or two independent groups, r up to 36), validity re-draws, dediscretize.
-// Structure: ONE loop over attempts (a re-drawing lane does not hold its wave back), boundaries in LDS,
+// Structure (HISTORY.md section 7): ONE loop over attempts (a re-drawing lane does not hold its wave back), boundaries in LDS,
 // persistent workgroups whose lanes take the next track from a queue when theirs ends (round 4), the recorded rows staged per lane in
 // LDS and written by the wave as contiguous pieces of a TRACK-MAJOR output (round 4), the velocity's direction carried
 // as an angle, sin/cos of the reduced angle as Horner sums, an instance for the terminal model's row shapes.

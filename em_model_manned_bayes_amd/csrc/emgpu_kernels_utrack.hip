@@ -3,7 +3,7 @@
 // reading the sampler's device output where it lies (init_val rows + the time-blocked dense trace).
 //
 // The reference integrates with em-core's run_dynamics_fast mex and differentiates the altitude with em-core's
-// computeVerticalRate; em-core is not vendored by the reference ("dynamics unpinned").  The point-mass
+// computeVerticalRate; em-core is not vendored by the reference ("dynamics unpinned", HISTORY.md section 10).  The point-mass
 // model used instead is built from the quantities the reference hands to run_dynamics_fast (ic = [v n e h psi theta phi a],
 // :443; dyn = [v_low v_high dh_min dh_max qmax rmax], :414; control rows [t hdot psidot a], :291-297), in f64 without
 // contraction.  dt = 0.1 s, g = 32.2 ft/s^2 (the constant of :440); per step, with the control row active at t:

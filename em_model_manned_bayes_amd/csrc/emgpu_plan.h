@@ -23,7 +23,7 @@
 // uniform: x' = min(x, 2^32-2); u = (x' + 0.5) * 2^-32.
 // Rounds of the Philox4x32 bijection: 7, the fewest that Salmon et al. (SC'11, table 2) report as Crush-resistant (BigCrush passed
 // with sequential counters -- exactly how the slot map uses it); Random123's default of 10 adds a safety margin that costs this
-// VALU-bound path 7-9 % (same-box A/B in DESIGN.md section 5; builds before round 3 were specified at 10).  The test suite's
+// VALU-bound path 7-9 % (same-box A/B in HISTORY.md section 5; builds before round 3 were specified at 10).  The test suite's
 // CPU checker is built with the same value (its EM_PHILOX_ROUNDS): a different value is a different generator.
 #ifndef EMGPU_PHILOX_ROUNDS
 #define EMGPU_PHILOX_ROUNDS 7

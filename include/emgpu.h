@@ -398,7 +398,7 @@ int emgpu_sample2track_host(emgpu_ctx *ctx, const emgpu_track_params *p, const d
  * fast kernels, later rounds an index list), integrates and tests them on the device; only a counter crosses PCIe per round.
  * DYNAMICS: the reference calls em-core's run_dynamics_fast / computeVerticalRate, which it does not vendor.  The point-mass
  * model used instead (dt 0.1 s, first-order pitch / bank response limited by dyn(5:6); "dynamics unpinned") is stated in
- * DESIGN.md section 10 and at the top of csrc/emgpu_kernels_utrack.hip.  The 'geodetic' branch (:480-540: DEM, obstacles, placeTrack) is out of scope.
+ * HISTORY.md section 10 and at the top of csrc/emgpu_kernels_utrack.hip.  The 'geodetic' branch (:480-540: DEM, obstacles, placeTrack) is out of scope.
  *   tracks   [n][S][8] f64: time_s north_ft east_ft up_ft speed_ft_s phi_rad theta_rad psi_rad, S = 10*T/record_stride + 1
  *   limits   [n][3] f64: minVel_ft_s maxVel_ft_s maxVertRate_ft_s of the accepted attempt (getDynamicLimits.m:129-133)
  *   attempts [n] i32: attempts used (>= 1); -1 => max_track_attempts reached (the call then returns EMGPU_ERR_REJECT_CAP)

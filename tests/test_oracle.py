@@ -176,7 +176,7 @@ def _philox_stats(rounds, n=1 << 20):
 
 
 def test_philox_round_count_statistics():
-    """DESIGN.md section 5 (the RNG-cost question): the generator runs Philox4x32-7.  On the counters the slot map really uses, 7 rounds
+    """HISTORY.md section 5 (the RNG-cost question): the generator runs Philox4x32-7.  On the counters the slot map really uses, 7 rounds
     are statistically indistinguishable from Random123's default of 10 -- full avalanche over every counter bit, uniform
     halfwords, no correlation between neighbouring trajectories -- and the same three tests DO see a generator that is too weak
     (3 rounds), so they have the power to notice.  (Crush-resistance of 7 rounds with sequential counters: Salmon et al., SC'11.)"""
