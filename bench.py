@@ -83,13 +83,19 @@ def parse_args(argv=None):
     ap.add_argument("--other-warmup", type=int, default=5, help="untimed steps ahead of each entry of `configs`")
     ap.add_argument("--settle-max", type=int, default=48,
                     help="entries of `configs`: after the warm-up steps, untimed steps are launched back to back in groups of four until the last two of a "
-                         "group agree within 1 %% (the GPU's clocks ramp for several launches after the idle seconds of a CPU leg), at most this many")
+                         "group agree within 1 %% and two consecutive groups' means within 0.5 %% (the GPU's clocks ramp after the idle seconds of a CPU "
+                         "leg), at most this many")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="minimum units timed on the CPU oracle (scaled up to ~10 s)")
     ap.add_argument("--local-smooth", action="store_true", help="terminal: add the smoothing pass of createEncounter.m:88-89 (k_terminal_smooth: the flagged stand-in for em-core's local_smooth; a second pass over the tracks)")
-    ap.add_argument("--prewarm-s", type=float, default=0.0,
-                    help="diagnostic: seconds of the same step launched back to back BEFORE the warm-up steps, untimed and reported in the line. "
-                         "(Measured with it, tools/thermal_probe.sh: a box's slow spells -- 7.1 ms per step at 1 270 W and 2 330 MHz instead of 6.0 ms "
-                         "at 1 346 W and 2 195 MHz -- are not a warm-up effect: three seconds of load ahead of the timed region change nothing.)")
+    ap.add_argument("--prewarm-s", type=float, default=1.0,
+                    help="seconds of the same step launched back to back BEFORE the warm-up steps, untimed and reported in the line (`roofline.prewarm`): "
+                         "from idle the GPU's clocks take 100-200 ms of load to settle (the first timed steps of a cold process read 5-10 %% long: "
+                         "round 5, profiles/r05_bench_lines.jsonl), which W = 5 short warm-up steps do not cover.  0: the W warm-up steps only. "
+                         "(Not what separates a box's fast and slow states: tools/thermal_probe.sh, HISTORY.md section 7.)")
+    ap.add_argument("--placement-candidates", type=int, default=3,
+                    help="uncor / cor / mixed: allocate this many candidate traces, time the step on each (untimed phase, after the pre-warm) and keep "
+                         "the fastest -- where a trace lies in memory decides how fast it is written (em_model_manned_bayes_amd/placement.py, "
+                         "profiles/r05_placement_probe.txt); the line reports the candidates' times.  1: take the first allocation as it comes")
     ap.add_argument("--telemetry-s", type=float, default=2.5,
                     help="seconds of untimed back-to-back steps AFTER the timed region during which the shader clock and socket power are read (0: skip); "
                          "nothing is sampled inside the timed region")
@@ -300,10 +306,8 @@ class DbnWorkload:
         # the trace's leading dimension (emgpu_sample_out.ld) is padded to a multiple of 1024 columns: every row of every array then
         # starts on a 1 KiB boundary and no wave store straddles a 128-byte line (6.25 M columns unpadded cost 18 %)
         self.ld = ld = -(-self.n // args.ld_pad) * args.ld_pad
-        self.init_bin = pl.empty((self.ni, ld), "uint8")
-        self.init_val = pl.empty((self.ni, ld), "float32")
-        self.dyn_bin = pl.empty((G4, self.nd, ld), "int32")
-        self.dyn_val = pl.empty((G4, self.nd, ld, 4), "float32")
+        self._shapes = (((self.ni, ld), "uint8"), ((self.ni, ld), "float32"), ((G4, self.nd, ld), "int32"), ((G4, self.nd, ld, 4), "float32"))
+        self.init_bin, self.init_val, self.dyn_bin, self.dyn_val = self._allocate_trace()
         self.bytes_per_unit = 5 * self.ni + 5 * self.T * self.nd
         self.mode = L.TRANSITION_PER_STEP if args.per_step else L.TRANSITION_REFERENCE_AUTO
         self.per_step = args.per_step
@@ -311,6 +315,35 @@ class DbnWorkload:
         self.launches_per_step = 1
         self.kernels = []
         self.ranges = []       # (step, first global index, n[, model blocks]) of every step launched (--ranges-out)
+
+    def _allocate_trace(self):
+        return tuple(self.pl.empty(shape, dt) for shape, dt in self._shapes)
+
+    def place(self, candidates):
+        """Keep the fastest of `candidates` separately allocated traces (placement.pick_fastest; untimed).  Skipped when the device's free
+        memory does not hold the extra candidates."""
+        t = getattr(self.pl, "torch", None)
+        if t is None or candidates < 2:
+            return
+        from em_model_manned_bayes_amd import placement
+        need = sum(x.numel() * x.element_size() for x in (self.init_bin, self.init_val, self.dyn_bin, self.dyn_val))
+        free = t.cuda.mem_get_info(self.pl.dev)[0]
+        candidates = int(min(candidates, 1 + max(0, (free - (8 << 30)) // need)))
+        if candidates < 2:
+            self.placement = {"candidates": 1, "note": "no memory for a second candidate"}
+            return
+
+        def run(c, k):
+            self.init_bin, self.init_val, self.dyn_bin, self.dyn_val = c
+            self.step(900_000 + k)        # (global indices away from every other phase's)
+        first = (self.init_bin, self.init_val, self.dyn_bin, self.dyn_val)
+        kept, rep = placement.pick_fastest(self._allocate_trace, run, self.sync, time.perf_counter, candidates=candidates, first=first)
+        self.init_bin, self.init_val, self.dyn_bin, self.dyn_val = kept
+        del kept, first
+        self.pl.release()
+        rep["how"] = ("%d traces allocated side by side, two rounds of 2 warm + 5 timed steps on each (untimed phase), the fastest kept, the others freed: where a trace "
+                      "lies in memory decides how fast it is written (profiles/r05_placement_probe.txt)" % rep["candidates"])
+        self.placement = rep
 
     def ptrs(self):
         return dict(init_bin=self.init_bin.data_ptr(), init_val=self.init_val.data_ptr(),
@@ -661,6 +694,20 @@ def measure(w, pl, args, warmup, steps, settle_max=0):
     durations come from HIP events on the stream the kernels are launched on.  Returns (elapsed_s max over ranks, [ms per step]).
     settle_max > 0 (the entries of `configs`, which start after seconds of GPU idleness): between the warm-up and the timed region, untimed
     groups of four back-to-back steps until the last two of a group agree within 1 % (w.settle says how many it took)."""
+    if hasattr(w, "place") and getattr(args, "placement_candidates", 1) > 1:   # (first: freeing the candidates not kept leaves the device idle again)
+        w.place(args.placement_candidates)
+    # (events and the telemetry reader are made BEFORE the pre-warm and the warm-up: milliseconds of host work between the warm-up and the timed region are
+    # milliseconds of GPU idleness, and the governor drops the clock within 3 ms: the first timed steps then read 5-10 % long)
+    ev = [(pl.event(), pl.event()) for _ in range(steps)]
+    tel = None
+    if hasattr(pl, "torch") and getattr(args, "telemetry_s", 0.0) > 0.0:
+        idx = getattr(getattr(pl, "dev", None), "index", 0) or 0
+        try:
+            pr = pl.torch.cuda.get_device_properties(idx)
+            pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except (AttributeError, RuntimeError):
+            pci = None
+        tel = GpuTelemetry(idx, pci)   # (started after the timed region: a 2 ms sampling thread would share the interpreter with the launch loop)
     prewarm_s = float(getattr(args, "prewarm_s", 0.0) or 0.0)
     if prewarm_s > 0.0 and hasattr(pl, "torch"):   # the device's sustained state first (untimed; the line says so)
         t_end, k, first = time.perf_counter() + prewarm_s, 0, []
@@ -677,7 +724,7 @@ def measure(w, pl, args, warmup, steps, settle_max=0):
         w.step(k)
     w.sync()
     if settle_max > 0 and hasattr(pl, "torch"):
-        used, last = 0, None
+        used, last, prev_mean = 0, None, None
         while used < settle_max:
             evs = [(pl.event(), pl.event()) for _ in range(4)]
             for a, b in evs:
@@ -687,20 +734,13 @@ def measure(w, pl, args, warmup, steps, settle_max=0):
                 used += 1
             w.sync()
             last = [pl.elapsed_ms(a, b) for a, b in evs]
-            if abs(last[3] - last[2]) <= 0.01 * last[2]:
+            mean = sum(last) / 4.0
+            if abs(last[3] - last[2]) <= 0.01 * last[2] and prev_mean is not None and abs(mean - prev_mean) <= 0.005 * prev_mean:
                 break
-        w.settle = {"untimed_steps": used, "last_group_ms": [round(x, 3) for x in last], "rule": "groups of 4 until the last two agree within 1 %%, at most %d" % settle_max}
+            prev_mean = mean
+        w.settle = {"untimed_steps": used, "last_group_ms": [round(x, 3) for x in last],
+                    "rule": "groups of 4 until the last two steps agree within 1 %% and the group's mean is within 0.5 %% of the group before, at most %d steps" % settle_max}
     pl.barrier()
-    ev = [(pl.event(), pl.event()) for _ in range(steps)]
-    tel = None
-    if hasattr(pl, "torch") and getattr(args, "telemetry_s", 0.0) > 0.0:
-        idx = getattr(getattr(pl, "dev", None), "index", 0) or 0
-        try:
-            pr = pl.torch.cuda.get_device_properties(idx)
-            pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-        except (AttributeError, RuntimeError):
-            pci = None
-        tel = GpuTelemetry(idx, pci)   # (started after the timed region: a 2 ms sampling thread would share the interpreter with the launch loop)
     t0 = time.perf_counter()
     for k in range(steps):
         pl.record(ev[k][0])
@@ -746,9 +786,9 @@ def box_state(tel):
         return "unknown (no telemetry)"
     if w_ >= 1310.0:
         return "fast"
-    if w_ >= 1200.0 and mhz >= 2280.0:
+    if w_ >= 1200.0 and 2280.0 <= mhz < 2385.0:
         return "slow"
-    return "below-the-power-limit"
+    return "below-the-power-limit"   # (e.g. 1 27x W at the full 2 39x MHz: a kernel that never reaches the limit)
 
 
 def roofline_of(w, step_ms, lib_version):
@@ -768,6 +808,8 @@ def roofline_of(w, step_ms, lib_version):
         r["output_bytes_per_unit"] = w.bytes_stored_per_unit
         r["output_bytes_unit"] = "75 B geometry + 20 B per row written (x y z heading speed as f32: createEncounter.m:162-167, the t = 0 row of an aircraft once)"
         r["frac_of_output_bytes"] = w.bytes_stored_per_unit * w.n / avg_step_s / 1e9 / HBM_PEAK_GBS
+    if getattr(w, "placement", None):
+        r["placement"] = w.placement
     if getattr(w, "settle", None):
         r["settle"] = w.settle
     if getattr(w, "prewarm", None):     # untimed launches ahead of the warm-up steps (--prewarm-s)
@@ -796,7 +838,7 @@ def other_configs(args, pl, lib_version):
     for name in OTHER_CONFIGS:
         a = copy.copy(args)
         a.config, a.n, a.model, a.per_step = name, 0, None, False
-        a.prewarm_s = min(1.5, float(getattr(args, "prewarm_s", 0.0) or 0.0))   # (the CPU leg of the entry before left the GPU idle for seconds)
+        a.prewarm_s = float(getattr(args, "prewarm_s", 0.0) or 0.0)   # (the CPU leg of the entry before left the GPU idle for seconds)
         cfg = CONFIGS[name]
         try:
             w = (TerminalWorkload if name == "terminal" else DbnWorkload)(a, cfg, pl, 0, 1)
@@ -822,7 +864,8 @@ def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
     if getattr(args, "ranges_out", None) and hasattr(w, "digest") and hasattr(pl, "torch"):
         os.makedirs(args.ranges_out, exist_ok=True)
         with open(os.path.join(args.ranges_out, "rank%d.json" % rank), "w") as f:
-            json.dump({"rank": rank, "world": world, "n": w.n, "ranges": w.ranges, "digest": w.digest()}, f)
+            # (the warm-up and timed steps: pre-warm, placement and settle steps use step numbers from 500 000 up)
+            json.dump({"rank": rank, "world": world, "n": w.n, "ranges": [r for r in w.ranges if r["step"] < 500_000], "digest": w.digest()}, f)
     line = None
     if rank == 0:
         from em_model_manned_bayes_amd import _lib as L
