@@ -775,11 +775,14 @@ def measure(w, pl, args, warmup, steps, settle_max=0):
     return elapsed, step_ms
 
 
-def box_state(tel):
-    """"fast" / "slow" by the telemetry rule of HISTORY.md section 7 (round 4: one and the same box spends minutes in either state): under the
+def box_state(tel, w=None):
+    """"fast" / "slow" by the telemetry rule of HISTORY.md section 7 -- round 5 (profiles/r05_placement_probe.txt): the state belongs to the
+    memory the trace lies in, not to the box; bench.py picks the fastest of a few candidate traces first (roofline.placement).  Under the
     headline kernel, which runs the socket at its power limit, the FAST state reads >= 1 310 W with the shader clock sagging below 2 280 MHz;
     the SLOW state reads 1 27x W at 2 3xx MHz (something other than socket power holds the chip back while the reported clock stays up;
     the kernel loses 17 %).  A kernel that does not reach the limit in either state cannot tell them apart: "below-the-power-limit"."""
+    if isinstance(w, TerminalWorkload):
+        return "not applicable (k_terminal_propagate does not reach the socket's power limit)"
     try:
         w_, mhz = tel["socket_power_w"]["median"], tel["sclk_mhz"]["median"]
     except (KeyError, TypeError):
@@ -845,7 +848,7 @@ def other_configs(args, pl, lib_version):
             elapsed, step_ms = measure(w, pl, a, args.other_warmup, args.other_steps, settle_max=args.settle_max)
             res[name] = {"metric": cfg["metric"], "value": w.n * args.other_steps / elapsed, "unit": cfg["unit"],
                          "ms_per_step": elapsed / args.other_steps * 1e3, "steps": args.other_steps, "warmup": args.other_warmup,
-                         "kernel": w.kernel_name(), "config": dict(w.config(), box_state=box_state(getattr(w, "telemetry", None))),
+                         "kernel": w.kernel_name(), "config": dict(w.config(), box_state=box_state(getattr(w, "telemetry", None), w)),
                          "roofline": roofline_of(w, step_ms, lib_version)}
             if not args.no_cpu_baseline:   # the same oracle beside every config, on a smaller sample (about 3 s per leg)
                 res[name]["cpu_baseline"] = w.cpu_baseline(args.cpu_sample, seconds=3.0)
@@ -878,7 +881,7 @@ def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 draws and compares; f64 dediscretize; f32 values stored", "data": "synthetic",
             "config": dict(w.config(), kernel=kernel, lib=lib_version, philox_rounds=int(L.lib().emgpu_philox_rounds()),
-                           box_state=box_state(getattr(w, "telemetry", None)), rank_ranges="step k of rank r of W samples global indices [(k W + r) n, (k W + r + 1) n)"),
+                           box_state=box_state(getattr(w, "telemetry", None), w), rank_ranges="step k of rank r of W samples global indices [(k W + r) n, (k W + r + 1) n)"),
             "roofline": roofline_of(w, step_ms, lib_version),
         }
         if getattr(pl, "shared", False):
