@@ -45,9 +45,14 @@ for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv")):
     rows = [r for r in csv.DictReader(open(f)) if summary.get("kernel") and r["Kernel_Name"] == summary["kernel"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
-    summary["kernel_launch_ms"] = [round(x, 4) for x in ms]
-    if len(ms) > 5:
-        summary["kernel_avg_ms_timed_region"] = sum(ms[5:]) / len(ms[5:])   # bench.py default --warmup 5
+    # round 5: bench.py launches more before its timed region (pre-warm, placement candidates, warm-up, settle steps); the timed region is
+    # the LAST `--steps` launches of the pass (default 10: the kernel-trace pass runs bench.py's defaults with --telemetry-s 0, nothing follows)
+    summary["kernel_launches_in_the_pass"] = len(ms)
+    summary["kernel_launch_ms"] = [round(x, 4) for x in ms[-40:]]
+    if len(ms) > 15:
+        summary["kernel_avg_ms_timed_region"] = sum(ms[-10:]) / 10.0
+    elif len(ms) > 5:
+        summary["kernel_avg_ms_timed_region"] = sum(ms[5:]) / len(ms[5:])   # (rounds 1-4: 5 warm-up launches, then the timed ones)
 # per-dispatch resource usage from the kernel trace
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
