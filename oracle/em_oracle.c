@@ -130,9 +130,10 @@ enum {
     EM_SEC_RES_LO = 10,
     /* terminal trajectory propagation (createEncounter.m:93-265): counter word 2 ("attempt") carries
      * role + 4*resample_attempt with role = 2*(aircraft-1) + (direction == backward); idx = step ii */
-    EM_SEC_TERM_TRANS = 11,  /* dbn_sample(...,2,start) transition draw: a = 0, idx = 4 ii + row: block ii holds the step's   */
-    EM_SEC_TERM_DEDISC = 12  /* dediscretize of an accepted event: the same     draws of all three dynamic variables (word =  */
-                             /* the variable's row of the temporal map): one Philox call per step and section                  */
+    EM_SEC_TERM_TRANS = 11,  /* dbn_sample(...,2,start) transition draw: a = 0, idx = 4 ii + row: block ii holds the step's draws of all  */
+                             /* three dynamic variables (word = the variable's row of the temporal map); round 5: word 3 of the block  */
+                             /* is the FIRST dediscretize draw the attempt makes (one Philox call per attempt for almost every step)   */
+    EM_SEC_TERM_DEDISC = 12  /* an attempt's SECOND and THIRD dediscretize draw (two events in one step): idx = 4 ii + row as above    */
 };
 
 enum { EM_RNG_MT19937 = 0, EM_RNG_PHILOX = 1 };

@@ -29,8 +29,41 @@ def pack_events(evs):
     return cnt, flat
 
 
+def terminal_golden(tmp):
+    """PropagateTrajectory in Philox mode (createEncounter.m:93-265 on the synthetic trajectory tables of synthetic.py): pins the TERM_TRANS /
+    TERM_DEDISC slots of DESIGN.md section 3 -- round 5 moved an attempt's first dediscretize draw to word 3 of its TERM_TRANS block."""
+    import glob
+    from em_model_manned_bayes_amd import synthetic
+    d = synthetic.write_terminal_directory(os.path.join(tmp, "terminal"))
+    files = [glob.glob(os.path.join(d, "*_" + stem + ".txt"))[0] for stem in synthetic.TERMINAL_FILE_STEMS]
+    oms = []
+    for f in files:
+        pp = O.parse_model_txt(f)
+        oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
+    n, seed, first = 32, 0x5EED0005, 7
+    rs = np.random.RandomState(20261004)
+    geo = np.zeros((n, 12))
+    mo = np.zeros((n, 4), dtype=np.int32)
+    for a in range(2):
+        dist, bear = rs.uniform(0.6, 6.0, n), rs.uniform(0, 360, n)
+        geo[:, 6 * a + 0] = dist * np.cos(np.deg2rad(bear)); geo[:, 6 * a + 1] = dist * np.sin(np.deg2rad(bear))
+        geo[:, 6 * a + 2] = rs.uniform(300, 3000, n); geo[:, 6 * a + 3] = rs.uniform(100, 400, n)
+        geo[:, 6 * a + 4] = rs.uniform(0, 360, n)
+    geo[:, 5] = rs.randint(1, 3, n); geo[:, 11] = rs.randint(1, 4, n)
+    mo[:, 0] = 2 * (geo[:, 5].astype(int) - 1); mo[:, 1] = mo[:, 0] + 1
+    mo[:, 2] = 4 + 2 * (geo[:, 11].astype(int) - 1); mo[:, 3] = mo[:, 2] + 1
+    dl = np.array([[50, 506, 12, 5000, 100.0], [68, 338, 3, 5000, 25.0]])          # GENERIC ownship, RTCA228_A2 intruder (getDynamicLimits.m:15-62)
+    out, rows = O.propagate(oms, mo, geo, seed, dl, first_index=first, tmax_s=120.0)
+    cap = out.shape[1]
+    keep = np.arange(cap)[None, :] < rows[:, None]
+    np.savez_compressed(os.path.join(HERE, "terminal_propagate_phx_seed5eed0005_first7_32.npz"), geo=geo, model_of=mo.reshape(-1), dyn_limits=dl,
+                        rows=rows, tracks=np.where(keep[:, :, None], out, 0.0), meta=np.array([n, seed, first, cap], dtype=np.int64))
+    print("wrote terminal_propagate_phx_seed5eed0005_first7_32 (%d track rows, %d tracks with an event-driven turn)" % (rows.sum(), (np.abs(np.diff(out[:, :, 4], axis=1)) > 0).any(axis=1).sum()))
+
+
 def main():
     tmp = tempfile.mkdtemp()
+    terminal_golden(tmp)
     # ---- config 1: uncor_1200code_v2p1, sample(100, 120, 'seed', 1), MT19937 stream
     path = em_io.materialize_model("uncor_1200code_v2p1", tmp)
     pp = O.parse_model_txt(path)

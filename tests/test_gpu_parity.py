@@ -979,6 +979,19 @@ def test_terminal_ten_million_encounters_properties(terminal_dir):
     assert 300 < total_seconds / (5 * n) < 488        # mean track-seconds per encounter (4 tracks x <= 122)
 
 
+def test_terminal_propagation_reproduces_the_committed_golden(terminal_dir, gpu_ctx):
+    """The HIP path against tests/golden/terminal_propagate_phx_*.npz (oracle-made; the slot map of DESIGN.md section 3, TERM_TRANS word 3
+    included): track lengths bit-exact, values the golden's f64 rounded to f32 or one f32 step."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "terminal_propagate_phx_seed5eed0005_first7_32.npz"))
+    n, seed, first, cap = [int(x) for x in g["meta"]]
+    t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=terminal_dir)
+    got, rows = native.propagate_terminal_host(gpu_ctx, [m.native for m in t._traj], g["geo"], g["model_of"], seed, first_index=first, tmax_s=120.0,
+                                               dyn_limits=g["dyn_limits"], cap=cap)
+    assert np.array_equal(rows, g["rows"])
+    for q in range(4 * n):
+        assert_f32_of_f64(got[q, :rows[q]], g["tracks"][q, :rows[q]], "track %d" % q)
+
+
 def _terminal_oracle_models(t):
     oms = []
     for f in [m.parameters_filename for m in t._traj]:

@@ -465,3 +465,22 @@ def test_sample2track_restatements_agree():
         seen.add((cfit, rej))
     assert len(seen) >= 3
 
+
+
+def test_golden_terminal_propagation_slot_map(tmp_path):
+    """The committed PropagateTrajectory golden (Philox mode, createEncounter.m:93-265 on the synthetic trajectory tables): pins the TERM_TRANS /
+    TERM_DEDISC slots across rounds -- since round 5 an attempt's first dediscretize draw is word 3 of its TERM_TRANS block."""
+    import glob as _g
+    from em_model_manned_bayes_amd import synthetic
+    g = np.load(os.path.join(GOLD, "terminal_propagate_phx_seed5eed0005_first7_32.npz"))
+    n, seed, first, cap = [int(x) for x in g["meta"]]
+    d = synthetic.write_terminal_directory(str(tmp_path))
+    oms = []
+    for stem in synthetic.TERMINAL_FILE_STEMS:
+        pp = O.parse_model_txt(_g.glob(os.path.join(d, "*_" + stem + ".txt"))[0])
+        oms.append(O.OracleModel(pp, alpha_transition=O.stay_prior_alpha(pp, 1.0)))
+    out, rows = O.propagate(oms, g["model_of"], g["geo"], seed, g["dyn_limits"], first_index=first, tmax_s=120.0, cap=cap)
+    assert np.array_equal(rows, g["rows"])
+    keep = np.arange(cap)[None, :] < rows[:, None]
+    assert np.array_equal(np.where(keep[:, :, None], out, 0.0), g["tracks"])
+    assert rows.min() >= 1 and rows.max() <= 122 and len(set(rows.tolist())) > 10
