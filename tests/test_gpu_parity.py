@@ -984,8 +984,16 @@ def test_terminal_propagation_reproduces_the_committed_golden(terminal_dir, gpu_
     included): track lengths bit-exact, values the golden's f64 rounded to f32 or one f32 step."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "terminal_propagate_phx_seed5eed0005_first7_32.npz"))
     n, seed, first, cap = [int(x) for x in g["meta"]]
-    t = E.CorTerminalModel(srcData="terminalradar", parameters_directory=terminal_dir)
-    got, rows = native.propagate_terminal_host(gpu_ctx, [m.native for m in t._traj], g["geo"], g["model_of"], seed, first_index=first, tmax_s=120.0,
+    # the ten files in synthetic.TERMINAL_FILE_STEMS order, each intent with its OWN reverse model (the golden's list; CorTerminalModel's
+    # default reproduces CorTerminalModel.m:97,100 and loads the landing reverse file three times)
+    import glob as _g
+    from em_model_manned_bayes_amd import synthetic
+    models = []
+    for stem in synthetic.TERMINAL_FILE_STEMS:
+        nm = native.NativeModel.load_txt(_g.glob(os.path.join(terminal_dir, "*_" + stem + ".txt"))[0])
+        nm.set_transition_stay_prior(1.0)                      # createEncounter.m:128-129
+        models.append(nm)
+    got, rows = native.propagate_terminal_host(gpu_ctx, models, g["geo"], g["model_of"], seed, first_index=first, tmax_s=120.0,
                                                dyn_limits=g["dyn_limits"], cap=cap)
     assert np.array_equal(rows, g["rows"])
     for q in range(4 * n):
