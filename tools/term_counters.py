@@ -31,9 +31,7 @@ print("encounters %d, track rows %d, wave-iterations %d (%.1f per 64 track rows)
 for k in (1, 2, 7, 3, 4, 5, 6, 19, 8, 11, 12):
     print("%-32s %6.2f of 64 per wave-iteration" % (names[k], c[k] / it))
 print("wave-iterations with: an event %.3f, a speed event %.3f, a turn %.3f, a rejected draw %.3f, a pivot-path lane %.3f" % (c[15] / it, c[18] / it, c[16] / it, c[17] / it, c[20] / it))
-print("pieces written per wave-iteration %.2f; refills per wave-iteration %.3f; bearing walk trips down %.2f up %.2f per wave-iteration" % (c[9] / it, c[10] / it, c[13] / it, c[14] / it))
-if c[22] or c[23]:
-    print("event queue: parked lanes %.2f of 64 per wave-iteration; the event code ran in %.3f of the wave-iterations" % (c[22] / it, c[23] / it))
+print("flush trips per wave-iteration %.2f; refills per wave-iteration %.3f; bearing walk trips down %.2f up %.2f per wave-iteration" % (c[9] / it, c[10] / it, c[13] / it, c[14] / it))
 if c[22] or c[23]:
     print("event queue: parked lanes %.2f of 64 per wave-iteration; the event code ran in %.3f of the wave-iterations "
           "(the per-path lines above that are counted inside the event block see only the wave-iterations in which lane 0 is parked)" % (c[22] / it, c[23] / it))
