@@ -792,6 +792,11 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert line["config"]["launches_per_step"] == 1 and line["config"]["model_blocks_per_step"] == 6
     rf = line["roofline"]   # every timed launch listed; the write ceiling of this box measured on the step's own buffers
     assert len(rf["step_ms"]) == 2 and rf["streaming_write"]["GB/s"] > 1000 and 0 < rf["frac_of_streaming_write"] < 1.5
+    # round 5: the trace was placed (three candidates timed in the untimed phase, the fastest kept) and the device pre-warmed; the line says so
+    pc = rf["placement"]
+    assert pc["candidates"] == 3 and len(pc["ms_per_step"]) == 3 and pc["ms_per_step"][pc["kept"]] == min(pc["ms_per_step"]) and pc["spread"] >= 1.0
+    assert rf["prewarm"]["seconds"] == 1.0 and rf["prewarm"]["steps"] >= 8
+    assert line["config"]["philox_rounds"] == O.philox_rounds() and line["config"]["box_state"]
     if "sclk_mhz" in rf:   # (a box that exposes its hwmon sensors) the shader clock of THIS rank's GPU under the load: an idle neighbour card reads ~100 MHz
         assert rf["sclk_mhz"] > 1000 and rf["gpu_telemetry"]["samples"] >= 1
 
