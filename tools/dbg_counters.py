@@ -11,7 +11,11 @@ ctx = native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 n, T = 1_000_000, 240
 tmp = tempfile.mkdtemp()
 for name in sys.argv[1:] or ["uncor_1200code_v2p1", "uncor_1200only_fwse_v1p2"]:
-    m = native.NativeModel.load_txt(em_io.materialize_model(name, tmp))
+    if name == "cor_v2p1_like":
+        from em_model_manned_bayes_amd import synthetic
+        m = native.NativeModel.load_txt(synthetic.write_correlated_v2p1_like(tmp))
+    else:
+        m = native.NativeModel.load_txt(em_io.materialize_model(name, tmp))
     labs = m.get_labels(L.F_LABELS_INITIAL)
     idx = {k: (labs.index('"%s"' % v) + 1 if '"%s"' % v in labs else 0) for k, v in (("idx_L", "L"), ("idx_v", "v"), ("idx_dh", "\\dot h"))}
     nd = m.n_dyn
