@@ -926,3 +926,16 @@ def test_pick_fastest_keeps_the_fastest_candidate_and_releases_the_rest():
         raise MemoryError
     kept, rep = placement.pick_fastest(boom, run, lambda: None, lambda: clock[0], candidates=3, first="c", rewarm_s=0.0)
     assert kept == "c" and rep["candidates"] == 1
+
+
+def test_bench_box_state_rule():
+    """bench.box_state: the telemetry rule that names a line's state (HISTORY.md section 7; round 5: the state belongs to the trace's
+    placement) -- fast at the socket's power limit, slow at 1 27x W with the clock UP at 2 3xx MHz, neither for a kernel at the full clock."""
+    sys.path.insert(0, ROOT)
+    import bench
+    tel = lambda w, mhz: {"socket_power_w": {"median": w}, "sclk_mhz": {"median": mhz}}
+    assert bench.box_state(tel(1346.0, 2195.0)) == "fast" and bench.box_state(tel(1361.0, 2251.0)) == "fast"
+    assert bench.box_state(tel(1270.0, 2330.0)) == "slow" and bench.box_state(tel(1256.0, 2349.0)) == "slow"
+    assert bench.box_state(tel(1287.0, 2392.0)).startswith("below-the-power-limit")        # full clock: the kernel never reaches the limit
+    assert bench.box_state(tel(1293.0, 2273.0)).startswith("below-the-power-limit")        # (between the two: 6.56 ms in profiles/r05_placement_probe.txt)
+    assert bench.box_state(None).startswith("unknown") and bench.box_state({}).startswith("unknown")
