@@ -19,7 +19,12 @@ index range with no collective (torch.distributed is only the barrier and the ma
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     -- algorithmic bytes / average step duration on the launch stream (HIP events)
                   against the 8 TB/s HBM3E peak,
-  cpu_baseline -- the CPU oracle (oracle/em_oracle.c, "port") timed on this host, rank 0, N=1 only.
+  cpu_baseline -- the CPU oracle (oracle/em_oracle.c, "port") timed on this host, rank 0, N=1 only,
+  configs      -- BASELINE.json configs[2..4] + config 2 under PER_STEP, one short entry each,
+  host_path    -- emgpu_sample_dbn_host end to end (PCIe-inclusive; never the headline).
+The line holds NUMBERS ONLY (it must fit the few KB of tail its reader keeps): what every field means and how it is measured is
+NOTES below = profiles/r06_bench_notes.json (`--write-notes`); the verbose record of a run (settle groups, telemetry, pre-warm) goes to
+stderr as one `DETAIL {...}` line and to `--detail-out FILE`.
 MATLAB cannot be timed: it is not installed here or on the GPU box.
 """
 import argparse
@@ -44,6 +49,10 @@ CONFIGS = {
     "uncor": dict(models=["uncor_1200code_v2p1"], n=10_000_000, seed=0x5EED0002, unit="trajectories/s",
                   metric="trajectory samples/sec (240 s uncor DBN)",
                   workload="%(model)s initial+transition DBN, %(n)d trajectories x %(T)d s per GPU"),
+    "uncor_per_step": dict(models=["uncor_1200code_v2p1"], n=10_000_000, seed=0x5EED0002, unit="trajectories/s", per_step=True,
+                           metric="trajectory samples/sec (240 s uncor DBN, PER_STEP transition semantics)",
+                           workload="%(model)s under EMGPU_TRANSITION_PER_STEP (the true per-timestep DBN of dbn_sample.m:65-93 instead of the frozen-parent "
+                                    "branch the reference takes for this file), %(n)d trajectories x %(T)d s per GPU"),
     "cor": dict(models=["cor_v1"], n=10_000_000, seed=0x5EED0003, unit="encounters/s",
                 metric="encounter samples/sec (240 s correlated two-aircraft DBN)",
                 workload="%(model)s correlated two-aircraft joint network (stand-in for cor_v2p1, absent from the reference mount), "
@@ -92,10 +101,16 @@ def parse_args(argv=None):
                          "from idle the GPU's clocks take 100-200 ms of load to settle (the first timed steps of a cold process read 5-10 %% long: "
                          "round 5, profiles/r05_bench_lines.jsonl), which W = 5 short warm-up steps do not cover.  0: the W warm-up steps only. "
                          "(Not what separates a box's fast and slow states: tools/thermal_probe.sh, HISTORY.md section 7.)")
-    ap.add_argument("--placement-candidates", type=int, default=3,
-                    help="uncor / cor / mixed: allocate this many candidate traces, time the step on each (untimed phase, after the pre-warm) and keep "
-                         "the fastest -- where a trace lies in memory decides how fast it is written (em_model_manned_bayes_amd/placement.py, "
-                         "profiles/r05_placement_probe.txt); the line reports the candidates' times.  1: take the first allocation as it comes")
+    ap.add_argument("--placement-candidates", type=int, default=0,
+                    help="uncor / cor / mixed: the `candidates` argument of emgpu_trace_alloc, the library's trace allocator (include/emgpu.h): it "
+                         "allocates that many candidate traces, times the step on each BEFORE anything else here runs and keeps the fastest -- where a "
+                         "trace lies in memory decides how fast it is written (profiles/r05_placement_probe.txt).  0 (default): the library's own "
+                         "policy (3, more while the two fastest disagree by over 1 %%); 1: the first allocation as it comes.  The line reports the "
+                         "candidates' times (roofline.placement) and the first one's as roofline.first_allocation_ms")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the `host_path` object (emgpu_sample_dbn_host end to end at 1 M trajectories)")
+    ap.add_argument("--host-n", type=int, default=1_000_000, help="trajectories of the `host_path` measurements")
+    ap.add_argument("--detail-out", default=None, help="write the verbose record of the run (what the line leaves out: settle groups, pre-warm, telemetry, samples) to this file")
+    ap.add_argument("--write-notes", default=None, help="write NOTES (what every field of the line means and how it is measured) to this file and exit")
     ap.add_argument("--telemetry-s", type=float, default=2.5,
                     help="seconds of untimed back-to-back steps AFTER the timed region during which the shader clock and socket power are read (0: skip); "
                          "nothing is sampled inside the timed region")
@@ -217,6 +232,14 @@ class TorchRocm:
     def from_numpy(self, a):
         return self.torch.from_numpy(a).to(self.dev)
 
+    def wrap(self, ptr, shape, dtype):
+        """A tensor over device memory somebody else owns (a trace of the library's pool): __cuda_array_interface__, no copy."""
+        ts = {"uint8": "|u1", "float32": "<f4", "int32": "<i4", "float64": "<f8"}[dtype]
+
+        class _Mem:
+            __cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": ts, "data": (int(ptr), False), "version": 2}
+        return self.torch.as_tensor(_Mem(), device=self.dev)
+
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
@@ -306,8 +329,7 @@ class DbnWorkload:
         # the trace's leading dimension (emgpu_sample_out.ld) is padded to a multiple of 1024 columns: every row of every array then
         # starts on a 1 KiB boundary and no wave store straddles a 128-byte line (6.25 M columns unpadded cost 18 %)
         self.ld = ld = -(-self.n // args.ld_pad) * args.ld_pad
-        self._shapes = (((self.ni, ld), "uint8"), ((self.ni, ld), "float32"), ((G4, self.nd, ld), "int32"), ((G4, self.nd, ld, 4), "float32"))
-        self.init_bin, self.init_val, self.dyn_bin, self.dyn_val = self._allocate_trace()
+        shapes = (((self.ni, ld), "uint8"), ((self.ni, ld), "float32"), ((G4, self.nd, ld), "int32"), ((G4, self.nd, ld, 4), "float32"))
         self.bytes_per_unit = 5 * self.ni + 5 * self.T * self.nd
         self.mode = L.TRANSITION_PER_STEP if args.per_step else L.TRANSITION_REFERENCE_AUTO
         self.per_step = args.per_step
@@ -315,39 +337,34 @@ class DbnWorkload:
         self.launches_per_step = 1
         self.kernels = []
         self.ranges = []       # (step, first global index, n[, model blocks]) of every step launched (--ranges-out)
+        self.trace = None
+        if hasattr(pl, "wrap") and hasattr(native, "Trace"):
+            # THE TRACE IS THE LIBRARY'S: emgpu_trace_alloc allocates the candidates, times this workload's own launch on each and keeps the
+            # fastest -- what any consumer of the C ABI gets by calling it instead of hipMalloc (a mixed batch is placed with its first model's
+            # launch over the whole trace: same kernel family, same store pattern)
+            p, _keep = native.make_params(self.n, self.T, self.seed, first_index=0, transition_mode=self.mode, **self.idx[0])
+            self.trace = native.Trace(self.ctx, self.models[0], p, want=L.TRACE_INIT | L.TRACE_DENSE, candidates=int(getattr(args, "placement_candidates", 0)))
+            assert self.trace.ld == ld, (self.trace.ld, ld)
+            self._ptrs = {k: v for k, v in self.trace.ptrs().items() if k in ("init_bin", "init_val", "dyn_bin", "dyn_val", "ld")}
+            self.init_bin, self.init_val, self.dyn_bin, self.dyn_val = (pl.wrap(self._ptrs[k], shape, dt) for k, (shape, dt) in
+                                                                        zip(("init_bin", "init_val", "dyn_bin", "dyn_val"), shapes))
+            self.placement = dict(self.trace.report, bytes=self.trace.bytes)
+        else:   # (tests/mp_plumbing.py: host memory behind the same interface)
+            self.init_bin, self.init_val, self.dyn_bin, self.dyn_val = (pl.empty(shape, dt) for shape, dt in shapes)
+            self._ptrs = dict(init_bin=self.init_bin.data_ptr(), init_val=self.init_val.data_ptr(), dyn_bin=self.dyn_bin.data_ptr(),
+                              dyn_val=self.dyn_val.data_ptr(), ld=self.ld)
 
-    def _allocate_trace(self):
-        return tuple(self.pl.empty(shape, dt) for shape, dt in self._shapes)
-
-    def place(self, candidates):
-        """Keep the fastest of `candidates` separately allocated traces (placement.pick_fastest; untimed).  Skipped when the device's free
-        memory does not hold the extra candidates."""
-        t = getattr(self.pl, "torch", None)
-        if t is None or candidates < 2:
-            return
-        from em_model_manned_bayes_amd import placement
-        need = sum(x.numel() * x.element_size() for x in (self.init_bin, self.init_val, self.dyn_bin, self.dyn_val))
-        free = t.cuda.mem_get_info(self.pl.dev)[0]
-        candidates = int(min(candidates, 1 + max(0, (free - (8 << 30)) // need)))
-        if candidates < 2:
-            self.placement = {"candidates": 1, "note": "no memory for a second candidate"}
-            return
-
-        def run(c, k):
-            self.init_bin, self.init_val, self.dyn_bin, self.dyn_val = c
-            self.step(900_000 + k)        # (global indices away from every other phase's)
-        first = (self.init_bin, self.init_val, self.dyn_bin, self.dyn_val)
-        kept, rep = placement.pick_fastest(self._allocate_trace, run, self.sync, time.perf_counter, candidates=candidates, first=first)
-        self.init_bin, self.init_val, self.dyn_bin, self.dyn_val = kept
-        del kept, first
-        self.pl.release()
-        rep["how"] = ("%d traces allocated side by side, two rounds of 2 warm + 5 timed steps on each (untimed phase), the fastest kept, the others freed: where a trace "
-                      "lies in memory decides how fast it is written (profiles/r05_placement_probe.txt)" % rep["candidates"])
-        self.placement = rep
+    def close(self):
+        """Give the trace back (the ctx's pool goes with the ctx) before the next workload allocates."""
+        self.init_bin = self.init_val = self.dyn_bin = self.dyn_val = None
+        if self.trace is not None:
+            self.trace.free()
+            self.trace = None
+        if hasattr(self.ctx, "trim"):
+            self.ctx.trim()
 
     def ptrs(self):
-        return dict(init_bin=self.init_bin.data_ptr(), init_val=self.init_val.data_ptr(),
-                    dyn_bin=self.dyn_bin.data_ptr(), dyn_val=self.dyn_val.data_ptr(), ld=self.ld)
+        return self._ptrs
 
     def step(self, k):
         from em_model_manned_bayes_amd import sharding
@@ -448,6 +465,7 @@ class DbnWorkload:
         dtm = time.perf_counter() - t0
         return {"value": n_mt / dtm, "unit": self.cfg["unit"], "cores": cores, "kind": "port",
                 "single_thread_value": n_cpu / dt1, "thread_scaling": (n_mt / dtm) / (n_cpu / dt1), "cores_note": cores_note,
+                "sample_short": "%s: %d units x %d s on %d threads in %.1f s; 1 thread: %d units in %.1f s" % (self.names[0], n_mt, T, cores, dtm, n_cpu, dt1),
                 "sample": "oracle/em_oracle.c (scalar port of the reference algorithm), Philox mode, model %s: %d units x %d s "
                           "on %d threads in %.1f s (thread-private dense outputs); 1 thread: %d units in %.1f s; MATLAB itself is not "
                           "installed and cannot be timed" % (self.names[0], n_mt, T, cores, dtm, n_cpu, dt1)}
@@ -576,6 +594,7 @@ class TerminalWorkload:
         dtm = time.perf_counter() - t0
         return {"value": n_mt / dtm, "unit": self.cfg["unit"], "cores": cores, "kind": "port",
                 "single_thread_value": n1 / dt1, "thread_scaling": (n_mt / dtm) / (n1 / dt1), "cores_note": cores_note,
+                "sample_short": "propagation of %d encounters on %d threads in %.1f s; 1 thread: %d in %.1f s" % (n_mt, cores, dtm, n1, dt1),
                 "sample": "oracle/em_oracle.c em_propagate_trajectory (scalar port of createEncounter.m:93-329), Philox mode: propagation of %d encounters "
                           "on %d threads in %.1f s (thread-private track buffers); 1 thread: %d encounters in %.1f s (the geometry draw, <1 %% of the "
                           "work, is not in these figures); MATLAB itself is not installed and cannot be timed" % (n_mt, cores, dtm, n1, dt1)}
@@ -694,8 +713,10 @@ def measure(w, pl, args, warmup, steps, settle_max=0):
     durations come from HIP events on the stream the kernels are launched on.  Returns (elapsed_s max over ranks, [ms per step]).
     settle_max > 0 (the entries of `configs`, which start after seconds of GPU idleness): between the warm-up and the timed region, untimed
     groups of four back-to-back steps until the last two of a group agree within 1 % (w.settle says how many it took)."""
-    if hasattr(w, "place") and getattr(args, "placement_candidates", 1) > 1:   # (first: freeing the candidates not kept leaves the device idle again)
-        w.place(args.placement_candidates)
+    # one untimed barrier + max-reduce first: a process group's first collectives set its communicator up (RCCL: lazily, hundreds of ms
+    # with 8 ranks) -- that must never land between t0 and t1 of a 0.1 s timed region
+    pl.barrier()
+    pl.max_over_ranks(0.0)
     # (events and the telemetry reader are made BEFORE the pre-warm and the warm-up: milliseconds of host work between the warm-up and the timed region are
     # milliseconds of GPU idleness, and the governor drops the clock within 3 ms: the first timed steps then read 5-10 % long)
     ev = [(pl.event(), pl.event()) for _ in range(steps)]
@@ -822,7 +843,15 @@ def roofline_of(w, step_ms, lib_version):
         r["gpu_telemetry"] = w.telemetry
     if w.launches_per_step > 1:   # blocks of different kernel instances: they run on the ctx stream and three side streams
         r["launches_overlap"] = "avg_launch_ms is avg_step_ms / launches_per_step; single launches in a kernel trace overlap"
-    r.update(recorded_traffic(kernel, per_launch, lib_version, data_dependent=getattr(w, "bytes_data_dependent", False)))
+    rec = recorded_traffic(kernel, per_launch, lib_version, data_dependent=getattr(w, "bytes_data_dependent", False))
+    insts = rec.pop("insts_valu", None)
+    r.update(rec)
+    if isinstance(w, TerminalWorkload):
+        # this kernel's ceiling is vector ISSUE at two-thirds-full waves, not HBM (HISTORY.md section 11.1): the HBM fraction stays (SURVEY.md 8d's
+        # unit), the bound is named for what it is, and the issue-slot fraction stands beside it when a committed PMC pass of this build has it
+        r["bound"] = "valu-issue"
+        if insts and r.get("sclk_mhz"):
+            r["issue_frac"] = insts * 4.0 / (1024.0 * (r["avg_launch_ms"] * 1e-3) * (r["sclk_mhz"] * 1e6))
     sw = w.streaming_write() if hasattr(w, "streaming_write") else None
     if sw:   # measured AFTER the timed region (the buffers' contents were checked by then)
         r["streaming_write"] = sw
@@ -830,33 +859,203 @@ def roofline_of(w, step_ms, lib_version):
     return r
 
 
-OTHER_CONFIGS = ["cor", "cor_v2p1_like", "mixed", "terminal"]
+OTHER_CONFIGS = ["uncor_per_step", "cor", "cor_v2p1_like", "mixed", "terminal"]
+
+# What the line's fields mean and how they are measured: static text, kept OUT of the line (`--write-notes` -> profiles/r06_bench_notes.json).
+NOTES = {
+    "step": "one pass of the hot path over one batch of fresh units (new global indices every step); 5 warm-up steps (headline: after --prewarm-s of "
+            "untimed launches), then K timed steps bracketed by barrier + device synchronisation; value = units of all ranks / max-over-ranks wall time",
+    "output": "dense trace of the DYNAMIC variables (u8 bin + f32 value per variable-second) + initial state (u8 + f32 per variable): "
+              "5 n_i + 5 T n_d bytes per unit (3 635 uncor, 4 880 cor at T = 240); re-draws of static variables appear only in the event-list output; "
+              "values are f32 at the boundary (f64 arithmetic inside, rounded on store), uniforms 32-bit",
+    "roofline": "achieved = algorithmic bytes (SURVEY.md 8d) / average launch duration from HIP events on the launch stream; peak = 8 TB/s; traffic = "
+                "WRITE_SIZE + 2 x FETCH_SIZE of a committed PMC pass of the same kernel, launch size and source hash (profiles/*_summary.json), else null; "
+                "frac_of_streaming_write = achieved / what torch's fill kernel reaches on the same buffers on this box",
+    "placement": "the trace comes from emgpu_trace_alloc (include/emgpu.h): the library allocates `candidates` traces, loads the device for 0.5 s, times "
+                 "2 untimed + 5 timed launches of this workload's own call on each, twice, keeps the fastest and frees the others; ms = per candidate in "
+                 "allocation order; first_allocation_ms = ms[0] = what a caller who keeps its first allocation gets on this box (profiles/r05_placement_probe.txt)",
+    "configs": "BASELINE.json configs[2..4] at their single-GPU sizes + config 2 under PER_STEP, measured in this process after the headline: 5 warm-up steps, "
+               "settle (groups of 4 untimed steps until the last two agree within 1 % and two groups' means within 0.5 %, at most 48), 10 timed steps; "
+               "cpu = the oracle on all allowed cores, about 3 s per leg",
+    "uncor_per_step": "config 2 under EMGPU_TRANSITION_PER_STEP: the true per-timestep DBN of dbn_sample.m:65-93 instead of the frozen-parent branch "
+                      "(dbn_sample.m:97-135) the reference takes for this file; SURVEY.md section 7 hard part 1 asks for both",
+    "cor": "cor_v1: stand-in for cor_v2p1.txt, which is absent from the reference mount; cor_v2p1_like: generator-made network with cor_v2p1's table sizes "
+           "(em_model_manned_bayes_amd/synthetic.py, seed 0x5EED0003)",
+    "mixed": "six uncor_*_v1p2 files, model = contiguous block of the global index range, one launch for the whole batch (6.25 M per GPU = 50 M on 8)",
+    "terminal": "CorTerminalModel: terminal_v3_radar geometry network + 10 synthetic trajectory models (the trained files are absent); per step k_bn (geometry "
+                "draw with rejection) + k_terminal_geo + k_terminal_propagate; frac follows SURVEY.md 8(d): 75 B + 15 B per track-second; "
+                "frac_of_output_bytes charges what is stored: 75 B + 20 B per row written; bound valu-issue: issue_frac = SQ_INSTS_VALU x 4 cycles / "
+                "(1 024 SIMDs x kernel time x sclk) from the committed PMC pass",
+    "cpu_baseline": "oracle/em_oracle.c (scalar port of the reference algorithm), Philox mode, thread-private dense outputs, on `cores` threads = the cgroup's "
+                    "CPU quota; single_thread_value beside it; MATLAB itself is not installed and cannot be timed",
+    "host_path": "emgpu_sample_dbn_host end to end at --host-n trajectories x 240 s of uncor_1200code_v2p1, second call of each kind (the first pins memory): "
+                 "dense_pinned = outputs in emgpu_host_alloc memory (the copy engine writes into the caller's arrays); dense_pageable = the caller's own "
+                 "(pre-faulted) numpy arrays through the library's pinned staging + host threads; events_pinned = event lists only, packed on the device "
+                 "(sum(ev_count) rows cross PCIe); GBps = bytes_d2h / total_ms; kernel_ms / d2h_ms / scatter_ms = the pipeline's phases (they overlap); "
+                 "pinned_d2h_GBps = one 1 GiB hipMemcpy device -> pinned on this box; class_sample = UncorEncounterModel.sample(n, 240) (class level, "
+                 "event lists + numpy reconstruction of out_samples / EncounterModelEvents): native_s = the library calls, format_s = the numpy / Python part",
+    "box_state": "fast / slow / below-the-power-limit by socket power and shader clock under the step (HISTORY.md section 7); since round 5 known to follow "
+                 "the trace's placement, which the library now picks",
+}
 
 
-def other_configs(args, pl, lib_version):
-    """BASELINE.json configs[2..4] (+ the cor_v2p1-sized stand-in) at their full single-GPU sizes, measured in this process after
-    the headline: each entry carries its own ms_per_step, kernel and roofline on that config's algorithmic bytes."""
+def _r(x, nd=4):
+    """Round floats for the line (4 significant decimals of a fraction, 3 of a millisecond value are what anybody reads)."""
+    if isinstance(x, float):
+        return float("%.*g" % (nd + 2, x))
+    if isinstance(x, list):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "avg_launch_ms", "launches_per_step", "step_ms",
+             "algorithmic_bytes_per_launch", "algorithmic_bytes_per_unit", "output_bytes_per_unit", "frac_of_output_bytes", "frac_of_streaming_write",
+             "issue_frac", "sclk_mhz")
+
+
+def compact_roofline(r):
+    out = {k: _r(r[k]) for k in ROOF_KEYS if k in r}
+    pm = r.get("placement")
+    if pm:
+        out["placement"] = {k: pm[k] for k in ("candidates", "ms", "kept", "reused") if k in pm}
+        out["first_allocation_ms"] = pm.get("first_allocation_ms") or None
+    if "streaming_write" in r:
+        out["streaming_write_GBps"] = round(r["streaming_write"]["GB/s"], 1)
+    tel = r.get("gpu_telemetry") or {}
+    if "socket_power_w" in tel:
+        out["socket_power_w"] = tel["socket_power_w"]["median"]
+    return out
+
+
+def compact_cpu(c):
+    return {"value": _r(c["value"]), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"], "single_thread_value": _r(c["single_thread_value"]),
+            "sample": c.get("sample_short", c["sample"])}
+
+
+def other_configs(args, pl, lib_version, detail):
+    """BASELINE.json configs[2..4] (+ the cor_v2p1-sized stand-in, + config 2 under PER_STEP) at their full single-GPU sizes, measured in this
+    process after the headline: each entry carries its own ms_per_step, kernel and roofline figures on that config's algorithmic bytes."""
     import copy
     res = {}
     for name in OTHER_CONFIGS:
         a = copy.copy(args)
-        a.config, a.n, a.model, a.per_step = name, 0, None, False
-        a.prewarm_s = float(getattr(args, "prewarm_s", 0.0) or 0.0)   # (the CPU leg of the entry before left the GPU idle for seconds)
         cfg = CONFIGS[name]
+        a.config, a.n, a.model, a.per_step = name, 0, None, bool(cfg.get("per_step", False))
+        a.prewarm_s = float(getattr(args, "prewarm_s", 0.0) or 0.0)   # (the CPU leg of the entry before left the GPU idle for seconds)
+        w = None
         try:
             w = (TerminalWorkload if name == "terminal" else DbnWorkload)(a, cfg, pl, 0, 1)
             elapsed, step_ms = measure(w, pl, a, args.other_warmup, args.other_steps, settle_max=args.settle_max)
-            res[name] = {"metric": cfg["metric"], "value": w.n * args.other_steps / elapsed, "unit": cfg["unit"],
-                         "ms_per_step": elapsed / args.other_steps * 1e3, "steps": args.other_steps, "warmup": args.other_warmup,
-                         "kernel": w.kernel_name(), "config": dict(w.config(), box_state=box_state(getattr(w, "telemetry", None), w)),
-                         "roofline": roofline_of(w, step_ms, lib_version)}
+            roof = roofline_of(w, step_ms, lib_version)
+            cr = compact_roofline(roof)
+            e = {"value": _r(w.n * args.other_steps / elapsed), "unit": cfg["unit"], "ms_per_step": _r(elapsed / args.other_steps * 1e3), "n": w.n,
+                 "kernel": w.kernel_name(), "bound": cr.get("bound"), "frac": cr.get("frac"), "traffic": cr.get("traffic"),
+                 "box_state": box_state(getattr(w, "telemetry", None), w)}
+            for k in ("issue_frac", "frac_of_output_bytes", "frac_of_streaming_write", "first_allocation_ms"):
+                if cr.get(k) is not None:
+                    e[k] = cr[k]
+            if "placement" in cr:
+                e["placement_ms"] = cr["placement"]["ms"]
+            if isinstance(w, TerminalWorkload):
+                e["track_seconds"] = _r(w.track_seconds)
+            detail["configs"][name] = {"metric": cfg["metric"], "steps": args.other_steps, "warmup": args.other_warmup, "config": w.config(), "roofline": roof}
             if not args.no_cpu_baseline:   # the same oracle beside every config, on a smaller sample (about 3 s per leg)
-                res[name]["cpu_baseline"] = w.cpu_baseline(args.cpu_sample, seconds=3.0)
-        except Exception as e:   # an entry that cannot run says so; the headline line is still printed
-            res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                c = w.cpu_baseline(args.cpu_sample, seconds=3.0)
+                e["cpu"] = {"value": _r(c["value"]), "cores": c["cores"], "single_thread_value": _r(c["single_thread_value"])}
+                detail["configs"][name]["cpu_baseline"] = c
+            res[name] = e
+        except Exception as ex:   # an entry that cannot run says so; the headline line is still printed
+            res[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        if w is not None and hasattr(w, "close"):
+            w.close()
         w = None
         pl.release()
     return res
+
+
+def host_path(args, pl, detail):
+    """emgpu_sample_dbn_host end to end (VERDICT r5 next #2b / #3): the path every drop-in caller of UncorEncounterModel.sample is on.
+    PCIe-inclusive figures: reported beside the headline, never as it."""
+    import numpy as np
+    import em_model_manned_bayes_amd as E
+    from em_model_manned_bayes_amd import _lib as L
+    native, t = pl.native, pl.torch
+    tmp = tempfile.mkdtemp(prefix="emgpu_bench_host_")
+    path = _materialize("uncor_1200code_v2p1", tmp)
+    nm = native.NativeModel.load_txt(path)
+    idx = _label_indices(nm)
+    n, T, seed = int(args.host_n), DEFAULT_T, 0x5EED0002
+    ctx = native.Context(pl.dev.index)
+    out = {"n": n, "T": T}
+
+    def summarise(st, units):
+        return {"total_ms": _r(st["total_ms"]), "kernel_ms": _r(st["kernel_ms"]), "d2h_ms": _r(st["d2h_ms"]), "scatter_ms": _r(st["scatter_ms"]),
+                "GBps": _r(st["bytes_d2h"] / st["total_ms"] / 1e6), "bytes_d2h": st["bytes_d2h"], "units_per_s": _r(units / st["total_ms"] * 1e3),
+                "chunks": st["chunks"], "threads": st["threads"], "direct": st["direct"]}
+    # what the box's copy engine reaches into pinned memory: one 1 GiB device -> pinned copy, best of 3
+    dsrc = t.empty(1 << 30, dtype=t.uint8, device=pl.dev)
+    hdst = t.empty(1 << 30, dtype=t.uint8, pin_memory=True)
+    best = 1e9
+    for _ in range(4):
+        a, b = pl.event(), pl.event()
+        pl.record(a)
+        hdst.copy_(dsrc, non_blocking=True)
+        pl.record(b)
+        t.cuda.synchronize()
+        best = min(best, pl.elapsed_ms(a, b))
+    out["pinned_d2h_GBps"] = _r((1 << 30) / best / 1e6)
+    del dsrc, hdst
+    # dense, pinned outputs (second call: the first pins the pool's blocks)
+    for rep in range(2):
+        r = native.sample_dbn_host(ctx, nm, n, T, seed, want_dense=True, want_events=False, pinned=True, raw=True, **idx)
+        st = r["host_stats"]
+        del r
+    out["dense_pinned"] = summarise(st, n)
+    detail["host_path"]["dense_pinned"] = st
+    # dense, the caller's own pageable arrays (touched once before: a fresh numpy array's first touch is the kernel's page-fault rate, not ours)
+    ni, nd, G4 = nm.n_initial, nm.n_dyn, (T + 3) // 4
+    ib, iv = np.zeros((ni, n), np.uint8), np.zeros((ni, n), np.float32)
+    db, dv = np.zeros((G4, nd, n), np.uint32), np.zeros((G4, nd, n, 4), np.float32)
+    att = np.zeros(n, np.int32)
+    p, _keep = native.make_params(n, T, seed, **idx)
+    o = L.SampleOut()
+    o.init_bin, o.init_val, o.dyn_bin, o.dyn_val, o.attempts = ib.ctypes.data, iv.ctypes.data, db.ctypes.data, dv.ctypes.data, att.ctypes.data
+    import ctypes as C
+    for rep in range(2):
+        t0 = time.perf_counter()
+        L.check(L.lib().emgpu_sample_dbn_host(ctx._h, nm._h, C.byref(p), C.byref(o)))
+        cold_or_warm = time.perf_counter() - t0
+        if rep == 0:
+            out["dense_pageable_first_call_ms"] = _r(cold_or_warm * 1e3)
+    st = ctx.host_stats()
+    out["dense_pageable"] = summarise(st, n)
+    detail["host_path"]["dense_pageable"] = st
+    del ib, iv, db, dv, att
+    # event lists only (what the class layer asks for): packed on the device
+    for rep in range(2):
+        r = native.sample_dbn_host(ctx, nm, n, T, seed, want_dense=False, want_events=True, event_cap=256, pinned=True, raw=True, **idx)
+        st = r["host_stats"]
+        del r
+    e = summarise(st, n)
+    e["event_rows"] = st["event_rows"]
+    e["bytes_if_unpacked"] = n * 256 * 8
+    out["events_pinned"] = e
+    detail["host_path"]["events_pinned"] = st
+    ctx.trim()
+    # the class level: UncorEncounterModel.sample(n_class, 240) -- host arrays, cells and EncounterModelEvents like the reference returns
+    n_class = min(n, 100_000)
+    mdl = E.UncorEncounterModel(path)
+    mdl.sample(2048, T, seed=1, ctx=ctx)       # (warm: tables uploaded, pool blocks pinned)
+    t0 = time.perf_counter()
+    mdl.sample(n_class, T, seed=seed, ctx=ctx)
+    dt = time.perf_counter() - t0
+    tm = dict(mdl.last_sample_timing)
+    out["class_sample"] = {"n": n_class, "total_s": _r(dt), "native_s": _r(tm["native_s"]), "kernel_ms": _r(tm["kernel_ms"]), "d2h_ms": _r(tm["d2h_ms"]),
+                           "format_s": _r(tm["format_s"]), "units_per_s": _r(n_class / dt)}
+    detail["host_path"]["class_sample"] = tm
+    del mdl, ctx
+    pl.release()
+    return out
 
 
 def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
@@ -876,24 +1075,46 @@ def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
         total = w.n * world * args.steps
         lib_version = L.lib().emgpu_version().decode()
         kernel = w.kernel_name()
+        roof = roofline_of(w, step_ms, lib_version)
+        wc = w.config()
+        detail = {"config": wc, "roofline": roof, "configs": {}, "host_path": {}, "notes": NOTES}
         line = {
             "metric": cfg["metric"], "value": total / elapsed, "unit": cfg["unit"], "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 draws and compares; f64 dediscretize; f32 values stored", "data": "synthetic",
-            "config": dict(w.config(), kernel=kernel, lib=lib_version, philox_rounds=int(L.lib().emgpu_philox_rounds()),
-                           box_state=box_state(getattr(w, "telemetry", None), w), rank_ranges="step k of rank r of W samples global indices [(k W + r) n, (k W + r + 1) n)"),
-            "roofline": roofline_of(w, step_ms, lib_version),
+            "config": {"workload": wc["workload"], "transition_mode": wc.get("transition_mode"), "kernel": kernel, "lib": lib_version,
+                       "philox_rounds": int(L.lib().emgpu_philox_rounds()), "trace_ld": wc.get("trace_ld"), "models": wc.get("models"),
+                       "launches_per_step": wc.get("launches_per_step"), "box_state": box_state(getattr(w, "telemetry", None), w),
+                       "notes": "profiles/r06_bench_notes.json"},
+            "roofline": compact_roofline(roof),
         }
+        if isinstance(w, TerminalWorkload):
+            line["config"]["track_seconds_per_encounter"] = wc.get("track_seconds_per_encounter")
         if getattr(pl, "shared", False):
             line["oversubscribed"] = True
         if args.step_gap_ms > 0.0:
             line["diagnostic"] = "idle gaps of %g ms between the launches (--step-gap-ms): value and ms_per_step include them" % args.step_gap_ms
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = w.cpu_baseline(args.cpu_sample)
-        if world == 1 and args.config == "uncor" and not args.no_other_configs and not args.model and not args.n and hasattr(pl, "release"):
+            c = w.cpu_baseline(args.cpu_sample)
+            detail["cpu_baseline"] = c
+            line["cpu_baseline"] = compact_cpu(c)
+        default_run = world == 1 and args.config == "uncor" and not args.model and not args.n and hasattr(pl, "release")
+        if default_run and (not args.no_other_configs or not args.no_host_path):
+            if hasattr(w, "close"):
+                w.close()
             w = None
             pl.release()
-            line["configs"] = other_configs(args, pl, lib_version)
+            if not args.no_other_configs:
+                line["configs"] = other_configs(args, pl, lib_version, detail)
+            if not args.no_host_path:
+                try:
+                    line["host_path"] = host_path(args, pl, detail)
+                except Exception as ex:
+                    line["host_path"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        sys.stderr.write("DETAIL " + json.dumps(detail) + "\n")
+        if getattr(args, "detail_out", None):
+            with open(args.detail_out, "w") as f:
+                json.dump(dict(detail, line=line), f, indent=1)
         out.write(json.dumps(line) + "\n")
         out.flush()
     pl.finish()
@@ -924,15 +1145,22 @@ def recorded_traffic(kernel_name, algorithmic_bytes, lib_version, data_dependent
                 and same_size                                            # ... on this launch size ...
                 and line.get("config", {}).get("lib") == lib_version)     # ... from these sources
         if same and "hbm_traffic_bytes_per_launch" in s:
-            best = (s["hbm_traffic_bytes_per_launch"], os.path.basename(f))
+            best = (s["hbm_traffic_bytes_per_launch"], os.path.basename(f), s.get("pmc_per_launch", {}).get("SQ_INSTS_VALU"))
     if best is None:
         return {"traffic": None}
-    return {"traffic": best[0], "traffic_source": "profiles/" + best[1]}
+    out = {"traffic": best[0], "traffic_source": "profiles/" + best[1]}
+    if best[2]:
+        out["insts_valu"] = best[2]
+    return out
 
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.write_notes:
+        with open(args.write_notes, "w") as f:
+            json.dump(NOTES, f, indent=1)
+        return 0
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -108,6 +108,20 @@ class TSampleParams(C.Structure):
                 ("max_attempts", C.c_int32), ("flags", C.c_uint32), ("bounds_sample", C.c_void_p), ("idx", C.c_int32 * 12)]
 
 
+class TraceReport(C.Structure):   # emgpu_trace_report_t
+    _fields_ = [("bytes", C.c_int64), ("ld", C.c_int64), ("candidates", C.c_int32), ("kept", C.c_int32), ("reused", C.c_int32), ("_pad", C.c_int32),
+                ("ms", C.c_float * 8), ("first_allocation_ms", C.c_float), ("kept_ms", C.c_float)]
+
+
+class HostStats(C.Structure):     # emgpu_host_stats_t
+    _fields_ = [("total_ms", C.c_double), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double), ("scatter_ms", C.c_double),
+                ("bytes_d2h", C.c_int64), ("event_rows", C.c_int64), ("chunks", C.c_int32), ("chunk_n", C.c_int32),
+                ("threads", C.c_int32), ("direct", C.c_int32)]
+
+
+TRACE_INIT, TRACE_DENSE, TRACE_EVENTS, TRACE_ATTEMPTS = 1, 2, 4, 8
+
+
 class BnParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_index", C.c_uint64), ("n", C.c_int64), ("flags", C.c_uint32),
                 ("max_attempts", C.c_int32), ("bounds_sample", C.c_void_p),
@@ -131,6 +145,7 @@ SYMBOLS = [
     "emgpu_sample_dbn_blocks_device", "emgpu_sample_dbn_multi_host", "emgpu_sample_dbn_multi_device",
     "emgpu_track_uncor_host", "emgpu_track_uncor_device", "emgpu_uncor_dynamic_limits", "emgpu_model_start_log_weight",
     "emgpu_track_terminal_host", "emgpu_debug_parent_masks", "emgpu_last_launch_count", "emgpu_debug_pk_column", "emgpu_debug_terminal_counters", "emgpu_debug_uncor_dynamics_host", "emgpu_model_save_bin", "emgpu_model_load_bin", "emgpu_philox_rounds", "emgpu_ctx_trim",
+    "emgpu_slot_map_revision", "emgpu_trace_alloc", "emgpu_trace_out", "emgpu_trace_report", "emgpu_trace_free", "emgpu_host_alloc", "emgpu_host_free", "emgpu_host_stats",
 ]
 
 _lib = None
@@ -275,6 +290,7 @@ def lib():
     for f in (L.emgpu_propagate_terminal_device, L.emgpu_propagate_terminal_host):
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(TermParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.emgpu_philox_rounds.restype = C.c_int32
+    L.emgpu_slot_map_revision.restype = C.c_int32
     L.emgpu_ctx_trim.argtypes = [C.c_void_p]
     L.emgpu_model_save_bin.argtypes = [C.c_void_p, C.c_char_p]
     L.emgpu_model_load_bin.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
@@ -283,6 +299,13 @@ def lib():
     L.emgpu_sample_terminal_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(TSampleParams)] + [C.c_void_p] * 7
     for f in (L.emgpu_sample2track_device, L.emgpu_sample2track_host):
         f.argtypes = [C.c_void_p, C.POINTER(TrackParams)] + [C.c_void_p] * 6
+    L.emgpu_trace_alloc.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SampleParams), C.c_uint32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.emgpu_trace_out.argtypes = [C.c_void_p, C.POINTER(SampleOut)]
+    L.emgpu_trace_report.argtypes = [C.c_void_p, C.POINTER(TraceReport)]
+    L.emgpu_trace_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.emgpu_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.emgpu_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.emgpu_host_stats.argtypes = [C.c_void_p, C.POINTER(HostStats)]
     _lib = L
     return L
 

@@ -18,83 +18,18 @@
 #include "emgpu_launch.h"
 #include "emgpu_model.hpp"
 
-using emgpu::CompiledPlan;
-using emgpu::Error;
-using emgpu::Model;
+#include "emgpu_internal.hpp"
 
-struct emgpu_model {
-    Model m;
-};
-
-namespace {
-thread_local std::string g_err;
+namespace emgpu_detail {
+std::string &last_error() {
+    thread_local std::string e;
+    return e;
+}
 int fail(int code, const std::string &msg) {
-    g_err = msg;
+    last_error() = msg;
     return code;
 }
-#define EMGPU_TRY try {
-#define EMGPU_CATCH                                                      \
-    }                                                                    \
-    catch (const Error &e) { return fail(e.code, e.what()); }            \
-    catch (const std::bad_alloc &) { return fail(EMGPU_ERR_ARG, "out of host memory"); } \
-    catch (const std::exception &e) { return fail(EMGPU_ERR_ARG, e.what()); }
-
-#define HIP_OK(expr)                                                                                  \
-    do {                                                                                              \
-        hipError_t _e = (expr);                                                                       \
-        if (_e != hipSuccess) throw Error(EMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-    } while (0)
-
-struct Uploaded {
-    uint64_t version = 0;
-    uint64_t last_use = 0;
-    CompiledPlan cp;
-    uint32_t *d_thr = nullptr;
-    uint32_t *d_cthr = nullptr;
-    uint32_t *d_pthr = nullptr;
-    double *d_bnd = nullptr;
-    void *d_planf = nullptr; // the plan itself (+ k_uncor_fast's resample thresholds) for launches that serve several models
-    double *d_logp = nullptr; // log P of the initial network (emgpu::initial_log_prob), uploaded when a call first asks for log-weights
-    uint32_t lp_off[EMGPU_MAX_NI] = {0};
-    void free_tables() {
-        (void)hipFree(d_thr); (void)hipFree(d_cthr); (void)hipFree(d_pthr); (void)hipFree(d_bnd); (void)hipFree(d_planf); (void)hipFree(d_logp);
-        d_thr = d_cthr = d_pthr = nullptr; d_bnd = nullptr; d_planf = nullptr; d_logp = nullptr;
-    }
-};
-} // namespace
-
-struct emgpu_ctx {
-    std::recursive_mutex mu; // serialises calls on this ctx (the *_host entry points re-enter through *_device)
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t own_stream = nullptr;
-    uint32_t *d_status = nullptr;
-    uint32_t *d_queue = nullptr;  // k_terminal_propagate: the launch's track queue (one word, zeroed by the launcher)
-    EmgpuPresets *d_presets = nullptr;   // the start grid / log-weight block of the last DBN call that had one
-    uint32_t *h_status = nullptr; // pinned
-    std::map<uint64_t, Uploaded> cache; // by Model::uid
-    uint64_t use_clock = 0;
-    std::string last_kernel;
-    int32_t last_launches = 0;
-    double *d_layers = nullptr;
-    size_t d_layers_cap = 0;
-    const uint32_t **d_thr_base = nullptr; // terminal propagation: per-model table pointers
-    size_t d_thr_base_cap = 0;
-    // Side streams for the blocks of a mixed batch (created on first use): independent launches that share the ctx stream's
-    // ordering at both ends, so that one block's tail runs under the next block's head instead of in front of it.
-    static constexpr int kSide = 3;
-    // Device scratch of the round drivers (UncorEncounterModel.track / CorTerminalModel.track), kept between calls and grown on demand:
-    // a fresh hipMalloc + hipFree of several gigabytes per call cost tens of milliseconds, at random (measured: 29 vs 127 ms per call)
-    struct Scratch { void *p = nullptr; size_t cap = 0; };
-    std::vector<Scratch> scratch;
-    // getDynamicLimits.m as a table, per (model uid, model version, the track variables): building it walks N_initial{v} and
-    // N_initial{\dot h} over every (G, A, L range, v range) -- 4 ms on the host for uncor_1200code_v2p1, per call before it was kept
-    std::map<std::array<uint64_t, 3>, emgpu::UncorLimits> limits_cache;
-    hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr, nullptr};
-};
-
-#define CTX_LOCK(ctx) std::lock_guard<std::recursive_mutex> _ctx_lock((ctx)->mu)
+} // namespace emgpu_detail
 
 template <typename T, typename V>
 static int64_t copy_out(const V &v, T *out, int64_t cap) {
@@ -113,8 +48,9 @@ const char *emgpu_last_error(void) { return g_err.c_str(); }
 #endif
 #define EMGPU_STR2(x) #x
 #define EMGPU_STR(x) EMGPU_STR2(x)
-const char *emgpu_version(void) { return "emgpu 0.3 (gfx950) philox4x32-" EMGPU_STR(EMGPU_PHILOX_ROUNDS) " src:" EMGPU_SRC_HASH; }
+const char *emgpu_version(void) { return "emgpu 0.4 (gfx950) philox4x32-" EMGPU_STR(EMGPU_PHILOX_ROUNDS) " src:" EMGPU_SRC_HASH; }
 int32_t emgpu_philox_rounds(void) { return EMGPU_PHILOX_ROUNDS; }
+int32_t emgpu_slot_map_revision(void) { return 2; }
 
 int emgpu_model_load_txt(const char *path, const int32_t *idx_zero_boundaries, int32_t n_idx,
                          int32_t is_overwrite_zero_boundaries, emgpu_model **out) {
@@ -433,6 +369,7 @@ int emgpu_ctx_trim(emgpu_ctx *ctx) {
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipStreamSynchronize(ctx->stream));
     for (auto &sc : ctx->scratch) { if (sc.p) HIP_OK(hipFree(sc.p)); sc.p = nullptr; sc.cap = 0; }
+    ctx_release_host_side(ctx, false);
     return EMGPU_OK;
     EMGPU_CATCH
 }
@@ -442,6 +379,7 @@ void emgpu_ctx_free(emgpu_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->cache) kv.second.free_tables();
     for (auto &sc : ctx->scratch) (void)hipFree(sc.p);
+    ctx_release_host_side(ctx, true);
     (void)hipFree(ctx->d_status);
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_presets);
@@ -525,7 +463,7 @@ static void ensure_logp(emgpu_ctx *ctx, Uploaded &u, const Model &m) {
 }
 
 // slot-th scratch buffer of the ctx, at least `bytes` long (contents undefined; valid until the next request for the same slot)
-static void *ctx_scratch(emgpu_ctx *ctx, size_t slot, size_t bytes) {
+void *ctx_scratch(emgpu_ctx *ctx, size_t slot, size_t bytes) {
     if (ctx->scratch.size() <= slot) ctx->scratch.resize(slot + 1);
     emgpu_ctx::Scratch &sc = ctx->scratch[slot];
     if (sc.cap < bytes || !sc.p) {
@@ -841,87 +779,7 @@ int emgpu_sample_dbn_multi_host(emgpu_ctx *const *ctxs, int32_t n_ctx, const emg
     EMGPU_CATCH
 }
 
-int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sample_params *p, const emgpu_sample_out *out) {
-    EMGPU_TRY
-    if (!ctx || !h || !p || !out) return fail(EMGPU_ERR_ARG, "null argument");
-    CTX_LOCK(ctx);
-    HIP_OK(hipSetDevice(ctx->device));
-    const Model &m = h->m;
-    const size_t n = (size_t)(p->n > 0 ? p->n : 0), ni = m.n_initial, nd = m.n_dyn();
-    const size_t G4 = ((size_t)p->sample_time + 3) / 4;
-    // the host arrays may be dimensioned for a larger batch (ld) of which this call fills columns [off, off + n)
-    const size_t ld = out->ld ? (size_t)out->ld : n, off = (size_t)out->col_offset;
-    if (out->ld < 0 || out->col_offset < 0 || off + n > ld) return fail(EMGPU_ERR_ARG, "col_offset + n exceeds ld");
-    emgpu_sample_out d{};
-    size_t slot = 0;
-    auto dalloc = [&](size_t bytes) -> void * { return ctx_scratch(ctx, slot++, bytes ? bytes : 1); };   // kept by the ctx between calls
-    int rc = EMGPU_OK;
-    try {
-        const size_t b_ib = ni * n, b_iv = ni * n * 4, b_db = G4 * nd * n * 4, b_dv = G4 * nd * n * 16;
-        const size_t b_ec = n * 4, b_ev = n * (size_t)(p->event_cap > 0 ? p->event_cap : 0) * 8, b_at = n * 4;
-        if (out->init_bin) d.init_bin = (uint8_t *)dalloc(b_ib);
-        if (out->init_val) d.init_val = (float *)dalloc(b_iv);
-        if (out->dyn_bin) d.dyn_bin = (uint32_t *)dalloc(b_db);
-        if (out->dyn_val) d.dyn_val = (float *)dalloc(b_dv);
-        if (out->ev_count) d.ev_count = (uint32_t *)dalloc(b_ec);
-        if (out->events) d.events = (emgpu_event *)dalloc(b_ev);
-        if (out->attempts) d.attempts = (int32_t *)dalloc(b_at);
-        emgpu_sample_params pd = *p;
-        if (out->log_weight) d.log_weight = (double *)dalloc(n * sizeof(double));
-        if (p->start && n) {     // the start grid is caller (host) memory here
-            int32_t *ds = (int32_t *)dalloc(n * ni * sizeof(int32_t));
-            HIP_OK(hipMemcpyAsync(ds, p->start, n * ni * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-            HIP_OK(hipStreamSynchronize(ctx->stream));
-            pd.start = ds;
-        }
-        if (p->indices && n) {   // the index list is caller (host) memory here
-            uint64_t *di = (uint64_t *)dalloc(n * sizeof(uint64_t));
-            HIP_OK(hipMemcpyAsync(di, p->indices, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-            HIP_OK(hipStreamSynchronize(ctx->stream));
-            pd.indices = di;
-        }
-        rc = emgpu_sample_dbn_device(ctx, h, &pd, &d);
-        if (rc == EMGPU_OK) {
-            // rows x (n elements of `elem` bytes) from the shard-sized device array into columns [off, off + n) of the host array
-            auto back = [&](void *dst, const void *src, size_t rows, size_t elem) {
-                if (!dst || !n || !rows) return;
-                char *dcol = (char *)dst + off * elem;
-                if (ld == n) HIP_OK(hipMemcpyAsync(dcol, src, rows * n * elem, hipMemcpyDeviceToHost, ctx->stream));
-                else HIP_OK(hipMemcpy2DAsync(dcol, ld * elem, src, n * elem, n * elem, rows, hipMemcpyDeviceToHost, ctx->stream));
-            };
-            back(out->init_bin, d.init_bin, ni, 1); back(out->init_val, d.init_val, ni, 4);
-            back(out->dyn_bin, d.dyn_bin, G4 * nd, 4); back(out->dyn_val, d.dyn_val, G4 * nd, 16);
-            back(out->ev_count, d.ev_count, 1, 4);
-            back(out->attempts, d.attempts, 1, 4);
-            if (out->log_weight && n) HIP_OK(hipMemcpyAsync(out->log_weight, d.log_weight, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            rc = emgpu_ctx_sync(ctx);
-            uint32_t *h_ec = out->ev_count ? out->ev_count + off : nullptr;
-            emgpu_event *h_ev = out->events ? out->events + off * (size_t)p->event_cap : nullptr;
-            if (out->events && b_ev) {
-                // only the used part of every event list crosses PCIe: rows past the longest list (or past
-                // ev_count[i]) are left as the caller passed them
-                const size_t cap = (size_t)p->event_cap;
-                size_t longest = cap;
-                if (h_ec) {
-                    longest = 0;
-                    for (size_t i = 0; i < n; i++) longest = h_ec[i] > longest ? h_ec[i] : longest;
-                    if (longest > cap) longest = cap;
-                }
-                if (longest && n) {
-                    HIP_OK(hipMemcpy2DAsync(h_ev, cap * sizeof(emgpu_event), d.events, cap * sizeof(emgpu_event),
-                                            longest * sizeof(emgpu_event), n, hipMemcpyDeviceToHost, ctx->stream));
-                    HIP_OK(hipStreamSynchronize(ctx->stream));
-                }
-            }
-        }
-    } catch (...) {
-        (void)hipStreamSynchronize(ctx->stream);
-        throw;
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    return rc;
-    EMGPU_CATCH
-}
+// (emgpu_sample_dbn_host, the trace pool and the pinned pool: emgpu_host.cpp)
 
 static void fill_bn(emgpu_ctx *ctx, const Uploaded &u, const Model &m, const emgpu_bn_params *p, EmgpuBnRun &A) {
     memset(&A, 0, sizeof A);

@@ -37,5 +37,9 @@ hipError_t launch_uncor_track(const EmgpuUTrackRun &A, hipStream_t s, const char
 size_t compact_scratch_words(int64_t n);
 hipError_t launch_compact_rejected(int64_t n, uint64_t first_index, const uint8_t *accepted, const uint64_t *gidx_in, const int64_t *slot_in,
                                    uint64_t *gidx_out, int64_t *slot_out, uint32_t *count, hipStream_t s);
+// event lists [n][cap] -> one packed run of rows (emgpu_kernels_pack.hip): scratch = pack_scratch_words(n) words, of which the first two
+// receive the total row count (u64) and word 2 + b the first packed row of workgroup b's 256 lists; packed: room for n x cap rows
+size_t pack_scratch_words(int64_t n);
+hipError_t launch_pack_events(int64_t n, uint32_t cap, const uint32_t *cnt, const uint64_t *ev, uint32_t *scratch, uint64_t *packed, hipStream_t s);
 hipError_t launch_sample2track(const EmgpuTrackRun &A, bool dense, hipStream_t s, const char **name);
 } // namespace emgpu

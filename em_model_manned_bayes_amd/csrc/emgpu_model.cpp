@@ -516,7 +516,8 @@ Model *load_bin(const char *path, const char *src_hash) {
     tag[sizeof tag - 1] = 0;
     if (strcmp(tag, src_hash ? src_hash : "") != 0)
         throw Error(EMGPU_ERR_PARSE, std::string("binary model cache written by other sources (") + tag + "): read the .txt again");
-    if (r.pod<uint64_t>() != payload_checksum(r.p, (size_t)(r.end - r.p)))
+    const uint64_t want_sum = r.pod<uint64_t>();   // (read first: the operands of != are unsequenced, and pod() moves r.p past the checksum)
+    if (want_sum != payload_checksum(r.p, (size_t)(r.end - r.p)))
         throw Error(EMGPU_ERR_PARSE, "binary model cache: checksum mismatch (damaged file): read the .txt again");
     std::unique_ptr<Model> m(new Model());
     m->n_initial = r.pod<int32_t>(); m->n_transition = r.pod<int32_t>();

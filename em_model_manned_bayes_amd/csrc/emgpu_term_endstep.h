@@ -11,8 +11,9 @@
             // v = rotationmatrix(delta) * v  (:262; rotationmatrix(0) is the identity).  Round 4 marked the velocity "due" and the next step
             // evaluated sincosd(vang) -- 75 vector instructions for the five lanes per wave-iteration that turn, in 85 % of the wave-iterations.
             // A turn is at most maxTurnRate (<= 12 degrees in getDynamicLimits.m:15-62): cosd / sind of such an angle are the reduced-argument
-            // sums themselves (n = round(delta / 90) = 0) and need a third of the terms for the same last bit (|x| <= 0.22: the next terms
-            // are below 2^-56 of the result), and the rotation is the reference's own 2 x 2 product (vector instructions per launch -8 %).
+            // sums themselves (n = round(delta / 90) = 0) and need a third of the terms (|x| <= 0.22: the first term left out is
+            // x^13 / 13! = 4e-19 for the sine and x^12 / 12! = 2.4e-17 for the cosine -- a quarter of an ulp of a value near 1, so the sum may differ from
+            // the full series' in the last bit; the GPU tests hold the tracks to the oracle's f64 rounded to f32, or one f32 step), and the rotation is the reference's own 2 x 2 product (vector instructions per launch -8 %).
             if (delta != 0.0) {
                 vang += delta;
                 if (fabs(delta) <= 12.5) {

@@ -327,8 +327,11 @@ class UncorEncounterModel(EncounterModel):
         idxEME = [int(np.nonzero(tm[:, 0] == v)[0][0]) + 1 for v in (idxDH, idxDPsi, idxDV)]  # :291
         vars_dyn = tm[:, 0].astype(np.int64) - 1
         chunk, cap, pos = max(1, min(32768, (96 << 20) // (8 * ni * T))), 256, 0   # the dense [chunk, ni, T] f64 block stays < 100 MB
+        import time as _time
+        t_call, tm = _time.perf_counter(), {"native_s": 0.0, "kernel_ms": 0.0, "d2h_ms": 0.0, "bytes_d2h": 0, "calls": 0}
         while pos < n_samples:
             nn = min(chunk, n_samples - pos)
+            t_nat = _time.perf_counter()
             try:
                 res = native.sample_dbn_host(ctx, m, nn, T, s, first_index=first + pos, want_dense=False, want_events=True,
                                              event_cap=cap, flags=flags, layers=layers, transition_mode=transition_mode,
@@ -338,6 +341,9 @@ class UncorEncounterModel(EncounterModel):
                     cap *= 2
                     continue
                 raise
+            tm["native_s"] += _time.perf_counter() - t_nat
+            st = res["host_stats"]
+            tm["kernel_ms"] += st["kernel_ms"]; tm["d2h_ms"] += st["d2h_ms"]; tm["bytes_d2h"] += st["bytes_d2h"]; tm["calls"] += 1
             iv = res["init_val"].astype(np.float64)
             out_inits[pos: pos + nn] = iv
             # The whole chunk at once (events2samples.m:9-26, events2controls.m:11-31 restated on flat arrays):
@@ -376,6 +382,11 @@ class UncorEncounterModel(EncounterModel):
                 out_samples[pos + k] = D[k]
                 out_EME[pos + k] = EncounterModelEvents(event=ctrl_split[k])
             pos += nn
+        # the call's three phases (bench.py `host_path.class_sample`): the library calls (kernel + PCIe + the binding's own copies), of which
+        # kernel_ms / d2h_ms are the device's share, and the numpy / Python reconstruction of out_samples, controls and EncounterModelEvents
+        tm["total_s"] = _time.perf_counter() - t_call
+        tm["format_s"] = tm["total_s"] - tm["native_s"]
+        self.last_sample_timing = tm
         return out_inits, out_events, out_samples, out_EME
 
     TRACK_FIELDS = ("time_s", "north_ft", "east_ft", "up_ft", "speed_ft_s", "phi_rad", "theta_rad", "psi_rad")

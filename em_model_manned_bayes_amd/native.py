@@ -210,6 +210,25 @@ class Context:
     def last_kernel(self):
         return L.lib().emgpu_last_kernel_name(self._h).decode()
 
+    def host_stats(self):
+        """emgpu_host_stats: the phases of the last sample_dbn_host call on this context, as a dict."""
+        st = L.HostStats()
+        L.check(L.lib().emgpu_host_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in L.HostStats._fields_}
+
+    def pinned_empty(self, shape, dtype):
+        """A numpy array over pinned host memory of this context's pool (emgpu_host_alloc): the copy engine writes the *_host entry
+        points' outputs straight into it.  The block goes back to the pool when the array (and every view of it) is gone."""
+        import weakref
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        ptr = C.c_void_p()
+        L.check(L.lib().emgpu_host_alloc(self._h, max(nbytes, 1), C.byref(ptr)))
+        buf = (C.c_char * max(nbytes, 1)).from_address(ptr.value)
+        a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+        weakref.finalize(buf, _host_free, self, ptr.value)   # (numpy keeps `buf` alive as the base of every view; the finalizer keeps the context alive)
+        return a
+
     def last_launches(self):
         """Kernel launches of the last sample_dbn_*_device call on this context."""
         return int(L.lib().emgpu_last_launch_count(self._h))
@@ -218,6 +237,54 @@ class Context:
         try:
             if self._h:
                 L.lib().emgpu_ctx_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _host_free(ctx, addr):
+    try:
+        if ctx._h:
+            L.lib().emgpu_host_free(ctx._h, C.c_void_p(addr))
+    except Exception:
+        pass
+
+
+class Trace:
+    """emgpu_trace: device memory for the outputs of sample_dbn_device, allocated and PLACED by the library (emgpu_trace_alloc times the
+    caller's own launch on a few candidate allocations and keeps the fastest: profiles/r05_placement_probe.txt).  `ptrs()` are the keyword
+    arguments of sample_dbn_device / sample_dbn_blocks_device; `report` says what was measured."""
+
+    def __init__(self, ctx, model, params, want=L.TRACE_INIT | L.TRACE_DENSE, candidates=0):
+        self._ctx = ctx
+        h = C.c_void_p()
+        L.check(L.lib().emgpu_trace_alloc(ctx._h, model._h, C.byref(params), int(want), int(candidates), C.byref(h)))
+        self._h = h
+        o = L.SampleOut()
+        L.check(L.lib().emgpu_trace_out(self._h, C.byref(o)))
+        self.out = o
+        r = L.TraceReport()
+        L.check(L.lib().emgpu_trace_report(self._h, C.byref(r)))
+        self.ld, self.bytes = int(r.ld), int(r.bytes)
+        self.report = {"candidates": int(r.candidates), "kept": int(r.kept), "reused": int(r.reused),
+                       "ms": [round(float(r.ms[i]), 3) for i in range(min(int(r.candidates), 8))] if r.candidates > 1 else [],
+                       "first_allocation_ms": round(float(r.first_allocation_ms), 3), "kept_ms": round(float(r.kept_ms), 3)}
+
+    def ptrs(self):
+        o = self.out
+        return dict(init_bin=o.init_bin or 0, init_val=o.init_val or 0, dyn_bin=o.dyn_bin or 0, dyn_val=o.dyn_val or 0,
+                    ev_count=o.ev_count or 0, events=o.events or 0, attempts=o.attempts or 0, ld=int(o.ld))
+
+    def free(self):
+        """Back to the context's pool (the next Trace it fits takes it without a new probe)."""
+        if self._h:
+            L.check(L.lib().emgpu_trace_free(self._ctx._h, self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            if self._h and self._ctx._h:
+                L.lib().emgpu_trace_free(self._ctx._h, self._h)
                 self._h = None
         except Exception:
             pass
@@ -330,30 +397,37 @@ def sample_dbn_multi_device(ctxs, model, params, outs):
     L.check(L.lib().emgpu_sample_dbn_multi_device(hs, len(ctxs), model._h, C.byref(params), arr))
 
 
-def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_events=False, event_cap=None, want_log_weight=False, **kw):
+def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_events=False, event_cap=None, want_log_weight=False, pinned=True,
+                    raw=False, **kw):
     """Synchronous host-buffer call.  Returns a dict of numpy arrays in user-facing shapes:
     init_bin [n, n_i] u8, init_val [n, n_i] f32, dyn_bin [n, T, n_d] u8, dyn_val [n, T, n_d] f32,
     events: list of structured arrays (EVENT_DTYPE), attempts [n].
     ctx may be a list of Contexts (one per device): the batch is then split over them inside ONE library call
     (emgpu_sample_dbn_multi_host: one host thread + one stream per device) with identical results.
+    pinned: the library's arrays come from the context's pinned pool (the copy engine writes straight into them); False: pageable numpy
+    arrays, which the library fills through its own staging buffers -- what a caller's own arrays (MATLAB's, a C host's) get.
+    raw: return the arrays in the library's layout (init_* [n_i, n], dyn_bin [G4, n_d, n] u32, dyn_val [G4, n_d, n, 4]) without the
+    transposing copies; `host_stats` = emgpu_host_stats of the call either way.
     """
     ni, nd, T = model.n_initial, model.n_dyn, int(sample_time)
     if want_events and event_cap is None:
         event_cap = min((ni + nd + 1) * T + 2, 4096)
     p, keep = make_params(n, T, seed, event_cap=event_cap or 0, **kw)
     G4 = (T + 3) // 4
+    ctx0 = ctx[0] if isinstance(ctx, (list, tuple)) else ctx
+    empty = ctx0.pinned_empty if pinned else (lambda shape, dt: np.zeros(shape, dtype=dt))
     o = L.SampleOut()
-    ib = np.zeros((ni, n), dtype=np.uint8)
-    iv = np.zeros((ni, n), dtype=np.float32)
-    att = np.zeros(n, dtype=np.int32)
+    ib = empty((ni, n), np.uint8)
+    iv = empty((ni, n), np.float32)
+    att = empty((n,), np.int32)
     o.init_bin, o.init_val, o.attempts = _p(ib), _p(iv), _p(att)
     if want_dense and nd > 0:
-        db = np.zeros((G4, nd, n), dtype=np.uint32)
-        dv = np.zeros((G4, nd, n, 4), dtype=np.float32)
+        db = empty((G4, nd, n), np.uint32)
+        dv = empty((G4, nd, n, 4), np.float32)
         o.dyn_bin, o.dyn_val = _p(db), _p(dv)
     if want_events:
-        ec = np.zeros(n, dtype=np.uint32)
-        ev = np.zeros((n, event_cap), dtype=EVENT_DTYPE)
+        ec = empty((n,), np.uint32)
+        ev = empty((n, event_cap), EVENT_DTYPE)
         o.ev_count, o.events = _p(ec), _p(ev)
     if want_log_weight:
         lw = np.zeros(n, dtype=np.float64)
@@ -361,19 +435,26 @@ def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_even
     if isinstance(ctx, (list, tuple)):
         hs = (C.c_void_p * len(ctx))(*[c._h for c in ctx])
         L.check(L.lib().emgpu_sample_dbn_multi_host(hs, len(ctx), model._h, C.byref(p), C.byref(o)))
-        ctx = ctx[0]
     else:
         L.check(L.lib().emgpu_sample_dbn_host(ctx._h, model._h, C.byref(p), C.byref(o)))
-    out = {"init_bin": ib.T.copy(), "init_val": iv.T.copy(), "attempts": att, "kernel": ctx.last_kernel()}
+    ctx = ctx0
+    out = {"attempts": np.array(att), "kernel": ctx.last_kernel(), "host_stats": ctx.host_stats()}
+    if raw:
+        out["init_bin"], out["init_val"] = ib, iv
+    else:
+        out["init_bin"], out["init_val"] = ib.T.copy(), iv.T.copy()
     if want_log_weight:
         out["log_weight"] = lw
     if want_dense and nd > 0:
-        out["dyn_bin"] = unpack_dyn_bin(db, T)
-        out["dyn_val"] = unpack_dyn_val(dv, T)
+        out["dyn_bin"] = db if raw else unpack_dyn_bin(db, T)
+        out["dyn_val"] = dv if raw else unpack_dyn_val(dv, T)
     if want_events:
-        out["events"] = [ev[i, : ec[i]] for i in range(n)]
+        ec = np.array(ec)
+        flat = ev[np.arange(ev.shape[1], dtype=np.uint32)[None, :] < ec[:, None]]   # all rows in order, one array (no per-sample concatenation; a copy)
         out["ev_count"] = ec
-        out["events_flat"] = ev[np.arange(ev.shape[1], dtype=np.uint32)[None, :] < ec[:, None]]   # all rows in order, one array (no per-sample concatenation)
+        out["events_flat"] = flat
+        ends = np.cumsum(ec.astype(np.int64))
+        out["events"] = np.split(flat, ends[:-1]) if n > 1 else [flat]
     return out
 
 

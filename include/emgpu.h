@@ -49,6 +49,12 @@ const char *emgpu_version(void);   /* "emgpu <version> (gfx950) philox4x32-<roun
  * round count is part of the sampler's identity: the same (seed, global index) gives other samples under another count, so data and
  * goldens of one count are not comparable with, or resumable by, a build of the other -- check it where that matters. */
 int32_t emgpu_philox_rounds(void);
+/* Revision of the RNG slot map (which Philox counter word every draw of the reference's algorithm takes).  Like the
+ * round count it is part of the sampler's identity: a change gives other samples for the same (seed, global index).
+ *   1  rounds 1-4 of this library
+ *   2  round 5 on ("emgpu 0.4" is the first version string to say so): terminal propagation takes an attempt's FIRST dediscretize draw from word 3 of its TERM_TRANS block (createEncounter.m:203,
+ *      208,216); every other section unchanged -- uncor / cor samples are identical under 1 and 2, terminal tracks are not. */
+int32_t emgpu_slot_map_revision(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Model: replaces em_read.m:1-206 and the data half of @EncounterModel/EncounterModel.m
@@ -233,11 +239,73 @@ typedef struct {
  * Deferred errors are reported by emgpu_ctx_sync. */
 int emgpu_sample_dbn_device(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_sample_params *p,
                             const emgpu_sample_out *out);
-/* Synchronous convenience for the MATLAB/Python class layer: HOST pointers in `out`; allocates
- * device buffers, runs, copies back (PCIe-inclusive; never the benchmarked path).  Of `events` only
- * rows [0, ev_count[i]) of list i are defined on return (with ev_count == NULL all event_cap rows are copied). */
+/* Synchronous, for the MATLAB / Python class layer: HOST pointers in `out` (UncorEncounterModel.m:283-300 hands host arrays back).
+ * A pipeline (round 6): the batch is cut into chunks; chunk k's kernel runs on the ctx stream while chunk k-1 crosses PCIe on a copy
+ * stream into pinned memory and chunk k-2 is copied into the caller's arrays by a few host threads (pageable arrays), or the copy engine
+ * writes straight into the caller's arrays (arrays from emgpu_host_alloc / hipHostMalloc / hipHostRegister).  Event lists are packed on
+ * the device first (a prefix sum over ev_count): sum(ev_count) rows cross PCIe, not n x event_cap.  PCIe-inclusive: reported by bench.py
+ * as `host_path`, never as the headline.  Of `events` only rows [0, min(ev_count[i], event_cap)) of list i are defined on return. */
 int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_sample_params *p,
                           const emgpu_sample_out *out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Trace placement (round 6).  WHERE a 36 GB trace lies in device memory decides how fast the sampler writes it: the same launch takes
+ * 6.0 ms into one allocation and 7.1 ms into another one of the same process, launch after launch (profiles/r05_placement_probe.txt).
+ * A consumer of emgpu_sample_dbn_device therefore asks the LIBRARY for its trace instead of calling hipMalloc: emgpu_trace_alloc
+ * allocates `candidates` separate blocks, times the caller's own call (m, p) on each -- 0.5 s of launches to load the device, then two
+ * rounds of 2 untimed + 5 timed launches per candidate, the better round counts -- keeps the fastest and frees the others.  What the
+ * loop over samples of UncorEncounterModel.m:244 writes into is, here, one such trace.
+ *   want        EMGPU_TRACE_* : which outputs the trace holds (events: [ld][p->event_cap] rows)
+ *   candidates  0 = automatic: one block (nothing timed) below 1 GiB, where the launch is too short for placement to matter; else 3, and
+ *               further ones (up to 6, memory permitting) until the two fastest agree within 1 %.  1 = the first allocation as it comes.
+ * The trace's trajectory dimension ld is p->n rounded up to 1 024 columns (every row of every array starts on a 1 KiB boundary).
+ * emgpu_trace_free gives the block back to the ctx's POOL: the next emgpu_trace_alloc it fits (and is not more than 25 % too large for) takes
+ * it without a new probe (report.reused = 1).  emgpu_ctx_trim / emgpu_ctx_free release the pool.  The probe launches overwrite the trace
+ * with the samples of (p->seed, p->first_index ...): the same samples the caller's own call will write.
+ * ---------------------------------------------------------------------------------------------- */
+#define EMGPU_TRACE_INIT 1u     /* init_bin + init_val                  */
+#define EMGPU_TRACE_DENSE 2u    /* dyn_bin + dyn_val                    */
+#define EMGPU_TRACE_EVENTS 4u   /* ev_count + events[ld][p->event_cap]  */
+#define EMGPU_TRACE_ATTEMPTS 8u /* attempts                             */
+typedef struct emgpu_trace emgpu_trace;
+typedef struct {
+    int64_t bytes;             /* size of one candidate = one device allocation                                         */
+    int64_t ld;                /* trajectory dimension of every array of the trace                                      */
+    int32_t candidates;        /* blocks allocated and timed (1: nothing was timed)                                     */
+    int32_t kept;              /* index of the kept one, in allocation order                                            */
+    int32_t reused;            /* 1: a block of the ctx's pool, placed by an earlier call; nothing was timed now        */
+    int32_t _pad;
+    float ms[8];               /* per candidate: ms per launch, the better of its two rounds                            */
+    float first_allocation_ms; /* = ms[0]: what a caller who keeps the first allocation gets (0: nothing was timed)     */
+    float kept_ms;
+} emgpu_trace_report_t;
+int emgpu_trace_alloc(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_sample_params *p, uint32_t want, int32_t candidates,
+                      emgpu_trace **out);
+/* The trace as the `out` argument of emgpu_sample_dbn_device / _blocks_device: device pointers, ld set, col_offset 0. */
+int emgpu_trace_out(const emgpu_trace *t, emgpu_sample_out *out);
+int emgpu_trace_report(const emgpu_trace *t, emgpu_trace_report_t *out);
+int emgpu_trace_free(emgpu_ctx *ctx, emgpu_trace *t);
+
+/* Pinned host memory for the outputs of the *_host entry points (hipHostMalloc, kept in a per-ctx pool: pinning gigabytes costs about as
+ * much as copying them).  emgpu_sample_dbn_host recognises pinned output arrays and lets the copy engine write straight into them;
+ * pageable arrays go through the library's own pinned staging buffers and a few host threads (below). */
+int emgpu_host_alloc(emgpu_ctx *ctx, uint64_t bytes, void **out);
+int emgpu_host_free(emgpu_ctx *ctx, void *p);   /* back to the pool; emgpu_ctx_trim releases the pool's free blocks */
+
+/* Phases of the last emgpu_sample_dbn_host call on this ctx (the call is a pipeline: chunk k's kernel runs while chunk k-1 crosses PCIe
+ * and chunk k-2 is copied from staging into the caller's arrays, so the phases overlap and do not add up to total_ms). */
+typedef struct {
+    double total_ms;        /* wall time of the call                                                                    */
+    double kernel_ms;       /* sum of the chunks' launch durations (HIP events on the launch stream)                    */
+    double d2h_ms;          /* sum of the chunks' copy durations (HIP events on the copy stream)                        */
+    double scatter_ms;      /* host wall time spent copying staging -> caller arrays (0 for pinned outputs)             */
+    int64_t bytes_d2h;      /* bytes that crossed PCIe                                                                  */
+    int64_t event_rows;     /* rows of the event lists copied (the lists are packed on the device first)               */
+    int32_t chunks, chunk_n;
+    int32_t threads;        /* host threads of the scatter                                                              */
+    int32_t direct;         /* 1: every large output was pinned memory (no staging)                                    */
+} emgpu_host_stats_t;
+int emgpu_host_stats(const emgpu_ctx *ctx, emgpu_host_stats_t *out);
 
 /* ------------------------------------------------------------------------------------------------
  * One batch, several models / several devices.  The reference shards only by running em_sample in

@@ -890,6 +890,9 @@ int em_propagate_trajectory(const em_model_t *m, em_rng_t *g, int role, int is_o
     const int ni = m->n_initial, nt = m->n_transition;
     const int IDX_DIST = 2, IDX_BEAR = 3, IDX_HEAD = 4, IDX_ALT = 5, IDX_SPD = 6;
     if (ni != 6 || m->n_dyn != 3) return -1;
+    /* "the attempt's first dediscretize draw" (slot map, round 5) is defined by the order heading, altitude, speed: the rows of the temporal map
+     * are walked below, so they must be those three variables in that order (em_read.m:158-177 builds the map in variable order) */
+    if (m->temporal_map[0] != IDX_HEAD || m->temporal_map[2] != IDX_ALT || m->temporal_map[4] != IDX_SPD) return -1;
     const double *bnd[7]; int nb[7];
     for (int v = 1; v <= 6; v++) { bnd[v] = m->boundaries + m->bnd_off[v - 1]; nb[v] = m->bnd_len[v - 1]; }
     /* discreteValidAlt / discreteValidV  (:121-127) */

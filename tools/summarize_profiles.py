@@ -39,6 +39,12 @@ for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
     summary["kernel_calls"] = int(top["Calls"])
     summary["kernel_avg_ms"] = float(top["AverageNs"]) / 1e6
     summary["kernel_pct_of_gpu_time"] = float(top["Percentage"])
+for f in glob.glob(os.path.join(src, "bench_plain.json")):
+    try:
+        summary["bench_line"] = json.loads(open(f).read().strip().split("\n")[-1])
+    except Exception:
+        pass
+timed_steps = int(summary.get("bench_line", {}).get("steps", 10) or 10)   # the pass's own --steps (the line says how many it timed)
 # every launch of the dominant kernel, in time order: the first five (clocks still ramping) are bench.py's warm-up,
 # the rest are its timed region -- their mean is what bench.py's roofline.avg_launch_ms must agree with
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv")):
@@ -49,8 +55,9 @@ for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_trace.csv")):
     # the LAST `--steps` launches of the pass (default 10: the kernel-trace pass runs bench.py's defaults with --telemetry-s 0, nothing follows)
     summary["kernel_launches_in_the_pass"] = len(ms)
     summary["kernel_launch_ms"] = [round(x, 4) for x in ms[-40:]]
-    if len(ms) > 15:
-        summary["kernel_avg_ms_timed_region"] = sum(ms[-10:]) / 10.0
+    if len(ms) > timed_steps + 5:
+        summary["kernel_avg_ms_timed_region"] = sum(ms[-timed_steps:]) / float(timed_steps)
+        summary["timed_steps"] = timed_steps
     elif len(ms) > 5:
         summary["kernel_avg_ms_timed_region"] = sum(ms[5:]) / len(ms[5:])   # (rounds 1-4: 5 warm-up launches, then the timed ones)
 # per-dispatch resource usage from the kernel trace
@@ -79,10 +86,5 @@ if "WRITE_SIZE" in pmc:
     summary["hbm_write_bytes_per_launch"] = wr
     summary["hbm_read_bytes_per_launch_corrected"] = rd
     summary["hbm_traffic_bytes_per_launch"] = wr + rd
-for f in glob.glob(os.path.join(src, "bench_plain.json")):
-    try:
-        summary["bench_line"] = json.loads(open(f).read().strip().split("\n")[-1])
-    except Exception:
-        pass
 json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in summary.items() if k != "bench_line"}, indent=1)[:3000])
