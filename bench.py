@@ -492,7 +492,13 @@ class TerminalWorkload:
         self.geom_val = pl.empty((ni, n), "float32")
         self.geo = pl.empty((n, 12), "float64")
         self.mof = pl.empty((4 * n,), "int32")
-        self.traj = pl.empty((2 * n, 2 * self.native.terminal_t0_row(self.cap), 5), "float32")
+        tshape = (2 * n, 2 * self.native.terminal_t0_row(self.cap), 5)
+        self._traj_addr = None
+        if hasattr(pl, "wrap") and hasattr(self.ctx, "device_alloc"):   # 131 GB of joined tracks: from the library's allocator (emgpu_device_alloc), like the traces
+            self._traj_addr = self.ctx.device_alloc(4 * tshape[0] * tshape[1] * tshape[2])
+            self.traj = pl.wrap(self._traj_addr, tshape, "float32")
+        else:
+            self.traj = pl.empty(tshape, "float32")
         self.rows = pl.empty((4 * n,), "int32")
         self.att = pl.empty((n,), "int32")
         self.bs = None if np.all(np.isinf(self.t.bounds_sample)) else self.t.bounds_sample
@@ -504,6 +510,12 @@ class TerminalWorkload:
         self.bytes_stored_per_unit = None        # 75 + 20 B x the rows the run really wrote (what the kernel stores: five f32 per row)
         self.launches_per_step = 1
         self.ranges = []
+
+    def close(self):
+        self.traj = None
+        if self._traj_addr:
+            self.ctx.device_free(self._traj_addr)
+            self._traj_addr = None
 
     def digest(self):
         t = self.pl.torch

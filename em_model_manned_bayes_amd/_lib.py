@@ -146,6 +146,7 @@ SYMBOLS = [
     "emgpu_track_uncor_host", "emgpu_track_uncor_device", "emgpu_uncor_dynamic_limits", "emgpu_model_start_log_weight",
     "emgpu_track_terminal_host", "emgpu_debug_parent_masks", "emgpu_last_launch_count", "emgpu_debug_pk_column", "emgpu_debug_terminal_counters", "emgpu_debug_uncor_dynamics_host", "emgpu_model_save_bin", "emgpu_model_load_bin", "emgpu_philox_rounds", "emgpu_ctx_trim",
     "emgpu_slot_map_revision", "emgpu_trace_alloc", "emgpu_trace_out", "emgpu_trace_report", "emgpu_trace_free", "emgpu_host_alloc", "emgpu_host_free", "emgpu_host_stats",
+    "emgpu_device_alloc", "emgpu_device_free",
 ]
 
 _lib = None
@@ -306,6 +307,8 @@ def lib():
     L.emgpu_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
     L.emgpu_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.emgpu_host_stats.argtypes = [C.c_void_p, C.POINTER(HostStats)]
+    L.emgpu_device_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.emgpu_device_free.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

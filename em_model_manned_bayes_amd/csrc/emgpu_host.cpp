@@ -28,27 +28,40 @@ double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std
 size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------ device blocks
-// How a block of the trace pool is obtained.  EMGPU_TRACE_ALLOC (read once) = "plain" (default): hipMalloc; "contiguous": hipExtMallocWithFlags(hipDeviceMallocContiguous)
-// -- physically contiguous VRAM; "vmm[:MiB]": a reserved address range backed by separately created physical chunks (hipMemCreate, default 1 024 MiB
-// each).  tools/placement_probe5.py measures what each gives on a box (profiles/r06_placement_probe.txt).
-struct VmmBlock { size_t bytes = 0, chunk = 0; std::vector<hipMemGenericAllocationHandle_t> handles; };
+// How a block of the trace pool is obtained (round 6, tools/placement_probe5.py, profiles/r06_placement_probe.txt).  The same launch writes a
+// 36 GB trace in 5.9, 6.6 or 7.0 ms depending on the allocation.  Blocks that hipMalloc hands out are mostly of the 6.6 ms kind, now and then
+// of the others; an ADDRESS RANGE THAT STARTS ON A 1 GiB BOUNDARY backed by separately created 1 GiB PHYSICAL CHUNKS (hipMemAddressReserve +
+// hipMemCreate + hipMemMap) is of the 5.9-6.0 ms kind in every process but the first one on a freshly booted box, where it is mixed (with the
+// range shifted off its boundary by 2 or 64 MiB it is mixed everywhere: alignment is what counts).  So: blocks of 1 GiB and more are built
+// that way (falling back to hipMalloc where the virtual-memory calls fail), smaller ones come from hipMalloc, and emgpu_trace_alloc still
+// measures its candidates -- candidate 0 a plain hipMalloc block, so that the report shows what a caller's own allocation would have got.
+// EMGPU_TRACE_ALLOC (read once; experiments) = "plain": hipMalloc only; "contiguous": hipExtMallocWithFlags(hipDeviceMallocContiguous);
+// "vmm:<chunk MiB>[:<shift MiB>]": another chunk size / the range mapped that far off its boundary.
+struct VmmBlock { size_t bytes = 0, chunk = 0, reserved = 0; void *va = nullptr; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_vmm_mu;
 std::map<void *, VmmBlock> g_vmm;
-int alloc_mode(size_t *chunk) {
+int alloc_mode(size_t *chunk, size_t *shift = nullptr) {
     static int mode = -1;
-    static size_t ch = (size_t)1 << 30;
+    static size_t ch = (size_t)1 << 30, sh = 0;
     if (mode < 0) {
         const char *e = getenv("EMGPU_TRACE_ALLOC");
-        mode = 0;
+        mode = 3;   // automatic: 1 GiB chunks behind a 1 GiB-aligned range for blocks of 1 GiB and more, hipMalloc below (and as the fallback)
+        if (e && !strncmp(e, "plain", 5)) mode = 0;
         if (e && !strncmp(e, "contiguous", 10)) mode = 1;
-        if (e && !strncmp(e, "vmm", 3)) { mode = 2; if (e[3] == ':' && atol(e + 4) > 0) ch = (size_t)atol(e + 4) << 20; }
+        if (e && !strncmp(e, "vmm", 3)) {
+            mode = 2;
+            if (e[3] == ':' && atol(e + 4) > 0) ch = (size_t)atol(e + 4) << 20;
+            const char *c2 = e[3] == ':' ? strchr(e + 4, ':') : nullptr;   // vmm:<chunk MiB>:<shift MiB> -- DIAGNOSTIC: map the chunks that far off the aligned address
+            if (c2 && atol(c2 + 1) > 0) sh = (size_t)atol(c2 + 1) << 20;
+        }
     }
     if (chunk) *chunk = ch;
+    if (shift) *shift = sh;
     return mode;
 }
 bool vmm_block(size_t bytes, void **p) {
-    size_t chunk = 0;
-    (void)alloc_mode(&chunk);
+    size_t chunk = 0, shift = 0;
+    (void)alloc_mode(&chunk, &shift);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     hipMemAllocationProp prop;
@@ -60,10 +73,15 @@ bool vmm_block(size_t bytes, void **p) {
     if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) { (void)hipGetLastError(); return false; }
     chunk = round_up(chunk, gran);
     const size_t total = round_up(bytes, chunk);
-    void *va = nullptr;
-    if (hipMemAddressReserve(&va, total, chunk <= ((size_t)1 << 30) ? chunk : 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    void *va0 = nullptr;
+    const size_t reserved = total + (shift ? round_up(shift, gran) : 0);
+    if (hipMemAddressReserve(&va0, reserved, chunk, nullptr, 0) != hipSuccess) {   // the address range starts on a chunk boundary
+        (void)hipGetLastError();
+        if (hipMemAddressReserve(&va0, reserved, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
+    void *va = (char *)va0 + (shift ? round_up(shift, gran) : 0);
     VmmBlock B;
-    B.bytes = total; B.chunk = chunk;
+    B.bytes = total; B.chunk = chunk; B.reserved = reserved; B.va = va0;
     bool ok = true;
     for (size_t o = 0; o < total && ok; o += chunk) {
         hipMemGenericAllocationHandle_t hnd;
@@ -81,7 +99,7 @@ bool vmm_block(size_t bytes, void **p) {
     if (!ok) {
         (void)hipGetLastError();
         for (size_t i = 0; i < B.handles.size(); i++) { (void)hipMemUnmap((char *)va + i * chunk, chunk); (void)hipMemRelease(B.handles[i]); }
-        (void)hipMemAddressFree(va, total);
+        (void)hipMemAddressFree(va0, reserved);
         (void)hipGetLastError();
         return false;
     }
@@ -90,10 +108,11 @@ bool vmm_block(size_t bytes, void **p) {
     *p = va;
     return true;
 }
-bool device_block(size_t bytes, void **p) {   // an allocation that reports failure instead of throwing (a candidate too many is not an error)
+bool device_block(size_t bytes, void **p, bool plain = false) {   // an allocation that reports failure instead of throwing (a candidate too many is not an error)
     *p = nullptr;
-    const int mode = alloc_mode(nullptr);
+    const int mode = plain ? 0 : alloc_mode(nullptr);
     if (mode == 2) return vmm_block(bytes, p);
+    if (mode == 3 && bytes >= ((size_t)1 << 30) && vmm_block(bytes, p)) return true;
     const hipError_t e = mode == 1 ? hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) : hipMalloc(p, bytes);
     if (e == hipSuccess) return true;
     (void)hipGetLastError();
@@ -108,7 +127,7 @@ void device_release(void *p) {
         if (it != g_vmm.end()) {
             VmmBlock &B = it->second;
             for (size_t i = 0; i < B.handles.size(); i++) { (void)hipMemUnmap((char *)p + i * B.chunk, B.chunk); (void)hipMemRelease(B.handles[i]); }
-            (void)hipMemAddressFree(p, B.bytes);
+            (void)hipMemAddressFree(B.va, B.reserved);
             g_vmm.erase(it);
             return;
         }
@@ -120,7 +139,7 @@ void pool_release(emgpu_ctx *ctx) {
     ctx->trace_pool.clear();
 }
 // a free block of the pool that fits (and is not more than a quarter too large), or a fresh allocation; {nullptr} when neither exists
-emgpu_ctx::TraceBlock pool_take(emgpu_ctx *ctx, size_t bytes, bool *from_pool) {
+emgpu_ctx::TraceBlock pool_take(emgpu_ctx *ctx, size_t bytes, bool *from_pool, bool plain = false) {
     int best = -1;
     for (int i = 0; i < (int)ctx->trace_pool.size(); i++) {
         const auto &b = ctx->trace_pool[(size_t)i];
@@ -133,10 +152,10 @@ emgpu_ctx::TraceBlock pool_take(emgpu_ctx *ctx, size_t bytes, bool *from_pool) {
         return b;
     }
     emgpu_ctx::TraceBlock b;
-    if (!device_block(bytes, &b.p)) {   // out of memory: give the pool's idle blocks back and try once more
+    if (!device_block(bytes, &b.p, plain)) {   // out of memory: give the pool's idle blocks back and try once more
         HIP_OK(hipStreamSynchronize(ctx->stream));
         pool_release(ctx);
-        if (!device_block(bytes, &b.p)) return b;
+        if (!device_block(bytes, &b.p, plain)) return b;
     }
     b.bytes = bytes;
     return b;
@@ -223,6 +242,7 @@ void run_parallel(int T, F fn) {   // fn(t) for t = 0..T-1, fn(0) on the calling
 
 void ctx_release_host_side(emgpu_ctx *ctx, bool everything) {
     pool_release(ctx);
+    if (everything) { for (void *p : ctx->device_blocks) device_release(p); ctx->device_blocks.clear(); }
     for (auto &b : ctx->chunk_buf) { device_release(b.p); b = emgpu_ctx::TraceBlock(); }
     for (auto &s : ctx->h_stage) { if (s) (void)hipHostFree(s); s = nullptr; }
     ctx->h_stage_cap = 0;
@@ -255,13 +275,13 @@ int emgpu_trace_alloc(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sample_p
     t->rep.bytes = (int64_t)L.bytes;
     t->rep.ld = L.ld;
     const bool automatic = candidates == 0;
-    int target = automatic ? (L.bytes < ((size_t)1 << 30) ? 1 : 3) : candidates;
-    if (p->n == 0) target = 1;
-    const int most = automatic ? 6 : target;
+    int target = automatic ? (L.bytes < ((size_t)1 << 30) ? 1 : 6) : candidates;   // (no early stop: a candidate costs a quarter of a second, and two
+    if (p->n == 0) target = 1;                                                      //  medium ones that agree say nothing about a fast one further on)
 
     bool from_pool = false;
     std::vector<emgpu_ctx::TraceBlock> cands;
-    cands.push_back(pool_take(ctx, L.bytes, &from_pool));
+    // candidate 0 of a probe is what hipMalloc hands a caller (the report's first_allocation_ms); the others are the library's own kind
+    cands.push_back(pool_take(ctx, L.bytes, &from_pool, /*plain=*/target > 1));
     if (!cands[0].p) return fail(EMGPU_ERR_HIP, "emgpu_trace_alloc: out of device memory (" + std::to_string(L.bytes) + " bytes)");
     auto give_up = [&]() { for (auto &c : cands) device_release(c.p); cands.clear(); };
     try {
@@ -298,18 +318,6 @@ int emgpu_trace_alloc(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_sample_p
                 std::vector<float> ms(cands.size(), 1e30f);
                 for (int round = 0; round < 2; round++)   // a b c a b c: what is left of a ramp does not favour the last one
                     for (size_t i = 0; i < cands.size(); i++) ms[i] = std::min(ms[i], time_launches(ctx, h, p, &outs[i], 2, 5, ev));
-                auto two_best_agree = [&]() {
-                    std::vector<float> s(ms);
-                    std::sort(s.begin(), s.end());
-                    return s[1] <= 1.01f * s[0];
-                };
-                while (automatic && (int)cands.size() < most && !two_best_agree() && one_more()) {   // e.g. the first ~70 GB a process is handed fade from slow to fast
-                    outs.emplace_back();
-                    trace_bind(L, want, cands.back().p, &outs.back());
-                    float best = 1e30f;
-                    for (int round = 0; round < 2; round++) best = std::min(best, time_launches(ctx, h, p, &outs.back(), 2, 5, ev));
-                    ms.push_back(best);
-                }
                 const size_t kept = (size_t)(std::min_element(ms.begin(), ms.end()) - ms.begin());
                 t->rep.candidates = (int32_t)cands.size();
                 t->rep.kept = (int32_t)kept;
@@ -360,6 +368,39 @@ int emgpu_trace_free(emgpu_ctx *ctx, emgpu_trace *t) {
     HIP_OK(hipStreamSynchronize(ctx->stream));   // nothing in flight may still write the block when somebody else takes it
     ctx->trace_pool.push_back(t->blk);
     delete t;
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+// Plain device memory from the same allocator as the traces (no probe): for outputs that are not a DBN trace -- the joined tracks of
+// emgpu_sample_terminal_device, a consumer's own buffers.
+int emgpu_device_alloc(emgpu_ctx *ctx, uint64_t bytes, void **out) {
+    EMGPU_TRY
+    if (!ctx || !out) return fail(EMGPU_ERR_ARG, "null argument");
+    CTX_LOCK(ctx);
+    HIP_OK(hipSetDevice(ctx->device));
+    void *p = nullptr;
+    const size_t need = std::max<size_t>((size_t)bytes, 256);
+    if (!device_block(need, &p)) {
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        pool_release(ctx);
+        if (!device_block(need, &p)) return fail(EMGPU_ERR_HIP, "emgpu_device_alloc: out of device memory (" + std::to_string(need) + " bytes)");
+    }
+    ctx->device_blocks.insert(p);
+    *out = p;
+    return EMGPU_OK;
+    EMGPU_CATCH
+}
+
+int emgpu_device_free(emgpu_ctx *ctx, void *p) {
+    EMGPU_TRY
+    if (!p) return EMGPU_OK;
+    if (!ctx) return fail(EMGPU_ERR_ARG, "null ctx");
+    CTX_LOCK(ctx);
+    if (!ctx->device_blocks.erase(p)) return fail(EMGPU_ERR_ARG, "emgpu_device_free: not a block of this ctx");
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    device_release(p);
     return EMGPU_OK;
     EMGPU_CATCH
 }

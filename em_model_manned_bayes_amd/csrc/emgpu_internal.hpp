@@ -93,6 +93,7 @@ struct emgpu_ctx {
     // given back stays here and the next request it fits takes it without a new probe; emgpu_ctx_trim / emgpu_ctx_free release them.
     struct TraceBlock { void *p = nullptr; size_t bytes = 0; float ms = 0.f; bool probed = false; };
     std::vector<TraceBlock> trace_pool;
+    std::set<void *> device_blocks;   // emgpu_device_alloc: blocks a caller holds (released with the ctx at the latest)
     // ---- the pipeline of the host-pointer entry points: a copy stream beside the launch stream, two chunk buffers on the device (blocks of
     // the trace pool), two pinned staging buffers, and pinned blocks handed to callers (emgpu_host_alloc)
     hipStream_t copy_stream = nullptr;

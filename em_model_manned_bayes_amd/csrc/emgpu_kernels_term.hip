@@ -25,9 +25,6 @@
 #include "emgpu_launch.h"
 
 namespace emgpu {
-#ifdef EMGPU_TERM_COUNTERS
-__device__ unsigned long long g_term_dbg[32];
-#endif
 
 // A constant held in a SCALAR register pair at its use: the f64 constants of the step loop are loop invariants, and left to the compiler
 // they are materialised once and then occupy ~60 vector registers through the whole loop of a kernel that is short of them.
@@ -121,11 +118,6 @@ __device__ __forceinline__ int t_bearing_bin(double x, double y, const double *_
         return k + 1;
     }
     auto ge = [&](int q) { const double2 d = s_dir[q]; return d.x * y - d.y * x >= 0.0; };
-#ifdef EMGPU_TERM_COUNTERS
-    while (k > 0 && !ge(k - 1)) { k--; if (__builtin_ctzll(__ballot(true)) == (int)(threadIdx.x & 63)) atomicAdd(&g_term_dbg[13], 1ull); }
-    while (k < n && ge(k)) { k++; if (__builtin_ctzll(__ballot(true)) == (int)(threadIdx.x & 63)) atomicAdd(&g_term_dbg[14], 1ull); }
-    return k + 1;
-#endif
     while (k > 0 && !ge(k - 1)) k--;
     while (k < n && ge(k)) k++;
     return k + 1;
@@ -186,22 +178,13 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         if (has_c8[k]) {                                      // wave-uniform
-#ifdef EMGPU_TERM_ABL_LOADS   // (measurement only: one 16-byte gather per variable instead of 5.3 per step -- what the address unit is worth)
-            const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)c8[k]; uint4u_t b = {0xFFFFFFFFu, 0xFFFFFFFFu, 0x04030201u + (a.x & 0x01010101u), 0x00070605u};
-#else
             const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)c8[k], b = *(const uint4u_t __attribute__((address_space(1))) *)(c8[k] + 4);
-#endif
             first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
             first[k][4] = b.x; first[k][5] = b.y; first[k][6] = b.z; first[k][7] = b.w;
         } else if (rm1[k] <= 8) {                             // wave-uniform
             // eight consecutive words from a 4-byte aligned address: two 16-byte loads
             const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)row[k];
             uint4u_t b = {0u, 0u, 0u, 0u};
-#ifdef EMGPU_TERM_ABL_LOADS
-            if (false) {}
-            else if (rm1[k] > 4) { b.x = 0xFFFFFFFFu; b.y = 0xFFFFFFFFu; }
-            else
-#endif
             if (rm1[k] > 6) b = *(const uint4u_t __attribute__((address_space(1))) *)(row[k] + 4);   // (wave-uniform; masked below either way)
             else if (rm1[k] > 4) { const uint2u_t b2 = *(const uint2u_t __attribute__((address_space(1))) *)(row[k] + 4); b.x = b2.x; b.y = b2.y; }
             first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
@@ -235,9 +218,6 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
                 for (int q = 0; q < 6; q++) nf += (xp >= first[k][q]) ? 1 : 0;
                 out.bin[k] = (int)((nf < 4 ? first[k][6] >> (8 * nf) : first[k][7] >> (8 * (nf - 4))) & 0xFFu);
                 pivots = (first[k][7] >> 24) != 0u;            // a row with more than six distinct thresholds (none in sparse tables)
-#ifdef EMGPU_TERM_COUNTERS
-                { const unsigned long long bm = __ballot(pivots); if ((threadIdx.x & 63) == 0 && bm) { atomicAdd(&g_term_dbg[12], (unsigned long long)__popcll(bm)); atomicAdd(&g_term_dbg[20], 1ull); } }
-#endif
                 if (pivots) {
                     const uint4u_t a = *(const uint4u_t __attribute__((address_space(1))) *)piv[k], b = *(const uint4u_t __attribute__((address_space(1))) *)(piv[k] + 4);
                     first[k][0] = a.x; first[k][1] = a.y; first[k][2] = a.z; first[k][3] = a.w;
@@ -272,14 +252,6 @@ __device__ __forceinline__ Draw3 t_draw3(const gptr_t (&row)[3], const gptr_t (&
 #ifndef EMGPU_TERM_WAVES
 #define EMGPU_TERM_WAVES 4
 #endif
-// -DEMGPU_TERM_COUNTERS: a measuring build (tools/term_counters.py) that counts, per launch, how many lanes take each path of the loop
-#ifdef EMGPU_TERM_COUNTERS
-#define TCNT(k, cond) dbg[k] += (unsigned)__popcll(__ballot(cond))
-#define TCNT1(k) dbg[k] += 1u
-#else
-#define TCNT(k, cond) ((void)0)
-#define TCNT1(k) ((void)0)
-#endif
 #ifndef EMGPU_TERM_ROWS
 #define EMGPU_TERM_ROWS 6
 #endif
@@ -293,16 +265,9 @@ static_assert(64 * kLaneStride <= 2048 && 5 * kRows < 32, "EMGPU_TERM_ROWS: a pi
 #endif
 constexpr int kRefillMin = EMGPU_TERM_REFILL; // idle lanes a wave collects before it spends the (divergent) track set-up on them
 constexpr uint32_t kChunk = 128;              // tracks a wave takes from the launch's queue at a time (>= 64)
-// THE WAVE-LEVEL EVENT QUEUE (round 5; VERDICT r4 next #3: "build it this time").  -DEMGPU_TERM_EVQ=N: a lane whose draw produced an event
-// (createEncounter.m:196-243) does not run the event code at once -- it parks with its three drawn bins, takes no part in the following
-// wave-iterations, and the event code runs ONCE for all parked lanes when N of them have collected (or when no lane of the wave can do
-// anything else).  The event code then runs on >= N lanes instead of ~12 and in fewer wave-iterations; the price is the parked lanes'
-// idle iterations.  Measured (profiles/r05_terminal_event_queue.txt; parity green at every N): it does not pay -- 15.7 ms per 2 M
-// encounters without it, 16.1 / 16.6 / 17.2 ms at N = 8 / 16 / 24 -- so 0 (off) is the default and compiles the straight-line step.
-#ifndef EMGPU_TERM_EVQ
-#define EMGPU_TERM_EVQ 0
-#endif
-constexpr int kEvq = EMGPU_TERM_EVQ;
+// (Round 5 built a wave-level EVENT QUEUE into this loop -- lanes with an event park until N have collected -- measured it at three
+// thresholds and dropped it: profiles/r05_terminal_event_queue.txt.  That variant, the ablation builds of HISTORY.md section 11.1 and the
+// path counters of tools/term_counters.py live in tools/patches/term_lab.patch, which tools/build_term_variant.sh applies to a copy.)
 
 // RM1_k: thresholds per row of dynamic variable k as a compile-time constant (0: read from the plan).  The instance built for the
 // terminal model's shape (36 headings, 7 altitude and 5 speed bins) folds every "is this index inside the row" test; left to run
@@ -451,15 +416,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
     double sh, chh;
     int ii = 1, rows = 0, cnt = 0;  // rows: recorded so far; cnt: of them staged in LDS, not yet written
     int att = 0, st[6] = {0, 0, 0, 0, 0, 0};
-#if EMGPU_TERM_EVQ > 0
-    bool parked = false;                   // (event queue) the lane holds drawn bins whose events are yet to be applied
-    uint32_t held = 0u, held_spare = 0u;   // (event queue) dH | dA << 8 | dS << 16, and the attempt's spare uniform
-#endif
     uint32_t colk[3] = {0u, 0u, 0u};   // the step's CPT columns; the row addresses are formed at the draw (nine 64-bit pointers kept per lane cost 18 registers)
-#ifdef EMGPU_TERM_COUNTERS
-    unsigned long long dbg[24];
-    for (int q = 0; q < 24; q++) dbg[q] = 0ull;
-#endif
     // ---- the wave's share of the queue (wave-uniform)
     uint32_t q_next = 0, q_end = 0;
     bool exhausted = false;
@@ -471,7 +428,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
             const uint32_t avail = q_end - q_next;
             uint32_t nb = 0;
             const bool grab = avail < (uint32_t)nidle;
-            TCNT1(10);
+
             if (grab) {
                 uint32_t b = 0;
                 if (lane == 0) b = atomicAdd(U(queue), kChunk);
@@ -496,11 +453,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                     rng.c0 = (uint32_t)gidx; rng.c1 = (uint32_t)(gidx >> 32);
                     const double *g = U(geo) + (size_t)e * 12 + ac * 6;
                     intent = (int)g[5];
-#ifdef EMGPU_TERM_ABL_ONEMODEL   // (measurement only: every track reads ONE model's tables -- what the tables' cache footprint costs)
-                    thr = (gptr_t)U(thr_base)[U(model_of)[L] & 0];
-#else
                     thr = (gptr_t)U(thr_base)[U(model_of)[L]];
-#endif
                     xy0 = g[0]; xy1 = g[1]; z_ft = g[2]; heading_deg = g[4]; prev_z_rec = 0;
                     speed = g[3];   // norm(v_ft_s), carried: the velocity is only ever speed * (cosd, sind) of a direction (its norm to 1e-16)
                     // The velocity is (speed, direction): it is only ever set to speed * (cosd, sind)(heading) (:96, :238-247) and rotated by the
@@ -510,11 +463,8 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                     // (v = 0 would give atan2d = 0: speeds are clamped to minVel > 0.)
                     vang = heading_deg; vdirty = true; fresh = true;
                     ii = 1; rows = 0; cnt = 0; att = 0; failed = false;
-#if EMGPU_TERM_EVQ > 0
-                    parked = false;
-#endif
                     active = true;
-                    TCNT(11, true);
+
                 }
             }
             if (grab) { q_next = nb + ((uint32_t)nidle - avail); q_end = nb + kChunk; }
@@ -522,12 +472,11 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
             exhausted = q_next >= total;
         }
         if (__ballot(active) == 0ull) break;   // (the queue is exhausted: an all-idle wave always tries to refill)
-        TCNT1(0); TCNT(1, active); TCNT(2, active && att == 0); TCNT(7, active && att != 0);
+
         // ---- ONE attempt of the lane's current step: a lane whose draw produced an invalid event (createEncounter.m:218-262 re-draws the
         // step) comes round again with att + 1 while its neighbours start their next step
         bool done = false;
         const bool bck = dt_s < 0.0;
-#if EMGPU_TERM_EVQ == 0
         if (active) do {
             if (att == 0) {
                 // ---- the step begins: record the state, move, discretize (createEncounter.m:156-200)
@@ -604,12 +553,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
                 piv[k] = (rm1[k] > 8 && rm1[k] <= 48) ? thr + (P.d_pivoff[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;   // wave-uniform
                 c8[k] = has_c8[k] ? thr + (P.d_c8off[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;
             }
-#ifdef EMGPU_TERM_ABL_NOEVENTS   // (measurement only: every draw "stays": no event, no re-draw, no turn)
-            Draw3 nb3 = t_draw3(row, piv, c8, has_c8, rm1, xw);
-            if (nb3.bin[0] != 999) { nb3.bin[kh] = st[3] + 1; nb3.bin[ka] = st[4] + 1; nb3.bin[ks] = st[5] + 1; }
-#else
             const Draw3 nb3 = t_draw3(row, piv, c8, has_c8, rm1, xw);
-#endif
             // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude
             // or speed bin makes the step be drawn again -- the events applied before it stay applied, as in the reference's loop
             bool resample = false;
@@ -619,120 +563,6 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
             if (resample) { att++; break; }
 #include "emgpu_term_endstep.h"
         } while (false);
-#else
-        // ---- THE WAVE-LEVEL EVENT QUEUE: a lane whose draw produced an event parks; the event code runs for all parked lanes at once
-        bool to_end = false;            // the lane's step reaches its end in this wave-iteration (no event, or its events were applied and accepted)
-        int dH = 0, dA = 0, dS = 0;
-        uint32_t spare = 0u;
-        if (active && !parked) do {
-            if (att == 0) {
-                // ---- the step begins: record the state, move, discretize (createEncounter.m:156-200)
-                if (rows >= A.cap) { failed = true; done = true; break; }
-                if (vdirty) {
-                    t_sincosd(vang, sh, chh);
-                    v0 = chh * speed; v1 = sh * speed;
-                    vdirty = false;
-                }
-                // forward lanes fill their staging area upwards, backward lanes downwards: either way it holds ascending rows of the
-                // joined track; the backward track's row 0 is the forward track's (bck(1, 2:end), createEncounter.m:77) and is not kept
-                float *rec = mine + 5 * (bck ? kRows - 1 - cnt : cnt);
-                rec[0] = (float)xy0; rec[1] = (float)xy1; rec[4] = (float)speed;
-                xy0 += (v0 * dt_s) * t_k(1.0 / 6076.1154855643);
-                xy1 += (v1 * dt_s) * t_k(1.0 / 6076.1154855643);
-                curr_hdg = (speed > 0.0) ? t_mod360(vang) : 0.0;
-                double rec_z = z_ft;
-                if (ii > 1) {
-                    const double alt_diff = z_ft - prev_z_rec;
-                    rec_z = prev_z_rec + t_sign(alt_diff) * fmin(T_LIMS(4), fabs(alt_diff));
-                }
-                prev_z_rec = rec_z;
-                rec[2] = (float)rec_z; rec[3] = (float)curr_hdg;
-                cnt += (bck && rows == 0) ? 0 : 1;
-                rows++;
-                // CreateStartDistribution (0-based bins), createEncounter.m:268-294
-                const double d2_nm = xy0 * xy0 + xy1 * xy1;
-                st[0] = intent - 1;
-                st[1] = (dist8 ? t_discretize8(d2_nm, s_cut8sq) : t_discretize(sqrt(d2_nm), s_bnd, gDist)) - 1;     // wave-uniform choices
-                int kb0 = st[2];
-                if (fresh) {   // a track's first step: the full discretize (once); from then on events keep `pend` and the bearing is walked
-                    const CutGrid gB = s_grid[1];
-                    kb0 = t_bearing_bin(xy0, xy1, s_bnd + gB.off + 1, s_dir, gB.n, gB.lo, gB.inv_step) - 1;
-                    pend = (uint32_t)(t_discretize(heading_deg, s_bnd, s_grid[2]) - 1) | ((uint32_t)(t_discretize(z_ft, s_bnd, s_grid[3]) - 1) << 8) |
-                           ((uint32_t)(t_discretize(speed, s_bnd, s_grid[4]) - 1) << 16);
-                    fresh = false;
-                }
-                st[2] = t_bearing_walk(xy0, xy1, s_bnd + kBndStride + 1, s_dir, bear_n, bear_kA, bear_kB, kb0) - 1;
-                st[3] = (int)(pend & 0xFFu); st[4] = (int)((pend >> 8) & 0xFFu); st[5] = (int)(pend >> 16);   // (speed: norm(v_ft_s) is `speed`)
-                // CPT column of each dynamic variable (asub2ind.m:13-14 as strides); topological position == variable id
-                uint32_t cstr[3][6];
-                {
-                    int z = 0;
-                    asm volatile("" : "+v"(z));   // (keeps these loads inside the loop: hoisted they would be 18 registers for its whole length)
-#pragma unroll
-                    for (int q = 0; q < 18; q++) cstr[q / 6][q % 6] = s_cstr[z + q];
-                }
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    uint32_t c = 0u;
-#pragma unroll
-                    for (int p = 0; p < 6; p++)   // st[0]: the intent, which never changes
-                        c = kShipped ? __umul24(cstr[k][p], (uint32_t)st[p]) + c   // one v_mad_u32_u24 (launch_terminal_propagate checks the strides fit 24 bits)
-                                     : cstr[k][p] * (uint32_t)st[p] + c;
-                    colk[k] = c;
-                }
-            }
-            // ---- one attempt at the step's transition draw (attempt number in the Philox key)
-            if (att >= A.max_resample) { failed = true; done = true; break; }
-            rng.attempt = (L & 3u) + 4u * (uint32_t)att;
-            uint32_t xw[3];
-            {   // block = the step, word = the variable's row of the temporal map: one Philox call for the three draws
-                // (the round keys are scalar adds at the call, not 14 registers kept for the loop)
-                { uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32); asm volatile("" : "+s"(k0), "+s"(k1)); rng.k0 = k0; rng.k1 = k1; }
-                const uint4 tw = rng.block(11u /* TERM_TRANS */, 0u, (uint32_t)ii);
-#pragma unroll
-                for (int k = 0; k < 3; k++) xw[k] = word_of(tw, drow[k]);
-                spare = tw.w;   // (the temporal map has three rows: words 0-2)
-            }
-            gptr_t row[3], piv[3], c8[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                row[k] = thr + (P.d_off[k] - P.d_off[0]) + (size_t)colk[k] * (uint32_t)rm1[k];
-                piv[k] = (rm1[k] > 8 && rm1[k] <= 48) ? thr + (P.d_pivoff[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;   // wave-uniform
-                c8[k] = has_c8[k] ? thr + (P.d_c8off[k] - P.d_off[0]) + (size_t)colk[k] * 8u : thr;
-            }
-#ifdef EMGPU_TERM_ABL_NOEVENTS   // (measurement only: every draw "stays": no event, no re-draw, no turn)
-            Draw3 nb3 = t_draw3(row, piv, c8, has_c8, rm1, xw);
-            if (nb3.bin[0] != 999) { nb3.bin[kh] = st[3] + 1; nb3.bin[ka] = st[4] + 1; nb3.bin[ks] = st[5] + 1; }
-#else
-            const Draw3 nb3 = t_draw3(row, piv, c8, has_c8, rm1, xw);
-#endif
-            // events in ascending variable id (createEncounter.m:218-262): heading (4), altitude (5), speed (6); an invalid altitude
-            // or speed bin makes the step be drawn again -- the events applied before it stay applied, as in the reference's loop
-            dH = kh == 0 ? nb3.bin[0] : (kh == 1 ? nb3.bin[1] : nb3.bin[2]); dA = ka == 0 ? nb3.bin[0] : (ka == 1 ? nb3.bin[1] : nb3.bin[2]);
-            dS = ks == 0 ? nb3.bin[0] : (ks == 1 ? nb3.bin[1] : nb3.bin[2]);
-            if (dH == st[3] + 1 && dA == st[4] + 1 && dS == st[5] + 1) to_end = true;   // no event: the step ends here
-            else { parked = true; held = (uint32_t)dH | ((uint32_t)dA << 8) | ((uint32_t)dS << 16); held_spare = spare; }
-        } while (false);
-        {
-            const int n_parked = __popcll(__ballot(parked)), n_active = __popcll(__ballot(active));
-            const bool run_events = n_parked >= kEvq || n_parked == n_active;   // enough lanes have collected, or nobody else can run
-            TCNT(22, parked);
-#ifdef EMGPU_TERM_COUNTERS
-            if (run_events && n_parked > 0) TCNT1(23);
-#endif
-            if (parked && run_events) do {
-                dH = (int)(held & 0xFFu); dA = (int)((held >> 8) & 0xFFu); dS = (int)(held >> 16); spare = held_spare;
-                parked = false;
-                bool resample = false;
-#include "emgpu_term_events.h"
-                if (resample) { att++; break; }
-                to_end = true;
-            } while (false);
-        }
-        if (to_end) {
-#include "emgpu_term_endstep.h"
-        }
-#endif
         if (done) {
             if (failed && !U(quiet)) atomicOr(U(status), 1u);
             U(rows)[L] = failed ? -rows - 1 : rows;
@@ -740,12 +570,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
         }
         // ---- staged rows leave for memory: a lane whose staging area is full, or whose track has just ended, hands its rows to the wave,
         // which writes them as one contiguous piece (lane j = dword j of the piece)
-#ifdef EMGPU_TERM_ABL_NOFLUSH   // (measurement only: rows are staged and dropped)
-        const bool fl = false;
-        if (cnt == kRows || done) cnt = 0;
-#else
         const bool fl = cnt == kRows || (done && cnt > 0);
-#endif
         const uint64_t fm = __ballot(fl);
         if (fm != 0ull) {
             // Round 5: FOUR PIECES PER TRIP.  Round 4 walked the flagged lanes one by one (find the lane, read its descriptor into scalar
@@ -776,7 +601,7 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
 #endif
             constexpr int kSlots = EMGPU_TERM_FLUSH_SLOTS;   // pieces per half-wave and trip
             for (int base = 0; base < np; base += 2 * kSlots) {
-                TCNT1(9);
+
                 uint2 d[kSlots];
                 float v[kSlots];
                 bool w[kSlots];
@@ -795,39 +620,21 @@ __global__ void __launch_bounds__(256, EMGPU_TERM_WAVES) k_terminal_propagate(co
 #pragma unroll
                 for (int s_ = 0; s_ < kSlots; s_++) {
                     gf_t *q = (gf_t *)(((uint64_t)(d[s_].y & 0xFFFFu) << 32) | d[s_].x) + li;
-#if defined(EMGPU_TERM_NOSTORE)
-                    if (w[s_] && v[s_] == 1.2345e-30f) *q = v[s_];   // (measurement only: the trips without their stores)
-#elif defined(EMGPU_TERM_PLAIN_STORES)
-                    if (w[s_]) *q = v[s_];
-#else
                     // nontemporal: a piece is a part of a line that nobody reads back here; written through L2 as ordinary stores the 260 000
                     // half-written lines of the lanes in flight crowd the trajectory tables out of it (round 4, measured: table fetches 13 -> 30 GB
                     // per 2 M encounters, +3 % run time)
                     if (w[s_]) __builtin_nontemporal_store(v[s_], q);
-#endif
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
-#ifdef EMGPU_TERM_COUNTERS
-    if (lane == 0) for (int q = 0; q < 24; q++) atomicAdd(&g_term_dbg[q], dbg[q]);
-#endif
 }
 
 // measuring builds only: read (and clear) the path counters of the launches so far; returns 0 in a normal build
 int terminal_debug_counters(unsigned long long *out, int n) {
-#ifdef EMGPU_TERM_COUNTERS
-    unsigned long long h[32];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_term_dbg), sizeof h) != hipSuccess) return -1;
-    for (int q = 0; q < n && q < 32; q++) out[q] = h[q];
-    memset(h, 0, sizeof h);
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_term_dbg), h, sizeof h) != hipSuccess) return -1;
-    return 1;
-#else
     (void)out; (void)n;
     return 0;
-#endif
 }
 
 hipError_t launch_terminal_propagate(const EmgpuPlan &P, const EmgpuTermRun &A, hipStream_t s, const char **name) {

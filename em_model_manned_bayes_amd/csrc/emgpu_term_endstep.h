@@ -4,10 +4,7 @@
             // ---- the step ends: turn towards the new heading, advance the clock, stop conditions
             const double turn1 = round((heading_deg - curr_hdg) * t_k(100.0)) * t_k(0.01);
             const double delta = fmin(fabs(turn1), T_LIMS(2)) * t_sign(turn1);
-            TCNT(8, delta != 0.0);
-#ifdef EMGPU_TERM_COUNTERS
-            if (__ballot(delta != 0.0)) TCNT1(16);
-#endif
+
             // v = rotationmatrix(delta) * v  (:262; rotationmatrix(0) is the identity).  Round 4 marked the velocity "due" and the next step
             // evaluated sincosd(vang) -- 75 vector instructions for the five lanes per wave-iteration that turn, in 85 % of the wave-iterations.
             // A turn is at most maxTurnRate (<= 12 degrees in getDynamicLimits.m:15-62): cosd / sind of such an angle are the reduced-argument

@@ -2,11 +2,7 @@
 // the straight-line step and once in the event-queue variant): the events of one attempt (createEncounter.m:196-243) applied to the lane's
 // state.  In: dH, dA, dS (the drawn 1-based bins of heading, altitude, speed), spare (the fourth word of the attempt's TERM_TRANS block),
 // st[], ac, ii, rng; out: resample ("the step is drawn again"), heading_deg / z_ft / speed / vang / vdirty / pend updated.
-            TCNT(3, dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1); TCNT(4, dH != st[3] + 1); TCNT(5, dA != st[4] + 1); TCNT(6, dS != st[5] + 1);
-#ifdef EMGPU_TERM_COUNTERS
-            if (__ballot(dH != st[3] + 1 || dA != st[4] + 1 || dS != st[5] + 1)) TCNT1(15);
-            if (__ballot(dS != st[5] + 1)) TCNT1(18);
-#endif
+
             // The step's dediscretize draws (slot map, round 5).  The FIRST one an attempt makes is the fourth word of the TERM_TRANS block the
             // attempt has in hand (words 0-2 are the three transition draws); only a lane with a SECOND one -- two events in one step, 0.5 % of
             // the steps -- calls Philox again (TERM_DEDISC, the variable's own word, as before).  Round 4 made that second call for every lane
@@ -24,7 +20,7 @@
             if ((int)evH + (int)okA + (int)okS >= 2) {
                 { uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32); asm volatile("" : "+s"(k0), "+s"(k1)); rng.k0 = k0; rng.k1 = k1; }
                 dw = rng.block(12u /* TERM_DEDISC */, 0u, (uint32_t)ii);
-                TCNT(21, true);
+
             }
             if (evH) {
                 heading_deg = t_dedisc(s_bnd + 2 * kBndStride, dH, spare);
@@ -47,7 +43,3 @@
                 vang = heading_deg; vdirty = true;     // v = rotationmatrix(heading_deg) * [s1; 0]  (:246-247)
                 speed = s1;
             }
-#ifdef EMGPU_TERM_COUNTERS
-            if (__ballot(resample)) TCNT1(17);
-            TCNT(19, resample);
-#endif

@@ -216,6 +216,15 @@ class Context:
         L.check(L.lib().emgpu_host_stats(self._h, C.byref(st)))
         return {f: getattr(st, f) for f, _ in L.HostStats._fields_}
 
+    def device_alloc(self, nbytes):
+        """emgpu_device_alloc: device memory from the allocator the traces come from; returns the address (free with device_free, or with the context)."""
+        ptr = C.c_void_p()
+        L.check(L.lib().emgpu_device_alloc(self._h, int(nbytes), C.byref(ptr)))
+        return int(ptr.value)
+
+    def device_free(self, addr):
+        L.check(L.lib().emgpu_device_free(self._h, C.c_void_p(int(addr))))
+
     def pinned_empty(self, shape, dtype):
         """A numpy array over pinned host memory of this context's pool (emgpu_host_alloc): the copy engine writes the *_host entry
         points' outputs straight into it.  The block goes back to the pool when the array (and every view of it) is gone."""

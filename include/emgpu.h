@@ -250,14 +250,17 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_samp
 
 /* ------------------------------------------------------------------------------------------------
  * Trace placement (round 6).  WHERE a 36 GB trace lies in device memory decides how fast the sampler writes it: the same launch takes
- * 6.0 ms into one allocation and 7.1 ms into another one of the same process, launch after launch (profiles/r05_placement_probe.txt).
- * A consumer of emgpu_sample_dbn_device therefore asks the LIBRARY for its trace instead of calling hipMalloc: emgpu_trace_alloc
- * allocates `candidates` separate blocks, times the caller's own call (m, p) on each -- 0.5 s of launches to load the device, then two
- * rounds of 2 untimed + 5 timed launches per candidate, the better round counts -- keeps the fastest and frees the others.  What the
- * loop over samples of UncorEncounterModel.m:244 writes into is, here, one such trace.
+ * 5.9, 6.6 or 7.0 ms depending on the allocation, launch after launch (profiles/r05_placement_probe.txt, profiles/r06_placement_probe.txt).
+ * A consumer of emgpu_sample_dbn_device therefore asks the LIBRARY for its trace instead of calling hipMalloc.  Two things happen there:
+ *   (i)  blocks of 1 GiB and more are an address range that starts on a 1 GiB boundary over 1 GiB physical chunks (the HIP virtual-memory
+ *        calls) -- in every process but the first on a freshly booted box these are all of the fast kind, where hipMalloc's are mostly not;
+ *   (ii) emgpu_trace_alloc allocates `candidates` blocks, times the caller's own call (m, p) on each -- 0.5 s of launches to load the device,
+ *        then two rounds of 2 untimed + 5 timed launches per candidate, the better round counts -- keeps the fastest and frees the others.
+ *        Candidate 0 is a plain hipMalloc block: report.first_allocation_ms is what the caller's own allocation would have got.
+ * What the loop over samples of UncorEncounterModel.m:244 writes into is, here, one such trace.
  *   want        EMGPU_TRACE_* : which outputs the trace holds (events: [ld][p->event_cap] rows)
- *   candidates  0 = automatic: one block (nothing timed) below 1 GiB, where the launch is too short for placement to matter; else 3, and
- *               further ones (up to 6, memory permitting) until the two fastest agree within 1 %.  1 = the first allocation as it comes.
+ *   candidates  0 = automatic: one block (nothing timed) below 1 GiB, where the launch is too short for placement to matter; else 6, or as
+ *               many as the device's free memory holds.  1 = one block of kind (i), nothing timed.  n > 1: that many.
  * The trace's trajectory dimension ld is p->n rounded up to 1 024 columns (every row of every array starts on a 1 KiB boundary).
  * emgpu_trace_free gives the block back to the ctx's POOL: the next emgpu_trace_alloc it fits (and is not more than 25 % too large for) takes
  * it without a new probe (report.reused = 1).  emgpu_ctx_trim / emgpu_ctx_free release the pool.  The probe launches overwrite the trace
@@ -285,6 +288,11 @@ int emgpu_trace_alloc(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_sample_p
 int emgpu_trace_out(const emgpu_trace *t, emgpu_sample_out *out);
 int emgpu_trace_report(const emgpu_trace *t, emgpu_trace_report_t *out);
 int emgpu_trace_free(emgpu_ctx *ctx, emgpu_trace *t);
+
+/* Device memory from the allocator the traces come from (nothing is timed): for outputs that are not a DBN trace -- the joined tracks of
+ * emgpu_sample_terminal_device (createEncounter.m:74-84), a consumer's own buffers.  Freed by emgpu_device_free, or with the ctx. */
+int emgpu_device_alloc(emgpu_ctx *ctx, uint64_t bytes, void **out);
+int emgpu_device_free(emgpu_ctx *ctx, void *p);
 
 /* Pinned host memory for the outputs of the *_host entry points (hipHostMalloc, kept in a per-ctx pool: pinning gigabytes costs about as
  * much as copying them).  emgpu_sample_dbn_host recognises pinned output arrays and lets the copy engine write straight into them;

@@ -106,6 +106,7 @@ class CpuGloo:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         self.ctx = _Ctx()
         self.bufs = []
+        self.calls = []     # the order of the collectives and the clock reads (what may and may not land between t0 and t1)
 
     def context(self):
         return self.ctx
@@ -117,18 +118,21 @@ class CpuGloo:
         return b
 
     def barrier(self):
+        self.calls.append("barrier")
         dist.barrier()
 
     def event(self):
         return [0.0]
 
     def record(self, ev):
+        self.calls.append("record")
         ev[0] = time.perf_counter()
 
     def elapsed_ms(self, a, b):
         return (b[0] - a[0]) * 1e3
 
     def max_over_ranks(self, x):
+        self.calls.append("max")
         t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())

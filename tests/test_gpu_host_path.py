@@ -220,5 +220,5 @@ def test_two_consecutive_processes_both_get_a_fast_trace_through_the_c_abi():
         out.append(json.loads(line[7:]))
     print(json.dumps(out))
     for res in out:
-        assert res["placed_report"]["candidates"] >= 3 and not res["placed_report"]["reused"], res
+        assert res["placed_report"]["candidates"] == 6 and not res["placed_report"]["reused"], res
         assert res["placed_ms"] <= 1.02 * min(res["five_ms"]), res

@@ -290,6 +290,41 @@ def test_uncor_class_sample_matches_reference_outputs(gpu_ctx, model_dir):
     assert ei.value.identifier == "dynvar:empty"
 
 
+@pytest.mark.parametrize("name", ["uncor_1200only_fwse_v1p2", "uncor_1200exclude_rotorcraft_v1p2"])
+def test_uncor_class_sample_of_a_v1p2_model_redraws_static_rows(name, gpu_ctx, model_dir):
+    """The *_v1p2 files carry non-zero resample rates on the STATIC variables L and v (model/uncor_1200only_fwse_v1p2.txt:41): the rows of
+    out_samples for L and v are re-drawn inside their bin over time (resample_events.m:24-28, events2samples.m:25).  Class level -- the numpy
+    reconstruction of encounter_model.py, not only the native event list: out_samples, out_events and the controls against the oracle's
+    events2samples / events2controls, and the static rows really do change."""
+    path = em_io.materialize_model(name, model_dir)
+    mdl = E.UncorEncounterModel(parameters_filename=path)
+    pp = O.parse_model_txt(path)
+    om = O.OracleModel(pp)
+    rates = np.asarray(pp["resample_rates"], dtype=np.float64)
+    iL, iV = pp["labels_initial"].index('"L"'), pp["labels_initial"].index('"v"')
+    assert rates[iL] > 0 and rates[iV] > 0                       # the premise: static variables with a resample rate
+    n, T, seed = 400, 240, 0x5EED0004
+    out_inits, out_events, out_samples, out_EME = mdl.sample(n, T, seed=seed, ctx=gpu_ctx)
+    ref = O.uncor_sample(om, n, T, seed)
+    moved_L = moved_v = 0
+    for i in range(n):
+        r = ref["events"][i]
+        assert np.array_equal(out_events[i][:, :2], r[:, :2]) and np.array_equal(out_events[i][:, 2].astype(np.float32), r[:, 2].astype(np.float32))
+        s = O.events2samples(ref["init_val"][i], r[:, :3])
+        assert np.array_equal(out_samples[i].astype(np.float32), s.astype(np.float32)), i
+        moved_L += int(np.ptp(s[iL]) > 0); moved_v += int(np.ptp(s[iV]) > 0)
+        # a re-drawn static value stays inside the bin of the initial draw (resample_events.m:26 emits the CURRENT bin)
+        for var, row in ((iL, out_samples[i][iL]), (iV, out_samples[i][iV])):
+            b = pp["boundaries"][var]
+            if len(b):
+                k = ref["init_bin"][i][var]
+                assert (row >= np.float32(b[k - 1])).all() and (row <= np.float32(b[k])).all(), (i, var)
+        ctl = O.events2controls(om, ref["init_val"][i], r[:, :3])[:, [0, 2, 3, 1]]
+        ctl[:, 1] /= 60.0; ctl[:, 2] = np.deg2rad(ctl[:, 2]); ctl[:, 3] *= 1.68780972222222
+        np.testing.assert_allclose(out_EME[i].event, ctl, rtol=1.2e-7, atol=0)
+    assert moved_L > n // 4 and moved_v > n // 4, (moved_L, moved_v)      # rates 0.0013-0.04 per second over 240 s
+
+
 def test_sharded_calls_equal_one_call(gpu_ctx, model_dir):
     """Multi-GPU rule on one GPU: two calls over [0, n/2) and [n/2, n) equal one call over [0, n)."""
     nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)

@@ -29,7 +29,7 @@ def _worker(rank, world, port, argv, q):
     pl = mp_plumbing.CpuGloo(rank, world)
     buf = io.StringIO()
     bench.run_rank(args, rank, rank, world, pl=pl, out=buf)
-    q.put((rank, buf.getvalue(), pl.ctx.launches, [b.a for b in pl.bufs]))
+    q.put((rank, buf.getvalue(), pl.ctx.launches, [b.a for b in pl.bufs], pl.calls))
 
 
 def _run(world, argv):
@@ -66,6 +66,14 @@ def test_two_rank_bench_runs_the_products_rank_logic(model_dir):
     # every step covers a fresh contiguous global range, rank r the r-th part of it
     for r in range(world):
         assert got[r][2] == [(0, (k * world + r) * n, n) for k in range(warmup + steps)]
+    # the process group's FIRST barrier and all-reduce come before anything is timed (RCCL sets its communicator up in them: hundreds of
+    # milliseconds at 8 ranks that must not land in a 0.1 s timed region); the timed region itself is barrier, 2 x steps records, barrier, max
+    for r in range(world):
+        calls = got[r][4]
+        assert calls[:2] == ["barrier", "max"], calls
+        first_record = calls.index("record")
+        assert calls[first_record - 1] == "barrier" and calls[first_record: first_record + 2 * steps] == ["record"] * (2 * steps)
+        assert calls[first_record + 2 * steps: first_record + 2 * steps + 2] == ["barrier", "max"], calls
     # the buffers hold the last step: ranks 0 and 1 together == one oracle run over that step's global range
     k = warmup + steps - 1
     om = O.OracleModel(O.parse_model_txt(em_io.materialize_model("uncor_1200code_v2p1", model_dir)))
