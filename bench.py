@@ -110,6 +110,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-host-path", action="store_true", help="skip the `host_path` object (emgpu_sample_dbn_host end to end at 1 M trajectories)")
     ap.add_argument("--host-n", type=int, default=1_000_000, help="trajectories of the `host_path` measurements")
     ap.add_argument("--detail-out", default=None, help="write the verbose record of the run (what the line leaves out: settle groups, pre-warm, telemetry, samples) to this file")
+    ap.add_argument("--verbose-line", action="store_true",
+                    help="print the verbose roofline / config / cpu_baseline objects in the line itself (the round-5 format: the probes under tools/ that read "
+                         "roofline.gpu_telemetry, roofline.avg_step_ms ... pass this); the default line holds numbers only")
     ap.add_argument("--write-notes", default=None, help="write NOTES (what every field of the line means and how it is measured) to this file and exit")
     ap.add_argument("--telemetry-s", type=float, default=2.5,
                     help="seconds of untimed back-to-back steps AFTER the timed region during which the shader clock and socket power are read (0: skip); "
@@ -900,7 +903,7 @@ NOTES = {
                 "(1 024 SIMDs x kernel time x sclk) from the committed PMC pass",
     "cpu_baseline": "oracle/em_oracle.c (scalar port of the reference algorithm), Philox mode, thread-private dense outputs, on `cores` threads = the cgroup's "
                     "CPU quota; single_thread_value beside it; MATLAB itself is not installed and cannot be timed",
-    "host_path": "emgpu_sample_dbn_host end to end at --host-n trajectories x 240 s of uncor_1200code_v2p1, second call of each kind (the first pins memory): "
+    "host_path": "emgpu_sample_dbn_host end to end at --host-n trajectories x 240 s of uncor_1200code_v2p1, third call of each kind (the first pins memory): "
                  "dense_pinned = outputs in emgpu_host_alloc memory (the copy engine writes into the caller's arrays); dense_pageable = the caller's own "
                  "(pre-faulted) numpy arrays through the library's pinned staging + host threads; events_pinned = event lists only, packed on the device "
                  "(sum(ev_count) rows cross PCIe); GBps = bytes_d2h / total_ms; kernel_ms / d2h_ms / scatter_ms = the pipeline's phases (they overlap); "
@@ -1017,8 +1020,8 @@ def host_path(args, pl, detail):
         best = min(best, pl.elapsed_ms(a, b))
     out["pinned_d2h_GBps"] = _r((1 << 30) / best / 1e6)
     del dsrc, hdst
-    # dense, pinned outputs (second call: the first pins the pool's blocks)
-    for rep in range(2):
+    # dense, pinned outputs (third call: the first pins the pool's blocks, the second still warms the mappings up)
+    for rep in range(3):
         r = native.sample_dbn_host(ctx, nm, n, T, seed, want_dense=True, want_events=False, pinned=True, raw=True, **idx)
         st = r["host_stats"]
         del r
@@ -1033,7 +1036,7 @@ def host_path(args, pl, detail):
     o = L.SampleOut()
     o.init_bin, o.init_val, o.dyn_bin, o.dyn_val, o.attempts = ib.ctypes.data, iv.ctypes.data, db.ctypes.data, dv.ctypes.data, att.ctypes.data
     import ctypes as C
-    for rep in range(2):
+    for rep in range(3):
         t0 = time.perf_counter()
         L.check(L.lib().emgpu_sample_dbn_host(ctx._h, nm._h, C.byref(p), C.byref(o)))
         cold_or_warm = time.perf_counter() - t0
@@ -1044,7 +1047,7 @@ def host_path(args, pl, detail):
     detail["host_path"]["dense_pageable"] = st
     del ib, iv, db, dv, att
     # event lists only (what the class layer asks for): packed on the device
-    for rep in range(2):
+    for rep in range(3):
         r = native.sample_dbn_host(ctx, nm, n, T, seed, want_dense=False, want_events=True, event_cap=256, pinned=True, raw=True, **idx)
         st = r["host_stats"]
         del r
@@ -1102,6 +1105,8 @@ def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
         }
         if isinstance(w, TerminalWorkload):
             line["config"]["track_seconds_per_encounter"] = wc.get("track_seconds_per_encounter")
+        if getattr(args, "verbose_line", False):
+            line["roofline"], line["config"] = roof, dict(wc, **line["config"])
         if getattr(pl, "shared", False):
             line["oversubscribed"] = True
         if args.step_gap_ms > 0.0:

@@ -495,11 +495,17 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_samp
     bpt += (out->init_bin ? ni : 0) + (out->init_val ? 4 * ni : 0);
     bpt += (out->dyn_bin ? 4 * G4 * nd : 0) + (out->dyn_val ? 16 * G4 * nd : 0);
     bpt += 16 * cap;   // the lists and their packed copy
+    // pinned outputs: one pitched copy per array (56.5 GB/s of the 57 GB/s a plain pinned copy reaches; row-by-row linear copies: 46 -- tools/host_path_probe.py)
+    static const bool direct_rows = [] { const char *e = getenv("EMGPU_HOST_DIRECT"); return e && !strcmp(e, "rows"); }();
     size_t target = (size_t)(direct ? 1024 : 256) << 20;   // pinned outputs: larger pieces (the copy engine writes row by row into the caller's pitch)
     if (const char *e = getenv("EMGPU_HOST_CHUNK_MB")) { const long v = atol(e); if (v > 0) target = (size_t)v << 20; }
     size_t C = std::max<size_t>(1024, target / std::max<size_t>(bpt, 1) / 1024 * 1024);
     if (cap) C = std::min(C, std::max<size_t>(1024, ((size_t)0xFFFF0000u / cap) / 1024 * 1024));   // a chunk's packed rows are counted in 32 bits
     if (C >= n) C = n;
+    else {   // chunks of equal size: the last one is not a sliver (and a staged copy moves whole chunk buffers)
+        const size_t k = (n + C - 1) / C;
+        C = std::min(C, round_up((n + k - 1) / k, 1024));
+    }
     const size_t Cp = round_up(C, 256), nchunks = (n + C - 1) / C;
     size_t o = 0;
     auto put = [&](size_t bytes) { const size_t at = o; o = round_up(o + bytes, 256); return at; };
@@ -608,6 +614,9 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_samp
             for (const Arr &a : large) {
                 char *dst = (char *)a.dst + (off + k0) * a.elem;
                 if (ld == c && Cp == c) HIP_OK(hipMemcpyAsync(dst, dev + a.dev_off, a.rows * c * a.elem, hipMemcpyDeviceToHost, ctx->copy_stream));
+                else if (direct_rows)   // row by row: linear copies (the copy engine's fastest form), 1-16 MB each
+                    for (size_t r = 0; r < a.rows; r++)
+                        HIP_OK(hipMemcpyAsync(dst + r * ld * a.elem, dev + a.dev_off + r * Cp * a.elem, c * a.elem, hipMemcpyDeviceToHost, ctx->copy_stream));
                 else HIP_OK(hipMemcpy2DAsync(dst, ld * a.elem, dev + a.dev_off, Cp * a.elem, c * a.elem, a.rows, hipMemcpyDeviceToHost, ctx->copy_stream));
                 st.bytes_d2h += (int64_t)(a.rows * c * a.elem);
             }

@@ -35,6 +35,13 @@ class EncounterModelEvents:
             sizes = {a.shape for a in (self.time_s, self.verticalRate_fps, self.turnRate_radps, self.longitudeAccel_ftpss)}
             assert len(sizes) == 1, "Sizes of time_s, verticalRate_fps, turnRate_radps, longitudeAccel_ftpss are not equal"
 
+    @classmethod
+    def _of_rows(cls, m):
+        """An object over the columns of an [k, 4] float64 control matrix, without the constructor's conversions (.sample builds one per trajectory)."""
+        e = object.__new__(cls)
+        e.time_s, e.verticalRate_fps, e.turnRate_radps, e.longitudeAccel_ftpss = m[:, 0], m[:, 1], m[:, 2], m[:, 3]
+        return e
+
     @property
     def event(self):
         m = np.stack([self.time_s.reshape(-1), self.verticalRate_fps.reshape(-1), self.turnRate_radps.reshape(-1),
@@ -377,10 +384,9 @@ class UncorEncounterModel(EncounterModel):
             ctrl[:, 3] = D[csid, vars_dyn[idxEME[2] - 1], ct0] * 1.68780972222222        # dv: kt/s -> ft/s^2      :297
             ev_split = np.split(ev_all, ends[:-1]) if nn > 1 else [ev_all]
             ctrl_split = np.split(ctrl, np.cumsum(np.bincount(csid, minlength=nn))[:-1]) if nn > 1 else [ctrl]
-            for k in range(nn):
-                out_events[pos + k] = ev_split[k]
-                out_samples[pos + k] = D[k]
-                out_EME[pos + k] = EncounterModelEvents(event=ctrl_split[k])
+            out_events[pos: pos + nn] = ev_split
+            out_samples[pos: pos + nn] = list(D)                              # nn views of the chunk's block
+            out_EME[pos: pos + nn] = [EncounterModelEvents._of_rows(c) for c in ctrl_split]
             pos += nn
         # the call's three phases (bench.py `host_path.class_sample`): the library calls (kernel + PCIe + the binding's own copies), of which
         # kernel_ms / d2h_ms are the device's share, and the numpy / Python reconstruction of out_samples, controls and EncounterModelEvents

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 N=${N:-2000000}
 for rep in 1 2 3; do
   for v in "$@"; do
-    ms=$(EMGPU_LIB=$PWD/$v timeout 120 python bench.py --config terminal --n $N --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print(l['roofline']['avg_step_ms'])")
+    ms=$(EMGPU_LIB=$PWD/$v timeout 120 python bench.py --config terminal --n $N --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-host-path --verbose-line 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print(l['roofline']['avg_step_ms'])")
     echo "rep $rep $v $ms"
   done
 done
@@ -13,7 +13,7 @@ if [ -n "${PMC:-}" ]; then
   for v in "$@"; do
     for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
       rm -rf gpurun_out/pmcab
-      EMGPU_LIB=$PWD/$v timeout 200 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmcab -- python3 bench.py --config terminal --n $N --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
+      EMGPU_LIB=$PWD/$v timeout 200 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmcab -- python3 bench.py --config terminal --n $N --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-host-path --verbose-line > /dev/null 2>&1
       python3 - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)

@@ -4,7 +4,7 @@
 ARGS="$1"; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pmcq
-timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmcq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --prewarm-s 0 --placement-candidates 1 $ARGS > /dev/null 2>&1
+timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmcq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-host-path --prewarm-s 0 --placement-candidates 1 $ARGS > /dev/null 2>&1
 python3 - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)

@@ -25,7 +25,7 @@ echo "== idle" >> $out
 sleep 1 & sample $!
 for gap in 0 ${GAP_MS:-3}; do
   echo "== back to back launches, gap ${gap} ms" >> $out
-  timeout 300 python3 bench.py --steps ${STEPS:-1500} --warmup 5 --no-cpu-baseline --no-other-configs --step-gap-ms $gap "$@" > gpurun_out/power_probe_bench_$gap.json 2>gpurun_out/power_probe_bench_$gap.err &
+  timeout 300 python3 bench.py --steps ${STEPS:-1500} --warmup 5 --no-cpu-baseline --no-other-configs --no-host-path --step-gap-ms $gap "$@" > gpurun_out/power_probe_bench_$gap.json 2>gpurun_out/power_probe_bench_$gap.err &
   pid=$!
   sample $pid
   wait $pid

@@ -12,7 +12,7 @@ run() { # name, program args...
   local name=$1; shift
   timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 "$@" > $OUT/$name.log 2>&1
 }
-B="--steps 5 --warmup 2 --no-cpu-baseline --no-other-configs"
+B="--steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-host-path"
 run v1p2 bench.py $B --model uncor_1200only_fwse_v1p2
 run mixed bench.py $B --config mixed
 run cor_v1 bench.py $B --config cor
@@ -24,5 +24,5 @@ run littoral_cor_v1 bench.py $B --model littoral_cor_v1
 run events tools/bench_events.py uncor_1200code_v2p1 uncor_1200only_fwse_v1p2 uncor_1200code_v1 glider_v1 cor_v1 littoral_cor_v1
 run track tools/bench_track.py 4000000 240
 run utrack tools/bench_utrack.py 1000000 240
-run terminal bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --config terminal --n 1000000
+run terminal bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-host-path --config terminal --n 1000000
 tail -n 6 $OUT/events.log; tail -n 1 $OUT/track.log $OUT/utrack.log

@@ -3,7 +3,7 @@
 # (tools/ab_checkout.sh <commit> <name> makes tools/ab/<name>/)
 cd "$GRAFT_REPO_ROOT"
 ROOT=$PWD
-one() { timeout 120 python bench.py --steps ${STEPS:-10} --warmup ${WARM:-5} --no-cpu-baseline --no-other-configs "$@" 2>/dev/null | tail -1 | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('%.3f ms  frac %.3f  %s' % (l['roofline']['avg_step_ms'], l['roofline']['frac'], l['config']['kernel']))"; }
+one() { timeout 120 python bench.py --steps ${STEPS:-10} --warmup ${WARM:-5} --no-cpu-baseline --no-other-configs --no-host-path --verbose-line "$@" 2>/dev/null | tail -1 | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('%.3f ms  frac %.3f  %s' % (l['roofline']['avg_step_ms'], l['roofline']['frac'], l['config']['kernel']))"; }
 for rep in 1 2; do
 for d in . "$@"; do
   cd $ROOT/$d

@@ -37,7 +37,7 @@ med, best = timed(lambda: float(0) if buf.sum() is None else None, reps=10, warm
 out["sum_36GB_read"] = {"median_ms": med, "best_ms": best, "TB_s_median": n_bytes / med / 1e9}
 del buf, src, half
 torch.cuda.empty_cache()
-line = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs"],
+line = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs --no-host-path"],
                       capture_output=True, text=True).stdout.strip().splitlines()[-1]
 d = json.loads(line)
 out["benchmark_kernel"] = {"kernel": d["config"]["kernel"], "avg_launch_ms": d["roofline"]["avg_launch_ms"], "TB_s_algorithmic": d["roofline"]["achieved"] / 1e3}
