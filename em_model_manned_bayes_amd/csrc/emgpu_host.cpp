@@ -40,24 +40,28 @@ size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct VmmBlock { size_t bytes = 0, chunk = 0, reserved = 0; void *va = nullptr; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_vmm_mu;
 std::map<void *, VmmBlock> g_vmm;
-int alloc_mode(size_t *chunk, size_t *shift = nullptr) {
-    static int mode = -1;
-    static size_t ch = (size_t)1 << 30, sh = 0;
-    if (mode < 0) {
+struct AllocMode { int mode; size_t chunk, shift; };
+const AllocMode &alloc_mode_once() {
+    static const AllocMode am = [] {   // (a function-local static: initialised once, also when several host threads come here together)
+        AllocMode a{3, (size_t)1 << 30, 0};   // automatic: 1 GiB chunks behind a 1 GiB-aligned range for blocks of 1 GiB and more, hipMalloc below (and as the fallback)
         const char *e = getenv("EMGPU_TRACE_ALLOC");
-        mode = 3;   // automatic: 1 GiB chunks behind a 1 GiB-aligned range for blocks of 1 GiB and more, hipMalloc below (and as the fallback)
-        if (e && !strncmp(e, "plain", 5)) mode = 0;
-        if (e && !strncmp(e, "contiguous", 10)) mode = 1;
+        if (e && !strncmp(e, "plain", 5)) a.mode = 0;
+        if (e && !strncmp(e, "contiguous", 10)) a.mode = 1;
         if (e && !strncmp(e, "vmm", 3)) {
-            mode = 2;
-            if (e[3] == ':' && atol(e + 4) > 0) ch = (size_t)atol(e + 4) << 20;
+            a.mode = 2;
+            if (e[3] == ':' && atol(e + 4) > 0) a.chunk = (size_t)atol(e + 4) << 20;
             const char *c2 = e[3] == ':' ? strchr(e + 4, ':') : nullptr;   // vmm:<chunk MiB>:<shift MiB> -- DIAGNOSTIC: map the chunks that far off the aligned address
-            if (c2 && atol(c2 + 1) > 0) sh = (size_t)atol(c2 + 1) << 20;
+            if (c2 && atol(c2 + 1) > 0) a.shift = (size_t)atol(c2 + 1) << 20;
         }
-    }
-    if (chunk) *chunk = ch;
-    if (shift) *shift = sh;
-    return mode;
+        return a;
+    }();
+    return am;
+}
+int alloc_mode(size_t *chunk, size_t *shift = nullptr) {
+    const AllocMode &a = alloc_mode_once();
+    if (chunk) *chunk = a.chunk;
+    if (shift) *shift = a.shift;
+    return a.mode;
 }
 bool vmm_block(size_t bytes, void **p) {
     size_t chunk = 0, shift = 0;

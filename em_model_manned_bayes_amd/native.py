@@ -463,7 +463,7 @@ def sample_dbn_host(ctx, model, n, sample_time, seed, want_dense=True, want_even
         out["ev_count"] = ec
         out["events_flat"] = flat
         ends = np.cumsum(ec.astype(np.int64))
-        out["events"] = np.split(flat, ends[:-1]) if n > 1 else [flat]
+        out["events"] = np.split(flat, ends[:-1]) if n > 1 else ([flat] if n == 1 else [])
     return out
 
 
