@@ -621,6 +621,8 @@ def make_workload(args, pl, rank, world):
         pl._shift = pl.empty((shift_mb, 1 << 20), "uint8")
         pl._shift.zero_()
     cfg = CONFIGS[args.config]
+    if cfg.get("per_step"):   # (--config uncor_per_step == --per-step on config 2)
+        args.per_step = True
     return (TerminalWorkload if args.config == "terminal" else DbnWorkload)(args, cfg, pl, rank, world)
 
 

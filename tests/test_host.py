@@ -905,29 +905,6 @@ def test_local_smooth_defaults_follow_the_reference_function_each_layer_mirrors(
     assert d(native.propagate_terminal_host) is False and d(native.propagate_terminal_joined_host) is False and d(native.terminal_sample_params) is False
 
 
-def test_pick_fastest_keeps_the_fastest_candidate_and_releases_the_rest():
-    """placement.pick_fastest (round 5: where a trace lies in memory decides how fast it is written): the loop bench.py places its trace
-    with, on a fake device whose candidates have known speeds."""
-    from em_model_manned_bayes_amd import placement
-    speed = {"a": 7.1e-3, "b": 6.0e-3, "c": 6.4e-3}
-    order = iter(["b", "c"])
-    clock = [0.0]
-    launched, released = [], []
-
-    def run(c, k):
-        launched.append((c, k)); clock[0] += speed[c]
-    kept, rep = placement.pick_fastest(lambda: next(order), run, lambda: None, lambda: clock[0], candidates=3, warm=2, timed=4, first="a",
-                                       release=released.append, rewarm_s=0.0)
-    assert kept == "b" and rep["kept"] == 1 and rep["candidates"] == 3 and sorted(released) == ["a", "c"]
-    assert rep["ms_per_step"] == [7.1, 6.0, 6.4] and abs(rep["spread"] - 7.1 / 6.0) < 1e-12
-    assert [c for c, _ in launched] == (["a"] * 6 + ["b"] * 6 + ["c"] * 6) * 2 and [k for _, k in launched] == list(range(36))   # two rounds
-    # an allocation that fails ends the search with the candidates there are
-    def boom():
-        raise MemoryError
-    kept, rep = placement.pick_fastest(boom, run, lambda: None, lambda: clock[0], candidates=3, first="c", rewarm_s=0.0)
-    assert kept == "c" and rep["candidates"] == 1
-
-
 def test_bench_box_state_rule():
     """bench.box_state: the telemetry rule that names a line's state (HISTORY.md section 7; round 5: the state belongs to the trace's
     placement) -- fast at the socket's power limit, slow at 1 27x W with the clock UP at 2 3xx MHz, neither for a kernel at the full clock."""
