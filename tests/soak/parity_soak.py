@@ -46,7 +46,9 @@ def main():
             kw = dict(idx)
             if per_step:
                 kw["transition_mode"] = L.TRANSITION_PER_STEP
-            got = native.sample_dbn_host(ctx, nm, n, T, seed, first_index=first, want_dense=True, want_events=False, **kw)
+            # (round 6: the host path is a pipeline -- every other chunk goes into pageable arrays, i.e. through the staging buffers and the host
+            # threads in two pieces; the others into the context's pinned pool, i.e. pitched copies by the copy engine)
+            got = native.sample_dbn_host(ctx, nm, n, T, seed, first_index=first, want_dense=True, want_events=False, pinned=(lo // chunk) % 2 == 0, **kw)
             kernels.add(got["kernel"])
             rb, rv = O.uncor_sample_mt(om, n, T, seed, thr, first_index=first, per_step=per_step)
             if not np.array_equal(got["dyn_bin"], rb):

@@ -44,6 +44,24 @@ def test_no_cpu_fallback_without_a_device():
     assert ei.value.code == L.ERR_NO_DEVICE
 
 
+def test_memory_entry_points_reject_missing_handles_without_touching_a_device():
+    """emgpu_trace_* / emgpu_device_* / emgpu_host_* (round 6) with null handles: an argument error and a message, never a crash, and nothing
+    here needs a GPU (there is no context to own the memory, and no CPU stand-in for one)."""
+    import ctypes as C
+    lib = L.lib()
+    p, _ = native.make_params(10, 10, 1)
+    h = C.c_void_p()
+    assert lib.emgpu_trace_alloc(None, None, C.byref(p), L.TRACE_DENSE, 0, C.byref(h)) == L.ERR_ARG and b"null" in lib.emgpu_last_error()
+    assert lib.emgpu_trace_out(None, None) == L.ERR_ARG and lib.emgpu_trace_report(None, None) == L.ERR_ARG
+    assert lib.emgpu_trace_free(None, None) == L.OK                      # freeing nothing is fine, like free(NULL)
+    assert lib.emgpu_device_alloc(None, 1024, C.byref(h)) == L.ERR_ARG and lib.emgpu_device_free(None, None) == L.OK
+    assert lib.emgpu_host_alloc(None, 1024, C.byref(h)) == L.ERR_ARG and lib.emgpu_host_free(None, None) == L.OK
+    assert lib.emgpu_host_free(None, C.c_void_p(64)) == L.ERR_ARG and lib.emgpu_host_stats(None, None) == L.ERR_ARG
+    assert int(lib.emgpu_slot_map_revision()) == 2 and "emgpu 0.4" in lib.emgpu_version().decode()
+    # the structs the binding mirrors: sizes as the header lays them out (a drifted field would shift everything behind it)
+    assert C.sizeof(L.TraceReport) == 8 + 8 + 4 * 4 + 8 * 4 + 4 + 4 and C.sizeof(L.HostStats) == 4 * 8 + 2 * 8 + 4 * 4
+
+
 @pytest.mark.parametrize("name", ALL_MODELS)
 def test_loader_matches_independent_parser(name, model_dir):
     path = em_io.materialize_model(name, model_dir)
