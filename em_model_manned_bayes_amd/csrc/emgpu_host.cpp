@@ -30,42 +30,40 @@ size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // ------------------------------------------------------------------------------------------------ device blocks
 // How a block of the trace pool is obtained (round 6, tools/placement_probe5.py, profiles/r06_placement_probe.txt).  The same launch writes a
 // 36 GB trace in 5.9, 6.6 or 7.0 ms depending on the allocation.  Blocks that hipMalloc hands out are mostly of the 6.6 ms kind, now and then
-// of the others; an ADDRESS RANGE THAT STARTS ON A 1 GiB BOUNDARY backed by separately created 1 GiB PHYSICAL CHUNKS (hipMemAddressReserve +
-// hipMemCreate + hipMemMap) is of the 5.9-6.0 ms kind in every process but the first one on a freshly booted box, where it is mixed (with the
-// range shifted off its boundary by 2 or 64 MiB it is mixed everywhere: alignment is what counts).  So: blocks of 1 GiB and more are built
-// that way (falling back to hipMalloc where the virtual-memory calls fail), smaller ones come from hipMalloc, and emgpu_trace_alloc still
-// measures its candidates -- candidate 0 a plain hipMalloc block, so that the report shows what a caller's own allocation would have got.
+// of the others; ONE ADDRESS RANGE BACKED BY SEPARATELY CREATED 1 GiB PHYSICAL CHUNKS (hipMemAddressReserve + hipMemCreate + hipMemMap) is of the
+// 5.9 ms kind four to six times out of six, of the 7.0 ms kind the rest (chunks of 256 MiB - 2 GiB alike, 4 GiB chunks like hipMalloc; where the
+// range starts -- on a 1 GiB boundary or 2 MiB off one -- makes no difference: measured both ways).  Why is not known; the allocator does not need
+// to know: blocks of 1 GiB and more are built that way (falling back to hipMalloc where the virtual-memory calls fail), smaller ones come from
+// hipMalloc, and emgpu_trace_alloc MEASURES its candidates -- candidate 0 a plain hipMalloc block, so that the report shows what a caller's own
+// allocation would have got.
 // EMGPU_TRACE_ALLOC (read once; experiments) = "plain": hipMalloc only; "contiguous": hipExtMallocWithFlags(hipDeviceMallocContiguous);
-// "vmm:<chunk MiB>[:<shift MiB>]": another chunk size / the range mapped that far off its boundary.
-struct VmmBlock { size_t bytes = 0, chunk = 0, reserved = 0; void *va = nullptr; std::vector<hipMemGenericAllocationHandle_t> handles; };
+// "vmm:<chunk MiB>": another chunk size.
+struct VmmBlock { size_t bytes = 0, chunk = 0; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_vmm_mu;
 std::map<void *, VmmBlock> g_vmm;
-struct AllocMode { int mode; size_t chunk, shift; };
+struct AllocMode { int mode; size_t chunk; };
 const AllocMode &alloc_mode_once() {
     static const AllocMode am = [] {   // (a function-local static: initialised once, also when several host threads come here together)
-        AllocMode a{3, (size_t)1 << 30, 0};   // automatic: 1 GiB chunks behind a 1 GiB-aligned range for blocks of 1 GiB and more, hipMalloc below (and as the fallback)
+        AllocMode a{3, (size_t)1 << 30};   // automatic: a range over 1 GiB chunks for blocks of 1 GiB and more, hipMalloc below (and as the fallback)
         const char *e = getenv("EMGPU_TRACE_ALLOC");
         if (e && !strncmp(e, "plain", 5)) a.mode = 0;
         if (e && !strncmp(e, "contiguous", 10)) a.mode = 1;
         if (e && !strncmp(e, "vmm", 3)) {
             a.mode = 2;
             if (e[3] == ':' && atol(e + 4) > 0) a.chunk = (size_t)atol(e + 4) << 20;
-            const char *c2 = e[3] == ':' ? strchr(e + 4, ':') : nullptr;   // vmm:<chunk MiB>:<shift MiB> -- DIAGNOSTIC: map the chunks that far off the aligned address
-            if (c2 && atol(c2 + 1) > 0) a.shift = (size_t)atol(c2 + 1) << 20;
         }
         return a;
     }();
     return am;
 }
-int alloc_mode(size_t *chunk, size_t *shift = nullptr) {
+int alloc_mode(size_t *chunk) {
     const AllocMode &a = alloc_mode_once();
     if (chunk) *chunk = a.chunk;
-    if (shift) *shift = a.shift;
     return a.mode;
 }
 bool vmm_block(size_t bytes, void **p) {
-    size_t chunk = 0, shift = 0;
-    (void)alloc_mode(&chunk, &shift);
+    size_t chunk = 0;
+    (void)alloc_mode(&chunk);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     hipMemAllocationProp prop;
@@ -77,15 +75,10 @@ bool vmm_block(size_t bytes, void **p) {
     if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) { (void)hipGetLastError(); return false; }
     chunk = round_up(chunk, gran);
     const size_t total = round_up(bytes, chunk);
-    void *va0 = nullptr;
-    const size_t reserved = total + (shift ? round_up(shift, gran) : 0);
-    if (hipMemAddressReserve(&va0, reserved, chunk, nullptr, 0) != hipSuccess) {   // the address range starts on a chunk boundary
-        (void)hipGetLastError();
-        if (hipMemAddressReserve(&va0, reserved, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-    }
-    void *va = (char *)va0 + (shift ? round_up(shift, gran) : 0);
+    void *va = nullptr;   // (hipMemAddressReserve returns 2 MiB-aligned ranges whatever alignment it is asked for: tools/ubench/vmm_repro.hip)
+    if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
     VmmBlock B;
-    B.bytes = total; B.chunk = chunk; B.reserved = reserved; B.va = va0;
+    B.bytes = total; B.chunk = chunk;
     bool ok = true;
     for (size_t o = 0; o < total && ok; o += chunk) {
         hipMemGenericAllocationHandle_t hnd;
@@ -103,7 +96,7 @@ bool vmm_block(size_t bytes, void **p) {
     if (!ok) {
         (void)hipGetLastError();
         for (size_t i = 0; i < B.handles.size(); i++) { (void)hipMemUnmap((char *)va + i * chunk, chunk); (void)hipMemRelease(B.handles[i]); }
-        (void)hipMemAddressFree(va0, reserved);
+        (void)hipMemAddressFree(va, total);
         (void)hipGetLastError();
         return false;
     }
@@ -131,7 +124,12 @@ void device_release(void *p) {
         if (it != g_vmm.end()) {
             VmmBlock &B = it->second;
             for (size_t i = 0; i < B.handles.size(); i++) { (void)hipMemUnmap((char *)p + i * B.chunk, B.chunk); (void)hipMemRelease(B.handles[i]); }
-            (void)hipMemAddressFree(B.va, B.reserved);
+            // The physical chunks go back; the ADDRESS RANGE does not (unless EMGPU_VMM_FREE_VA is set).  A HIP runtime (the 7.0 build PyTorch wheels
+            // bundle) crashes in hipMemMap -- VirtualGPU::submitVirtualMap -- when a new range overlaps one whose block had been the source of
+            // hipMemcpyAsync calls before it was released (tools/copy_placement_probe.py; the 7.2 system runtime does not).  A reservation costs
+            // address space only (47 bits of it: a thousand 36 GB traces are 36 TiB), so ranges are simply never handed back for re-use.
+            static const bool free_va = getenv("EMGPU_VMM_FREE_VA") != nullptr;
+            if (free_va) (void)hipMemAddressFree(p, B.bytes);
             g_vmm.erase(it);
             return;
         }
@@ -527,13 +525,14 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *h, const emgpu_samp
     const size_t dev_bytes = std::max<size_t>(o, 256);
     const size_t stage_bytes = std::max<size_t>(stage_prefix + (cap ? C * cap * 8 : 0), 256);
 
-    // the chunk buffers are blocks of the trace pool (below 1 GiB nothing is probed: these launches are microseconds beside their copies)
+    // the chunk buffers are blocks of the trace pool's allocator (nothing is probed: these launches are microseconds beside their copies)
     for (size_t q = 0; q < (nchunks == 1 ? 1u : 2u); q++) {
         emgpu_ctx::TraceBlock &b = ctx->chunk_buf[q];
         if (b.bytes >= dev_bytes) continue;
         HIP_OK(hipStreamSynchronize(ctx->stream));
         if (b.p) { device_release(b.p); b = emgpu_ctx::TraceBlock(); }
-        b = pool_take(ctx, dev_bytes + dev_bytes / 8, nullptr);   // (some headroom: batch sizes that wobble do not reallocate)
+        // (plain hipMalloc blocks: these buffers are the SOURCE of copies, which is all their placement could matter for -- measured: it does not)
+        b = pool_take(ctx, dev_bytes + dev_bytes / 8, nullptr, /*plain=*/true);   // (some headroom: batch sizes that wobble do not reallocate)
         if (!b.p) return fail(EMGPU_ERR_HIP, "emgpu_sample_dbn_host: out of device memory");
     }
     if (ctx->h_stage_cap < stage_bytes) {

@@ -252,8 +252,8 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_samp
  * Trace placement (round 6).  WHERE a 36 GB trace lies in device memory decides how fast the sampler writes it: the same launch takes
  * 5.9, 6.6 or 7.0 ms depending on the allocation, launch after launch (profiles/r05_placement_probe.txt, profiles/r06_placement_probe.txt).
  * A consumer of emgpu_sample_dbn_device therefore asks the LIBRARY for its trace instead of calling hipMalloc.  Two things happen there:
- *   (i)  blocks of 1 GiB and more are an address range that starts on a 1 GiB boundary over 1 GiB physical chunks (the HIP virtual-memory
- *        calls) -- in every process but the first on a freshly booted box these are all of the fast kind, where hipMalloc's are mostly not;
+ *   (i)  blocks of 1 GiB and more are ONE address range backed by separately created 1 GiB physical chunks (the HIP virtual-memory calls):
+ *        four to six of six such blocks are of the fast kind where hipMalloc's are mostly of the middle one (why is not known: measured);
  *   (ii) emgpu_trace_alloc allocates `candidates` blocks, times the caller's own call (m, p) on each -- 0.5 s of launches to load the device,
  *        then two rounds of 2 untimed + 5 timed launches per candidate, the better round counts -- keeps the fastest and frees the others.
  *        Candidate 0 is a plain hipMalloc block: report.first_allocation_ms is what the caller's own allocation would have got.

@@ -1,7 +1,9 @@
 """tools/placement_probe5.py [K] -- which ALLOCATION gives a fast trace?  Round 6: the same launch writes a 36 GB trace in 5.9, 6.6 or 7.0 ms
 depending on the allocation (three classes on one box, the fast one rare).  One child process per allocation mode of the library's trace
 pool (EMGPU_TRACE_ALLOC = plain | contiguous | vmm:<MiB>), each allocating K traces through the C ABI (emgpu_trace_alloc, candidates = 1),
-timing the headline launch on each (two rounds of 2 + 5 launches, HIP events) and printing the times.  -> profiles/r06_placement_probe.txt"""
+timing the headline launch on each (two rounds of 2 + 5 launches, HIP events) and printing the times.  -> profiles/r06_placement_probe.txt
+(The recorded runs also show "vmm:<MiB>:<shift>" and "vmmu:" modes: diagnostic builds of round 6 that mapped the chunks off the start of the range /
+placed the block by hand on a 1 GiB boundary.  Neither makes a difference and neither is in the library.)"""
 import json
 import os
 import subprocess
