@@ -222,3 +222,34 @@ def test_two_consecutive_processes_both_get_a_fast_trace_through_the_c_abi():
     for res in out:
         assert res["placed_report"]["candidates"] == 6 and not res["placed_report"]["reused"], res
         assert res["placed_ms"] <= 1.02 * min(res["five_ms"]), res
+
+
+def test_library_blocks_survive_copies_release_and_reuse(model_dir):
+    """The sequence that made a HIP runtime segfault in hipMemMap (the 7.0 build PyTorch wheels bundle; HISTORY.md section 12.1): chunked blocks are the
+    SOURCE of device -> host copies that span two physical chunks, are released, and a larger block is built afterwards.  The allocator keeps its address
+    ranges, so the new block never overlaps a released one: the sequence runs, twice, and the trace built last holds what the sampler writes."""
+    ctx = native.Context(0)
+    nm, pp, _ = load_pair("uncor_1200code_v2p1", model_dir)
+    idx = uncor_indices(pp)
+    hip = C.CDLL(None)
+    host = ctx.pinned_empty((1200 << 20,), np.uint8)
+    n, T, seed = 320_000, 240, 77                     # 1.16 GB of trace: a chunked block (>= 1 GiB)
+    p, _ = native.make_params(n, T, seed, **idx)
+    for cycle in range(2):
+        blocks = [ctx.device_alloc(1200 << 20) for _ in range(3)]
+        for addr in blocks:                           # 1 200 MiB out of a block of two 1 GiB chunks: the copy spans both
+            assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(addr), C.c_size_t(1200 << 20), 2) == 0
+        for addr in blocks:
+            ctx.device_free(addr)
+        t = native.Trace(ctx, nm, p, candidates=1)
+        assert t.bytes >= 1 << 30 and t.report["candidates"] == 1
+        native.sample_dbn_device(ctx, nm, p, **{k: v for k, v in t.ptrs().items() if k in ("init_bin", "init_val", "dyn_bin", "dyn_val", "ld")})
+        ctx.sync()
+        dv = np.empty((T // 4, nm.n_dyn, t.ld, 4), np.float32)
+        assert hip.hipMemcpy(C.c_void_p(dv.ctypes.data), C.c_void_p(t.ptrs()["dyn_val"]), C.c_size_t(dv.nbytes), 2) == 0   # (a copy out of the trace too)
+        t.free()
+        ctx.trim()
+    one = native.sample_dbn_host(ctx, nm, 5000, T, seed, want_dense=True, want_events=False, **idx)
+    assert np.array_equal(native.unpack_dyn_val(dv[:, :, :5000], T), one["dyn_val"])
+    with pytest.raises(L.EmgpuError):
+        ctx.device_free(12345)                        # not a block of this context
