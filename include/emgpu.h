@@ -263,8 +263,10 @@ int emgpu_sample_dbn_host(emgpu_ctx *ctx, const emgpu_model *m, const emgpu_samp
  *               many as the device's free memory holds.  1 = one block of kind (i), nothing timed.  n > 1: that many.
  * The trace's trajectory dimension ld is p->n rounded up to 1 024 columns (every row of every array starts on a 1 KiB boundary).
  * emgpu_trace_free gives the block back to the ctx's POOL: the next emgpu_trace_alloc it fits (and is not more than 25 % too large for) takes
- * it without a new probe (report.reused = 1).  emgpu_ctx_trim / emgpu_ctx_free release the pool.  The probe launches overwrite the trace
- * with the samples of (p->seed, p->first_index ...): the same samples the caller's own call will write.
+ * it without a new probe (report.reused = 1).  emgpu_ctx_trim / emgpu_ctx_free release the pool (the memory goes back to the device; the
+ * ADDRESS RANGE of a chunked block is never re-used -- a HIP runtime crashes when a new range overlaps a released one that had been the source
+ * of copies; address space is the only cost).  A trace must be freed before its ctx.  The probe launches overwrite the trace with the samples
+ * of (p->seed, p->first_index ...): the same samples the caller's own call will write.
  * ---------------------------------------------------------------------------------------------- */
 #define EMGPU_TRACE_INIT 1u     /* init_bin + init_val                  */
 #define EMGPU_TRACE_DENSE 2u    /* dyn_bin + dyn_val                    */

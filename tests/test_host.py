@@ -35,6 +35,34 @@ def test_version_names_the_generator_and_the_sources():
     assert r == O.philox_rounds()        # (tests/conftest.py refuses to start a session otherwise)
 
 
+def _source_hash():
+    """The hash csrc/Makefile bakes into emgpu_version(): sha256 over the sorted sources + the public header, first 12 hex digits."""
+    import glob
+    import hashlib
+    csrc = os.path.join(ROOT, "em_model_manned_bayes_amd", "csrc")
+    names = sorted({os.path.basename(f) for pat in ("*.hip", "*.cpp", "*.h", "*.hpp") for f in glob.glob(os.path.join(csrc, pat))})
+    h = hashlib.sha256()
+    h.update(open(os.path.join(ROOT, "include", "emgpu.h"), "rb").read())       # "../../include/emgpu.h" sorts first
+    for nme in names:
+        h.update(open(os.path.join(csrc, nme), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def test_the_library_and_the_rounds_profiles_are_of_the_sources_in_the_tree():
+    """bench.py reports roofline.traffic only from a profile summary recorded with the SAME sources as the loaded library (the hash in
+    emgpu_version()).  A comment edited in a header after the profiles were taken silently turns every `traffic` into null at the next build:
+    the built library must be current, and the newest round's summaries must name the sources that are in the tree."""
+    import glob
+    import json
+    want = _source_hash()
+    assert ("src:" + want) in L.lib().emgpu_version().decode(), "libemgpu.so is stale: rebuild (make -C em_model_manned_bayes_amd/csrc)"
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))[-1]
+    tag = os.path.basename(newest).split("_")[0]
+    for f in glob.glob(os.path.join(ROOT, "profiles", tag + "*_summary.json")):
+        lib = json.load(open(f))["bench_line"]["config"]["lib"]
+        assert lib.endswith("src:" + want), "%s was recorded from %s, the tree is src:%s: re-run tools/profile_round.sh" % (os.path.basename(f), lib, want)
+
+
 def test_no_cpu_fallback_without_a_device():
     import torch
     if torch.cuda.is_available():
