@@ -906,8 +906,8 @@ NOTES = {
     "cpu_baseline": "oracle/em_oracle.c (scalar port of the reference algorithm), Philox mode, thread-private dense outputs, on `cores` threads = the cgroup's "
                     "CPU quota; single_thread_value beside it; MATLAB itself is not installed and cannot be timed",
     "host_path": "emgpu_sample_dbn_host end to end at --host-n trajectories x 240 s of uncor_1200code_v2p1, third call of each kind (the first pins memory), "
-                 "measured BEFORE the headline (a process that has wrapped a 36 GB trace in a torch tensor -- this script's own plumbing -- copies at 47 GB/s afterwards: "
-                 "tools/host_path_bisect.sh): "
+                 "measured BEFORE the headline (a process that has laid a torch tensor over a 36 GB trace -- this script's own plumbing -- and freed the trace copies at "
+                 "47 GB/s afterwards: tools/host_path_bisect.sh): "
                  "dense_pinned = outputs in emgpu_host_alloc memory (the copy engine writes into the caller's arrays); dense_pageable = the caller's own "
                  "(pre-faulted) numpy arrays through the library's pinned staging + host threads; events_pinned = event lists only, packed on the device "
                  "(sum(ev_count) rows cross PCIe); GBps = bytes_d2h / total_ms; kernel_ms / d2h_ms / scatter_ms = the pipeline's phases (they overlap); "
@@ -1083,9 +1083,9 @@ def run_rank(args, rank, local_rank, world, pl=None, out=sys.stdout):
     default_run = world == 1 and args.config == "uncor" and not args.model and not args.n and hasattr(pl, "release")
     hp, hp_detail = None, {"host_path": {}}
     if rank == 0 and default_run and not args.no_host_path:
-        # FIRST, in the state a consumer's process is in: once this process has wrapped a 36 GB trace in a torch tensor (the plumbing of the checks
-        # below), every later device -> host copy of it runs at 47 instead of 56.5 GB/s (40 instead of 55 through the staging buffers) -- found by
-        # tools/host_path_bisect.sh; a trace that is only ever touched through the C ABI does not have that effect
+        # FIRST, in the state a consumer's process is in: once this process has laid a torch tensor over a 36 GB trace (the plumbing of the checks
+        # below) and then FREED that trace, the host path's copies run at 47 instead of 56.5 GB/s (40 instead of 55 through the staging buffers) --
+        # tools/host_path_bisect.sh; a trace that is only touched through the C ABI, or that stays alive, does not have that effect
         try:
             hp = host_path(args, pl, hp_detail)
         except Exception as ex:

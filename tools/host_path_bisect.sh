@@ -19,6 +19,17 @@ if mode in ("rawtrace", "rawtrace_plain", "rawtrace_keep"):
     c = pl.context() if mode != "rawtrace_plain" else native.Context(0)
     p, _k = native.make_params(10_000_000, 240, 1, **bench._label_indices(nm))
     t = native.Trace(c, nm, p, candidates=1)
+    wrapped = []
+    if os.environ.get("WRAP"):
+        ld, ptrs = t.ld, t.ptrs()
+        shapes = {"init_bin": ((7, ld), "uint8"), "init_val": ((7, ld), "float32"), "dyn_bin": ((60, 3, ld), "int32"), "dyn_val": ((60, 3, ld, 4), "float32")}
+        for k in os.environ["WRAP"].split(","):
+            wrapped.append(pl.wrap(ptrs[k], *shapes[k]))
+        if os.environ.get("TOUCH"):
+            print("touch", int(wrapped[0].reshape(-1)[:1000].sum()))
+        if os.environ.get("DROP"):
+            wrapped = []
+            import gc; gc.collect()
     if mode != "rawtrace_keep":
         t.free(); c.trim()
 elif os.environ.get("HEADLINE", "1") == "1":
@@ -38,7 +49,7 @@ h = bench.host_path(args, pl, detail)
 print(os.environ.get("TAG", ""), "pinned", h["dense_pinned"]["GBps"], "pageable", h["dense_pageable"]["GBps"], "plain copy", h["pinned_d2h_GBps"])
 PY
 }
-TAG="raw Trace on torch stream ctx, freed " MODE=rawtrace one --no-cpu-baseline
-TAG="raw Trace on own-stream ctx, freed   " MODE=rawtrace_plain one --no-cpu-baseline
-TAG="raw Trace kept alive                 " MODE=rawtrace_keep one --no-cpu-baseline
-TAG="EMGPU_TRACE_ALLOC=plain, workload    " EMGPU_TRACE_ALLOC=plain MODE=alloc one --no-cpu-baseline --placement-candidates 1
+TAG="raw trace + wrap 4 arrays (kept)     " MODE=rawtrace_keep WRAP=init_bin,init_val,dyn_bin,dyn_val one --no-cpu-baseline
+TAG="raw trace + wrap dyn_val only (kept)  " MODE=rawtrace_keep WRAP=dyn_val one --no-cpu-baseline
+TAG="raw trace + wrap 4, dropped, freed    " MODE=rawtrace WRAP=init_bin,init_val,dyn_bin,dyn_val DROP=1 one --no-cpu-baseline
+TAG="raw trace + wrap init_bin only (kept) " MODE=rawtrace_keep WRAP=init_bin one --no-cpu-baseline
