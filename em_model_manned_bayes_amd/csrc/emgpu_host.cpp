@@ -12,6 +12,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <system_error>
 #include <thread>
 
 #include "emgpu_internal.hpp"
@@ -234,10 +235,14 @@ int host_threads() {
     return n;
 }
 template <typename F>
-void run_parallel(int T, F fn) {   // fn(t) for t = 0..T-1, fn(0) on the calling thread
+void run_parallel(int T, F fn) {   // fn(t) for t = 0..T-1, fn(0) on the calling thread; fn does not throw (memcpy loops)
     std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back(fn, t);
+    int started = 1;
+    try {
+        for (int t = 1; t < T; t++) { th.emplace_back(fn, t); started = t + 1; }
+    } catch (const std::system_error &) {}   // the host will not give another thread: the parts not started run here (a joinable thread must not be destroyed)
     fn(0);
+    for (int t = started; t < T; t++) fn(t);
     for (auto &x : th) x.join();
 }
 } // namespace
@@ -413,7 +418,7 @@ int emgpu_host_alloc(emgpu_ctx *ctx, uint64_t bytes, void **out) {
     if (!ctx || !out) return fail(EMGPU_ERR_ARG, "null argument");
     CTX_LOCK(ctx);
     HIP_OK(hipSetDevice(ctx->device));
-    const size_t need = std::max<size_t>((size_t)bytes, 64);
+    const size_t need = std::max<size_t>((size_t)bytes, 64);   // (portable: emgpu_sample_dbn_multi_host hands one caller array to the contexts of several devices)
     emgpu_ctx::HostBlock *best = nullptr;
     for (auto &b : ctx->host_pool)
         if (!b.in_use && b.bytes >= need && b.bytes <= need + need / 2 + (1u << 20) && (!best || b.bytes < best->bytes)) best = &b;
@@ -423,11 +428,11 @@ int emgpu_host_alloc(emgpu_ctx *ctx, uint64_t bytes, void **out) {
         return EMGPU_OK;
     }
     void *p = nullptr;
-    if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&p, need, hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
         for (auto it = ctx->host_pool.begin(); it != ctx->host_pool.end();)   // the pool's idle blocks first, then once more
             if (!it->in_use) { (void)hipHostFree(it->p); it = ctx->host_pool.erase(it); } else ++it;
-        HIP_OK(hipHostMalloc(&p, need, hipHostMallocDefault));
+        HIP_OK(hipHostMalloc(&p, need, hipHostMallocPortable));
     }
     ctx->host_pool.push_back({p, need, true});
     *out = p;
