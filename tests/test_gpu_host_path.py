@@ -253,3 +253,22 @@ def test_library_blocks_survive_copies_release_and_reuse(model_dir):
     assert np.array_equal(native.unpack_dyn_val(dv[:, :, :5000], T), one["dyn_val"])
     with pytest.raises(L.EmgpuError):
         ctx.device_free(12345)                        # not a block of this context
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_multi_context_host_call_through_the_chunked_pipeline(pinned, model_dir, small_chunks):
+    """emgpu_sample_dbn_multi_host (one host thread + one stream per context inside ONE call) with every context running its own pipeline of
+    several chunks into its columns of the caller's arrays: three contexts (on this box's one device), 7 000 trajectories -> shards of 2 334 /
+    2 333 / 2 333 in chunks of 1 024; equal to one single-context call, event lists included."""
+    nm, pp, _ = load_pair("uncor_1200only_fwse_v1p2", model_dir)
+    idx = uncor_indices(pp)
+    n, T, seed, first = 7000, 120, 0xBEEF, 2**35
+    ctxs = [native.Context(0) for _ in range(3)]
+    got = native.sample_dbn_host(ctxs, nm, n, T, seed, first_index=first, want_dense=True, want_events=True, event_cap=300, pinned=pinned, **idx)
+    one = native.sample_dbn_host(ctxs[0], nm, n, T, seed, first_index=first, want_dense=True, want_events=True, event_cap=300, pinned=pinned, **idx)
+    for k in ("init_bin", "init_val", "dyn_bin", "dyn_val", "ev_count", "attempts"):
+        assert np.array_equal(got[k], one[k]), k
+    assert all(np.array_equal(a, b) for a, b in zip(got["events"], one["events"]))
+    assert all(c.host_stats()["chunks"] == 3 for c in ctxs[1:]) and ctxs[1].host_stats()["direct"] == int(pinned)
+    ref = O.uncor_sample(O.OracleModel(pp), 500, T, seed, mode=O.RNG_PHILOX, first_index=first + 4000)
+    assert np.array_equal(got["dyn_bin"][4000:4500], ref["dense_bin"]) and np.array_equal(got["dyn_val"][4000:4500], ref["dense_val"].astype(np.float32))
