@@ -167,6 +167,15 @@ def test_trace_alloc_report_pool_and_use(model_dir):
     te = native.Trace(ctx, nm, pe, want=L.TRACE_EVENTS | L.TRACE_ATTEMPTS)
     ptr = te.ptrs()
     assert ptr["events"] and ptr["ev_count"] and ptr["attempts"] and not ptr["dyn_val"] and te.ld == 5120
+    # ... filled by the device entry point and read back: the lists and attempts of the host path
+    native.sample_dbn_device(ctx, nm, pe, ev_count=ptr["ev_count"], events=ptr["events"], attempts=ptr["attempts"], ld=te.ld)
+    ctx.sync()
+    cnt = np.empty(te.ld, np.uint32); evs = np.empty((te.ld, 64), native.EVENT_DTYPE); att = np.empty(te.ld, np.int32)
+    for arr, key in ((cnt, "ev_count"), (evs, "events"), (att, "attempts")):
+        assert hip.hipMemcpy(C.c_void_p(arr.ctypes.data), C.c_void_p(ptr[key]), C.c_size_t(arr.nbytes), 2) == 0
+    ref = native.sample_dbn_host(ctx, nm, 5000, 60, seed, want_dense=False, want_events=True, event_cap=64, **idx)
+    assert np.array_equal(cnt[:5000], ref["ev_count"]) and np.array_equal(att[:5000], ref["attempts"])
+    assert all(np.array_equal(evs[i, : cnt[i]], ref["events"][i]) for i in range(0, 5000, 11))
     with pytest.raises(L.EmgpuError):
         native.Trace(ctx, nm, p, want=L.TRACE_EVENTS)   # event_cap 0
 
